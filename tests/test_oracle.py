@@ -1,0 +1,237 @@
+"""CPU tests of the oracle itself (known answers, autograd cross-check, finite differences).
+
+The reference ships no tests; these are the closed-form cases the survey
+lists.  Tolerances: see each test.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from util import oracle_settings, rel_l2, small_scene
+from splatco_amd.cameras import make_camera
+from splatco_amd.synthetic import synthetic_camera, synthetic_gaussians
+from oracle import torch_ref
+
+
+def _cam(W=64, H=64, fov=60.0):
+    return synthetic_camera(W, H, fov)
+
+
+def _one(orc, cam, means, scales, op, col, bg=(0, 0, 0), rot=None, **kw):
+    means = np.asarray(means, np.float32).reshape(-1, 3)
+    P = means.shape[0]
+    scales = np.asarray(scales, np.float32).reshape(P, 3)
+    rot = np.tile(np.array([1, 0, 0, 0], np.float32), (P, 1)) if rot is None else np.asarray(rot, np.float32)
+    st = oracle_settings(orc, cam, bg)
+    return st, orc.forward(st, means, np.asarray(op, np.float32).reshape(P, 1), scales, rot,
+                           colors_precomp=np.asarray(col, np.float32).reshape(P, 3), **kw)
+
+
+def _unproject(cam, px, py, z):
+    W, H = cam.image_width, cam.image_height
+    tx, ty = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+    return [((2 * px + 1) / W - 1) * tx * z, ((2 * py + 1) / H - 1) * ty * z, z]
+
+
+def test_single_isotropic_gaussian_centre_pixel(oracle):
+    cam = _cam()
+    st, f = _one(oracle, cam, _unproject(cam, 31, 29, 5.0), [0.2] * 3, 0.7, [1.0, 0.5, 0.25], bg=(0.1, 0.2, 0.3))
+    assert f["radii"][0] > 0
+    np.testing.assert_allclose(f["xy"][0], [31, 29], atol=1e-3)
+    # at the centre pixel power = 0 -> alpha = opacity; C = o*c + (1-o)*bg
+    want = 0.7 * np.array([1.0, 0.5, 0.25]) + 0.3 * np.array([0.1, 0.2, 0.3])
+    np.testing.assert_allclose(f["color"][:, 29, 31], want, atol=2e-5)
+    assert f["n_contrib"][29, 31] == 1
+    np.testing.assert_allclose(f["final_T"][29, 31], 0.3, atol=1e-6)
+    # radius: isotropic sigma_px = f*s/z ; cov = sigma^2 + 0.3
+    fpx = 64 / (2 * math.tan(cam.FoVx / 2))
+    sig2 = (fpx * 0.2 / 5.0) ** 2 + 0.3
+    # the eigenvalue guard max(0.1, mid^2 - det) adds sqrt(0.1) for an isotropic footprint
+    assert f["radii"][0] == math.ceil(3 * math.sqrt(sig2 + math.sqrt(0.1)))
+    # far corner: only background
+    np.testing.assert_allclose(f["color"][:, 0, 0], [0.1, 0.2, 0.3], atol=1e-6)
+    assert f["n_contrib"][0, 0] == 0
+
+
+def test_two_gaussians_depth_order(oracle):
+    cam = _cam()
+    near = _unproject(cam, 20, 20, 3.0)
+    far = _unproject(cam, 20, 20, 6.0)
+    # listed far first: the sort must put the near one in front
+    st, f = _one(oracle, cam, [far, near], [[0.3] * 3, [0.15] * 3], [0.5, 0.6], [[0, 1, 0], [1, 0, 0]])
+    want = 0.6 * np.array([1, 0, 0]) + 0.4 * 0.5 * np.array([0, 1, 0])
+    np.testing.assert_allclose(f["color"][:, 20, 20], want, atol=2e-5)
+    t = 20 // 16 + (20 // 16) * st.grid[0]
+    lo, hi = f["ranges"][t]
+    assert list(f["point_list"][lo:hi]) == [1, 0]
+    assert f["n_contrib"][20, 20] == 2
+
+
+def test_alpha_cap_and_early_stop(oracle):
+    cam = _cam()
+    P = 12
+    means = [_unproject(cam, 40, 40, 2.0 + 0.1 * i) for i in range(P)]
+    st, f = _one(oracle, cam, means, [[0.2] * 3] * P, [1.0] * P, [[1, 1, 1]] * P)
+    # alpha capped at 0.99 -> T = 0.01 ; the second splat would give 0.01*(1-0.99f) < 1e-4 -> stop
+    assert f["n_contrib"][40, 40] == 1
+    np.testing.assert_allclose(f["final_T"][40, 40], 0.01, rtol=1e-5)
+    st, f = _one(oracle, cam, means, [[0.2] * 3] * P, [0.8] * P, [[1, 1, 1]] * P)
+    # T = 0.2^k : 0.2^5 = 3.2e-4 kept, 0.2^6 = 6.4e-5 < 1e-4 -> the 6th splat stops the pixel
+    assert f["n_contrib"][40, 40] == 5
+    np.testing.assert_allclose(f["final_T"][40, 40], 0.2 ** 5, rtol=1e-5)
+    np.testing.assert_allclose(f["color"][:, 40, 40], 1 - 0.2 ** 5, rtol=1e-5)
+
+
+def test_near_cull_and_offscreen(oracle):
+    cam = _cam()
+    st, f = _one(oracle, cam, [[0, 0, 0.2], [0, 0, 0.21], [500.0, 0, 5.0], [0, 0, -3.0]],
+                 [[0.01] * 3] * 4, [0.5] * 4, [[1, 1, 1]] * 4)
+    assert f["radii"][0] == 0          # z <= 0.2
+    assert f["radii"][1] > 0
+    assert f["radii"][2] == 0          # zero tile area
+    assert f["radii"][3] == 0          # behind the camera
+    assert list(f["tiles_touched"]) == [0, f["tiles_touched"][1], 0, 0]
+    vis = oracle.mark_visible(st, np.array([[0, 0, 0.2], [0, 0, 0.21], [500.0, 0, 5.0], [0, 0, -3.0]], np.float32))
+    assert list(vis) == [False, True, True, False]
+
+
+def test_empty_input(oracle):
+    cam = _cam()
+    st = oracle_settings(oracle, cam, (0.3, 0.4, 0.5))
+    f = oracle.forward(st, np.zeros((0, 3), np.float32), np.zeros((0, 1), np.float32),
+                       np.zeros((0, 3), np.float32), np.zeros((0, 4), np.float32),
+                       colors_precomp=np.zeros((0, 3), np.float32))
+    assert f["num_rendered"] == 0
+    np.testing.assert_allclose(f["color"][:, 5, 7], [0.3, 0.4, 0.5])
+
+
+def test_binning_invariants(oracle):
+    cam = synthetic_camera(400, 400)
+    g = synthetic_gaussians(3000, 400, 400, seed=5)
+    g["means3D"][100:110, 2] = g["means3D"][100, 2]      # force depth ties
+    st = oracle_settings(oracle, cam, g["bg"])
+    f = oracle.forward(st, g["means3D"], g["opacities"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+    keys, ids = f["keys_sorted"], f["point_list"]
+    assert f["num_rendered"] == int(f["tiles_touched"].sum()) == len(keys)
+    assert np.all(keys[1:] >= keys[:-1])
+    same = keys[1:] == keys[:-1]
+    assert np.all(ids[1:][same] > ids[:-1][same])         # stable: ties keep ascending id
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    for t in np.unique(tiles):
+        lo, hi = f["ranges"][t]
+        assert np.all(tiles[lo:hi] == t) and hi - lo == (tiles == t).sum()
+    d32 = f["depth"].astype(np.float32).view(np.uint32)
+    assert np.all((keys & np.uint64(0xFFFFFFFF)).astype(np.uint32) == d32[ids])
+    assert f["point_offsets"][-1] == f["num_rendered"]
+
+
+def _torch_run(cam, g, dt, bg, colors=True, shs=None, cov=None, deg=1, scale_modifier=1.0):
+    t = lambda a: torch.tensor(np.asarray(a), dtype=dt, requires_grad=True)
+    m, o = t(g["means3D"]), t(g["opacities"])
+    s, r = (t(g["scales"]), t(g["rotations"])) if cov is None else (None, None)
+    c = t(g["colors"]) if colors else None
+    sh = t(shs) if shs is not None else None
+    cv = t(cov) if cov is not None else None
+    img, radii, ndc = torch_ref.rasterize(
+        cam.image_height, cam.image_width, float(np.float32(math.tan(cam.FoVx / 2))),
+        float(np.float32(math.tan(cam.FoVy / 2))),      # the ABI carries tanfov as binary32
+        torch.tensor(bg), float(np.float32(scale_modifier)), cam.world_view_transform, cam.full_proj_transform, deg,
+        cam.camera_center, m, o, s, r, cv, sh, c)
+    ndc.retain_grad()
+    return img, radii, ndc, dict(means3D=m, opacities=o, scales=s, rotations=r, colors_precomp=c, sh=sh,
+                                 cov3D_precomp=cv)
+
+
+@pytest.mark.parametrize("mode", ["colors", "sh", "cov"])
+def test_oracle_matches_torch_autograd(oracle, mode):
+    """Analytic backward of the C oracle == autograd through the dense torch restatement.
+    f64 vs f64: rel-L2 <= 1e-9 (same maths, different summation order); f32 oracle vs f64
+    oracle <= 1e-3."""
+    cam, g = small_scene(P=80)
+    rng = np.random.default_rng(11)
+    shs = rng.standard_normal((80, 16, 3)).astype(np.float32) * 0.4 if mode == "sh" else None
+    cov = None
+    if mode == "cov":
+        A = rng.standard_normal((80, 3, 3)) * 0.15
+        S = A @ A.transpose(0, 2, 1) + 1e-3 * np.eye(3)
+        cov = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).astype(np.float32)
+    deg = 3
+    st = oracle_settings(oracle, cam, g["bg"], scale_modifier=1.1, sh_degree=deg)
+    kw = dict(scales=None if cov is not None else g["scales"], rotations=None if cov is not None else g["rotations"],
+              cov3D_precomp=cov, shs=shs, colors_precomp=None if mode == "sh" else g["colors"])
+    dL = rng.standard_normal((3, cam.image_height, cam.image_width))
+    res = {}
+    for f64 in (False, True):
+        f = oracle.forward(st, g["means3D"], g["opacities"], f64=f64, **kw)
+        b = oracle.backward(st, f, dL, g["means3D"], f64=f64, **kw)
+        res[f64] = (f, b)
+    img, radii, ndc, leaves = _torch_run(cam, g, torch.float64, g["bg"], colors=mode != "sh", shs=shs, cov=cov,
+                                         deg=deg, scale_modifier=1.1)
+    (img * torch.tensor(dL)).sum().backward()
+    f64o, b64 = res[True]
+    assert (f64o["radii"] > 0).sum() > 40
+    assert np.array_equal(radii.numpy(), f64o["radii"])
+    np.testing.assert_allclose(img.detach().numpy(), f64o["color"], atol=1e-10)
+    pairs = [("means3D", leaves["means3D"].grad), ("opacities", leaves["opacities"].grad)]
+    if cov is None:
+        pairs += [("scales", leaves["scales"].grad), ("rotations", leaves["rotations"].grad)]
+    else:
+        pairs += [("cov3D_precomp", leaves["cov3D_precomp"].grad)]
+    pairs += [("sh", leaves["sh"].grad)] if mode == "sh" else [("colors_precomp", leaves["colors_precomp"].grad)]
+    for name, tg in pairs:
+        assert rel_l2(b64[name], tg.numpy().reshape(b64[name].shape)) < 1e-9, name
+    assert rel_l2(b64["means2D"][:, :2], ndc.grad.numpy()) < 1e-9
+    assert np.all(b64["means2D"][:, 2] == 0)
+    # fp32 oracle against fp64 oracle
+    f32o, b32 = res[False]
+    if np.array_equal(f32o["point_list"], f64o["point_list"]) and np.array_equal(f32o["n_contrib"], f64o["n_contrib"]):
+        assert np.abs(f32o["color"] - f64o["color"]).max() < 1e-5
+        for name, _ in pairs + [("means2D", None)]:
+            assert rel_l2(b32[name], b64[name]) < 1e-3, name
+
+
+def test_oracle_finite_differences(oracle):
+    """fp64 central differences (h = 1e-6, so the discontinuities of the forward at the
+    alpha = 1/255 / power = 0 / T = 1e-4 boundaries are practically never straddled) of the
+    dense torch forward -- which equals the oracle's f64 forward to 1e-10 (previous test) --
+    against the oracle's analytic backward."""
+    cam, g = small_scene(P=24, W=48, H=32, seed=9)
+    st = oracle_settings(oracle, cam, g["bg"])
+    rng = np.random.default_rng(2)
+    dL = rng.standard_normal((3, 32, 48))
+    f0 = oracle.forward(st, g["means3D"], g["opacities"], g["scales"], g["rotations"],
+                        colors_precomp=g["colors"], f64=True)
+    b = oracle.backward(st, f0, dL, g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"], f64=True)
+    tdL = torch.tensor(dL)
+    tf = float(np.float32(math.tan(cam.FoVx / 2))), float(np.float32(math.tan(cam.FoVy / 2)))
+
+    def loss(v):
+        t = lambda a: torch.tensor(a, dtype=torch.float64)
+        with torch.no_grad():
+            img, _, _ = torch_ref.rasterize(cam.image_height, cam.image_width, tf[0], tf[1], torch.tensor(g["bg"]),
+                                            1.0, cam.world_view_transform, cam.full_proj_transform, 1,
+                                            cam.camera_center, t(v["means3D"]), t(v["opacities"]), t(v["scales"]),
+                                            t(v["rotations"]), None, None, t(v["colors"]))
+        return float((img * tdL).sum())
+
+    base = {k: g[k].astype(np.float64) for k in ("means3D", "opacities", "scales", "rotations", "colors")}
+    names = dict(means3D="means3D", opacities="opacities", scales="scales", rotations="rotations", colors="colors_precomp")
+    checked = 0
+    for key, gname in names.items():
+        for _ in range(8):
+            i = int(rng.integers(0, 24))
+            j = int(rng.integers(0, base[key].shape[1]))
+            if f0["radii"][i] == 0:
+                continue
+            h = 1e-6 * max(abs(base[key][i, j]), 0.05)
+            vp = {k: v.copy() for k, v in base.items()}
+            vm = {k: v.copy() for k, v in base.items()}
+            vp[key][i, j] += h
+            vm[key][i, j] -= h
+            fd = (loss(vp) - loss(vm)) / (2 * h)
+            an = b[gname][i, j]
+            assert abs(fd - an) <= 1e-4 * max(abs(an), abs(fd), 1e-3), (key, i, j, fd, an)
+            checked += 1
+    assert checked >= 20

@@ -1,0 +1,45 @@
+"""Shared helpers for the tests (scene builders, tolerances)."""
+import math
+
+import numpy as np
+import torch
+
+from splatco_amd.cameras import look_at_camera, make_camera
+from splatco_amd.synthetic import synthetic_camera, synthetic_gaussians
+
+
+def oracle_settings(orc, cam, bg, scale_modifier=1.0, sh_degree=1):
+    return orc.Settings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5),
+                        math.tan(cam.FoVy * 0.5), np.asarray(bg, np.float32), scale_modifier,
+                        cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), sh_degree,
+                        cam.camera_center.numpy())
+
+
+def small_scene(P=96, W=64, H=48, seed=3, spread=1.0):
+    """A small random scene seen by an off-axis camera (exercises every matrix entry)."""
+    rng = np.random.default_rng(seed)
+    cam = look_at_camera(eye=(0.6, -0.4, -4.0), target=(0.1, 0.05, 0.0), up=(0.05, -1.0, 0.1),
+                         FoVx=math.radians(55.0), width=W, height=H)
+    means = rng.uniform(-1.2, 1.2, (P, 3)) * spread
+    scales = np.exp(rng.uniform(math.log(0.03), math.log(0.35), (P, 3)))
+    q = rng.standard_normal((P, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q *= rng.uniform(0.8, 1.2, (P, 1))       # the operator does not normalise quaternions
+    op = rng.uniform(0.05, 0.95, (P, 1))
+    col = rng.uniform(0, 1, (P, 3))
+    f = np.float32
+    return cam, dict(means3D=means.astype(f), scales=scales.astype(f), rotations=q.astype(f),
+                     opacities=op.astype(f), colors=col.astype(f),
+                     bg=np.array([0.2, 0.5, 0.9], f))
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def psnr(a, b):
+    """utils/image_utils.py:17-19 (mean over channels of per-channel PSNR)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    mse = ((a - b) ** 2).reshape(a.shape[0], -1).mean(1)
+    return float(np.mean(20 * np.log10(1.0 / np.sqrt(np.maximum(mse, 1e-300)))))
