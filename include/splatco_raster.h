@@ -1,0 +1,121 @@
+/*
+ * include/splatco_raster.h  --  C-ABI of the MI355X-native differentiable Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for SplatCo's gaussian_renderer.render() path.  The reference
+ * binds the same functionality through the pybind module `diff_gaussian_rasterization._C`
+ * (absent from /root/reference); the entry points below are what a
+ * binding for the three reference call sites needs:
+ *
+ *   scr_visible_filter   <- GaussianRasterizer.visible_filter   gaussian_renderer/__init__.py:239-242
+ *   scr_forward_plan/run <- GaussianRasterizer.forward          gaussian_renderer/__init__.py:163-171
+ *   scr_backward         <- autograd backward of the above      train.py:240 (total_loss.backward())
+ *   scr_mark_visible     <- GaussianRasterizer.markVisible      (operator family API; unused by SplatCo)
+ *   scr_settings         <- GaussianRasterizationSettings       gaussian_renderer/__init__.py:145-158
+ *
+ * Conventions
+ *   - Plain C, no exceptions, no torch types.  Every pointer is a DEVICE pointer unless the
+ *     name ends in `_host`.  All arrays are contiguous fp32 / int32 / uint32 as stated.
+ *   - `stream` is a hipStream_t passed as void*.  Nothing synchronises the device; the only
+ *     host wait is the stream-sync inside scr_forward_plan that returns num_rendered
+ *     (and a sync + error check after every kernel when settings.debug != 0).
+ *   - The library owns no memory and keeps no state between calls: the caller allocates every
+ *     buffer (sizes from the scr_*_bytes queries) -- so several forward graphs (the mv views
+ *     of train.py:171-240) can be alive at once.  One host thread per process/GPU.
+ *   - Return value: 0 = ok, non-zero = error; scr_last_error() returns a thread-local message.
+ */
+#ifndef SPLATCO_RASTER_H
+#define SPLATCO_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCR_ABI_VERSION 1
+#define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
+
+/* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
+ * viewmatrix / projmatrix are the flattened row-major [4,4] tensors of scene/cameras.py:54-56
+ * (row-vector convention: p_view = [x,y,z,1] * viewmatrix). */
+typedef struct scr_settings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    const float* bg;         /* device [3] */
+    float scale_modifier;
+    const float* viewmatrix; /* device [16] */
+    const float* projmatrix; /* device [16] */
+    int32_t sh_degree;
+    const float* campos;     /* device [3] */
+    int32_t prefiltered;
+    int32_t debug;
+} scr_settings;
+
+int scr_abi_version(void);
+const char* scr_last_error(void);
+
+/* ---- buffer sizes (bytes).  Buffers must be 256-byte aligned (any hipMalloc / torch allocation is). */
+size_t scr_geom_bytes(int64_t P, int32_t image_height, int32_t image_width); /* per-Gaussian state + per-tile counters */
+size_t scr_binning_bytes(int64_t num_rendered);                              /* per tile-instance lists */
+size_t scr_image_bytes(int32_t image_height, int32_t image_width);           /* final_T + n_contrib */
+size_t scr_backward_scratch_bytes(int64_t num_rendered);                     /* per-instance gradient records */
+
+/* ---- visible_filter: radii_out[P] int32 (> 0 <=> visible).  Either (scales, rotations) or cov3D_precomp. */
+int scr_visible_filter(int64_t P, const float* means3D, const float* scales, const float* rotations,
+                       const float* cov3D_precomp, const scr_settings* settings, int32_t* radii_out,
+                       void* stream);
+
+/* ---- markVisible: present_out[P] uint8 (view-space z > 0.2). */
+int scr_mark_visible(int64_t P, const float* means3D, const float* viewmatrix, uint8_t* present_out,
+                     void* stream);
+
+/* ---- forward, phase 1: projection / culling / tile counting / offsets.
+ * Exactly one of (shs, colors_precomp) and one of ((scales, rotations), cov3D_precomp) non-NULL.
+ * M = SH coefficients per Gaussian (shs is [P, M, 3]); opacities is [P] (or [P,1]).
+ * Writes radii_out[P] and geom_buf; returns the number of (Gaussian, tile) instances through
+ * *num_rendered_host (host pointer; the call stream-synchronises once to read it). */
+int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* scales,
+                     const float* rotations, const float* cov3D_precomp, const float* opacities,
+                     const float* shs, const float* colors_precomp, const scr_settings* settings,
+                     void* geom_buf, int32_t* radii_out, int64_t* num_rendered_host, void* stream);
+
+/* ---- forward, phase 2: per-tile bucketing, depth sort, front-to-back blend.
+ * out_color is [3, H, W] fp32.  geom_buf / binning_buf / image_buf must be kept for scr_backward. */
+int scr_forward_run(int64_t P, int64_t num_rendered, const scr_settings* settings, void* geom_buf,
+                    void* binning_buf, void* image_buf, float* out_color, void* stream);
+
+/* ---- backward.  dL_dcolor is [3,H,W].  Outputs (each may be NULL when its input was NULL):
+ * dL_dmeans3D[P,3], dL_dmeans2D[P,3] (d/d NDC position, z = 0: the gradient SplatCo reads back
+ * at scene/gaussian_model.py:779), dL_dcolors[P,3], dL_dsh[P,M,3], dL_dopacity[P], dL_dscales[P,3],
+ * dL_drotations[P,4], dL_dcov3D[P,6].  Every output element is written (zeros for culled Gaussians).
+ * Deterministic: bit-identical results run to run (no floating-point atomics). */
+int scr_backward(int64_t P, int32_t M, int64_t num_rendered, const float* means3D, const float* scales,
+                 const float* rotations, const float* cov3D_precomp, const float* shs,
+                 const scr_settings* settings, const int32_t* radii, const void* geom_buf,
+                 const void* binning_buf, const void* image_buf, const float* dL_dcolor, void* scratch,
+                 float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
+                 float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                 void* stream);
+
+/* ---- debug getters: copy the integer / float intermediates out of the opaque buffers (parity tests).
+ * which: see SCR_DBG_*.  `out` is a device buffer of the stated element count. */
+enum {
+    SCR_DBG_TILES_TOUCHED = 0, /* uint32[P]          geom   */
+    SCR_DBG_POINT_OFFSETS = 1, /* uint32[P] inclusive scan of tiles_touched  (geom, valid after forward_run) */
+    SCR_DBG_RANGES = 2,        /* uint32[tiles][2]   geom   */
+    SCR_DBG_POINT_LIST = 3,    /* uint32[I] sorted Gaussian ids  binning */
+    SCR_DBG_N_CONTRIB = 4,     /* uint32[H*W]        image  */
+    SCR_DBG_FINAL_T = 5,       /* float[H*W]         image  */
+    SCR_DBG_SPLAT_RECORDS = 6  /* float[P][12]: mx,my,-Qxx/2,-Qxy,-Qyy/2,opacity,r,g,b,depth,rect bits x2   geom */
+};
+int scr_debug_get(int which, int64_t P, int64_t num_rendered, int32_t image_height, int32_t image_width,
+                  const void* geom_buf, const void* binning_buf, const void* image_buf, void* out,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLATCO_RASTER_H */

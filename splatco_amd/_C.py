@@ -1,0 +1,76 @@
+"""ctypes binding of the C-ABI in include/splatco_raster.h (libsplatco_raster.so, gfx950).
+
+This is the binding a maintainer of the reference would write in place of the pybind module
+`diff_gaussian_rasterization._C`.  There is NO fallback: if the HIP library
+is missing or was built against another ABI version, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsplatco_raster.so")
+
+SYMBOLS = [
+    "scr_abi_version", "scr_last_error", "scr_geom_bytes", "scr_binning_bytes", "scr_image_bytes",
+    "scr_backward_scratch_bytes", "scr_visible_filter", "scr_mark_visible", "scr_forward_plan",
+    "scr_forward_run", "scr_backward", "scr_debug_get",
+]
+ABI_VERSION = 1
+
+DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
+
+
+class Settings(C.Structure):
+    """struct scr_settings (include/splatco_raster.h): the 12 fields of
+    GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158)."""
+    _fields_ = [
+        ("image_height", C.c_int32), ("image_width", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+        ("bg", C.c_void_p), ("scale_modifier", C.c_float),
+        ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+        ("sh_degree", C.c_int32), ("campos", C.c_void_p),
+        ("prefiltered", C.c_int32), ("debug", C.c_int32),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP rasterizer library is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C splatco_amd/csrc`). "
+            "There is deliberately no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise ImportError(f"{LIB_PATH} does not export {s}")
+    lib.scr_abi_version.restype = C.c_int
+    if lib.scr_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {lib.scr_abi_version()}, expected {ABI_VERSION}")
+    lib.scr_last_error.restype = C.c_char_p
+    for f in ("scr_geom_bytes", "scr_binning_bytes", "scr_image_bytes", "scr_backward_scratch_bytes"):
+        getattr(lib, f).restype = C.c_size_t
+    lib.scr_geom_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    lib.scr_binning_bytes.argtypes = [C.c_int64]
+    lib.scr_image_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.scr_backward_scratch_bytes.argtypes = [C.c_int64]
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+    sp = C.POINTER(Settings)
+    lib.scr_visible_filter.argtypes = [i64, vp, vp, vp, vp, sp, vp, vp]
+    lib.scr_mark_visible.argtypes = [i64, vp, vp, vp, vp]
+    lib.scr_forward_plan.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, sp, vp, vp, C.POINTER(C.c_int64), vp]
+    lib.scr_forward_run.argtypes = [i64, i64, sp, vp, vp, vp, vp, vp]
+    lib.scr_backward.argtypes = [i64, i32, i64, vp, vp, vp, vp, vp, sp, vp, vp, vp, vp, vp, vp,
+                                 vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.scr_debug_get.argtypes = [C.c_int, i64, i64, i32, i32, vp, vp, vp, vp, vp]
+    for f in ("scr_visible_filter", "scr_mark_visible", "scr_forward_plan", "scr_forward_run",
+              "scr_backward", "scr_debug_get"):
+        getattr(lib, f).restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("splatco_raster: " + lib.scr_last_error().decode())

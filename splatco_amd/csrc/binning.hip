@@ -1,0 +1,240 @@
+// splatco_amd/csrc/binning.hip -- per-tile bucketing and depth sort (gfx950).
+//
+// The operator family sorts all (tile | depth) 64-bit keys with a global multi-pass radix sort.
+// Here the same ordered lists are produced MI355X-style in two HBM passes:
+//   1. bucket:  per-tile instance counts (integer atomics fused into the preprocess kernel) ->
+//               exclusive scan -> every instance is dropped into its tile's segment
+//               (key = depth_bits << 32 | gaussian id).  Slot order inside a segment is arbitrary.
+//   2. sort:    one workgroup per tile sorts its segment by the 64-bit key in LDS (bitonic
+//               network, 160 KiB LDS lets a 8192-instance tile stay on chip).  Sorting by
+//               (depth, id) reproduces the stable (tile, depth) order of the reference semantics,
+//               so point_list / ranges are bit-identical to the oracle's.
+// Both passes move 8-12 B per instance once instead of 6+ radix passes over 12 B.
+#include "common.h"
+
+namespace scr {
+
+// ------------------------------------------------------------------ block-wide exclusive scan
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds_waves /*[THREADS/64+1]*/,
+                                                         uint32_t& block_total) {
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint32_t n = __shfl_up(inc, d, WAVE);
+        if (lane >= d) inc += n;
+    }
+    if (lane == WAVE - 1) lds_waves[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < THREADS / WAVE; ++k) {
+        uint32_t s = lds_waves[k];
+        if (k < w) base += s;
+        tot += s;
+    }
+    block_total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------ plan scans (2 workgroups)
+// block 0: block_sums[nblk] -> exclusive prefix in place, total -> *total
+// block 1: tile_count[tiles] -> ranges[tiles] = (start, end), cursor[tiles] = 0
+__global__ void __launch_bounds__(1024) plan_scan_kernel(uint32_t nblk, uint32_t* __restrict__ block_sums,
+                                                         unsigned long long* __restrict__ total,
+                                                         uint32_t tiles, const uint32_t* __restrict__ tile_count,
+                                                         uint32_t* __restrict__ ranges,
+                                                         uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t lds[1024 / WAVE + 1];
+    if (blockIdx.x == 0) {
+        unsigned long long carry = 0;
+        for (uint32_t base = 0; base < nblk; base += 1024) {
+            uint32_t i = base + threadIdx.x;
+            uint32_t v = i < nblk ? block_sums[i] : 0u, tot;
+            uint32_t ex = block_exclusive_scan<1024>(v, lds, tot);
+            if (i < nblk) block_sums[i] = (uint32_t)carry + ex;
+            carry += tot;
+        }
+        if (threadIdx.x == 0) *total = carry;
+    } else {
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < tiles; base += 1024) {
+            uint32_t i = base + threadIdx.x;
+            uint32_t v = i < tiles ? tile_count[i] : 0u, tot;
+            uint32_t ex = block_exclusive_scan<1024>(v, lds, tot);
+            if (i < tiles) {
+                ranges[2 * i] = carry + ex;
+                ranges[2 * i + 1] = carry + ex + v;
+                cursor[i] = 0;
+            }
+            carry += tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ scatter into tile segments
+__global__ void __launch_bounds__(PRE_BLOCK)
+scatter_kernel(int64_t P, int gx, const float4* __restrict__ rec, const uint32_t* __restrict__ tiles_touched,
+               const uint32_t* __restrict__ block_prefix, uint32_t* __restrict__ point_offsets,
+               const uint32_t* __restrict__ ranges, uint32_t* __restrict__ cursor,
+               unsigned long long* __restrict__ keys, uint32_t* __restrict__ inst_slot) {
+    __shared__ uint32_t lds[PRE_BLOCK / WAVE + 1];
+    int64_t i = (int64_t)blockIdx.x * PRE_BLOCK + threadIdx.x;
+    uint32_t tt = i < P ? tiles_touched[i] : 0u, tot;
+    uint32_t off = block_prefix[blockIdx.x] + block_exclusive_scan<PRE_BLOCK>(tt, lds, tot);
+    if (i >= P) return;
+    point_offsets[i] = off + tt;  // inclusive, as in the reference semantics
+    if (!tt) return;
+    float4 r2 = rec[3 * i + 2];
+    uint32_t dbits = __float_as_uint(r2.y), rlo = __float_as_uint(r2.z), rhi = __float_as_uint(r2.w);
+    int minx = rlo & 0xffff, miny = rlo >> 16, maxx = rhi & 0xffff, maxy = rhi >> 16;
+    unsigned long long key = ((unsigned long long)dbits << 32) | (uint32_t)i;
+    uint32_t k = off;
+    for (int ty = miny; ty < maxy; ++ty)
+        for (int tx = minx; tx < maxx; ++tx) {
+            uint32_t t = (uint32_t)(ty * gx + tx);
+            uint32_t slot = ranges[2 * t] + atomicAdd(&cursor[t], 1u);
+            keys[slot] = key;
+            inst_slot[k++] = slot;
+        }
+}
+
+// ------------------------------------------------------------------ per-tile sort
+// Bitonic merge network in its "all ascending" form: merging two sorted runs of length k/2
+// starts with a mirrored compare (i <-> block_end - i) followed by half-cleaners at distance
+// k/4 .. 1.  Every compare-exchange puts the larger key at the larger index, so a segment of
+// arbitrary length n needs no padding: a partner index >= n is +infinity and never moves.
+// c = index of the compare-exchange inside one step (m/2 per step, m = next pow2 >= n).
+__device__ __forceinline__ void ce_indices(uint32_t c, uint32_t k, uint32_t j, bool mirror, uint32_t& i,
+                                           uint32_t& p) {
+    if (mirror) {
+        uint32_t half = k >> 1, blk = c / half, r = c - blk * half;
+        i = blk * k + r;
+        p = blk * k + k - 1 - r;
+    } else {
+        i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
+        p = i + j;
+    }
+}
+
+// One workgroup per tile sorts (key64, payload32) in LDS.  CAP: largest segment this
+// instantiation handles; segments in (LOWER, CAP] are taken, others skipped (the launcher issues
+// one launch per size class; a workgroup whose tile is not in the class exits at once).
+template <int CAP, int LOWER>
+__global__ void __launch_bounds__(256)
+tile_sort_kernel(int tiles, const uint32_t* __restrict__ ranges, const unsigned long long* __restrict__ keys,
+                 uint32_t* __restrict__ point_list, uint32_t* __restrict__ orig_slot) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* sk = (unsigned long long*)smem;  // [CAP]
+    uint32_t* sp = (uint32_t*)(smem + (size_t)CAP * 8);   // [CAP]
+    int t = xcd_tile(blockIdx.x, tiles);
+    if (t < 0) return;
+    uint32_t lo = ranges[2 * t], hi = ranges[2 * t + 1];
+    uint32_t n = hi - lo;
+    if (n <= (uint32_t)LOWER || n > (uint32_t)CAP) return;
+    uint32_t m = 1;
+    while (m < n) m <<= 1;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        sk[i] = keys[lo + i];
+        sp[i] = i;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= m; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t c = threadIdx.x; c < (m >> 1); c += 256) {
+                uint32_t i, p;
+                ce_indices(c, k, j, j == (k >> 1), i, p);
+                if (p < n) {
+                    unsigned long long a = sk[i], b = sk[p];
+                    if (a > b) {
+                        sk[i] = b;
+                        sk[p] = a;
+                        uint32_t pa = sp[i], pb = sp[p];
+                        sp[i] = pb;
+                        sp[p] = pa;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        point_list[lo + i] = (uint32_t)sk[i];
+        orig_slot[lo + i] = lo + sp[i];
+    }
+}
+
+// Fallback for segments that do not fit the largest LDS class: the same network run in place on
+// global memory by one workgroup (rare: > 8192 instances in one 16x16 tile).  The payload lives
+// in orig_slot.  Data stays inside one workgroup, so workgroup-scope visibility suffices
+// (__syncthreads orders this workgroup's global accesses through its own CU's L1/L2 path).
+__global__ void __launch_bounds__(256)
+tile_sort_global_kernel(int tiles, uint32_t lower, const uint32_t* __restrict__ ranges,
+                        unsigned long long* keys, uint32_t* __restrict__ point_list, uint32_t* orig_slot) {
+    int t = xcd_tile(blockIdx.x, tiles);
+    if (t < 0) return;
+    uint32_t lo = ranges[2 * t], hi = ranges[2 * t + 1];
+    uint32_t n = hi - lo;
+    if (n <= lower) return;
+    uint32_t m = 1;
+    while (m < n) m <<= 1;
+    volatile unsigned long long* sk = keys + lo;
+    volatile uint32_t* sp = orig_slot + lo;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) sp[i] = lo + i;
+    __syncthreads();
+    for (uint32_t k = 2; k <= m; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t c = threadIdx.x; c < (m >> 1); c += 256) {
+                uint32_t i, p;
+                ce_indices(c, k, j, j == (k >> 1), i, p);
+                if (p < n) {
+                    unsigned long long a = sk[i], b = sk[p];
+                    if (a > b) {
+                        sk[i] = b;
+                        sk[p] = a;
+                        uint32_t pa = sp[i], pb = sp[p];
+                        sp[i] = pb;
+                        sp[p] = pa;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[lo + i] = (uint32_t)sk[i];
+}
+
+// ------------------------------------------------------------------ launchers
+void launch_plan_scans(int64_t P, const KSettings& ks, const GeomView& gv, hipStream_t st) {
+    Grid g(ks.H, ks.W);
+    uint32_t nb = (uint32_t)((P + PRE_BLOCK - 1) / PRE_BLOCK);
+    plan_scan_kernel<<<2, 1024, 0, st>>>(nb, gv.block_sums, gv.total, (uint32_t)g.tiles, gv.tile_count,
+                                         gv.ranges, gv.cursor);
+}
+
+void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const BinView& bv, hipStream_t st) {
+    if (P <= 0) return;
+    Grid g(ks.H, ks.W);
+    scatter_kernel<<<(unsigned)((P + PRE_BLOCK - 1) / PRE_BLOCK), PRE_BLOCK, 0, st>>>(
+        P, g.gx, gv.rec, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor, bv.keys,
+        bv.inst_slot);
+}
+
+void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, hipStream_t st) {
+    Grid g(ks.H, ks.W);
+    unsigned grid = (unsigned)xcd_grid(g.tiles);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)tile_sort_kernel<8192, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            8192 * 12);
+        attr_set = true;
+    }
+    tile_sort_kernel<512, 0><<<grid, 256, 512 * 12, st>>>(g.tiles, gv.ranges, bv.keys, bv.point_list, bv.orig_slot);
+    tile_sort_kernel<2048, 512><<<grid, 256, 2048 * 12, st>>>(g.tiles, gv.ranges, bv.keys, bv.point_list, bv.orig_slot);
+    tile_sort_kernel<8192, 2048><<<grid, 256, 8192 * 12, st>>>(g.tiles, gv.ranges, bv.keys, bv.point_list, bv.orig_slot);
+    tile_sort_global_kernel<<<grid, 256, 0, st>>>(g.tiles, 8192u, gv.ranges, bv.keys, bv.point_list, bv.orig_slot);
+}
+
+}  // namespace scr

@@ -1,0 +1,199 @@
+// splatco_amd/csrc/capi.hip -- the C-ABI of include/splatco_raster.h over the gfx950 kernels.
+// No global state: every buffer is caller-owned (several forward graphs are alive
+// at once in the mv loop of train.py:171-240).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+using namespace scr;
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// after a kernel launch: always catch launch errors; in debug mode also run it to completion
+#define CHECK_LAUNCH(name, debug, st)                                                      \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess) return fail("launch of %s failed: %s", name, hipGetErrorString(e_)); \
+        if (debug) {                                                                       \
+            e_ = hipStreamSynchronize(st);                                                 \
+            if (e_ != hipSuccess) return fail("%s faulted: %s", name, hipGetErrorString(e_)); \
+        }                                                                                  \
+    } while (0)
+
+static int check_settings(const scr_settings* s) {
+    if (!s) return fail("settings is NULL");
+    if (s->image_height <= 0 || s->image_width <= 0) return fail("image size must be positive");
+    if (s->image_width > 16 * 65535 || s->image_height > 16 * 65535) return fail("image too large for 16-bit tile coordinates");
+    if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos) return fail("bg / viewmatrix / projmatrix / campos must be device pointers");
+    if (s->sh_degree < 0 || s->sh_degree > 3) return fail("sh_degree must be 0..3");
+    return 0;
+}
+
+extern "C" {
+
+int scr_abi_version(void) { return SCR_ABI_VERSION; }
+const char* scr_last_error(void) { return g_err; }
+
+size_t scr_geom_bytes(int64_t P, int32_t H, int32_t W) { return geom_view(nullptr, P, H, W).bytes; }
+size_t scr_binning_bytes(int64_t I) { return bin_view(nullptr, I).bytes; }
+size_t scr_image_bytes(int32_t H, int32_t W) { return img_view(nullptr, H, W).bytes; }
+size_t scr_backward_scratch_bytes(int64_t I) { return align_up((size_t)(I > 0 ? I : 1) * GRAD_F * 4); }
+
+int scr_visible_filter(int64_t P, const float* means3D, const float* scales, const float* rotations,
+                       const float* cov3D_precomp, const scr_settings* settings, int32_t* radii_out,
+                       void* stream) {
+    if (check_settings(settings)) return 1;
+    if (P < 0) return fail("P < 0");
+    if (P == 0) return 0;
+    if (!means3D || !radii_out) return fail("means3D / radii_out is NULL");
+    if (!cov3D_precomp && !(scales && rotations)) return fail("provide (scales, rotations) or cov3D_precomp");
+    hipStream_t st = (hipStream_t)stream;
+    launch_filter(P, means3D, scales, rotations, cov3D_precomp, ksettings(settings), radii_out, st);
+    CHECK_LAUNCH("filter_kernel", settings->debug, st);
+    return 0;
+}
+
+int scr_mark_visible(int64_t P, const float* means3D, const float* viewmatrix, uint8_t* present_out,
+                     void* stream) {
+    if (P < 0) return fail("P < 0");
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !present_out) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    launch_mark_visible(P, means3D, viewmatrix, present_out, st);
+    CHECK_LAUNCH("mark_visible_kernel", 0, st);
+    return 0;
+}
+
+int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* scales,
+                     const float* rotations, const float* cov3D_precomp, const float* opacities,
+                     const float* shs, const float* colors_precomp, const scr_settings* settings,
+                     void* geom_buf, int32_t* radii_out, int64_t* num_rendered_host, void* stream) {
+    if (check_settings(settings)) return 1;
+    if (P < 0) return fail("P < 0");
+    if (!num_rendered_host) return fail("num_rendered_host is NULL");
+    *num_rendered_host = 0;
+    if (!geom_buf) return fail("geom_buf is NULL");
+    if ((shs != nullptr) == (colors_precomp != nullptr))
+        return fail("Please provide exactly one of either SHs or precomputed colors!");
+    if (((scales != nullptr) || (rotations != nullptr)) == (cov3D_precomp != nullptr) || ((scales != nullptr) != (rotations != nullptr)))
+        if (!(cov3D_precomp && !scales && !rotations) && !(scales && rotations && !cov3D_precomp))
+            return fail("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (P > 0 && (!means3D || !opacities || !radii_out)) return fail("means3D / opacities / radii_out is NULL");
+    if (shs && (M < (settings->sh_degree + 1) * (settings->sh_degree + 1)))
+        return fail("shs has %d coefficients, sh_degree %d needs %d", M, settings->sh_degree,
+                    (settings->sh_degree + 1) * (settings->sh_degree + 1));
+    hipStream_t st = (hipStream_t)stream;
+    KSettings ks = ksettings(settings);
+    GeomView gv = geom_view(geom_buf, P, ks.H, ks.W);
+    Grid g(ks.H, ks.W);
+    HIP_TRY(hipMemsetAsync(gv.tile_count, 0, (size_t)g.tiles * 4, st));
+    launch_preprocess(P, M, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, ks, gv,
+                      radii_out, st);
+    CHECK_LAUNCH("preprocess_kernel", settings->debug, st);
+    launch_plan_scans(P, ks, gv, st);
+    CHECK_LAUNCH("plan_scan_kernel", settings->debug, st);
+    unsigned long long total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, gv.total, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (total >= (1ull << 32)) return fail("num_rendered = %llu does not fit 32-bit instance indices", total);
+    *num_rendered_host = (int64_t)total;
+    return 0;
+}
+
+int scr_forward_run(int64_t P, int64_t I, const scr_settings* settings, void* geom_buf, void* binning_buf,
+                    void* image_buf, float* out_color, void* stream) {
+    if (check_settings(settings)) return 1;
+    if (!geom_buf || !binning_buf || !image_buf || !out_color) return fail("NULL buffer");
+    hipStream_t st = (hipStream_t)stream;
+    KSettings ks = ksettings(settings);
+    GeomView gv = geom_view(geom_buf, P, ks.H, ks.W);
+    BinView bv = bin_view(binning_buf, I);
+    ImgView iv = img_view(image_buf, ks.H, ks.W);
+    if (I > 0) {
+        launch_scatter(P, ks, gv, bv, st);
+        CHECK_LAUNCH("scatter_kernel", settings->debug, st);
+        launch_tile_sort(ks, gv, bv, st);
+        CHECK_LAUNCH("tile_sort_kernel", settings->debug, st);
+    }
+    launch_blend_forward(ks, gv, bv, iv, out_color, st);
+    CHECK_LAUNCH("blend_forward_kernel", settings->debug, st);
+    return 0;
+}
+
+int scr_backward(int64_t P, int32_t M, int64_t I, const float* means3D, const float* scales,
+                 const float* rotations, const float* cov3D_precomp, const float* shs,
+                 const scr_settings* settings, const int32_t* radii, const void* geom_buf,
+                 const void* binning_buf, const void* image_buf, const float* dL_dcolor, void* scratch,
+                 float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
+                 float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                 void* stream) {
+    if (check_settings(settings)) return 1;
+    if (P == 0) return 0;
+    if (!geom_buf || !binning_buf || !image_buf || !dL_dcolor || !scratch) return fail("NULL buffer");
+    if (!means3D || !radii || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity) return fail("NULL argument");
+    if (shs ? !dL_dsh : !dL_dcolors) return fail("colour gradient output missing");
+    if (cov3D_precomp ? !dL_dcov3D : !(dL_dscales && dL_drotations && scales && rotations))
+        return fail("covariance gradient output missing");
+    hipStream_t st = (hipStream_t)stream;
+    KSettings ks = ksettings(settings);
+    GeomView gv = geom_view((void*)geom_buf, P, ks.H, ks.W);
+    BinView bv = bin_view((void*)binning_buf, I);
+    ImgView iv = img_view((void*)image_buf, ks.H, ks.W);
+    if (I > 0) {
+        launch_blend_backward(ks, gv, bv, iv, dL_dcolor, (float4*)scratch, st);
+        CHECK_LAUNCH("blend_backward_kernel", settings->debug, st);
+    }
+    launch_preprocess_backward(P, M, means3D, scales, rotations, cov3D_precomp, shs, ks, radii, gv, bv,
+                               (const float4*)scratch, dL_dmeans3D, dL_dmeans2D, shs ? nullptr : dL_dcolors,
+                               shs ? dL_dsh : nullptr, dL_dopacity, cov3D_precomp ? nullptr : dL_dscales,
+                               cov3D_precomp ? nullptr : dL_drotations, cov3D_precomp ? dL_dcov3D : nullptr, st);
+    CHECK_LAUNCH("preprocess_backward_kernel", settings->debug, st);
+    return 0;
+}
+
+int scr_debug_get(int which, int64_t P, int64_t I, int32_t H, int32_t W, const void* geom_buf,
+                  const void* binning_buf, const void* image_buf, void* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    Grid g(H, W);
+    const void* src = nullptr;
+    size_t bytes = 0;
+    if (which <= SCR_DBG_RANGES || which == SCR_DBG_SPLAT_RECORDS) {
+        if (!geom_buf) return fail("geom_buf is NULL");
+        GeomView gv = geom_view((void*)geom_buf, P, H, W);
+        if (which == SCR_DBG_TILES_TOUCHED) { src = gv.tiles_touched; bytes = (size_t)P * 4; }
+        else if (which == SCR_DBG_POINT_OFFSETS) { src = gv.point_offsets; bytes = (size_t)P * 4; }
+        else if (which == SCR_DBG_RANGES) { src = gv.ranges; bytes = (size_t)g.tiles * 8; }
+        else { src = gv.rec; bytes = (size_t)P * REC_F * 4; }
+    } else if (which == SCR_DBG_POINT_LIST) {
+        if (!binning_buf) return fail("binning_buf is NULL");
+        src = bin_view((void*)binning_buf, I).point_list;
+        bytes = (size_t)I * 4;
+    } else if (which == SCR_DBG_N_CONTRIB || which == SCR_DBG_FINAL_T) {
+        if (!image_buf) return fail("image_buf is NULL");
+        ImgView iv = img_view((void*)image_buf, H, W);
+        src = which == SCR_DBG_N_CONTRIB ? (const void*)iv.n_contrib : (const void*)iv.final_T;
+        bytes = (size_t)H * W * 4;
+    } else {
+        return fail("unknown debug selector %d", which);
+    }
+    if (bytes) HIP_TRY(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+}  // extern "C"

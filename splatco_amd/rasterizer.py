@@ -1,0 +1,231 @@
+"""Host side of the rasterizer operator: the reference's `diff_gaussian_rasterization` API
+(GaussianRasterizationSettings / GaussianRasterizer, imported at gaussian_renderer/__init__.py:15)
+over the C-ABI of include/splatco_raster.h.
+
+Autograd contract: differentiable w.r.t. means3D, colors_precomp | shs, opacities,
+scales + rotations | cov3D_precomp; `means2D` receives the NDC-space mean gradient although its
+value is unused (read back through .grad at scene/gaussian_model.py:779); radii is int32 and
+non-differentiable.  Saved state is per call, so the mv live graphs of train.py:171-240 coexist.
+PyTorch is used for device memory and streams only.
+"""
+from typing import NamedTuple
+
+import ctypes as C
+import torch
+import torch.nn as nn
+
+from . import _C
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _dev_f32(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a device tensor (the rasterizer has no CPU path)")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.contiguous().float()
+    return t
+
+
+def _ptr(t):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+class _CSettings:
+    """Keeps the device tensors alive next to the C struct that points at them."""
+
+    def __init__(self, rs: GaussianRasterizationSettings):
+        self.bg = _dev_f32(rs.bg, "bg")
+        self.view = _dev_f32(rs.viewmatrix, "viewmatrix")
+        self.proj = _dev_f32(rs.projmatrix, "projmatrix")
+        self.campos = _dev_f32(rs.campos, "campos")
+        s = _C.Settings()
+        s.image_height, s.image_width = int(rs.image_height), int(rs.image_width)
+        s.tanfovx, s.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
+        s.bg, s.viewmatrix, s.projmatrix, s.campos = (self.bg.data_ptr(), self.view.data_ptr(),
+                                                      self.proj.data_ptr(), self.campos.data_ptr())
+        s.scale_modifier = float(rs.scale_modifier)
+        s.sh_degree = int(rs.sh_degree)
+        s.prefiltered, s.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
+        self.c = s
+        self.H, self.W = s.image_height, s.image_width
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bytes(n, device):
+    return torch.empty(max(int(n), 1), dtype=torch.uint8, device=device)
+
+
+class RasterState:
+    """Per-call saved buffers (opaque to Python) + what the debug getters need."""
+    __slots__ = ("P", "M", "I", "cs", "geom", "binning", "image", "radii")
+
+    def debug(self, which):
+        """Integer / float intermediates for the parity tests (SCR_DBG_* selectors)."""
+        dev = self.geom.device
+        tiles = ((self.cs.W + 15) // 16) * ((self.cs.H + 15) // 16)
+        shapes = {
+            _C.DBG_TILES_TOUCHED: ((self.P,), torch.int32), _C.DBG_POINT_OFFSETS: ((self.P,), torch.int32),
+            _C.DBG_RANGES: ((tiles, 2), torch.int32), _C.DBG_POINT_LIST: ((self.I,), torch.int32),
+            _C.DBG_N_CONTRIB: ((self.cs.H, self.cs.W), torch.int32),
+            _C.DBG_FINAL_T: ((self.cs.H, self.cs.W), torch.float32),
+            _C.DBG_SPLAT_RECORDS: ((self.P, 12), torch.float32),
+        }
+        shape, dt = shapes[which]
+        out = torch.empty(shape, dtype=dt, device=dev)
+        if out.numel():
+            _C.check(_C.lib.scr_debug_get(which, self.P, self.I, self.cs.H, self.cs.W, _ptr(self.geom),
+                                          _ptr(self.binning), _ptr(self.image), out.data_ptr(), _stream()))
+        return out
+
+
+def rasterize_forward(cs, means3D, opacities, scales, rotations, cov3D_precomp, shs, colors_precomp):
+    """plan + run through the C-ABI.  Returns (color, radii, RasterState)."""
+    dev = means3D.device
+    P = means3D.shape[0]
+    M = 0 if shs is None else shs.shape[1]
+    st = RasterState()
+    st.P, st.M, st.cs = P, M, cs
+    st.geom = _bytes(_C.lib.scr_geom_bytes(P, cs.H, cs.W), dev)
+    st.image = _bytes(_C.lib.scr_image_bytes(cs.H, cs.W), dev)
+    radii = torch.zeros(P, dtype=torch.int32, device=dev)
+    color = torch.empty(3, cs.H, cs.W, dtype=torch.float32, device=dev)
+    n = C.c_int64(0)
+    _C.check(_C.lib.scr_forward_plan(P, M, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+                                     _ptr(opacities), _ptr(shs), _ptr(colors_precomp), cs.ref(),
+                                     st.geom.data_ptr(), _ptr(radii), C.byref(n), _stream()))
+    st.I = int(n.value)
+    st.binning = _bytes(_C.lib.scr_binning_bytes(st.I), dev)
+    _C.check(_C.lib.scr_forward_run(P, st.I, cs.ref(), st.geom.data_ptr(), st.binning.data_ptr(),
+                                    st.image.data_ptr(), color.data_ptr(), _stream()))
+    st.radii = radii
+    return color, radii, st
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        cs = _CSettings(raster_settings)
+        means3D = _dev_f32(means3D, "means3D")
+        none_if_empty = lambda t, n: None if t is None or t.numel() == 0 else _dev_f32(t, n)
+        sh, colors_precomp = none_if_empty(sh, "shs"), none_if_empty(colors_precomp, "colors_precomp")
+        scales, rotations = none_if_empty(scales, "scales"), none_if_empty(rotations, "rotations")
+        cov3Ds_precomp = none_if_empty(cov3Ds_precomp, "cov3D_precomp")
+        opacities = _dev_f32(opacities, "opacities")
+        P = means3D.shape[0]
+        if P == 0:  # nothing to launch: background only
+            color = cs.bg.reshape(3, 1, 1).expand(3, cs.H, cs.W).contiguous()
+            radii = torch.zeros(0, dtype=torch.int32, device=means3D.device)
+            ctx.state = None
+            ctx.shapes = (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+            ctx.mark_non_differentiable(radii)
+            return color, radii
+        color, radii, st = rasterize_forward(cs, means3D, opacities, scales, rotations, cov3Ds_precomp, sh,
+                                             colors_precomp)
+        ctx.state = st
+        ctx.save_for_backward(means3D, scales, rotations, cov3Ds_precomp, sh, colors_precomp, opacities)
+        ctx.m2d_shape = tuple(means2D.shape)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        st = ctx.state
+        if st is None:
+            return tuple(None if t is None else torch.zeros_like(t) for t in ctx.shapes) + (None,)
+        means3D, scales, rotations, cov3D, sh, colors, opacities = ctx.saved_tensors
+        dev, P, cs = means3D.device, st.P, st.cs
+        g = _dev_f32(grad_out_color, "grad_out_color")
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        g_means3D, g_means2D, g_op = new(P, 3), new(P, 3), new(P, 1)
+        g_col = new(P, 3) if colors is not None else None
+        g_sh = new(P, st.M, 3) if sh is not None else None
+        g_scales = new(P, 3) if cov3D is None else None
+        g_rot = new(P, 4) if cov3D is None else None
+        g_cov = new(P, 6) if cov3D is not None else None
+        scratch = _bytes(_C.lib.scr_backward_scratch_bytes(st.I), dev)
+        _C.check(_C.lib.scr_backward(P, st.M, st.I, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D),
+                                     _ptr(sh), cs.ref(), st.radii.data_ptr(), st.geom.data_ptr(),
+                                     st.binning.data_ptr(), st.image.data_ptr(), g.data_ptr(), scratch.data_ptr(),
+                                     g_means3D.data_ptr(), g_means2D.data_ptr(), _ptr(g_col), _ptr(g_sh),
+                                     g_op.data_ptr(), _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), _stream()))
+        g_op = g_op.reshape(opacities.shape)
+        if ctx.m2d_shape != (P, 3):
+            g_means2D = g_means2D[:, :ctx.m2d_shape[1]].reshape(ctx.m2d_shape) if len(ctx.m2d_shape) == 2 else None
+        # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
+        return g_means3D, g_means2D, g_sh, g_col, g_op, g_scales, g_rot, g_cov, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    """Same constructor / forward / visible_filter / markVisible as the reference operator."""
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            positions = _dev_f32(positions, "positions")
+            P = positions.shape[0]
+            out = torch.zeros(P, dtype=torch.uint8, device=positions.device)
+            view = _dev_f32(self.raster_settings.viewmatrix, "viewmatrix")
+            if P:
+                _C.check(_C.lib.scr_mark_visible(P, positions.data_ptr(), view.data_ptr(), out.data_ptr(), _stream()))
+            return out.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        return rasterize_gaussians(
+            means3D, means2D, empty if shs is None else shs, empty if colors_precomp is None else colors_precomp,
+            opacities, empty if scales is None else scales, empty if rotations is None else rotations,
+            empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings)
+
+    def visible_filter(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        with torch.no_grad():
+            cs = _CSettings(self.raster_settings)
+            means3D = _dev_f32(means3D, "means3D")
+            scales, rotations = _dev_f32(scales, "scales"), _dev_f32(rotations, "rotations")
+            cov3D_precomp = _dev_f32(cov3D_precomp, "cov3D_precomp")
+            P = means3D.shape[0]
+            radii = torch.zeros(P, dtype=torch.int32, device=means3D.device)
+            if P:
+                _C.check(_C.lib.scr_visible_filter(P, means3D.data_ptr(), _ptr(scales), _ptr(rotations),
+                                                   _ptr(cov3D_precomp), cs.ref(), radii.data_ptr(), _stream()))
+            return radii
