@@ -115,6 +115,20 @@ int scr_debug_get(int which, int64_t P, int64_t num_rendered, int32_t image_heig
                   const void* geom_buf, const void* binning_buf, const void* image_buf, void* out,
                   void* stream);
 
+/* ---- opt-in kernel timing (bench / profiling only; process-global, off by default).
+ * While enabled, every kernel launch of this library is bracketed by hipEventRecord on the
+ * launch stream.  scr_profile_read() waits for the recorded events, ADDS the elapsed time and
+ * launch count of each kernel class since the last read into total_ms[SCR_PROF_COUNT] /
+ * launches[SCR_PROF_COUNT], and resets. */
+enum {
+    SCR_PROF_FILTER = 0, SCR_PROF_PREPROCESS = 1, SCR_PROF_PLAN_SCAN = 2, SCR_PROF_SCATTER = 3,
+    SCR_PROF_TILE_SORT = 4, SCR_PROF_BLEND_FORWARD = 5, SCR_PROF_BLEND_BACKWARD = 6,
+    SCR_PROF_PREPROCESS_BACKWARD = 7, SCR_PROF_COUNT = 8
+};
+int scr_profile_enable(int on);
+int scr_profile_read(double* total_ms, int64_t* launches);
+const char* scr_profile_kernel_name(int idx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,8 +13,10 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsplatco_raster.so")
 SYMBOLS = [
     "scr_abi_version", "scr_last_error", "scr_geom_bytes", "scr_binning_bytes", "scr_image_bytes",
     "scr_backward_scratch_bytes", "scr_visible_filter", "scr_mark_visible", "scr_forward_plan",
-    "scr_forward_run", "scr_backward", "scr_debug_get",
+    "scr_forward_run", "scr_backward", "scr_debug_get", "scr_profile_enable", "scr_profile_read",
+    "scr_profile_kernel_name",
 ]
+PROF_COUNT = 8
 ABI_VERSION = 1
 
 DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
@@ -62,6 +64,10 @@ def _load():
     lib.scr_backward.argtypes = [i64, i32, i64, vp, vp, vp, vp, vp, sp, vp, vp, vp, vp, vp, vp,
                                  vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.scr_debug_get.argtypes = [C.c_int, i64, i64, i32, i32, vp, vp, vp, vp, vp]
+    lib.scr_profile_enable.argtypes = [C.c_int]
+    lib.scr_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.scr_profile_kernel_name.argtypes = [C.c_int]
+    lib.scr_profile_kernel_name.restype = C.c_char_p
     for f in ("scr_visible_filter", "scr_mark_visible", "scr_forward_plan", "scr_forward_run",
               "scr_backward", "scr_debug_get"):
         getattr(lib, f).restype = C.c_int
@@ -69,6 +75,18 @@ def _load():
 
 
 lib = _load()
+
+
+def profile_enable(on):
+    lib.scr_profile_enable(int(bool(on)))
+
+
+def profile_read():
+    """{kernel name: (total ms, launches)} since the last read (HIP events on the launch stream)."""
+    ms = (C.c_double * PROF_COUNT)()
+    n = (C.c_int64 * PROF_COUNT)()
+    check(lib.scr_profile_read(ms, n))
+    return {lib.scr_profile_kernel_name(i).decode(): (ms[i], n[i]) for i in range(PROF_COUNT)}
 
 
 def check(rc):

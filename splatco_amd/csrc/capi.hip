@@ -36,6 +36,31 @@ static int fail(const char* fmt, ...) {
         }                                                                                  \
     } while (0)
 
+// ---- opt-in kernel timing (scr_profile_*): hipEvent pairs on the launch stream
+#include <vector>
+namespace {
+struct ProfRec { int idx; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t prof_event() {
+    hipEvent_t e;
+    if (!g_prof_pool.empty()) { e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    bool on; hipStream_t st; ProfRec r;
+    ProfScope(int idx, hipStream_t s) : on(g_prof_on), st(s) {
+        if (on) { r.idx = idx; r.a = prof_event(); r.b = prof_event(); (void)hipEventRecord(r.a, st); }
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); g_prof_recs.push_back(r); } }
+};
+const char* const kProfNames[SCR_PROF_COUNT] = {
+    "filter_kernel", "preprocess_kernel", "plan_scan_kernel", "scatter_kernel", "tile_sort_kernel",
+    "blend_forward_kernel", "blend_backward_kernel", "preprocess_backward_kernel"};
+}  // namespace
+
 static int check_settings(const scr_settings* s) {
     if (!s) return fail("settings is NULL");
     if (s->image_height <= 0 || s->image_width <= 0) return fail("image size must be positive");
@@ -64,7 +89,8 @@ int scr_visible_filter(int64_t P, const float* means3D, const float* scales, con
     if (!means3D || !radii_out) return fail("means3D / radii_out is NULL");
     if (!cov3D_precomp && !(scales && rotations)) return fail("provide (scales, rotations) or cov3D_precomp");
     hipStream_t st = (hipStream_t)stream;
-    launch_filter(P, means3D, scales, rotations, cov3D_precomp, ksettings(settings), radii_out, st);
+    { ProfScope ps_(SCR_PROF_FILTER, st);
+      launch_filter(P, means3D, scales, rotations, cov3D_precomp, ksettings(settings), radii_out, st); }
     CHECK_LAUNCH("filter_kernel", settings->debug, st);
     return 0;
 }
@@ -103,10 +129,11 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
     GeomView gv = geom_view(geom_buf, P, ks.H, ks.W);
     Grid g(ks.H, ks.W);
     HIP_TRY(hipMemsetAsync(gv.tile_count, 0, (size_t)g.tiles * 4, st));
-    launch_preprocess(P, M, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, ks, gv,
-                      radii_out, st);
+    { ProfScope ps_(SCR_PROF_PREPROCESS, st);
+      launch_preprocess(P, M, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, ks, gv,
+                        radii_out, st); }
     CHECK_LAUNCH("preprocess_kernel", settings->debug, st);
-    launch_plan_scans(P, ks, gv, st);
+    { ProfScope ps_(SCR_PROF_PLAN_SCAN, st); launch_plan_scans(P, ks, gv, st); }
     CHECK_LAUNCH("plan_scan_kernel", settings->debug, st);
     unsigned long long total = 0;
     HIP_TRY(hipMemcpyAsync(&total, gv.total, 8, hipMemcpyDeviceToHost, st));
@@ -126,12 +153,12 @@ int scr_forward_run(int64_t P, int64_t I, const scr_settings* settings, void* ge
     BinView bv = bin_view(binning_buf, I);
     ImgView iv = img_view(image_buf, ks.H, ks.W);
     if (I > 0) {
-        launch_scatter(P, ks, gv, bv, st);
+        { ProfScope ps_(SCR_PROF_SCATTER, st); launch_scatter(P, ks, gv, bv, st); }
         CHECK_LAUNCH("scatter_kernel", settings->debug, st);
-        launch_tile_sort(ks, gv, bv, st);
+        { ProfScope ps_(SCR_PROF_TILE_SORT, st); launch_tile_sort(ks, gv, bv, st); }
         CHECK_LAUNCH("tile_sort_kernel", settings->debug, st);
     }
-    launch_blend_forward(ks, gv, bv, iv, out_color, st);
+    { ProfScope ps_(SCR_PROF_BLEND_FORWARD, st); launch_blend_forward(ks, gv, bv, iv, out_color, st); }
     CHECK_LAUNCH("blend_forward_kernel", settings->debug, st);
     return 0;
 }
@@ -156,13 +183,15 @@ int scr_backward(int64_t P, int32_t M, int64_t I, const float* means3D, const fl
     BinView bv = bin_view((void*)binning_buf, I);
     ImgView iv = img_view((void*)image_buf, ks.H, ks.W);
     if (I > 0) {
-        launch_blend_backward(ks, gv, bv, iv, dL_dcolor, (float4*)scratch, st);
+        { ProfScope ps_(SCR_PROF_BLEND_BACKWARD, st);
+          launch_blend_backward(ks, gv, bv, iv, dL_dcolor, (float4*)scratch, st); }
         CHECK_LAUNCH("blend_backward_kernel", settings->debug, st);
     }
-    launch_preprocess_backward(P, M, means3D, scales, rotations, cov3D_precomp, shs, ks, radii, gv, bv,
-                               (const float4*)scratch, dL_dmeans3D, dL_dmeans2D, shs ? nullptr : dL_dcolors,
-                               shs ? dL_dsh : nullptr, dL_dopacity, cov3D_precomp ? nullptr : dL_dscales,
-                               cov3D_precomp ? nullptr : dL_drotations, cov3D_precomp ? dL_dcov3D : nullptr, st);
+    { ProfScope ps_(SCR_PROF_PREPROCESS_BACKWARD, st);
+      launch_preprocess_backward(P, M, means3D, scales, rotations, cov3D_precomp, shs, ks, radii, gv, bv,
+                                 (const float4*)scratch, dL_dmeans3D, dL_dmeans2D, shs ? nullptr : dL_dcolors,
+                                 shs ? dL_dsh : nullptr, dL_dopacity, cov3D_precomp ? nullptr : dL_dscales,
+                                 cov3D_precomp ? nullptr : dL_drotations, cov3D_precomp ? dL_dcov3D : nullptr, st); }
     CHECK_LAUNCH("preprocess_backward_kernel", settings->debug, st);
     return 0;
 }
@@ -195,5 +224,27 @@ int scr_debug_get(int which, int64_t P, int64_t I, int32_t H, int32_t W, const v
     if (bytes) HIP_TRY(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToDevice, st));
     return 0;
 }
+
+int scr_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return 0;
+}
+
+int scr_profile_read(double* total_ms, int64_t* launches) {
+    if (!total_ms || !launches) return fail("NULL argument");
+    for (auto& r : g_prof_recs) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        total_ms[r.idx] += ms;
+        launches[r.idx] += 1;
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
+    }
+    g_prof_recs.clear();
+    return 0;
+}
+
+const char* scr_profile_kernel_name(int idx) { return idx >= 0 && idx < SCR_PROF_COUNT ? kProfNames[idx] : ""; }
 
 }  // extern "C"
