@@ -124,8 +124,10 @@ __device__ __forceinline__ void ce_indices(uint32_t c, uint32_t k, uint32_t j, b
 // one launch per size class; a workgroup whose tile is not in the class exits at once).
 template <int CAP, int LOWER>
 __global__ void __launch_bounds__(256)
-tile_sort_kernel(int tiles, const uint32_t* __restrict__ ranges, const unsigned long long* __restrict__ keys,
-                 uint32_t* __restrict__ point_list, uint32_t* __restrict__ orig_slot) {
+tile_sort_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges,
+                 const unsigned long long* __restrict__ keys, const float4* __restrict__ rec,
+                 uint32_t* __restrict__ point_list, uint32_t* __restrict__ orig_slot,
+                 uint8_t* __restrict__ qmask) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* sk = (unsigned long long*)smem;  // [CAP]
     uint32_t* sp = (uint32_t*)(smem + (size_t)CAP * 8);   // [CAP]
@@ -160,9 +162,12 @@ tile_sort_kernel(int tiles, const uint32_t* __restrict__ ranges, const unsigned 
             __syncthreads();
         }
     }
+    const int tx0 = (t % gx) * TILE, ty0 = (t / gx) * TILE;
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        point_list[lo + i] = (uint32_t)sk[i];
+        uint32_t g = (uint32_t)sk[i];
+        point_list[lo + i] = g;
         orig_slot[lo + i] = lo + sp[i];
+        qmask[lo + i] = (uint8_t)quadrant_mask(rec[3 * (size_t)g], rec[3 * (size_t)g + 1], tx0, ty0);
     }
 }
 
@@ -171,8 +176,9 @@ tile_sort_kernel(int tiles, const uint32_t* __restrict__ ranges, const unsigned 
 // in orig_slot.  Data stays inside one workgroup, so workgroup-scope visibility suffices
 // (__syncthreads orders this workgroup's global accesses through its own CU's L1/L2 path).
 __global__ void __launch_bounds__(256)
-tile_sort_global_kernel(int tiles, uint32_t lower, const uint32_t* __restrict__ ranges,
-                        unsigned long long* keys, uint32_t* __restrict__ point_list, uint32_t* orig_slot) {
+tile_sort_global_kernel(int tiles, int gx, uint32_t lower, const uint32_t* __restrict__ ranges,
+                        unsigned long long* keys, const float4* __restrict__ rec,
+                        uint32_t* __restrict__ point_list, uint32_t* orig_slot, uint8_t* __restrict__ qmask) {
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
     uint32_t lo = ranges[2 * t], hi = ranges[2 * t + 1];
@@ -203,7 +209,12 @@ tile_sort_global_kernel(int tiles, uint32_t lower, const uint32_t* __restrict__ 
             __syncthreads();
         }
     }
-    for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[lo + i] = (uint32_t)sk[i];
+    const int tx0 = (t % gx) * TILE, ty0 = (t / gx) * TILE;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        uint32_t g = (uint32_t)sk[i];
+        point_list[lo + i] = g;
+        qmask[lo + i] = (uint8_t)quadrant_mask(rec[3 * (size_t)g], rec[3 * (size_t)g + 1], tx0, ty0);
+    }
 }
 
 // ------------------------------------------------------------------ launchers
@@ -231,10 +242,14 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
                             8192 * 12);
         attr_set = true;
     }
-    tile_sort_kernel<512, 0><<<grid, 256, 512 * 12, st>>>(g.tiles, gv.ranges, bv.keys, bv.point_list, bv.orig_slot);
-    tile_sort_kernel<2048, 512><<<grid, 256, 2048 * 12, st>>>(g.tiles, gv.ranges, bv.keys, bv.point_list, bv.orig_slot);
-    tile_sort_kernel<8192, 2048><<<grid, 256, 8192 * 12, st>>>(g.tiles, gv.ranges, bv.keys, bv.point_list, bv.orig_slot);
-    tile_sort_global_kernel<<<grid, 256, 0, st>>>(g.tiles, 8192u, gv.ranges, bv.keys, bv.point_list, bv.orig_slot);
+    tile_sort_kernel<512, 0><<<grid, 256, 512 * 12, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.rec, bv.point_list,
+                                                          bv.orig_slot, bv.qmask);
+    tile_sort_kernel<2048, 512><<<grid, 256, 2048 * 12, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.rec,
+                                                              bv.point_list, bv.orig_slot, bv.qmask);
+    tile_sort_kernel<8192, 2048><<<grid, 256, 8192 * 12, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.rec,
+                                                               bv.point_list, bv.orig_slot, bv.qmask);
+    tile_sort_global_kernel<<<grid, 256, 0, st>>>(g.tiles, g.gx, 8192u, gv.ranges, bv.keys, gv.rec, bv.point_list,
+                                                  bv.orig_slot, bv.qmask);
 }
 
 }  // namespace scr

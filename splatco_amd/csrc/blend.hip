@@ -1,12 +1,17 @@
 // splatco_amd/csrc/blend.hip -- front-to-back tile alpha blending, forward and backward (gfx950).
 //
-// One 256-thread workgroup (4 wave64) per 16x16 tile, one pixel per lane; a wave owns a 16x4
-// pixel strip.  The tile's depth-sorted splat list is streamed in batches of 256: each lane
-// gathers one 48-byte splat record (three float4) into LDS, then all lanes walk the batch with
-// conflict-free broadcast ds_read_b128.
+// Decomposition (wave64-first): a 16x16 tile is four 8x8-pixel quadrants, ONE WAVE PER QUADRANT,
+// one pixel per lane.  The tile's depth-sorted splat list carries a 4-bit quadrant mask per
+// instance (written by the sort kernel, common.h quadrant_mask): a wave walks only the splats that
+// can reach its quadrant (about a third of the list at the benchmark density), compacted with
+// wave ballots + mbcnt prefix counts.  Splat records (48 B) are gathered once per surviving
+// (wave, splat) into LDS and then read back with conflict-free broadcast ds_read_b128.
 //
-// Backward: per (tile, Gaussian) gradients are reduced on chip -- DPP row/bank shifts inside the
-// wave, one LDS slot per (wave, splat), a fixed-order 4-way add -- and written ONCE as a 48-byte
+// Forward: waves are independent -> one-wave workgroups, no barriers; the next chunk's masks,
+// ids and records are in flight while the current chunk is blended.
+// Backward: the four waves of a tile share one workgroup.  Per (tile, Gaussian) gradients are
+// reduced on chip -- DPP row shifts / row broadcasts inside the wave, one LDS slot per
+// (wave, splat), a fixed-order add over the waves that took part -- and written ONCE as a 48-byte
 // record into the slot the instance occupied before the depth sort.  No floating-point atomics:
 // results are bit-reproducible.  The per-Gaussian sum over tiles happens in
 // preprocess_backward_kernel.
@@ -18,63 +23,106 @@
 
 namespace scr {
 
-constexpr int BATCH = 256;
-
 __device__ __forceinline__ float fast_exp(float x) {  // v_exp_f32(x * log2 e)
     return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
 }
 
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long ballot) {  // popcount of lower lanes
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+}
+
+// XCD-aware block -> (tile, quadrant): the four quadrant waves of a tile, and neighbouring
+// tiles, run on the same XCD so the record gathers they share hit one L2.
+__device__ __forceinline__ bool block_to_tile_quad(int block, int tiles, int& tile, int& quad) {
+    int chunk = (tiles + NUM_XCD - 1) / NUM_XCD;
+    int xcd = block % NUM_XCD, slot = block / NUM_XCD;
+    tile = xcd * chunk + (slot >> 2);
+    quad = slot & 3;
+    return (slot >> 2) < chunk && tile < tiles;
+}
+
 // ------------------------------------------------------------------ forward
-__global__ void __launch_bounds__(256)
+constexpr int FCHUNK = 64;  // list entries examined per round (one per lane)
+
+__global__ void __launch_bounds__(64)
 blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict__ ranges,
-                     const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
-                     const float* __restrict__ bg, float* __restrict__ out_color,
-                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
-    __shared__ float4 s0[BATCH], s1[BATCH];
-    __shared__ float s2[BATCH];
-    int t = xcd_tile(blockIdx.x, tiles);
-    if (t < 0) return;
-    const int tx = t % gx, ty = t / gx;
-    // lane -> pixel: wave w covers rows 4w..4w+3 of the tile
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int px = tx * TILE + lx, py = ty * TILE + ly;
+                     const uint32_t* __restrict__ point_list, const uint8_t* __restrict__ qmask,
+                     const float4* __restrict__ rec, const float* __restrict__ bg,
+                     float* __restrict__ out_color, float* __restrict__ final_T,
+                     uint32_t* __restrict__ n_contrib) {
+    __shared__ float4 s0[FCHUNK], s1[FCHUNK];
+    __shared__ float2 s2[FCHUNK];
+    int t, quad;
+    if (!block_to_tile_quad(blockIdx.x, tiles, t, quad)) return;
+    const int lane = threadIdx.x;
+    const int px = (t % gx) * TILE + (quad & 1) * 8 + (lane & 7);
+    const int py = (t / gx) * TILE + (quad >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const uint32_t lo = ranges[2 * t], hi = ranges[2 * t + 1];
+    const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
     bool done = !inside;
     float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
-    uint32_t contributor = 0, last = 0;
-    for (uint32_t base = lo; base < hi; base += BATCH) {
-        if (__syncthreads_count(done) == 256) break;
-        uint32_t idx = base + threadIdx.x;
-        if (idx < hi) {
-            uint32_t g = point_list[idx];
-            s0[threadIdx.x] = rec[3 * (size_t)g];
-            s1[threadIdx.x] = rec[3 * (size_t)g + 1];
-            s2[threadIdx.x] = rec[3 * (size_t)g + 2].x;
+    uint32_t last = 0;
+
+    // software pipeline: (mask, id) two chunks ahead, gathered records one chunk ahead
+    uint32_t m_next = 0, id_next = 0;           // chunk c+1's mask bit / id for this lane
+    bool sel_cur = false;                       // chunk c: this lane holds a surviving splat
+    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
+    float r2x = 0.0f;
+    auto load_mask_id = [&](uint32_t base, uint32_t& m, uint32_t& id) {
+        uint32_t i = base + lane;
+        bool have = i < n;
+        m = have ? ((qmask[lo + i] >> quad) & 1u) : 0u;
+        id = have ? point_list[lo + i] : 0u;
+    };
+    auto gather = [&](uint32_t m, uint32_t id) {
+        sel_cur = m != 0;
+        if (sel_cur) {
+            r0 = rec[3 * (size_t)id];
+            r1 = rec[3 * (size_t)id + 1];
+            r2x = rec[3 * (size_t)id + 2].x;
         }
-        __syncthreads();
-        const int cnt = min((uint32_t)BATCH, hi - base);
-        for (int j = 0; !done && j < cnt; ++j) {
-            ++contributor;
-            float4 a = s0[j], b = s1[j];
-            float dx = a.x - pxf, dy = a.y - pyf;
-            float power = __builtin_fmaf(dx, __builtin_fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy);
-            if (power > 0.0f) continue;
-            float alpha = fminf(0.99f, b.y * fast_exp(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            float test_T = T * (1.0f - alpha);
-            if (test_T < 0.0001f) {
-                done = true;
-                continue;
-            }
-            float w = alpha * T;
-            C0 = __builtin_fmaf(b.z, w, C0);
-            C1 = __builtin_fmaf(b.w, w, C1);
-            C2 = __builtin_fmaf(s2[j], w, C2);
-            T = test_T;
-            last = contributor;
+    };
+    uint32_t m0, id0;
+    load_mask_id(0, m0, id0);
+    gather(m0, id0);
+    load_mask_id(FCHUNK, m_next, id_next);
+
+    for (uint32_t base = 0; base < n; base += FCHUNK) {
+        // ---- stage chunk `base` (already in registers), compacted in list order
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(sel_cur);
+        const int cnt = __builtin_popcountll(bal);
+        if (sel_cur) {
+            uint32_t pos = lanes_below(bal);
+            s0[pos] = r0;
+            s1[pos] = r1;
+            s2[pos] = make_float2(r2x, __uint_as_float(base + lane + 1));  // contributor number
         }
+        // ---- put the next chunk's gathers and the one after's mask/id loads in flight
+        gather(m_next, id_next);
+        load_mask_id(base + 2 * FCHUNK, m_next, id_next);
+        __syncthreads();  // one-wave workgroup: orders the LDS writes above before the reads below
+        for (int k = 0; k < cnt; ++k) {
+            const float4 a = s0[k], b = s1[k];
+            const float2 c = s2[k];
+            const float dx = a.x - pxf, dy = a.y - pyf;
+            const float power = __builtin_fmaf(dx, __builtin_fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy);
+            const float alpha = fminf(0.99f, b.y * fast_exp(power));
+            const bool hit = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;
+            const float test_T = T * (1.0f - alpha);
+            const bool stop = hit && (test_T < 0.0001f);
+            const bool upd = hit && !stop;
+            done = done || stop;
+            const float w = alpha * T;
+            C0 = upd ? __builtin_fmaf(b.z, w, C0) : C0;
+            C1 = upd ? __builtin_fmaf(b.w, w, C1) : C1;
+            C2 = upd ? __builtin_fmaf(c.x, w, C2) : C2;
+            T = upd ? test_T : T;
+            last = upd ? __float_as_uint(c.y) : last;
+        }
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+        __syncthreads();  // reads of this chunk finished before the next chunk overwrites LDS
     }
     if (inside) {
         size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
@@ -86,149 +134,206 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
     }
 }
 
-// ------------------------------------------------------------------ wave64 sum via DPP
-// Inclusive row scans (row_shr 1,2,4,8) then row_bcast15 / row_bcast31: lane 63 ends up with the
-// sum over the wave, always added in the same order.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_step(float v) {
-    int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, /*bound_ctrl=*/true);
-    return v + __int_as_float(moved);
+// ------------------------------------------------------------------ wave64 sums via DPP
+// Nine per-splat partial sums are reduced together: inclusive row scans (row_shr 1,2,4,8) then
+// row_bcast15 / row_bcast31, so lane 63 ends up with each sum over the wave, always added in the
+// same order (bit-reproducible).  Written as one asm block: hipcc splits the builtin form into
+// v_mov_dpp + v_add pairs padded with s_nop (127 instructions for 54 adds); here the nine chains
+// are interleaved, which also covers the 2-wait-state VALU-write -> DPP-read hazard between steps
+// (each register is re-read 9 instructions after it was written).  The leading s_nop 1 covers
+// the same hazard against whatever the compiler issued just before the block.
+#define SCR_DPP9(ctrl)                              \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\t"         \
+    "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t"         \
+    "v_add_f32_dpp %2, %2, %2 " ctrl "\n\t"         \
+    "v_add_f32_dpp %3, %3, %3 " ctrl "\n\t"         \
+    "v_add_f32_dpp %4, %4, %4 " ctrl "\n\t"         \
+    "v_add_f32_dpp %5, %5, %5 " ctrl "\n\t"         \
+    "v_add_f32_dpp %6, %6, %6 " ctrl "\n\t"         \
+    "v_add_f32_dpp %7, %7, %7 " ctrl "\n\t"         \
+    "v_add_f32_dpp %8, %8, %8 " ctrl "\n\t"
+__device__ __forceinline__ void wave_sum9_to_lane63(float& v0, float& v1, float& v2, float& v3, float& v4,
+                                                    float& v5, float& v6, float& v7, float& v8) {
+    asm volatile("s_nop 1\n\t"
+                 SCR_DPP9("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 SCR_DPP9("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 SCR_DPP9("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 SCR_DPP9("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 SCR_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 SCR_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
 }
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v = dpp_step<0x111, 0xf>(v);  // row_shr:1
-    v = dpp_step<0x112, 0xf>(v);  // row_shr:2
-    v = dpp_step<0x114, 0xf>(v);  // row_shr:4
-    v = dpp_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row = row sum
-    v = dpp_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
-    v = dpp_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3
-    return v;
+
+// Per-pixel gradient of one contributing splat (back-to-front recurrences).  Not decision
+// bearing, so the compiler may contract mul+add pairs here (fewer VALU issues); the tolerance is
+// the gradient bar of the parity tests (rel-L2 <= 1e-4 vs the oracle).
+struct PixState {
+    float T, T_final, bg_dot, dLp0, dLp1, dLp2;
+    float ac0, ac1, ac2, last_alpha, lc0, lc1, lc2;
+};
+__device__ __forceinline__ void splat_pixel_grad(PixState& s, float4 a, float4 b, float cb, float dx, float dy,
+                                                 float G, float alpha, float& g_mx, float& g_my, float& g_qxx,
+                                                 float& g_qxy, float& g_qyy, float& g_o, float& g_c0, float& g_c1,
+                                                 float& g_c2) {
+#pragma clang fp contract(fast)
+    const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);
+    s.T = s.T * rcp;  // transmittance in front of this splat
+    const float dchan = alpha * s.T;
+    const float om = 1.0f - s.last_alpha;
+    s.ac0 = s.last_alpha * s.lc0 + om * s.ac0;
+    s.ac1 = s.last_alpha * s.lc1 + om * s.ac1;
+    s.ac2 = s.last_alpha * s.lc2 + om * s.ac2;
+    s.lc0 = b.z; s.lc1 = b.w; s.lc2 = cb;
+    float dL_dalpha = (b.z - s.ac0) * s.dLp0 + (b.w - s.ac1) * s.dLp1 + (cb - s.ac2) * s.dLp2;
+    g_c0 = dchan * s.dLp0; g_c1 = dchan * s.dLp1; g_c2 = dchan * s.dLp2;
+    s.last_alpha = alpha;
+    dL_dalpha = dL_dalpha * s.T - (s.T_final * rcp) * s.bg_dot;
+    const float dL_dG = b.y * dL_dalpha;  // straight-through min(0.99, .)
+    const float wG = dL_dG * G;
+    const float wx = wG * dx, wy = wG * dy;
+    // Q = (-2A, -B, -2C):  dG/dmean = -G Q d
+    g_mx = 2.0f * a.z * wx + a.w * wy;
+    g_my = 2.0f * b.x * wy + a.w * wx;
+    g_qxx = -0.5f * wx * dx;
+    g_qxy = -wx * dy;
+    g_qyy = -0.5f * wy * dy;
+    g_o = G * dL_dalpha;
 }
 
 // ------------------------------------------------------------------ backward
+constexpr int BCH = 64;  // list entries per round: one per lane of each wave
+
 __global__ void __launch_bounds__(256)
 blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict__ ranges,
                       const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ orig_slot,
-                      const float4* __restrict__ rec, const float* __restrict__ bg,
-                      const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                      const float* __restrict__ dL_dpix, float4* __restrict__ grad_rec) {
-    __shared__ float4 s0[BATCH], s1[BATCH];
-    __shared__ float s2[BATCH];
-    __shared__ float acc[4][BATCH][9];  // per-wave partial sums for the current batch
+                      const uint8_t* __restrict__ qmask, const float4* __restrict__ rec,
+                      const float* __restrict__ bg, const float* __restrict__ final_T,
+                      const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                      float4* __restrict__ grad_rec) {
+    __shared__ float4 s0[4][BCH], s1[4][BCH];  // wave-private compacted records of the round
+    __shared__ float2 s2[4][BCH];              // (blue, position in round)
+    __shared__ float4 acc[4][BCH][3];          // per-wave sums per position (9 of 12 floats used)
     __shared__ uint32_t wave_max[4];
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
-    const int tx = t % gx, ty = t / gx;
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int px = tx * TILE + lx, py = ty * TILE + ly;
+    const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
+    if (n == 0) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;  // wave == quadrant
+    const int px = (t % gx) * TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = (t / gx) * TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const uint32_t lo = ranges[2 * t], hi = ranges[2 * t + 1];
-    const uint32_t n = hi - lo;
-    if (n == 0) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
     const uint32_t last = inside ? n_contrib[pix] : 0u;
-    const float T_final = inside ? final_T[pix] : 0.0f;
-    float T = T_final;
-    float dLp0 = 0, dLp1 = 0, dLp2 = 0;
+    PixState ps;
+    ps.T_final = inside ? final_T[pix] : 0.0f;
+    ps.T = ps.T_final;
+    ps.dLp0 = ps.dLp1 = ps.dLp2 = 0.0f;
     if (inside) {
-        dLp0 = dL_dpix[pix];
-        dLp1 = dL_dpix[hw + pix];
-        dLp2 = dL_dpix[2 * hw + pix];
+        ps.dLp0 = dL_dpix[pix];
+        ps.dLp1 = dL_dpix[hw + pix];
+        ps.dLp2 = dL_dpix[2 * hw + pix];
     }
-    const float bg_dot = (bg[0] * dLp0 + bg[1] * dLp1) + bg[2] * dLp2;
-    float ac0 = 0, ac1 = 0, ac2 = 0, last_alpha = 0, lc0 = 0, lc1 = 0, lc2 = 0;
-    // workgroup-wide largest contributor count: batches past it hold only zero gradients
+    ps.bg_dot = (bg[0] * ps.dLp0 + bg[1] * ps.dLp1) + bg[2] * ps.dLp2;
+    ps.ac0 = ps.ac1 = ps.ac2 = ps.last_alpha = ps.lc0 = ps.lc1 = ps.lc2 = 0.0f;
+    // per-wave largest contributor count: list positions >= it cannot matter to the wave
     uint32_t wm = last;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) wm = max(wm, (uint32_t)__shfl_xor((int)wm, d, WAVE));
     if (lane == 0) wave_max[wave] = wm;
     __syncthreads();
-    const uint32_t max_last = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
-    const uint32_t wave_last = wave_max[wave];
-    const int nbatch = (int)((n + BATCH - 1) / BATCH);
-    for (int bi = nbatch - 1; bi >= 0; --bi) {
-        const uint32_t base = (uint32_t)bi * BATCH;  // list position of the batch's first splat
-        const int cnt = (int)min((uint32_t)BATCH, n - base);
-        const bool live = base < max_last;
-        __syncthreads();  // previous batch's acc / staging fully consumed
-        if (live) {
-            if (threadIdx.x < cnt) {
-                uint32_t g = point_list[lo + base + threadIdx.x];
-                s0[threadIdx.x] = rec[3 * (size_t)g];
-                s1[threadIdx.x] = rec[3 * (size_t)g + 1];
-                s2[threadIdx.x] = rec[3 * (size_t)g + 2].x;
-            }
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
-#pragma unroll
-                for (int c = 0; c < 9; ++c) acc[w][threadIdx.x][c] = 0.0f;
-            __syncthreads();
-            // back to front inside the batch; a wave skips splats behind all of its pixels
-            int jstart = cnt - 1;
-            if (base + (uint32_t)cnt > wave_last) jstart = (int)wave_last - (int)base - 1;
-            for (int j = jstart; j >= 0; --j) {
-                const uint32_t q = base + (uint32_t)j;  // list position; contributor number q+1
-                float4 a = s0[j], b = s1[j];
-                float cb = s2[j];
-                float dx = a.x - pxf, dy = a.y - pyf;
-                float power = __builtin_fmaf(dx, __builtin_fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy);
-                float G = fast_exp(power);
-                float alpha = fminf(0.99f, b.y * G);
-                bool hit = (q < last) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;
-                float g_mx = 0, g_my = 0, g_qxx = 0, g_qxy = 0, g_qyy = 0, g_o = 0, g_c0 = 0, g_c1 = 0, g_c2 = 0;
-                if (hit) {
-                    T = T * __builtin_amdgcn_rcpf(1.0f - alpha);
-                    const float dchan = alpha * T;
-                    ac0 = last_alpha * lc0 + (1.0f - last_alpha) * ac0;
-                    ac1 = last_alpha * lc1 + (1.0f - last_alpha) * ac1;
-                    ac2 = last_alpha * lc2 + (1.0f - last_alpha) * ac2;
-                    lc0 = b.z; lc1 = b.w; lc2 = cb;
-                    float dL_dalpha = ((b.z - ac0) * dLp0 + (b.w - ac1) * dLp1) + (cb - ac2) * dLp2;
-                    g_c0 = dchan * dLp0; g_c1 = dchan * dLp1; g_c2 = dchan * dLp2;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final * __builtin_amdgcn_rcpf(1.0f - alpha)) * bg_dot;
-                    const float dL_dG = b.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    // Q = (-2A, -B, -2C)
-                    const float Qxx = -2.0f * a.z, Qxy = -a.w, Qyy = -2.0f * b.x;
-                    g_mx = dL_dG * (-gdx * Qxx - gdy * Qxy);
-                    g_my = dL_dG * (-gdy * Qyy - gdx * Qxy);
-                    g_qxx = -0.5f * gdx * dx * dL_dG;
-                    g_qxy = -gdx * dy * dL_dG;
-                    g_qyy = -0.5f * gdy * dy * dL_dG;
-                    g_o = G * dL_dalpha;
-                }
-                g_mx = wave_sum_to_lane63(g_mx);
-                g_my = wave_sum_to_lane63(g_my);
-                g_qxx = wave_sum_to_lane63(g_qxx);
-                g_qxy = wave_sum_to_lane63(g_qxy);
-                g_qyy = wave_sum_to_lane63(g_qyy);
-                g_o = wave_sum_to_lane63(g_o);
-                g_c0 = wave_sum_to_lane63(g_c0);
-                g_c1 = wave_sum_to_lane63(g_c1);
-                g_c2 = wave_sum_to_lane63(g_c2);
-                if (lane == 63) {
-                    float* d = acc[wave][j];
-                    d[0] = g_mx; d[1] = g_my; d[2] = g_qxx; d[3] = g_qxy; d[4] = g_qyy;
-                    d[5] = g_o; d[6] = g_c0; d[7] = g_c1; d[8] = g_c2;
-                }
-            }
-            __syncthreads();
+    const uint32_t wmax0 = wave_max[0], wmax1 = wave_max[1], wmax2 = wave_max[2], wmax3 = wave_max[3];
+    const uint32_t max_last = max(max(wmax0, wmax1), max(wmax2, wmax3));
+    const uint32_t wave_last = wave == 0 ? wmax0 : wave == 1 ? wmax1 : wave == 2 ? wmax2 : wmax3;
+    const int nround = (int)((n + BCH - 1) / BCH);
+    const int live_top = max_last ? (int)((max_last - 1) / BCH) : -1;  // last round with any work
+
+    // ---- rounds behind every pixel's last contributor: all-zero records (waves 0..2 write one float4 each)
+    if (wave < 3)
+        for (int ci = nround - 1; ci > live_top; --ci) {
+            uint32_t i = (uint32_t)ci * BCH + lane;
+            if (i < n) grad_rec[3 * (size_t)orig_slot[lo + i] + wave] = make_float4(0, 0, 0, 0);
         }
-        if (threadIdx.x < cnt) {
-            float r[9];
-#pragma unroll
-            for (int c = 0; c < 9; ++c)
-                r[c] = live ? ((acc[0][threadIdx.x][c] + acc[1][threadIdx.x][c]) + acc[2][threadIdx.x][c]) +
-                                  acc[3][threadIdx.x][c]
-                            : 0.0f;
-            size_t slot = orig_slot[lo + base + threadIdx.x];
-            grad_rec[3 * slot + 0] = make_float4(r[0], r[1], r[2], r[3]);
-            grad_rec[3 * slot + 1] = make_float4(r[4], r[5], r[6], r[7]);
-            grad_rec[3 * slot + 2] = make_float4(r[8], 0.0f, 0.0f, 0.0f);
+
+    // ---- software pipeline over the live rounds, back to front:
+    // (mask, id, slot) two rounds ahead, gathered records one round ahead
+    uint32_t m_next = 0, id_next = 0, slot_next = 0;  // round ci-1
+    uint32_t m_cur = 0, slot_cur = 0;                 // round ci (records in r0/r1/r2x)
+    bool sel_cur = false;
+    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
+    float r2x = 0.0f;
+    auto load_meta = [&](int ci, uint32_t& m, uint32_t& id, uint32_t& slot) {
+        const uint32_t i = (uint32_t)ci * BCH + lane;
+        const bool have = ci >= 0 && i < n;
+        m = have ? qmask[lo + i] : 0u;
+        id = have ? point_list[lo + i] : 0u;
+        slot = have ? orig_slot[lo + i] : 0u;
+    };
+    auto gather = [&](int ci, uint32_t m, uint32_t id, uint32_t slot) {
+        const uint32_t i = (uint32_t)ci * BCH + lane;
+        sel_cur = ((m >> wave) & 1u) && i < wave_last;
+        m_cur = m;
+        slot_cur = slot;
+        if (sel_cur) {
+            r0 = rec[3 * (size_t)id];
+            r1 = rec[3 * (size_t)id + 1];
+            r2x = rec[3 * (size_t)id + 2].x;
+        }
+    };
+    if (live_top >= 0) {
+        uint32_t m0, id0, sl0;
+        load_meta(live_top, m0, id0, sl0);
+        gather(live_top, m0, id0, sl0);
+        load_meta(live_top - 1, m_next, id_next, slot_next);
+    }
+    for (int ci = live_top; ci >= 0; --ci) {
+        const uint32_t base = (uint32_t)ci * BCH;
+        // ---- stage this round's surviving records (wave-private, list order)
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(sel_cur);
+        const int cnt = __builtin_popcountll(bal);
+        if (sel_cur) {
+            const uint32_t pos = lanes_below(bal);
+            s0[wave][pos] = r0;
+            s1[wave][pos] = r1;
+            s2[wave][pos] = make_float2(r2x, __uint_as_float((uint32_t)lane));
+        }
+        const uint32_t m_this = m_cur, slot_this = slot_cur;
+        gather(ci - 1, m_next, id_next, slot_next);
+        load_meta(ci - 2, m_next, id_next, slot_next);
+        __syncthreads();  // A: the previous round's combine has read acc
+        for (int k = cnt - 1; k >= 0; --k) {  // back to front
+            const float4 a = s0[wave][k], b = s1[wave][k];
+            const float2 c = s2[wave][k];
+            const uint32_t j = __float_as_uint(c.y);
+            const uint32_t q = base + j;  // list position; contributor number q+1
+            const float dx = a.x - pxf, dy = a.y - pyf;
+            const float power = __builtin_fmaf(dx, __builtin_fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy);
+            const float G = fast_exp(power);
+            const float alpha = fminf(0.99f, b.y * G);
+            const bool hit = (q < last) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            float g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0, g8 = 0;
+            if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+                if (hit) splat_pixel_grad(ps, a, b, c.x, dx, dy, G, alpha, g0, g1, g2, g3, g4, g5, g6, g7, g8);
+                wave_sum9_to_lane63(g0, g1, g2, g3, g4, g5, g6, g7, g8);
+            }
+            if (lane == 63) {  // every listed position is written (zeros when nothing hit)
+                acc[wave][j][0] = make_float4(g0, g1, g2, g3);
+                acc[wave][j][1] = make_float4(g4, g5, g6, g7);
+                acc[wave][j][2] = make_float4(g8, 0.0f, 0.0f, 0.0f);
+            }
+        }
+        __syncthreads();  // B: every wave's sums for this round are in acc
+        // ---- combine: wave p (< 3) writes float4 part p of the 48-byte record of position `lane`,
+        // adding the waves that took part in a fixed order
+        if (wave < 3 && base + lane < n) {
+            const uint32_t i = base + lane;
+            float4 r = make_float4(0, 0, 0, 0);
+            if (((m_this >> 0) & 1u) && i < wmax0) { const float4 x = acc[0][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
+            if (((m_this >> 1) & 1u) && i < wmax1) { const float4 x = acc[1][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
+            if (((m_this >> 2) & 1u) && i < wmax2) { const float4 x = acc[2][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
+            if (((m_this >> 3) & 1u) && i < wmax3) { const float4 x = acc[3][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
+            grad_rec[3 * (size_t)slot_this + wave] = r;
         }
     }
 }
@@ -237,15 +342,16 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
 void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
                           float* out_color, hipStream_t st) {
     Grid g(ks.H, ks.W);
-    blend_forward_kernel<<<(unsigned)xcd_grid(g.tiles), 256, 0, st>>>(
-        ks.W, ks.H, g.gx, g.tiles, gv.ranges, bv.point_list, gv.rec, ks.bg, out_color, iv.final_T, iv.n_contrib);
+    blend_forward_kernel<<<(unsigned)xcd_grid(g.tiles) * 4, 64, 0, st>>>(
+        ks.W, ks.H, g.gx, g.tiles, gv.ranges, bv.point_list, bv.qmask, gv.rec, ks.bg, out_color, iv.final_T,
+        iv.n_contrib);
 }
 
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
                            const float* dL_dcolor, float4* grad_rec, hipStream_t st) {
     Grid g(ks.H, ks.W);
     blend_backward_kernel<<<(unsigned)xcd_grid(g.tiles), 256, 0, st>>>(
-        ks.W, ks.H, g.gx, g.tiles, gv.ranges, bv.point_list, bv.orig_slot, gv.rec, ks.bg, iv.final_T,
+        ks.W, ks.H, g.gx, g.tiles, gv.ranges, bv.point_list, bv.orig_slot, bv.qmask, gv.rec, ks.bg, iv.final_T,
         iv.n_contrib, dL_dcolor, grad_rec);
 }
 

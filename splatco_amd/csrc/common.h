@@ -64,6 +64,7 @@ struct BinView {
     uint32_t* inst_slot;       // [I] indexed by (point_offset_exclusive + k): slot in the tile-grouped arrays
     uint32_t* point_list;      // [I] Gaussian ids, per tile sorted by (depth, id)
     uint32_t* orig_slot;       // [I] sorted position -> slot the instance occupied before the sort
+    uint8_t* qmask;            // [I] sorted position -> 4-bit mask of the tile's 8x8 quadrants the splat can touch
     size_t bytes;
 };
 
@@ -77,6 +78,7 @@ inline __host__ BinView bin_view(void* base, int64_t I) {
     v.inst_slot = (uint32_t*)take(n * 4);
     v.point_list = (uint32_t*)take(n * 4);
     v.orig_slot = (uint32_t*)take(n * 4);
+    v.qmask = (uint8_t*)take(n);
     v.bytes = off;
     return v;
 }
@@ -137,6 +139,59 @@ __device__ inline int xcd_tile(int block, int tiles) {
     return t < tiles ? t : -1;
 }
 inline __host__ int xcd_grid(int tiles) { return ((tiles + NUM_XCD - 1) / NUM_XCD) * NUM_XCD; }
+
+// Conservative sub-tile culling.  A 16x16 tile is blended by four waves, one per 8x8-pixel
+// quadrant (bit q = (y half << 1) | x half).  Bit q is CLEARED only when no pixel of the quadrant
+// can pass the blend kernels' `alpha >= 1/255` test: the minimum of the quadratic form
+// q(d) = -power(d) over the quadrant's (continuous) pixel box is bounded below, and the splat is
+// dropped when o * exp(-qmin) is below 1/255 by a safety margin that dwarfs the rounding
+// difference between this bound and the per-pixel evaluation.  Dropping such a splat cannot
+// change any result (it would be skipped by every pixel anyway), so lists, n_contrib and images
+// stay bit-identical to the un-culled semantics.  NaNs compare false -> kept.
+__device__ inline uint32_t quadrant_mask(float4 r0, float4 r1, int tile_x0, int tile_y0) {
+    const float mx = r0.x, my = r0.y;
+    const float a = -r0.z, b = -r0.w, c = -r1.x;  // q = a dx^2 + b dx dy + c dy^2, a,c > 0
+    const float o = r1.y;
+    const float thr = __logf(255.0f * o) + 0.01f;  // q above this -> alpha < 1/255 (with margin)
+    // the bound below needs a finite, positive-definite form; anything else is simply kept
+    if (!(a > 0.0f && c > 0.0f && 4.0f * a * c - b * b > 0.0f) || !(mx - mx == 0.0f) || !(my - my == 0.0f) ||
+        !(thr - thr == 0.0f))
+        return 0xfu;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = (float)(tile_x0 + (q & 1) * 8), y0 = (float)(tile_y0 + (q >> 1) * 8);
+        // d = mean - pixel, pixel in [x0, x0+7] x [y0, y0+7]
+        const float dxl = mx - (x0 + 7.0f), dxh = mx - x0, dyl = my - (y0 + 7.0f), dyh = my - y0;
+        float qmin, mag;
+        if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) {
+            qmin = 0.0f;
+            mag = 0.0f;
+        } else {
+            qmin = 3.0e38f;
+            mag = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // edges: dx = dxl, dx = dxh (free dy), dy = dyl, dy = dyh (free dx)
+                const bool xe = e < 2;
+                const float fix = e == 0 ? dxl : e == 1 ? dxh : e == 2 ? dyl : dyh;
+                const float kf = xe ? a : c, kv = xe ? c : a;  // q = kf fix^2 + b fix v + kv v^2
+                const float lo = xe ? dyl : dxl, hi = xe ? dyh : dxh;
+                float v = -b * fix / (2.0f * kv);
+                v = fminf(hi, fmaxf(lo, v));
+                const float t0 = kf * fix * fix, t1 = b * fix * v, t2 = kv * v * v;
+                const float qe = t0 + t1 + t2;
+                if (qe < qmin) {
+                    qmin = qe;
+                    mag = fabsf(t0) + fabsf(t1) + fabsf(t2);
+                }
+            }
+        }
+        const bool cull = qmin > thr + 1.0e-5f * mag;
+        if (!cull) mask |= 1u << q;
+    }
+    return mask;
+}
 
 // launchers (defined in the .hip files)
 void launch_filter(int64_t P, const float* means3D, const float* scales, const float* rotations,
