@@ -134,14 +134,16 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
     }
 }
 
-// ------------------------------------------------------------------ wave64 sums via DPP
-// Nine per-splat partial sums are reduced together: inclusive row scans (row_shr 1,2,4,8) then
-// row_bcast15 / row_bcast31, so lane 63 ends up with each sum over the wave, always added in the
-// same order (bit-reproducible).  Written as one asm block: hipcc splits the builtin form into
-// v_mov_dpp + v_add pairs padded with s_nop (127 instructions for 54 adds); here the nine chains
-// are interleaved, which also covers the 2-wait-state VALU-write -> DPP-read hazard between steps
-// (each register is re-read 9 instructions after it was written).  The leading s_nop 1 covers
-// the same hazard against whatever the compiler issued just before the block.
+// ------------------------------------------------------------------ wave64 sums, four splats at a time
+// The nine per-splat partial sums of FOUR consecutive splats (A,B,C,D) are reduced together:
+//   v_permlane32_swap folds the wave in half   (A|B and C|D share a register: 2 swaps + 2 adds)
+//   v_permlane16_swap folds the halves again   (row 0: A, row 1: C, row 2: B, row 3: D)
+//   four DPP row_shr adds finish inside each 16-lane row -> lanes 15 / 31 / 47 / 63 hold the sums
+// = 10 instructions per value for four splats (2.5 per splat-value instead of 6), always added
+// in the same order (bit-reproducible).  The row steps are one asm block: hipcc splits the
+// builtin DPP form into v_mov_dpp + v_add pairs padded with s_nop; here the nine chains are
+// interleaved, which also covers the 2-wait-state VALU-write -> DPP-read hazard between steps.
+// The leading s_nop 1 covers the same hazard against the instruction just before the block.
 #define SCR_DPP9(ctrl)                              \
     "v_add_f32_dpp %0, %0, %0 " ctrl "\n\t"         \
     "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t"         \
@@ -152,17 +154,23 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
     "v_add_f32_dpp %6, %6, %6 " ctrl "\n\t"         \
     "v_add_f32_dpp %7, %7, %7 " ctrl "\n\t"         \
     "v_add_f32_dpp %8, %8, %8 " ctrl "\n\t"
-__device__ __forceinline__ void wave_sum9_to_lane63(float& v0, float& v1, float& v2, float& v3, float& v4,
-                                                    float& v5, float& v6, float& v7, float& v8) {
+__device__ __forceinline__ void row_sums9(float (&v)[9]) {  // lane 15 of every 16-lane row <- row sum
     asm volatile("s_nop 1\n\t"
                  SCR_DPP9("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
                  SCR_DPP9("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
                  SCR_DPP9("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
                  SCR_DPP9("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                 SCR_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 SCR_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf")
                  "s_nop 1"
-                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                   "+v"(v[8]));
+}
+__device__ __forceinline__ float fold4(float a, float b, float c, float d) {
+    auto ab = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    auto cd = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(d), false, false);
+    const float sab = __uint_as_float(ab[0]) + __uint_as_float(ab[1]);  // [A.lo+A.hi | B.lo+B.hi]
+    const float scd = __uint_as_float(cd[0]) + __uint_as_float(cd[1]);  // [C.lo+C.hi | D.lo+D.hi]
+    auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(sab), __float_as_uint(scd), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);               // rows: A, C, B, D
 }
 
 // Per-pixel gradient of one contributing splat (back-to-front recurrences).  Not decision
@@ -302,25 +310,47 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         gather(ci - 1, m_next, id_next, slot_next);
         load_meta(ci - 2, m_next, id_next, slot_next);
         __syncthreads();  // A: the previous round's combine has read acc
-        for (int k = cnt - 1; k >= 0; --k) {  // back to front
-            const float4 a = s0[wave][k], b = s1[wave][k];
-            const float2 c = s2[wave][k];
-            const uint32_t j = __float_as_uint(c.y);
-            const uint32_t q = base + j;  // list position; contributor number q+1
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float power = __builtin_fmaf(dx, __builtin_fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy);
-            const float G = fast_exp(power);
-            const float alpha = fminf(0.99f, b.y * G);
-            const bool hit = (q < last) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            float g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0, g8 = 0;
-            if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
-                if (hit) splat_pixel_grad(ps, a, b, c.x, dx, dy, G, alpha, g0, g1, g2, g3, g4, g5, g6, g7, g8);
-                wave_sum9_to_lane63(g0, g1, g2, g3, g4, g5, g6, g7, g8);
+        for (int k = cnt - 1; k >= 0; k -= 4) {  // back to front, four splats per reduction
+            float g[4][9];
+            uint32_t jj[4];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool valid = k - u >= 0;  // wave-uniform
+                const int ks = valid ? k - u : 0;
+                const float4 a = s0[wave][ks], b = s1[wave][ks];
+                const float2 c = s2[wave][ks];
+                const uint32_t j = __float_as_uint(c.y);
+                const uint32_t q = base + j;  // list position; contributor number q+1
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float power = __builtin_fmaf(dx, __builtin_fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy);
+                const float G = fast_exp(power);
+                const float alpha = fminf(0.99f, b.y * G);
+                const bool hit = valid && (q < last) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+#pragma unroll
+                for (int v = 0; v < 9; ++v) g[u][v] = 0.0f;
+                if (hit)
+                    splat_pixel_grad(ps, a, b, c.x, dx, dy, G, alpha, g[u][0], g[u][1], g[u][2], g[u][3], g[u][4],
+                                     g[u][5], g[u][6], g[u][7], g[u][8]);
+                any = any || (__builtin_amdgcn_ballot_w64(hit) != 0ull);
+                jj[u] = valid ? j : 0xffffffffu;
             }
-            if (lane == 63) {  // every listed position is written (zeros when nothing hit)
-                acc[wave][j][0] = make_float4(g0, g1, g2, g3);
-                acc[wave][j][1] = make_float4(g4, g5, g6, g7);
-                acc[wave][j][2] = make_float4(g8, 0.0f, 0.0f, 0.0f);
+            float r[9];
+            if (any) {
+#pragma unroll
+                for (int v = 0; v < 9; ++v) r[v] = fold4(g[0][v], g[1][v], g[2][v], g[3][v]);
+                row_sums9(r);
+            } else {
+#pragma unroll
+                for (int v = 0; v < 9; ++v) r[v] = 0.0f;
+            }
+            // lanes 15 / 31 / 47 / 63 hold splat u = 0 / 2 / 1 / 3 of the group
+            const int row = lane >> 4;
+            const uint32_t jw = row == 0 ? jj[0] : row == 1 ? jj[2] : row == 2 ? jj[1] : jj[3];
+            if ((lane & 15) == 15 && jw != 0xffffffffu) {  // every listed position is written
+                acc[wave][jw][0] = make_float4(r[0], r[1], r[2], r[3]);
+                acc[wave][jw][1] = make_float4(r[4], r[5], r[6], r[7]);
+                acc[wave][jw][2] = make_float4(r[8], 0.0f, 0.0f, 0.0f);
             }
         }
         __syncthreads();  // B: every wave's sums for this round are in acc
