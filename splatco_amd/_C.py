@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsplatco_raster.so")
+# developer override for A/B experiments with variant builds of the same library
+LIB_PATH = os.environ.get("SPLATCO_RASTER_LIB", os.path.join(_HERE, "csrc", "libsplatco_raster.so"))
 
 SYMBOLS = [
     "scr_abi_version", "scr_last_error", "scr_geom_bytes", "scr_binning_bytes", "scr_image_bytes",

@@ -260,8 +260,10 @@ preprocess_kernel(int64_t P, int M, const float* __restrict__ means3D, const flo
             rec[3 * i + 2] = make_float4(rgb[2], ps.t[2], __uint_as_float(rlo), __uint_as_float(rhi));
             radii[i] = ft.radius;
             int gx = (ks.W + TILE - 1) / TILE;
+#ifndef SCR_EXP_NO_COUNT_ATOMICS
             for (int ty = ft.rminy; ty < ft.rmaxy; ++ty)
                 for (int tx = ft.rminx; tx < ft.rmaxx; ++tx) atomicAdd(&tile_count[ty * gx + tx], 1u);
+#endif
         } else {
             radii[i] = 0;
             if (clamped) clamped[i] = 0;

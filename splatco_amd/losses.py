@@ -1,0 +1,48 @@
+"""Loss / metric functions of the training step around the rasterizer (plain PyTorch), restating
+utils/loss_utils.py:17-63 and utils/image_utils.py:14-19; pinned by tests/golden/losses.npz.
+psnr() is the parity metric of BASELINE.json ("PSNR-match")."""
+from math import exp
+
+import torch
+import torch.nn.functional as F
+
+
+def l1_loss(network_output, gt):
+    return torch.abs(network_output - gt).mean()
+
+
+def l2_loss(network_output, gt):
+    return ((network_output - gt) ** 2).mean()
+
+
+def psnr(img1, img2):
+    mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+
+def _window(window_size, channel, like):
+    g = torch.tensor([exp(-(x - window_size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(window_size)])
+    g = (g / g.sum()).unsqueeze(1)
+    w2d = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+    return w2d.expand(channel, 1, window_size, window_size).contiguous().to(like)
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    channel = img1.size(-3)
+    window = _window(window_size, channel, img1)
+    pad = window_size // 2
+    mu1 = F.conv2d(img1, window, padding=pad, groups=channel)
+    mu2 = F.conv2d(img2, window, padding=pad, groups=channel)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=channel) - mu1_sq
+    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=channel) - mu2_sq
+    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=channel) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+    return ssim_map.mean() if size_average else ssim_map.mean(1).mean(1).mean(1)
+
+
+def view_loss(image, gt_image, scaling, lambda_dssim=0.2):
+    """Per-view training loss (train.py:192-196): 0.8 L1 + 0.2 (1 - SSIM) + 0.01 mean(prod(scaling))."""
+    return (1.0 - lambda_dssim) * l1_loss(image, gt_image) + lambda_dssim * (1.0 - ssim(image, gt_image)) + \
+        0.01 * scaling.prod(dim=1).mean()

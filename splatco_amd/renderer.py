@@ -1,0 +1,96 @@
+"""Drop-in for the reference's gaussian_renderer module: prefilter_voxel / generate_neural_gaussians
+/ render with the same signatures, result-dict keys and autograd behaviour
+(gaussian_renderer/__init__.py:18-244), calling the MI355X rasterizer operator.
+
+`pc` is any object with the GaussianModel attributes the reference reads (e.g.
+splatco_amd.scene_model.AnchorGaussianModel or the reference's own GaussianModel).
+"""
+import math
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False):
+    """Anchors -> neural Gaussians (gaussian_renderer/__init__.py:18-116), same op order."""
+    if visible_mask is None:
+        visible_mask = torch.ones(pc.get_anchor.shape[0], dtype=torch.bool, device=pc.get_anchor.device)
+    feat = pc._anchor_feat[visible_mask]
+    anchor = pc.get_anchor[visible_mask]
+    grid_offsets = pc._offset[visible_mask]
+    grid_scaling = pc.get_scaling[visible_mask]
+    V, k = anchor.shape[0], pc.n_offsets
+    geo_fea = pc.feat_planes.inference(
+        anchor, torch.concat((feat, anchor, grid_offsets.reshape(V, -1), grid_scaling), dim=1), 0)
+    ob_view = anchor - viewpoint_camera.camera_center
+    ob_dist = ob_view.norm(dim=1, keepdim=True)
+    ob_view = ob_view / ob_dist
+    if getattr(pc, "use_feat_bank", False) or getattr(pc, "appearance_dim", 0) > 0:
+        raise NotImplementedError("feature bank / appearance embedding are off on the benchmarked path")
+    cat_local_view = torch.cat([feat, ob_view, ob_dist, geo_fea], dim=1)
+    cat_local_view_wodist = torch.cat([feat, ob_view, geo_fea], dim=1)
+    neural_opacity = pc.get_opacity_mlp(cat_local_view if pc.add_opacity_dist else cat_local_view_wodist)
+    neural_opacity = neural_opacity.reshape([-1, 1])
+    mask = (neural_opacity > 0.0).view(-1)
+    opacity = neural_opacity[mask]
+    color = pc.get_color_mlp(cat_local_view if pc.add_color_dist else cat_local_view_wodist).reshape([V * k, 3])
+    scale_rot = pc.get_cov_mlp(cat_local_view if pc.add_cov_dist else cat_local_view_wodist).reshape([V * k, 7])
+    offsets = grid_offsets.view([-1, 3])
+    # combine for parallel masking (:96-103): [scaling 6 | anchor 3] repeated k times, then one gather
+    concatenated = torch.cat([grid_scaling, anchor], dim=-1)
+    concatenated_repeated = concatenated.unsqueeze(1).expand(V, k, 9).reshape(V * k, 9)
+    concatenated_all = torch.cat([concatenated_repeated, color, scale_rot, offsets], dim=-1)
+    masked = concatenated_all[mask]
+    scaling_repeat, repeat_anchor, color, scale_rot, offsets = masked.split([6, 3, 3, 7, 3], dim=-1)
+    scaling = scaling_repeat[:, 3:] * torch.sigmoid(scale_rot[:, :3])
+    rot = pc.rotation_activation(scale_rot[:, 3:7])
+    offsets = offsets * scaling_repeat[:, :3]
+    xyz = repeat_anchor + offsets
+    if is_training:
+        return xyz, color, opacity, scaling, rot, neural_opacity, mask
+    return xyz, color, opacity, scaling, rot
+
+
+def _settings(viewpoint_camera, bg_color, scaling_modifier, debug):
+    return GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=1, campos=viewpoint_camera.camera_center,
+        prefiltered=False, debug=debug)
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, visible_mask=None, retain_grad=False):
+    """gaussian_renderer/__init__.py:118-188.  Background tensor must be on the GPU."""
+    is_training = pc.get_color_mlp.training
+    out = generate_neural_gaussians(viewpoint_camera, pc, visible_mask, is_training=is_training)
+    xyz, color, opacity, scaling, rot = out[:5]
+    # zero tensor whose .grad receives the screen-space mean gradient (:133-138)
+    screenspace_points = torch.zeros_like(xyz, dtype=pc.get_anchor.dtype, requires_grad=True) + 0
+    if retain_grad:
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, bg_color, scaling_modifier, pipe.debug))
+    rendered_image, radii = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=color,
+                                       opacities=opacity, scales=scaling, rotations=rot, cov3D_precomp=None)
+    res = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+           "radii": radii}
+    if is_training:
+        res.update({"selection_mask": out[6], "neural_opacity": out[5], "scaling": scaling})
+    return res
+
+
+def prefilter_voxel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+    """Anchor visibility (gaussian_renderer/__init__.py:191-244): radii_pure > 0."""
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, bg_color, scaling_modifier, pipe.debug))
+    if pipe.compute_cov3D_python:
+        # the reference would crash here (scales is None at :239); only the
+        # scale / rotation path is live
+        raise NotImplementedError("compute_cov3D_python is not a live path of the reference's prefilter_voxel")
+    with torch.no_grad():
+        radii_pure = rasterizer.visible_filter(means3D=pc.get_anchor, scales=pc.get_scaling[:, :3],
+                                               rotations=pc.get_rotation, cov3D_precomp=None)
+    return radii_pure > 0

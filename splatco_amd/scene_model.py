@@ -1,0 +1,201 @@
+"""Host-side model pieces on the render() path (plain PyTorch; rocBLAS does the tiny GEMMs).
+
+Restates -- does not import -- what gaussian_renderer.generate_neural_gaussians() reads from the
+reference's GaussianModel: the tri-plane feature grids (scene/grids.py:22-64,102-201), the
+multi-level FeaturePlanes / GaussianLearner (scene/gaussian_model.py:97-220) and the three MLP
+heads (scene/gaussian_model.py:315-337).  Module / parameter names mirror the reference so its
+state_dicts load unchanged (tests/golden/neural_gaussians.npz was captured from the reference).
+
+Out of scope here: optimiser, densification, PLY io, entropy models, the
+dead Spatial_CTX grids.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class ChannelAttention(nn.Module):            # scene/grids.py:22-36
+    def __init__(self, in_planes, ratio=5):
+        super().__init__()
+        self.sharedMLP = nn.Sequential(nn.Conv2d(in_planes, in_planes // ratio, 1, bias=False), nn.ReLU(),
+                                       nn.Conv2d(in_planes // ratio, in_planes, 1, bias=False))
+
+    def forward(self, x):
+        avg = self.sharedMLP(F.adaptive_avg_pool2d(x, 1))
+        mx = self.sharedMLP(F.adaptive_max_pool2d(x, 1))
+        return torch.sigmoid(avg + mx)
+
+
+class SpatialAttention(nn.Module):            # scene/grids.py:38-52
+    def __init__(self, kernel_size=7):
+        super().__init__()
+        self.conv = nn.Conv2d(2, 1, kernel_size, padding=3 if kernel_size == 7 else 1, bias=False)
+
+    def forward(self, x):
+        avg = torch.mean(x, dim=1, keepdim=True)
+        mx, _ = torch.max(x, dim=1, keepdim=True)
+        return torch.sigmoid(self.conv(torch.cat([avg, mx], dim=1)))
+
+
+class TriPlaneAttention(nn.Module):           # scene/grids.py:55-64
+    def __init__(self, planes):
+        super().__init__()
+        self.ca = ChannelAttention(planes)
+        self.sa = SpatialAttention()
+
+    def forward(self, x):
+        x = self.ca(x) * x
+        return self.sa(x) * x
+
+
+def _sample(plane, ind_norm, cols):
+    # F.grid_sample bilinear, align_corners=True, zeros padding (scene/grids.py:148-150)
+    return F.grid_sample(plane, ind_norm[:, :, :, cols], mode="bilinear", align_corners=True).flatten(0, 2).T
+
+
+class PlaneGrid(nn.Module):                   # scene/grids.py:102-201
+    def __init__(self, channels, world_size, xyz_min, xyz_max, TAflag=False, factor=1):
+        super().__init__()
+        self.channels, self.TAflag = channels, TAflag
+        self.register_buffer("xyz_min", torch.as_tensor(xyz_min))
+        self.register_buffer("xyz_max", torch.as_tensor(xyz_max))
+        X, Y, Z = (int(w) * factor for w in world_size)
+        R = channels // 3
+        self.xy_plane = nn.Parameter(torch.randn(1, R, X, Y) * 0.1)
+        self.xz_plane = nn.Parameter(torch.randn(1, R, X, Z) * 0.1)
+        self.yz_plane = nn.Parameter(torch.randn(1, R, Y, Z) * 0.1)
+        if TAflag:
+            self.TA = TriPlaneAttention(channels)
+
+    def get_dim(self):
+        return self.channels * 2 if self.TAflag else self.channels
+
+    def forward(self, xyz, Q=0):
+        shape = xyz.shape[:-1]
+        xyz = xyz.reshape(1, 1, -1, 3)
+        ind = (xyz - self.xyz_min) / (self.xyz_max - self.xyz_min) * 2 - 1
+        ind = torch.cat([ind, torch.zeros_like(ind[..., [0]])], dim=-1)
+        xy, xz, yz = _sample(self.xy_plane, ind, [1, 0]), _sample(self.xz_plane, ind, [2, 0]), _sample(self.yz_plane, ind, [2, 1])
+        if Q != 0:                                              # training-time uniform noise (:159-164)
+            xy = xy + torch.empty_like(xy).uniform_(-0.5, 0.5) * Q
+            xz = xz + torch.empty_like(xz).uniform_(-0.5, 0.5) * Q
+            yz = yz + torch.empty_like(yz).uniform_(-0.5, 0.5) * Q
+        if not self.TAflag:
+            return torch.cat([xy, xz, yz], dim=-1).reshape(*shape, self.channels)
+        tri = self.TA(torch.cat((self.xy_plane, self.xz_plane, self.yz_plane), dim=1))   # every call (:166-168)
+        xyA, xzA, yzA = torch.chunk(tri, 3, dim=1)
+        feat = torch.cat([xy, _sample(xyA, ind, [1, 0]), xz, _sample(xzA, ind, [2, 0]), yz, _sample(yzA, ind, [2, 1])], dim=-1)
+        return feat.reshape(*shape, self.channels * 2)
+
+
+class FeaturePlanes(nn.Module):               # scene/gaussian_model.py:97-169
+    def __init__(self, world_size, xyz_min, xyz_max, feat_dim=24, out_dim=32):
+        super().__init__()
+        self.activate_level, self.num_levels, self.level_factor = 0, 3, 0.5
+        t_ws = torch.tensor(world_size)
+        self.k0s = nn.ModuleList()
+        for i in range(self.num_levels):
+            cur = (t_ws * self.level_factor ** (self.num_levels - i - 1)).int().tolist()
+            if i == 0:
+                self.k0s.append(PlaneGrid(feat_dim, cur, xyz_min, xyz_max, TAflag=True))
+            self.k0s.append(PlaneGrid(feat_dim, cur, xyz_min, xyz_max))
+        self.models, self.CTX_models = nn.ModuleList(), nn.ModuleList()
+        for i in range(self.num_levels):
+            d = self.k0s[i].get_dim()
+            self.models.append(nn.Sequential(nn.BatchNorm1d(d), nn.Linear(d, out_dim)))
+            self.CTX_models.append(nn.Sequential(nn.BatchNorm1d(71), nn.Linear(71, out_dim)))
+
+    def forward(self, x, g_fea, Q=0):
+        res = []
+        for i in range(self.activate_level + 1):
+            feat = self.k0s[i](x, Q)
+            res.append(torch.cat((self.models[i](feat), self.CTX_models[i](g_fea)), dim=1))
+        return sum(res)
+
+
+class GaussianLearner(nn.Module):             # scene/gaussian_model.py:184-220
+    def __init__(self, plane_size, num_channels, xyz_min=(-2, -2, -2), xyz_max=(2, 2, 2)):
+        super().__init__()
+        self.Q0 = 0.03
+        self._feat = FeaturePlanes([plane_size] * 3, torch.tensor(xyz_min), torch.tensor(xyz_max), feat_dim=num_channels)
+        self.register_buffer("opacity_scale", torch.tensor(10))
+
+    def activate_plane_level(self):
+        self._feat.activate_level += 1
+
+    def inference(self, xyz, g_fea, Q0):
+        # the reference ignores the Q0 argument and uses self.Q0 (:209-215); xyz is detached
+        return self._feat(xyz.detach(), g_fea, self.Q0)
+
+
+class AnchorGaussianModel(nn.Module):
+    """The attributes of the reference's GaussianModel that render() / prefilter_voxel() touch
+    (scene/gaussian_model.py:253-337,396-432), with the same names."""
+
+    def __init__(self, feat_dim=32, n_offsets=10, appearance_dim=0, plane_size=2800, num_channels=15,
+                 use_feat_bank=False, add_opacity_dist=False, add_cov_dist=False, add_color_dist=False):
+        super().__init__()
+        if use_feat_bank or appearance_dim > 0:
+            raise NotImplementedError("use_feat_bank / appearance embedding are off on the benchmarked path "
+                                      "(arguments/__init__.py:57, README.md:93 --appearance_dim 0)")
+        self.feat_dim, self.n_offsets, self.appearance_dim, self.use_feat_bank = feat_dim, n_offsets, appearance_dim, use_feat_bank
+        self.add_opacity_dist, self.add_cov_dist, self.add_color_dist = add_opacity_dist, add_cov_dist, add_color_dist
+        od, cd, kd = int(add_opacity_dist), int(add_cov_dist), int(add_color_dist)
+        self.mlp_opacity = nn.Sequential(nn.Linear(feat_dim + 3 + od + 64, feat_dim), nn.ReLU(True),
+                                         nn.Linear(feat_dim, n_offsets), nn.Tanh())
+        self.mlp_cov = nn.Sequential(nn.Linear(feat_dim + 3 + cd + 64, feat_dim), nn.ReLU(True),
+                                     nn.Linear(feat_dim, 7 * n_offsets))
+        self.mlp_color = nn.Sequential(nn.Linear(feat_dim + 3 + kd + appearance_dim + 64, feat_dim), nn.ReLU(True),
+                                       nn.Linear(feat_dim, 3 * n_offsets), nn.Sigmoid())
+        self.feat_planes = GaussianLearner(plane_size, num_channels)
+        self._anchor = nn.Parameter(torch.empty(0, 3))
+        self._offset = nn.Parameter(torch.empty(0, n_offsets, 3))
+        self._anchor_feat = nn.Parameter(torch.empty(0, feat_dim))
+        self._scaling = nn.Parameter(torch.empty(0, 6))
+        self._rotation = nn.Parameter(torch.empty(0, 4), requires_grad=False)   # requires_grad False in the reference
+        self.rotation_activation = F.normalize
+
+    def set_anchors(self, anchor, offset, anchor_feat, scaling, rotation=None):
+        N = anchor.shape[0]
+        self._anchor = nn.Parameter(anchor.float())
+        self._offset = nn.Parameter(offset.float())
+        self._anchor_feat = nn.Parameter(anchor_feat.float())
+        self._scaling = nn.Parameter(scaling.float())
+        if rotation is None:
+            rotation = torch.zeros(N, 4, device=anchor.device)
+            rotation[:, 0] = 1
+        self._rotation = nn.Parameter(rotation.float(), requires_grad=False)
+
+    # the reference's eval()/train() touch only the three MLP heads; BatchNorm in FeaturePlanes
+    # stays in train mode forever (scene/gaussian_model.py:350-366)
+    def eval(self):
+        self.mlp_opacity.eval(); self.mlp_cov.eval(); self.mlp_color.eval()
+        return self
+
+    def train(self, mode=True):
+        self.mlp_opacity.train(mode); self.mlp_cov.train(mode); self.mlp_color.train(mode)
+        return self
+
+    @property
+    def get_anchor(self):
+        return self._anchor
+
+    @property
+    def get_scaling(self):
+        return 1.0 * torch.exp(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return self.rotation_activation(self._rotation)
+
+    @property
+    def get_opacity_mlp(self):
+        return self.mlp_opacity
+
+    @property
+    def get_cov_mlp(self):
+        return self.mlp_cov
+
+    @property
+    def get_color_mlp(self):
+        return self.mlp_color

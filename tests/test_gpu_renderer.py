@@ -1,0 +1,78 @@
+"""GPU tests of the drop-in renderer path: prefilter_voxel -> generate_neural_gaussians -> render
+(gaussian_renderer/__init__.py:118-244) on the model captured in tests/golden/neural_gaussians.npz."""
+import math
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from util import oracle_settings
+from splatco_amd.cameras import look_at_camera
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _model(dev):
+    from test_host_golden import _model_from_fixture
+    d = np.load(os.path.join(GOLD, "neural_gaussians.npz"))
+    return _model_from_fixture(d).to(dev), d
+
+
+def test_prefilter_and_render_contract(oracle):
+    from splatco_amd.renderer import prefilter_voxel, render
+    from splatco_amd.stats import training_statis
+    dev = torch.device("cuda:0")
+    pc, d = _model(dev)
+    cam = look_at_camera(eye=(0.3, -0.2, -4.5), target=(0, 0, 0), up=(0, -1, 0), FoVx=math.radians(60), width=200,
+                         height=120).to(dev)
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False, mv=4)
+    bg = torch.tensor([1.0, 1.0, 1.0], device=dev)
+    pc.train()
+    # a2: anchor visibility == oracle radii > 0 on exp(_scaling)[:, :3], normalised rotation
+    vis = prefilter_voxel(cam, pc, pipe, bg)
+    cpu_cam = cam.to("cpu")
+    st = oracle_settings(oracle, cpu_cam, bg.cpu().numpy())
+    want = oracle.visible_filter(st, d["anchor"], np.exp(d["scaling"])[:, :3],
+                                 np.tile(np.array([1, 0, 0, 0], np.float32), (512, 1)))
+    assert vis.dtype == torch.bool and np.array_equal(vis.cpu().numpy(), want > 0)
+    # a4: result dict, autograd contract
+    out = render(cam, pc, pipe, bg, visible_mask=vis, retain_grad=True)
+    assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii", "selection_mask",
+                        "neural_opacity", "scaling"}
+    P = out["viewspace_points"].shape[0]
+    assert out["render"].shape == (3, 120, 200) and out["render"].dtype == torch.float32
+    assert out["radii"].dtype == torch.int32 and out["radii"].shape == (P,)
+    assert out["visibility_filter"].dtype == torch.bool
+    assert out["selection_mask"].shape == (int(vis.sum()) * pc.n_offsets,)
+    assert int(out["selection_mask"].sum()) == P
+    target = torch.rand(3, 120, 200, device=dev)
+    loss = (out["render"] - target).abs().mean() + 0.01 * out["scaling"].prod(dim=1).mean()
+    loss.backward()
+    g = out["viewspace_points"].grad
+    assert g is not None and g.shape == (P, 3) and torch.all(g[:, 2] == 0) and g[:, :2].abs().sum() > 0
+    for p in (pc._anchor, pc._offset, pc._anchor_feat, pc._scaling, pc.mlp_color[0].weight,
+              pc.feat_planes._feat.k0s[0].xy_plane):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0
+    # a8: the consumer of the means2D gradient runs on these tensors
+    N, k = 512, pc.n_offsets
+    acc = [torch.zeros(N, 1, device=dev), torch.zeros(N, 1, device=dev), torch.zeros(N * k, 1, device=dev),
+           torch.zeros(N * k, 1, device=dev)]
+    training_statis(*acc, k, g, out["neural_opacity"], out["visibility_filter"], out["selection_mask"], vis)
+    assert acc[3].sum() == out["visibility_filter"].sum()
+    # image equals the oracle's rendering of the same neural Gaussians
+    from splatco_amd.renderer import generate_neural_gaussians
+    with torch.no_grad():
+        xyz, color, opacity, scaling, rot, _, _ = generate_neural_gaussians(cam, pc, vis, is_training=True)
+    f = oracle.forward(st, xyz.cpu().numpy(), opacity.cpu().numpy(), scaling.cpu().numpy(), rot.cpu().numpy(),
+                       colors_precomp=color.cpu().numpy())
+    same = f["margin"] > 1e-5
+    assert np.abs(out["render"].detach().cpu().numpy() - f["color"])[:, same].max() <= 1e-4
+    assert np.array_equal(out["radii"].cpu().numpy(), f["radii"])
+    # eval mode: 4 keys
+    pc.eval()
+    with torch.no_grad():
+        out2 = render(cam, pc, pipe, bg, visible_mask=vis)
+    assert set(out2) == {"render", "viewspace_points", "visibility_filter", "radii"}

@@ -1,0 +1,111 @@
+"""Host-side restatements against golden vectors captured from the reference's own Python
+(tools/make_golden.py; fixtures in tests/golden/).  CPU only."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _npz(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def test_camera_conventions():
+    from splatco_amd.cameras import get_projection_matrix, get_world2view2, make_camera
+    d = _npz("cameras.npz")
+    for i in range(3):
+        w2v = get_world2view2(d[f"R{i}"], d[f"T{i}"], d[f"trans{i}"], float(d[f"scale{i}"]))
+        np.testing.assert_array_equal(w2v, d[f"w2v{i}"])
+        proj = get_projection_matrix(0.01, 100.0, float(d[f"fovx{i}"]), float(d[f"fovy{i}"]))
+        np.testing.assert_array_equal(proj.numpy(), d[f"proj{i}"])
+        cam = make_camera(d[f"R{i}"], d[f"T{i}"], float(d[f"fovx{i}"]), float(d[f"fovy{i}"]), 640, 480,
+                          trans=d[f"trans{i}"], scale=float(d[f"scale{i}"]))
+        np.testing.assert_array_equal(cam.world_view_transform.numpy(), d[f"world_view_transform{i}"])
+        np.testing.assert_allclose(cam.full_proj_transform.numpy(), d[f"full_proj_transform{i}"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(cam.camera_center.numpy(), d[f"camera_center{i}"], rtol=0, atol=1e-6)
+    # row-vector convention (utils/graphics_utils.py:22-29)
+    pts = torch.tensor(d["points"])
+    hom = torch.cat([pts, torch.ones(20, 1)], 1) @ torch.tensor(d["full_proj_transform0"])
+    np.testing.assert_allclose((hom[:, :3] / (hom[:, 3:] + 1e-7)).numpy(), d["points_ndc0"], rtol=1e-5, atol=1e-6)
+
+
+def test_losses():
+    from splatco_amd.losses import l1_loss, psnr, ssim
+    d = _npz("losses.npz")
+    for i in range(3):
+        a, b = torch.tensor(d[f"a{i}"]), torch.tensor(d[f"b{i}"])
+        np.testing.assert_allclose(l1_loss(a, b).numpy(), d[f"l1_{i}"], rtol=1e-6)
+        np.testing.assert_allclose(ssim(a, b).numpy(), d[f"ssim_{i}"], rtol=1e-5)
+        np.testing.assert_allclose(psnr(a, b).numpy(), d[f"psnr_{i}"], rtol=1e-6)
+
+
+def _load_prefixed(module, d, prefix):
+    sd = {k[len(prefix):]: torch.tensor(d[k]) for k in d.files if k.startswith(prefix) and not k.endswith(".out")}
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("num_batches_tracked" in m for m in missing), missing
+
+
+@pytest.mark.parametrize("name,ta", [("plain", False), ("ta", True)])
+def test_planegrid(name, ta):
+    from splatco_amd.scene_model import PlaneGrid
+    d = _npz("planegrid.npz")
+    pg = PlaneGrid(15, [24, 24, 24], [-2.0, -2.0, -2.0], [2.0, 2.0, 2.0], TAflag=ta)
+    _load_prefixed(pg, d, name + ".")
+    with torch.no_grad():
+        y = pg(torch.tensor(d["xyz"]), 0)
+    assert y.shape == (1000, 30 if ta else 15)
+    np.testing.assert_allclose(y.numpy(), d[f"{name}.out"], rtol=1e-5, atol=1e-6)
+
+
+def _model_from_fixture(d):
+    from splatco_amd.scene_model import AnchorGaussianModel
+    pc = AnchorGaussianModel(feat_dim=32, n_offsets=int(d["n_offsets"]), appearance_dim=0, plane_size=40, num_channels=15)
+    _load_prefixed(pc.mlp_opacity, d, "mlp_opacity.")
+    _load_prefixed(pc.mlp_cov, d, "mlp_cov.")
+    _load_prefixed(pc.mlp_color, d, "mlp_color.")
+    _load_prefixed(pc.feat_planes, d, "feat_planes.")
+    pc.set_anchors(torch.tensor(d["anchor"]), torch.tensor(d["offset"]), torch.tensor(d["anchor_feat"]),
+                   torch.tensor(d["scaling"]))
+    pc.feat_planes.Q0 = 0
+    return pc
+
+
+@pytest.mark.parametrize("level", [0, 2])
+@pytest.mark.parametrize("training", [True, False])
+def test_generate_neural_gaussians(level, training):
+    from splatco_amd.renderer import generate_neural_gaussians
+    d = _npz("neural_gaussians.npz")
+    pc = _model_from_fixture(d)
+    pc.feat_planes._feat.activate_level = level
+    pc.train(training)
+    cam = types.SimpleNamespace(camera_center=torch.tensor(d["camera_center"]), uid=0)
+    with torch.no_grad():
+        res = generate_neural_gaussians(cam, pc, torch.tensor(d["visible_mask"]), is_training=training)
+    names = ["xyz", "color", "opacity", "scaling", "rot", "neural_opacity", "mask"][:len(res)]
+    tag = f"L{level}_{'train' if training else 'eval'}"
+    assert len(res) == (7 if training else 5)
+    for n, v in zip(names, res):
+        want = d[f"{tag}.{n}"]
+        assert tuple(v.shape) == want.shape, n
+        if v.dtype == torch.bool:
+            np.testing.assert_array_equal(v.numpy(), want)
+        else:
+            np.testing.assert_allclose(v.numpy(), want, rtol=2e-5, atol=2e-6, err_msg=n)
+
+
+def test_training_statis():
+    from splatco_amd.stats import training_statis
+    d = _npz("training_statis.npz")
+    k = int(d["n_offsets"])
+    Nn = d["anchor_visible_mask"].shape[0]
+    acc = [torch.zeros(Nn, 1), torch.zeros(Nn, 1), torch.zeros(Nn * k, 1), torch.zeros(Nn * k, 1)]
+    out = training_statis(*acc, k, torch.tensor(d["viewspace_grad"]), torch.tensor(d["neural_opacity"]),
+                          torch.tensor(d["update_filter"]), torch.tensor(d["offset_selection_mask"]),
+                          torch.tensor(d["anchor_visible_mask"]))
+    for got, name in zip(out, ["opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"]):
+        np.testing.assert_allclose(got.numpy(), d[name], rtol=1e-6, atol=1e-7)

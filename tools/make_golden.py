@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference's own Python
+(/root/reference, build container only -- the GPU box has no reference) and recording seeded
+inputs -> outputs.  Only arrays are written; no reference source text is stored.
+
+Recipe = SURVEY.md Appendix B: stub the native modules that are absent from the reference tree
+(diff_gaussian_rasterization, torch_scatter, simple_knn._C, plyfile, cv2, _gridcreater,
+_gridencoder, kornia, jaxtyping), make .cuda() the identity, and patch the one helper that
+hard-codes device='cuda' (FeaturePlanes.get_offsets, scene/gaussian_model.py:171-180).
+
+Fixtures (all float32 / int, a few hundred KB in total):
+  cameras.npz    getWorld2View2 / getProjectionMatrix / camera tensors for 3 seeded poses
+                 (utils/graphics_utils.py:38-71, scene/cameras.py:54-58)
+  losses.npz     l1_loss / ssim / psnr on seeded [3,64,64] pairs (utils/loss_utils.py, utils/image_utils.py)
+  planegrid.npz  PlaneGrid with and without TriPlaneAttention, [1000,3] -> [1000,15] / [1000,30]
+                 (scene/grids.py:102-201)
+  neural_gaussians.npz  generate_neural_gaussians, N=512 anchors, plane_size=40, num_channels=15,
+                 appearance_dim=0, Q0=0, train and eval variants, activate_level 0 and 2
+                 (gaussian_renderer/__init__.py:18-116) + every state_dict it needs
+  training_statis.npz  GaussianModel.training_statis on small seeded masks (scene/gaussian_model.py:761-782)
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def install_stubs():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+    class _Shaped:
+        def __class_getitem__(cls, item):
+            return cls
+
+    stub("diff_gaussian_rasterization", GaussianRasterizationSettings=_Dummy, GaussianRasterizer=_Dummy)
+    stub("torch_scatter", scatter_max=None)
+    stub("simple_knn")
+    stub("simple_knn._C", distCUDA2=None)
+    stub("plyfile", PlyData=_Dummy, PlyElement=_Dummy)
+    stub("cv2")
+    stub("_gridcreater")
+    stub("_gridencoder")
+    stub("kornia", create_meshgrid=None)
+    stub("jaxtyping", Shaped=_Shaped)
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+def f32(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def sd_np(prefix, module):
+    return {f"{prefix}{k}": v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+def make_cameras():
+    gu = _load("utils/graphics_utils.py", "ref_graphics_utils")
+    rng = np.random.default_rng(0)
+    out = {}
+    for i in range(3):
+        q = rng.standard_normal(4)
+        q /= np.linalg.norm(q)
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        T = rng.uniform(-2, 2, 3)
+        trans = rng.uniform(-0.5, 0.5, 3) if i == 2 else np.zeros(3)
+        scale = 1.5 if i == 2 else 1.0
+        fovx, fovy = float(rng.uniform(0.6, 1.4)), float(rng.uniform(0.5, 1.2))
+        w2v = gu.getWorld2View2(R, T, trans, scale)
+        proj = gu.getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy)
+        wvt = torch.tensor(w2v).transpose(0, 1)                       # scene/cameras.py:54
+        pm = proj.transpose(0, 1)                                     # :55
+        full = wvt.unsqueeze(0).bmm(pm.unsqueeze(0)).squeeze(0)       # :56
+        center = wvt.inverse()[3, :3]                                 # :58
+        out.update({f"R{i}": R, f"T{i}": T, f"trans{i}": trans, f"scale{i}": np.float64(scale),
+                    f"fovx{i}": np.float64(fovx), f"fovy{i}": np.float64(fovy), f"w2v{i}": w2v,
+                    f"proj{i}": f32(proj), f"world_view_transform{i}": f32(wvt),
+                    f"full_proj_transform{i}": f32(full), f"camera_center{i}": f32(center)})
+    pts = torch.tensor(rng.standard_normal((20, 3)), dtype=torch.float32)
+    out["points"] = f32(pts)
+    out["points_ndc0"] = f32(gu.geom_transform_points(pts, torch.tensor(out["full_proj_transform0"])))
+    np.savez_compressed(os.path.join(OUT, "cameras.npz"), **out)
+
+
+def make_losses():
+    lu = _load("utils/loss_utils.py", "ref_loss_utils")
+    iu = _load("utils/image_utils.py", "ref_image_utils")
+    g = torch.Generator().manual_seed(0)
+    out = {}
+    for i in range(3):
+        a = torch.rand(3, 64, 64, generator=g)
+        b = (a + 0.1 * (i + 1) * torch.randn(3, 64, 64, generator=g)).clamp(0, 1)
+        out.update({f"a{i}": f32(a), f"b{i}": f32(b), f"l1_{i}": f32(lu.l1_loss(a, b)), f"ssim_{i}": f32(lu.ssim(a, b)),
+                    f"psnr_{i}": f32(iu.psnr(a, b))})
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), **out)
+
+
+def make_planegrid():
+    grids = _load("scene/grids.py", "ref_grids")
+    out = {}
+    g = torch.Generator().manual_seed(1)
+    xyz = (torch.rand(1000, 3, generator=g) * 4.4 - 2.2)     # some samples fall outside [-2,2] (zeros padding)
+    out["xyz"] = f32(xyz)
+    for name, ta in (("plain", False), ("ta", True)):
+        torch.manual_seed(2)
+        pg = grids.PlaneGrid(15, [24, 24, 24], [-2.0, -2.0, -2.0], [2.0, 2.0, 2.0], config={"factor": 1}, TAflag=ta)
+        with torch.no_grad():
+            y = pg(xyz, 0)
+        out.update(sd_np(f"{name}.", pg))
+        out[f"{name}.out"] = f32(y)
+    np.savez_compressed(os.path.join(OUT, "planegrid.npz"), **out)
+
+
+def make_neural_gaussians():
+    import scene.gaussian_model as gm
+    import gaussian_renderer as gr
+    from arguments import ModelParams
+
+    def get_offsets_cpu(self, resolutions_list, dim=3):
+        offsets_list, offsets = [0], 0
+        for r in resolutions_list:
+            offsets += r ** dim
+            offsets_list.append(offsets)
+        return torch.tensor(resolutions_list, dtype=torch.int), torch.tensor(offsets_list, dtype=torch.int)
+
+    gm.FeaturePlanes.get_offsets = get_offsets_cpu
+    parser = argparse.ArgumentParser()
+    mp = ModelParams(parser)
+    args = parser.parse_args(["--num_channels", "15", "--plane_size", "40", "--appearance_dim", "0"])
+    ds = mp.extract(args)
+    torch.manual_seed(0)
+    pc = gm.GaussianModel(ds.feat_dim, ds.n_offsets, ds.voxel_size, ds.update_depth, ds.update_init_factor,
+                          ds.update_hierachy_factor, ds.use_feat_bank, ds.appearance_dim, ds.ratio,
+                          ds.add_opacity_dist, ds.add_cov_dist, ds.add_color_dist, model_params=ds)
+    N, k = 512, ds.n_offsets
+    g = torch.Generator().manual_seed(3)
+    pc._anchor = (torch.rand(N, 3, generator=g) * 3.6 - 1.8)
+    pc._offset = torch.randn(N, k, 3, generator=g) * 0.5
+    pc._anchor_feat = torch.randn(N, 32, generator=g) * 0.5
+    pc._scaling = torch.randn(N, 6, generator=g) * 0.3 - 3.0
+    pc.feat_planes.Q0 = 0                     # render.py:79 -- no plane noise
+    # non-trivial MLP / BN parameters so that the opacity mask is mixed
+    with torch.no_grad():
+        for m in list(pc.mlp_opacity) + list(pc.mlp_cov) + list(pc.mlp_color):
+            if isinstance(m, torch.nn.Linear):
+                m.weight.mul_(3.0)
+    cam = types.SimpleNamespace(camera_center=torch.tensor([0.3, -0.2, -4.5]), uid=0)
+    vis = torch.rand(N, generator=g) > 0.25
+    out = {"anchor": f32(pc._anchor), "offset": f32(pc._offset), "anchor_feat": f32(pc._anchor_feat),
+           "scaling": f32(pc._scaling), "camera_center": f32(cam.camera_center), "visible_mask": vis.numpy(),
+           "n_offsets": np.int64(k)}
+    out.update(sd_np("mlp_opacity.", pc.mlp_opacity))
+    out.update(sd_np("mlp_cov.", pc.mlp_cov))
+    out.update(sd_np("mlp_color.", pc.mlp_color))
+    fp = {f"feat_planes.{kk}": v for kk, v in
+          ((kk, v.detach().cpu().numpy()) for kk, v in pc.feat_planes.state_dict().items())
+          if "num_batches_tracked" not in kk}
+    out.update(fp)
+    names = ["xyz", "color", "opacity", "scaling", "rot", "neural_opacity", "mask"]
+    for level in (0, 2):
+        pc.feat_planes._feat.activate_level = level
+        for training in (True, False):
+            # BatchNorm layers stay in train mode: outputs depend on the batch
+            pc.mlp_opacity.train(training); pc.mlp_cov.train(training); pc.mlp_color.train(training)
+            with torch.no_grad():
+                res = gr.generate_neural_gaussians(cam, pc, vis, is_training=training)
+            tag = f"L{level}_{'train' if training else 'eval'}"
+            for nme, v in zip(names, res):
+                out[f"{tag}.{nme}"] = v.numpy() if v.dtype == torch.bool else f32(v)
+    np.savez_compressed(os.path.join(OUT, "neural_gaussians.npz"), **out)
+
+    # ---- training_statis (scene/gaussian_model.py:761-782) on the same model object
+    g = torch.Generator().manual_seed(5)
+    Nn = 40
+    pc.opacity_accum = torch.zeros(Nn, 1)
+    pc.anchor_demon = torch.zeros(Nn, 1)
+    pc.offset_gradient_accum = torch.zeros(Nn * k, 1)
+    pc.offset_denom = torch.zeros(Nn * k, 1)
+    anchor_vis = torch.rand(Nn, generator=g) > 0.4
+    V = int(anchor_vis.sum())
+    neural_opacity = torch.randn(V * k, 1, generator=g)
+    sel = (neural_opacity > 0).view(-1)
+    P = int(sel.sum())
+    update_filter = torch.rand(P, generator=g) > 0.3
+    vsp = types.SimpleNamespace(grad=torch.randn(P, 3, generator=g))
+    pc.training_statis(vsp, neural_opacity, update_filter, sel, anchor_vis)
+    np.savez_compressed(os.path.join(OUT, "training_statis.npz"), anchor_visible_mask=anchor_vis.numpy(),
+                        neural_opacity=f32(neural_opacity), offset_selection_mask=sel.numpy(),
+                        update_filter=update_filter.numpy(), viewspace_grad=f32(vsp.grad), n_offsets=np.int64(k),
+                        opacity_accum=f32(pc.opacity_accum), anchor_demon=f32(pc.anchor_demon),
+                        offset_gradient_accum=f32(pc.offset_gradient_accum), offset_denom=f32(pc.offset_denom))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    install_stubs()
+    make_cameras()
+    make_losses()
+    make_planegrid()
+    make_neural_gaussians()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
