@@ -75,30 +75,68 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(uint32_t nblk, uint32_t
 }
 
 // ------------------------------------------------------------------ scatter into tile segments
-__global__ void __launch_bounds__(PRE_BLOCK)
-scatter_kernel(int64_t P, int gx, const float4* __restrict__ rec, const uint32_t* __restrict__ tiles_touched,
-               const uint32_t* __restrict__ block_prefix, uint32_t* __restrict__ point_offsets,
-               const uint32_t* __restrict__ ranges, uint32_t* __restrict__ cursor,
-               unsigned long long* __restrict__ keys, uint32_t* __restrict__ inst_slot) {
-    __shared__ uint32_t lds[PRE_BLOCK / WAVE + 1];
-    int64_t i = (int64_t)blockIdx.x * PRE_BLOCK + threadIdx.x;
-    uint32_t tt = i < P ? tiles_touched[i] : 0u, tot;
-    uint32_t off = block_prefix[blockIdx.x] + block_exclusive_scan<PRE_BLOCK>(tt, lds, tot);
-    if (i >= P) return;
-    point_offsets[i] = off + tt;  // inclusive, as in the reference semantics
-    if (!tt) return;
-    float4 r2 = rec[3 * i + 2];
-    uint32_t dbits = __float_as_uint(r2.y), rlo = __float_as_uint(r2.z), rhi = __float_as_uint(r2.w);
-    int minx = rlo & 0xffff, miny = rlo >> 16, maxx = rhi & 0xffff, maxy = rhi >> 16;
-    unsigned long long key = ((unsigned long long)dbits << 32) | (uint32_t)i;
-    uint32_t k = off;
-    for (int ty = miny; ty < maxy; ++ty)
-        for (int tx = minx; tx < maxx; ++tx) {
-            uint32_t t = (uint32_t)(ty * gx + tx);
-            uint32_t slot = ranges[2 * t] + atomicAdd(&cursor[t], 1u);
-            keys[slot] = key;
-            inst_slot[k++] = slot;
+// Same workgroup shape as the preprocess kernel (1024 threads x 4 Gaussians, in index order).
+// LDS_HIST: the workgroup counts its instances per tile in LDS, reserves a contiguous run of
+// each tile's segment with ONE returning global atomic per touched tile, then hands out the
+// slots of the run with returning LDS atomics.  Slot order inside a segment is arbitrary either
+// way; the tile sort restores the canonical (depth, id) order.
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(BIN_THREADS)
+scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec,
+               const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
+               uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ ranges,
+               uint32_t* __restrict__ cursor, unsigned long long* __restrict__ keys,
+               uint32_t* __restrict__ inst_slot) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // [tiles] when LDS_HIST
+    __shared__ uint32_t lds[BIN_THREADS / WAVE + 1];
+    if (LDS_HIST) {
+        for (int t = threadIdx.x; t < tiles; t += BIN_THREADS) hist[t] = 0;
+        __syncthreads();
+    }
+    uint32_t off[BIN_ROUNDS], tts[BIN_ROUNDS], rlo[BIN_ROUNDS], rhi[BIN_ROUNDS], dbits[BIN_ROUNDS];
+    uint32_t carry = block_prefix[blockIdx.x];
+#pragma unroll
+    for (int r = 0; r < BIN_ROUNDS; ++r) {
+        const int64_t i = (int64_t)blockIdx.x * BIN_GPW + r * BIN_THREADS + threadIdx.x;
+        const uint32_t tt = i < P ? tiles_touched[i] : 0u;
+        uint32_t tot;
+        off[r] = carry + block_exclusive_scan<BIN_THREADS>(tt, lds, tot);
+        carry += tot;
+        tts[r] = tt;
+        rlo[r] = rhi[r] = dbits[r] = 0;
+        if (i < P) point_offsets[i] = off[r] + tt;  // inclusive, as in the reference semantics
+        if (tt) {
+            const float4 r2 = rec[3 * i + 2];
+            dbits[r] = __float_as_uint(r2.y);
+            rlo[r] = __float_as_uint(r2.z);
+            rhi[r] = __float_as_uint(r2.w);
+            if (LDS_HIST)
+                for (int ty = rlo[r] >> 16; ty < (int)(rhi[r] >> 16); ++ty)
+                    for (int tx = rlo[r] & 0xffff; tx < (int)(rhi[r] & 0xffff); ++tx) atomicAdd(&hist[ty * gx + tx], 1u);
         }
+    }
+    if (LDS_HIST) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < tiles; t += BIN_THREADS) {
+            const uint32_t c = hist[t];
+            if (c) hist[t] = ranges[2 * t] + atomicAdd(&cursor[t], c);  // first slot of this workgroup's run
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < BIN_ROUNDS; ++r) {
+        if (!tts[r]) continue;
+        const int64_t i = (int64_t)blockIdx.x * BIN_GPW + r * BIN_THREADS + threadIdx.x;
+        const unsigned long long key = ((unsigned long long)dbits[r] << 32) | (uint32_t)i;
+        uint32_t k = off[r];
+        for (int ty = rlo[r] >> 16; ty < (int)(rhi[r] >> 16); ++ty)
+            for (int tx = rlo[r] & 0xffff; tx < (int)(rhi[r] & 0xffff); ++tx) {
+                const uint32_t t = (uint32_t)(ty * gx + tx);
+                const uint32_t slot = LDS_HIST ? atomicAdd(&hist[t], 1u) : ranges[2 * t] + atomicAdd(&cursor[t], 1u);
+                keys[slot] = key;
+                inst_slot[k++] = slot;
+            }
+    }
 }
 
 // ------------------------------------------------------------------ per-tile sort
@@ -220,7 +258,7 @@ tile_sort_global_kernel(int tiles, int gx, uint32_t lower, const uint32_t* __res
 // ------------------------------------------------------------------ launchers
 void launch_plan_scans(int64_t P, const KSettings& ks, const GeomView& gv, hipStream_t st) {
     Grid g(ks.H, ks.W);
-    uint32_t nb = (uint32_t)((P + PRE_BLOCK - 1) / PRE_BLOCK);
+    uint32_t nb = (uint32_t)((P + BIN_GPW - 1) / BIN_GPW);
     plan_scan_kernel<<<2, 1024, 0, st>>>(nb, gv.block_sums, gv.total, (uint32_t)g.tiles, gv.tile_count,
                                          gv.ranges, gv.cursor);
 }
@@ -228,9 +266,15 @@ void launch_plan_scans(int64_t P, const KSettings& ks, const GeomView& gv, hipSt
 void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const BinView& bv, hipStream_t st) {
     if (P <= 0) return;
     Grid g(ks.H, ks.W);
-    scatter_kernel<<<(unsigned)((P + PRE_BLOCK - 1) / PRE_BLOCK), PRE_BLOCK, 0, st>>>(
-        P, g.gx, gv.rec, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor, bv.keys,
-        bv.inst_slot);
+    const unsigned nb = (unsigned)((P + BIN_GPW - 1) / BIN_GPW);
+    if (g.tiles <= LDS_HIST_MAX_TILES)
+        scatter_kernel<true><<<nb, BIN_THREADS, (size_t)g.tiles * 4, st>>>(
+            P, g.gx, g.tiles, gv.rec, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor,
+            bv.keys, bv.inst_slot);
+    else
+        scatter_kernel<false><<<nb, BIN_THREADS, 0, st>>>(
+            P, g.gx, g.tiles, gv.rec, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor,
+            bv.keys, bv.inst_slot);
 }
 
 void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, hipStream_t st) {

@@ -12,7 +12,11 @@ constexpr int TILE = SCR_TILE;          // 16x16 pixels
 constexpr int TILE_PIX = TILE * TILE;   // 256
 constexpr int WAVE = 64;                // CDNA wavefront
 constexpr int NUM_XCD = 8;
-constexpr int PRE_BLOCK = 256;          // Gaussians per preprocess / scatter / reduce workgroup
+constexpr int PRE_BLOCK = 256;          // Gaussians per preprocess-backward workgroup
+constexpr int BIN_THREADS = 1024;       // threads of a preprocess / scatter workgroup
+constexpr int BIN_ROUNDS = 4;           // Gaussians per thread
+constexpr int BIN_GPW = BIN_THREADS * BIN_ROUNDS;  // Gaussians per preprocess / scatter workgroup
+constexpr int LDS_HIST_MAX_TILES = 16000;          // per-tile LDS histogram (4 B / tile) must fit 64 KB
 constexpr int REC_F = 12;               // floats per splat record (48 B, three float4)
 constexpr int GRAD_F = 12;              // floats per per-instance gradient record (9 used)
 
@@ -30,7 +34,7 @@ struct GeomView {
     uint32_t* tiles_touched;  // [P]
     uint32_t* point_offsets;  // [P] inclusive scan of tiles_touched (written by the scatter kernel)
     uint8_t* clamped;         // [P] bit c set when SH colour channel c was clamped at 0
-    uint32_t* block_sums;     // [ceil(P/PRE_BLOCK)] -> exclusive prefix after scan
+    uint32_t* block_sums;     // [ceil(P/BIN_GPW)] -> exclusive prefix after scan
     uint32_t* tile_count;     // [tiles]
     uint32_t* ranges;         // [tiles][2] (start, end)
     uint32_t* cursor;         // [tiles]
@@ -44,7 +48,7 @@ inline __host__ GeomView geom_view(void* base, int64_t P, int H, int W) {
     size_t off = 0;
     GeomView v;
     auto take = [&](size_t n) { char* q = p ? p + off : nullptr; off += align_up(n); return q; };
-    size_t nblk = (size_t)((P + PRE_BLOCK - 1) / PRE_BLOCK);
+    size_t nblk = (size_t)((P + BIN_GPW - 1) / BIN_GPW);
     v.rec = (float4*)take((size_t)P * REC_F * 4);
     v.tiles_touched = (uint32_t*)take((size_t)P * 4);
     v.point_offsets = (uint32_t*)take((size_t)P * 4);

@@ -218,20 +218,35 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float* __restrict__ sh,
 }
 
 // ------------------------------------------------------------------ forward preprocess
-// Writes radii, the 48-byte splat record, tiles_touched; bumps the per-tile instance counters
-// (integer atomics, no return value); leaves the workgroup's tiles_touched sum in block_sums.
-__global__ void __launch_bounds__(PRE_BLOCK)
+// Writes radii, the 48-byte splat record, tiles_touched; counts instances per tile; leaves the
+// workgroup's tiles_touched sum in block_sums.
+//
+// Per-tile counting: device integer atomics run at ~28 G/s on MI355X whatever their scope
+// (tools/exp/atomics_probe.hip), so a workgroup of 1024 threads x 4 Gaussians first counts into an
+// LDS histogram of all tiles (ds_add_u32) and then issues ONE global atomic per tile it touched
+// (LDS_HIST; ~2.5x fewer global atomics at the benchmark density, far fewer for coherent scenes
+// and large splats).  Images with more than LDS_HIST_MAX_TILES tiles count directly in global memory.
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(BIN_THREADS)
 preprocess_kernel(int64_t P, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
                   const float* __restrict__ rotations, const float* __restrict__ cov3D,
                   const float* __restrict__ opacities, const float* __restrict__ shs,
-                  const float* __restrict__ colors, KSettings ks, float4* __restrict__ rec,
+                  const float* __restrict__ colors, KSettings ks, int tiles, float4* __restrict__ rec,
                   uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped,
                   uint32_t* __restrict__ block_sums, uint32_t* __restrict__ tile_count,
                   int32_t* __restrict__ radii) {
-    __shared__ uint32_t wave_sum[PRE_BLOCK / WAVE];
-    int64_t i = (int64_t)blockIdx.x * PRE_BLOCK + threadIdx.x;
-    uint32_t tt = 0;
-    if (i < P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // [tiles] when LDS_HIST
+    __shared__ uint32_t wave_sum[BIN_THREADS / WAVE];
+    if (LDS_HIST) {
+        for (int t = threadIdx.x; t < tiles; t += BIN_THREADS) hist[t] = 0;
+        __syncthreads();
+    }
+    const int gx = (ks.W + TILE - 1) / TILE;
+    uint32_t tsum = 0;
+    for (int r = 0; r < BIN_ROUNDS; ++r) {
+        const int64_t i = (int64_t)blockIdx.x * BIN_GPW + r * BIN_THREADS + threadIdx.x;
+        if (i >= P) break;
+        uint32_t tt = 0;
         Proj ps;
         Foot ft;
         bool vis = project(i, means3D, scales, rotations, cov3D, ks, ps, ft);
@@ -259,29 +274,35 @@ preprocess_kernel(int64_t P, int M, const float* __restrict__ means3D, const flo
             rec[3 * i + 1] = make_float4(-0.5f * Qyy, opacities[i], rgb[0], rgb[1]);
             rec[3 * i + 2] = make_float4(rgb[2], ps.t[2], __uint_as_float(rlo), __uint_as_float(rhi));
             radii[i] = ft.radius;
-            int gx = (ks.W + TILE - 1) / TILE;
-#ifndef SCR_EXP_NO_COUNT_ATOMICS
             for (int ty = ft.rminy; ty < ft.rmaxy; ++ty)
-                for (int tx = ft.rminx; tx < ft.rmaxx; ++tx) atomicAdd(&tile_count[ty * gx + tx], 1u);
-#endif
+                for (int tx = ft.rminx; tx < ft.rmaxx; ++tx) {
+                    if (LDS_HIST) atomicAdd(&hist[ty * gx + tx], 1u);
+                    else atomicAdd(&tile_count[ty * gx + tx], 1u);
+                }
         } else {
             radii[i] = 0;
             if (clamped) clamped[i] = 0;
         }
         tiles_touched[i] = tt;
+        tsum += tt;
     }
-    // workgroup sum of tiles_touched (wave reduction, then 4 partials through LDS)
-    uint32_t s = tt;
+    // workgroup sum of tiles_touched (wave reduction, then the wave partials through LDS)
+    uint32_t s = tsum;
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) s += __shfl_down(s, d, WAVE);
     if ((threadIdx.x & (WAVE - 1)) == 0) wave_sum[threadIdx.x / WAVE] = s;
-    __syncthreads();
+    __syncthreads();  // also: every LDS histogram update of the workgroup is done
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
 #pragma unroll
-        for (int w = 0; w < PRE_BLOCK / WAVE; ++w) tot += wave_sum[w];
+        for (int w = 0; w < BIN_THREADS / WAVE; ++w) tot += wave_sum[w];
         block_sums[blockIdx.x] = tot;
     }
+    if (LDS_HIST)
+        for (int t = threadIdx.x; t < tiles; t += BIN_THREADS) {
+            const uint32_t c = hist[t];
+            if (c) atomicAdd(&tile_count[t], c);
+        }
 }
 
 // ------------------------------------------------------------------ backward: reduce + chain
@@ -520,9 +541,15 @@ void launch_preprocess(int64_t P, int M, const float* means3D, const float* scal
                        const float* cov3D, const float* opacities, const float* shs, const float* colors,
                        const KSettings& ks, const GeomView& gv, int32_t* radii, hipStream_t st) {
     if (P <= 0) return;
-    preprocess_kernel<<<nblk(P, PRE_BLOCK), PRE_BLOCK, 0, st>>>(
-        P, M, means3D, scales, rotations, cov3D, opacities, shs, colors, ks, gv.rec, gv.tiles_touched,
-        shs ? gv.clamped : nullptr, gv.block_sums, gv.tile_count, radii);
+    Grid g(ks.H, ks.W);
+    if (g.tiles <= LDS_HIST_MAX_TILES)
+        preprocess_kernel<true><<<nblk(P, BIN_GPW), BIN_THREADS, (size_t)g.tiles * 4, st>>>(
+            P, M, means3D, scales, rotations, cov3D, opacities, shs, colors, ks, g.tiles, gv.rec, gv.tiles_touched,
+            shs ? gv.clamped : nullptr, gv.block_sums, gv.tile_count, radii);
+    else
+        preprocess_kernel<false><<<nblk(P, BIN_GPW), BIN_THREADS, 0, st>>>(
+            P, M, means3D, scales, rotations, cov3D, opacities, shs, colors, ks, g.tiles, gv.rec, gv.tiles_touched,
+            shs ? gv.clamped : nullptr, gv.block_sums, gv.tile_count, radii);
 }
 
 void launch_preprocess_backward(int64_t P, int M, const float* means3D, const float* scales,
