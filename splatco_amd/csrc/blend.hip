@@ -221,7 +221,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                       float4* __restrict__ grad_rec) {
     __shared__ float4 s0[4][BCH], s1[4][BCH];  // wave-private compacted records of the round
     __shared__ float2 s2[4][BCH];              // (blue, position in round)
-    __shared__ float4 acc[4][BCH][3];          // per-wave sums per position (9 of 12 floats used)
+    __shared__ float4 acc[2][4][BCH][3];       // [round parity][wave]: sums per position (9 of 12 floats used)
     __shared__ uint32_t wave_max[4];
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
@@ -309,7 +309,10 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         const uint32_t m_this = m_cur, slot_this = slot_cur;
         gather(ci - 1, m_next, id_next, slot_next);
         load_meta(ci - 2, m_next, id_next, slot_next);
-        __syncthreads();  // A: the previous round's combine has read acc
+        // acc is double-buffered by round parity: this round's writes cannot collide with the
+        // previous round's combine, so ONE barrier per round suffices (a wave reaches the writes of
+        // round r+2 only after barrier B of round r+1, which every wave passes after its combine of r)
+        float4 (*accw)[BCH][3] = acc[ci & 1];
         for (int k = cnt - 1; k >= 0; k -= 4) {  // back to front, four splats per reduction
             float g[4][9];
             uint32_t jj[4];
@@ -348,9 +351,9 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             const int row = lane >> 4;
             const uint32_t jw = row == 0 ? jj[0] : row == 1 ? jj[2] : row == 2 ? jj[1] : jj[3];
             if ((lane & 15) == 15 && jw != 0xffffffffu) {  // every listed position is written
-                acc[wave][jw][0] = make_float4(r[0], r[1], r[2], r[3]);
-                acc[wave][jw][1] = make_float4(r[4], r[5], r[6], r[7]);
-                acc[wave][jw][2] = make_float4(r[8], 0.0f, 0.0f, 0.0f);
+                accw[wave][jw][0] = make_float4(r[0], r[1], r[2], r[3]);
+                accw[wave][jw][1] = make_float4(r[4], r[5], r[6], r[7]);
+                accw[wave][jw][2] = make_float4(r[8], 0.0f, 0.0f, 0.0f);
             }
         }
         __syncthreads();  // B: every wave's sums for this round are in acc
@@ -359,10 +362,10 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         if (wave < 3 && base + lane < n) {
             const uint32_t i = base + lane;
             float4 r = make_float4(0, 0, 0, 0);
-            if (((m_this >> 0) & 1u) && i < wmax0) { const float4 x = acc[0][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
-            if (((m_this >> 1) & 1u) && i < wmax1) { const float4 x = acc[1][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
-            if (((m_this >> 2) & 1u) && i < wmax2) { const float4 x = acc[2][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
-            if (((m_this >> 3) & 1u) && i < wmax3) { const float4 x = acc[3][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
+            if (((m_this >> 0) & 1u) && i < wmax0) { const float4 x = accw[0][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
+            if (((m_this >> 1) & 1u) && i < wmax1) { const float4 x = accw[1][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
+            if (((m_this >> 2) & 1u) && i < wmax2) { const float4 x = accw[2][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
+            if (((m_this >> 3) & 1u) && i < wmax3) { const float4 x = accw[3][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
             grad_rec[3 * (size_t)slot_this + wave] = r;
         }
     }
