@@ -116,8 +116,10 @@ int scr_debug_get(int which, int64_t P, int64_t num_rendered, int32_t image_heig
                   void* stream);
 
 /* ---- opt-in kernel timing (bench / profiling only; process-global, off by default).
- * While enabled, every kernel launch of this library is bracketed by hipEventRecord on the
- * launch stream.  scr_profile_read() waits for the recorded events, ADDS the elapsed time and
+ * scr_profile_enable(mask): bit i of mask selects kernel class i (SCR_PROF_*); -1 = all, 0 = off.
+ * Launches of the selected classes are bracketed by hipEventRecord on the launch stream (each
+ * event pair costs a few microseconds of stream time, so a benchmark times only the class it
+ * reports).  scr_profile_read() waits for the recorded events, ADDS the elapsed time and
  * launch count of each kernel class since the last read into total_ms[SCR_PROF_COUNT] /
  * launches[SCR_PROF_COUNT], and resets. */
 enum {
@@ -125,7 +127,7 @@ enum {
     SCR_PROF_TILE_SORT = 4, SCR_PROF_BLEND_FORWARD = 5, SCR_PROF_BLEND_BACKWARD = 6,
     SCR_PROF_PREPROCESS_BACKWARD = 7, SCR_PROF_COUNT = 8
 };
-int scr_profile_enable(int on);
+int scr_profile_enable(int mask);
 int scr_profile_read(double* total_ms, int64_t* launches);
 const char* scr_profile_kernel_name(int idx);
 

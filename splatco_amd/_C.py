@@ -78,8 +78,14 @@ def _load():
 lib = _load()
 
 
-def profile_enable(on):
-    lib.scr_profile_enable(int(bool(on)))
+def profile_enable(which):
+    """True / -1: time every kernel class; False / 0: off; a kernel name: only that class."""
+    if isinstance(which, str):
+        names = [lib.scr_profile_kernel_name(i).decode() for i in range(PROF_COUNT)]
+        mask = 1 << names.index(which)
+    else:
+        mask = -1 if which is True or which == -1 else int(which)
+    lib.scr_profile_enable(mask)
 
 
 def profile_read():

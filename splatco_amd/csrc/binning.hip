@@ -4,7 +4,8 @@
 // Here the same ordered lists are produced MI355X-style in two HBM passes:
 //   1. bucket:  per-tile instance counts (integer atomics fused into the preprocess kernel) ->
 //               exclusive scan -> every instance is dropped into its tile's segment
-//               (key = depth_bits << 32 | gaussian id).  Slot order inside a segment is arbitrary.
+//               (key = depth_bits << 32 | gaussian id << 4 | quadrant mask; payload = the instance's
+//               Gaussian-major index).  Slot order inside a segment is arbitrary.
 //   2. sort:    one workgroup per tile sorts its segment by the 64-bit key in LDS (bitonic
 //               network, 160 KiB LDS lets a 8192-instance tile stay on chip).  Sorting by
 //               (depth, id) reproduces the stable (tile, depth) order of the reference semantics,
@@ -86,7 +87,7 @@ scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec,
                const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
                uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ ranges,
                uint32_t* __restrict__ cursor, unsigned long long* __restrict__ keys,
-               uint32_t* __restrict__ inst_slot) {
+               uint32_t* __restrict__ upay) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // [tiles] when LDS_HIST
     __shared__ uint32_t lds[BIN_THREADS / WAVE + 1];
     if (LDS_HIST) {
@@ -127,14 +128,15 @@ scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec,
     for (int r = 0; r < BIN_ROUNDS; ++r) {
         if (!tts[r]) continue;
         const int64_t i = (int64_t)blockIdx.x * BIN_GPW + r * BIN_THREADS + threadIdx.x;
-        const unsigned long long key = ((unsigned long long)dbits[r] << 32) | (uint32_t)i;
-        uint32_t k = off[r];
+        const unsigned long long key = ((unsigned long long)dbits[r] << 32) | ((uint32_t)i << 4);
+        const float4 r0 = rec[3 * i], r1 = rec[3 * i + 1];
+        uint32_t k = off[r];  // Gaussian-major index of this Gaussian's first instance
         for (int ty = rlo[r] >> 16; ty < (int)(rhi[r] >> 16); ++ty)
             for (int tx = rlo[r] & 0xffff; tx < (int)(rhi[r] & 0xffff); ++tx) {
                 const uint32_t t = (uint32_t)(ty * gx + tx);
                 const uint32_t slot = LDS_HIST ? atomicAdd(&hist[t], 1u) : ranges[2 * t] + atomicAdd(&cursor[t], 1u);
-                keys[slot] = key;
-                inst_slot[k++] = slot;
+                keys[slot] = key | quadrant_mask(r0, r1, tx * TILE, ty * TILE);
+                upay[slot] = k++;
             }
     }
 }
@@ -162,10 +164,9 @@ __device__ __forceinline__ void ce_indices(uint32_t c, uint32_t k, uint32_t j, b
 // one launch per size class; a workgroup whose tile is not in the class exits at once).
 template <int CAP, int LOWER>
 __global__ void __launch_bounds__(256)
-tile_sort_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges,
-                 const unsigned long long* __restrict__ keys, const float4* __restrict__ rec,
-                 uint32_t* __restrict__ point_list, uint32_t* __restrict__ orig_slot,
-                 uint8_t* __restrict__ qmask) {
+tile_sort_kernel(int tiles, const uint32_t* __restrict__ ranges, const unsigned long long* __restrict__ keys,
+                 const uint32_t* __restrict__ upay, uint32_t* __restrict__ point_list,
+                 uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* sk = (unsigned long long*)smem;  // [CAP]
     uint32_t* sp = (uint32_t*)(smem + (size_t)CAP * 8);   // [CAP]
@@ -178,7 +179,7 @@ tile_sort_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges,
     while (m < n) m <<= 1;
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         sk[i] = keys[lo + i];
-        sp[i] = i;
+        sp[i] = upay[lo + i];
     }
     __syncthreads();
     for (uint32_t k = 2; k <= m; k <<= 1) {
@@ -200,23 +201,142 @@ tile_sort_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges,
             __syncthreads();
         }
     }
-    const int tx0 = (t % gx) * TILE, ty0 = (t / gx) * TILE;
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        uint32_t g = (uint32_t)sk[i];
-        point_list[lo + i] = g;
-        orig_slot[lo + i] = lo + sp[i];
-        qmask[lo + i] = (uint8_t)quadrant_mask(rec[3 * (size_t)g], rec[3 * (size_t)g + 1], tx0, ty0);
+        const uint32_t kl = (uint32_t)sk[i];
+        point_list[lo + i] = kl >> 4;
+        qmask[lo + i] = (uint8_t)(kl & 15u);
+        gm_index[lo + i] = sp[i];
     }
 }
 
+// ------------------------------------------------------------------ per-tile sort, one wave per tile
+// Tiles with at most 1024 instances (the common case) are sorted by ONE wave entirely in
+// registers: lane l holds E = m/64 elements (index i = l*E + e), m = 64..1024.  The bitonic
+// network's compare-exchanges at distance j < E are register-to-register; at distance j >= E the
+// partner sits in lane l ^ (j/E) and is fetched with DPP (quad_perm for lane distance 1, 2;
+// bank-masked row_shl/row_shr for 4, 8) or v_permlane16_swap / v_permlane32_swap (16, 32).  No
+// LDS, no barriers, no s_waitcnt inside the network -- the LDS version spends most of its time in
+// 55 barrier-separated steps.  Padding elements are +inf keys and sort to the end.
+template <int D>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {  // value of lane (l ^ D)
+    if constexpr (D == 1) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);  // quad_perm:[1,0,3,2]
+    } else if constexpr (D == 2) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);  // quad_perm:[2,3,0,1]
+    } else if constexpr (D == 4) {
+        int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xf, 0x5, false);  // row_shl:4 -> banks 0,2
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xf, 0xA, false);  // row_shr:4 -> banks 1,3
+    } else if constexpr (D == 8) {
+        int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x108, 0xf, 0x3, false);  // row_shl:8 -> banks 0,1
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x118, 0xf, 0xC, false);  // row_shr:8 -> banks 2,3
+    } else if constexpr (D == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // r[0] = (x0,x0,x2,x2), r[1] = (x1,x1,x3,x3)
+        return (threadIdx.x & 16) ? r[0] : r[1];
+    } else {
+        auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // r[0] = (lo,lo), r[1] = (hi,hi)
+        return (threadIdx.x & 32) ? r[0] : r[1];
+    }
+}
+
+template <int E, int K, int J>
+__device__ __forceinline__ void bitonic_step(uint32_t (&klo)[E], uint32_t (&khi)[E], uint32_t (&pay)[E], int lane) {
+    if constexpr (J < E) {  // partner in the same lane
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if ((e & J) != 0) continue;
+            const int f = e | J;
+            bool asc;
+            if constexpr (K < E) asc = (e & K) == 0;
+            else asc = (lane & (K / E)) == 0;  // K == 64*E: bit outside the lane range -> ascending
+            const unsigned long long a = ((unsigned long long)khi[e] << 32) | klo[e];
+            const unsigned long long b = ((unsigned long long)khi[f] << 32) | klo[f];
+            const bool sw = (a > b) == asc;
+            const uint32_t t0 = klo[e], t1 = khi[e], t2 = pay[e];
+            klo[e] = sw ? klo[f] : t0; khi[e] = sw ? khi[f] : t1; pay[e] = sw ? pay[f] : t2;
+            klo[f] = sw ? t0 : klo[f]; khi[f] = sw ? t1 : khi[f]; pay[f] = sw ? t2 : pay[f];
+        }
+    } else {  // partner in lane ^ (J / E)
+        constexpr int D = J / E;
+        const bool lower = (lane & D) == 0;
+        const bool asc = (lane & (K / E)) == 0;
+        const bool keep_min = lower == asc;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t olo = lane_xor<D>(klo[e]), ohi = lane_xor<D>(khi[e]), opay = lane_xor<D>(pay[e]);
+            const unsigned long long mine = ((unsigned long long)khi[e] << 32) | klo[e];
+            const unsigned long long theirs = ((unsigned long long)ohi << 32) | olo;
+            const bool take = keep_min ? (theirs < mine) : (theirs > mine);
+            klo[e] = take ? olo : klo[e];
+            khi[e] = take ? ohi : khi[e];
+            pay[e] = take ? opay : pay[e];
+        }
+    }
+}
+
+template <int E, int K, int J>
+__device__ __forceinline__ void bitonic_stage(uint32_t (&klo)[E], uint32_t (&khi)[E], uint32_t (&pay)[E], int lane) {
+    bitonic_step<E, K, J>(klo, khi, pay, lane);
+    if constexpr (J > 1) bitonic_stage<E, K, J / 2>(klo, khi, pay, lane);
+}
+template <int E, int K>
+__device__ __forceinline__ void bitonic_network(uint32_t (&klo)[E], uint32_t (&khi)[E], uint32_t (&pay)[E], int lane) {
+    bitonic_stage<E, K, K / 2>(klo, khi, pay, lane);
+    if constexpr (K < 64 * E) bitonic_network<E, K * 2>(klo, khi, pay, lane);
+}
+
+template <int E>
+__device__ __forceinline__ void wave_sort_tile(uint32_t lo, uint32_t n, const unsigned long long* __restrict__ keys,
+                                               const uint32_t* __restrict__ upay,
+                                               uint32_t* __restrict__ point_list, uint32_t* __restrict__ gm_index,
+                                               uint8_t* __restrict__ qmask) {
+    const int lane = threadIdx.x & 63;
+    uint32_t klo[E], khi[E], pay[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {  // coalesced load; the network does not care where an element starts
+        const uint32_t i = (uint32_t)e * 64 + lane;
+        const unsigned long long k = i < n ? keys[lo + i] : ~0ull;
+        klo[e] = (uint32_t)k;
+        khi[e] = (uint32_t)(k >> 32);
+        pay[e] = i < n ? upay[lo + i] : 0u;
+    }
+    bitonic_network<E, 2>(klo, khi, pay, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)lane * E + e;  // sorted position
+        if (i < n) {
+            point_list[lo + i] = klo[e] >> 4;
+            qmask[lo + i] = (uint8_t)(klo[e] & 15u);
+            gm_index[lo + i] = pay[e];
+        }
+    }
+}
+
+constexpr int WAVE_SORT_MAX = 1024;
+
+__global__ void __launch_bounds__(64)
+tile_sort_wave_kernel(int tiles, const uint32_t* __restrict__ ranges,
+                      const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ upay,
+                      uint32_t* __restrict__ point_list, uint32_t* __restrict__ gm_index,
+                      uint8_t* __restrict__ qmask) {
+    int t = xcd_tile(blockIdx.x, tiles);
+    if (t < 0) return;
+    const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
+    if (n == 0 || n > (uint32_t)WAVE_SORT_MAX) return;
+    if (n <= 64) wave_sort_tile<1>(lo, n, keys, upay, point_list, gm_index, qmask);
+    else if (n <= 128) wave_sort_tile<2>(lo, n, keys, upay, point_list, gm_index, qmask);
+    else if (n <= 256) wave_sort_tile<4>(lo, n, keys, upay, point_list, gm_index, qmask);
+    else if (n <= 512) wave_sort_tile<8>(lo, n, keys, upay, point_list, gm_index, qmask);
+    else wave_sort_tile<16>(lo, n, keys, upay, point_list, gm_index, qmask);
+}
+
 // Fallback for segments that do not fit the largest LDS class: the same network run in place on
-// global memory by one workgroup (rare: > 8192 instances in one 16x16 tile).  The payload lives
-// in orig_slot.  Data stays inside one workgroup, so workgroup-scope visibility suffices
+// global memory by one workgroup (rare: > 8192 instances in one 16x16 tile).  The payload is
+// sorted in place in upay.  Data stays inside one workgroup, so workgroup-scope visibility suffices
 // (__syncthreads orders this workgroup's global accesses through its own CU's L1/L2 path).
 __global__ void __launch_bounds__(256)
-tile_sort_global_kernel(int tiles, int gx, uint32_t lower, const uint32_t* __restrict__ ranges,
-                        unsigned long long* keys, const float4* __restrict__ rec,
-                        uint32_t* __restrict__ point_list, uint32_t* orig_slot, uint8_t* __restrict__ qmask) {
+tile_sort_global_kernel(int tiles, uint32_t lower, const uint32_t* __restrict__ ranges,
+                        unsigned long long* keys, uint32_t* upay, uint32_t* __restrict__ point_list,
+                        uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
     uint32_t lo = ranges[2 * t], hi = ranges[2 * t + 1];
@@ -225,9 +345,7 @@ tile_sort_global_kernel(int tiles, int gx, uint32_t lower, const uint32_t* __res
     uint32_t m = 1;
     while (m < n) m <<= 1;
     volatile unsigned long long* sk = keys + lo;
-    volatile uint32_t* sp = orig_slot + lo;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) sp[i] = lo + i;
-    __syncthreads();
+    volatile uint32_t* sp = upay + lo;  // payload sorted in place along with the keys
     for (uint32_t k = 2; k <= m; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t c = threadIdx.x; c < (m >> 1); c += 256) {
@@ -247,11 +365,11 @@ tile_sort_global_kernel(int tiles, int gx, uint32_t lower, const uint32_t* __res
             __syncthreads();
         }
     }
-    const int tx0 = (t % gx) * TILE, ty0 = (t / gx) * TILE;
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        uint32_t g = (uint32_t)sk[i];
-        point_list[lo + i] = g;
-        qmask[lo + i] = (uint8_t)quadrant_mask(rec[3 * (size_t)g], rec[3 * (size_t)g + 1], tx0, ty0);
+        const uint32_t kl = (uint32_t)sk[i];
+        point_list[lo + i] = kl >> 4;
+        qmask[lo + i] = (uint8_t)(kl & 15u);
+        gm_index[lo + i] = sp[i];
     }
 }
 
@@ -270,11 +388,11 @@ void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const Bi
     if (g.tiles <= LDS_HIST_MAX_TILES)
         scatter_kernel<true><<<nb, BIN_THREADS, (size_t)g.tiles * 4, st>>>(
             P, g.gx, g.tiles, gv.rec, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor,
-            bv.keys, bv.inst_slot);
+            bv.keys, bv.upay);
     else
         scatter_kernel<false><<<nb, BIN_THREADS, 0, st>>>(
             P, g.gx, g.tiles, gv.rec, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor,
-            bv.keys, bv.inst_slot);
+            bv.keys, bv.upay);
 }
 
 void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, hipStream_t st) {
@@ -286,14 +404,13 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
                             8192 * 12);
         attr_set = true;
     }
-    tile_sort_kernel<512, 0><<<grid, 256, 512 * 12, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.rec, bv.point_list,
-                                                          bv.orig_slot, bv.qmask);
-    tile_sort_kernel<2048, 512><<<grid, 256, 2048 * 12, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.rec,
-                                                              bv.point_list, bv.orig_slot, bv.qmask);
-    tile_sort_kernel<8192, 2048><<<grid, 256, 8192 * 12, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.rec,
-                                                               bv.point_list, bv.orig_slot, bv.qmask);
-    tile_sort_global_kernel<<<grid, 256, 0, st>>>(g.tiles, g.gx, 8192u, gv.ranges, bv.keys, gv.rec, bv.point_list,
-                                                  bv.orig_slot, bv.qmask);
+    tile_sort_wave_kernel<<<grid, 64, 0, st>>>(g.tiles, gv.ranges, bv.keys, bv.upay, bv.point_list, bv.gm_index, bv.qmask);
+    tile_sort_kernel<2048, WAVE_SORT_MAX><<<grid, 256, 2048 * 12, st>>>(g.tiles, gv.ranges, bv.keys, bv.upay,
+                                                                        bv.point_list, bv.gm_index, bv.qmask);
+    tile_sort_kernel<8192, 2048><<<grid, 256, 8192 * 12, st>>>(g.tiles, gv.ranges, bv.keys, bv.upay, bv.point_list,
+                                                               bv.gm_index, bv.qmask);
+    tile_sort_global_kernel<<<grid, 256, 0, st>>>(g.tiles, 8192u, gv.ranges, bv.keys, bv.upay, bv.point_list, bv.gm_index,
+                                                  bv.qmask);
 }
 
 }  // namespace scr

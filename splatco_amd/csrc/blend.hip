@@ -12,7 +12,8 @@
 // Backward: the four waves of a tile share one workgroup.  Per (tile, Gaussian) gradients are
 // reduced on chip -- DPP row shifts / row broadcasts inside the wave, one LDS slot per
 // (wave, splat), a fixed-order add over the waves that took part -- and written ONCE as a 48-byte
-// record into the slot the instance occupied before the depth sort.  No floating-point atomics:
+// record at the instance's Gaussian-major index (so the per-Gaussian reduction reads its records
+// contiguously).  No floating-point atomics:
 // results are bit-reproducible.  The per-Gaussian sum over tiles happens in
 // preprocess_backward_kernel.
 //
@@ -211,17 +212,24 @@ __device__ __forceinline__ void splat_pixel_grad(PixState& s, float4 a, float4 b
 
 // ------------------------------------------------------------------ backward
 constexpr int BCH = 64;  // list entries per round: one per lane of each wave
+#ifndef SCR_BWD_ACC_BUFS
+#define SCR_BWD_ACC_BUFS 2
+#endif
+#ifndef SCR_BWD_MIN_WAVES
+#define SCR_BWD_MIN_WAVES 1
+#endif
+constexpr int ACC_BUFS = SCR_BWD_ACC_BUFS;  // 2: per-round sums double-buffered (one barrier per round)
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, SCR_BWD_MIN_WAVES)
 blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict__ ranges,
-                      const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ orig_slot,
+                      const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ gm_index,
                       const uint8_t* __restrict__ qmask, const float4* __restrict__ rec,
                       const float* __restrict__ bg, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                       float4* __restrict__ grad_rec) {
     __shared__ float4 s0[4][BCH], s1[4][BCH];  // wave-private compacted records of the round
     __shared__ float2 s2[4][BCH];              // (blue, position in round)
-    __shared__ float4 acc[2][4][BCH][3];       // [round parity][wave]: sums per position (9 of 12 floats used)
+    __shared__ float4 acc[ACC_BUFS][4][BCH][3];       // [round parity][wave]: sums per position (9 of 12 floats used)
     __shared__ uint32_t wave_max[4];
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
@@ -261,7 +269,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     if (wave < 3)
         for (int ci = nround - 1; ci > live_top; --ci) {
             uint32_t i = (uint32_t)ci * BCH + lane;
-            if (i < n) grad_rec[3 * (size_t)orig_slot[lo + i] + wave] = make_float4(0, 0, 0, 0);
+            if (i < n) grad_rec[3 * (size_t)gm_index[lo + i] + wave] = make_float4(0, 0, 0, 0);
         }
 
     // ---- software pipeline over the live rounds, back to front:
@@ -276,7 +284,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         const bool have = ci >= 0 && i < n;
         m = have ? qmask[lo + i] : 0u;
         id = have ? point_list[lo + i] : 0u;
-        slot = have ? orig_slot[lo + i] : 0u;
+        slot = have ? gm_index[lo + i] : 0u;
     };
     auto gather = [&](int ci, uint32_t m, uint32_t id, uint32_t slot) {
         const uint32_t i = (uint32_t)ci * BCH + lane;
@@ -312,7 +320,8 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         // acc is double-buffered by round parity: this round's writes cannot collide with the
         // previous round's combine, so ONE barrier per round suffices (a wave reaches the writes of
         // round r+2 only after barrier B of round r+1, which every wave passes after its combine of r)
-        float4 (*accw)[BCH][3] = acc[ci & 1];
+        float4 (*accw)[BCH][3] = acc[ACC_BUFS == 2 ? (ci & 1) : 0];
+        if (ACC_BUFS == 1) __syncthreads();  // A: the previous round's combine has read acc
         for (int k = cnt - 1; k >= 0; k -= 4) {  // back to front, four splats per reduction
             float g[4][9];
             uint32_t jj[4];
@@ -384,7 +393,7 @@ void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinVie
                            const float* dL_dcolor, float4* grad_rec, hipStream_t st) {
     Grid g(ks.H, ks.W);
     blend_backward_kernel<<<(unsigned)xcd_grid(g.tiles), 256, 0, st>>>(
-        ks.W, ks.H, g.gx, g.tiles, gv.ranges, bv.point_list, bv.orig_slot, bv.qmask, gv.rec, ks.bg, iv.final_T,
+        ks.W, ks.H, g.gx, g.tiles, gv.ranges, bv.point_list, bv.gm_index, bv.qmask, gv.rec, ks.bg, iv.final_T,
         iv.n_contrib, dL_dcolor, grad_rec);
 }
 

@@ -40,7 +40,7 @@ static int fail(const char* fmt, ...) {
 #include <vector>
 namespace {
 struct ProfRec { int idx; hipEvent_t a, b; };
-bool g_prof_on = false;
+unsigned g_prof_mask = 0;  // bit i set: kernel class i is timed
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
 hipEvent_t prof_event() {
@@ -51,7 +51,7 @@ hipEvent_t prof_event() {
 }
 struct ProfScope {
     bool on; hipStream_t st; ProfRec r;
-    ProfScope(int idx, hipStream_t s) : on(g_prof_on), st(s) {
+    ProfScope(int idx, hipStream_t s) : on((g_prof_mask >> idx) & 1u), st(s) {
         if (on) { r.idx = idx; r.a = prof_event(); r.b = prof_event(); (void)hipEventRecord(r.a, st); }
     }
     ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); g_prof_recs.push_back(r); } }
@@ -121,6 +121,7 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
         if (!(cov3D_precomp && !scales && !rotations) && !(scales && rotations && !cov3D_precomp))
             return fail("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
     if (P > 0 && (!means3D || !opacities || !radii_out)) return fail("means3D / opacities / radii_out is NULL");
+    if (P >= (1ll << ID_BITS)) return fail("P = %lld exceeds the 2^%d Gaussians a sort key can index", (long long)P, ID_BITS);
     if (shs && (M < (settings->sh_degree + 1) * (settings->sh_degree + 1)))
         return fail("shs has %d coefficients, sh_degree %d needs %d", M, settings->sh_degree,
                     (settings->sh_degree + 1) * (settings->sh_degree + 1));
@@ -225,8 +226,8 @@ int scr_debug_get(int which, int64_t P, int64_t I, int32_t H, int32_t W, const v
     return 0;
 }
 
-int scr_profile_enable(int on) {
-    g_prof_on = on != 0;
+int scr_profile_enable(int mask) {
+    g_prof_mask = mask < 0 ? 0xffffffffu : (unsigned)mask;
     return 0;
 }
 

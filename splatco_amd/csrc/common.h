@@ -17,6 +17,7 @@ constexpr int BIN_THREADS = 1024;       // threads of a preprocess / scatter wor
 constexpr int BIN_ROUNDS = 4;           // Gaussians per thread
 constexpr int BIN_GPW = BIN_THREADS * BIN_ROUNDS;  // Gaussians per preprocess / scatter workgroup
 constexpr int LDS_HIST_MAX_TILES = 16000;          // per-tile LDS histogram (4 B / tile) must fit 64 KB
+constexpr int ID_BITS = 28;             // sort key = depth:32 | id:28 | quadrant mask:4  ->  P < 2^28
 constexpr int REC_F = 12;               // floats per splat record (48 B, three float4)
 constexpr int GRAD_F = 12;              // floats per per-instance gradient record (9 used)
 
@@ -64,10 +65,10 @@ inline __host__ GeomView geom_view(void* base, int64_t P, int H, int W) {
 
 // ---- binning buffer: per (Gaussian, tile) instance lists ----
 struct BinView {
-    unsigned long long* keys;  // [I] (depth_bits << 32 | gaussian id), grouped by tile, unsorted
-    uint32_t* inst_slot;       // [I] indexed by (point_offset_exclusive + k): slot in the tile-grouped arrays
+    unsigned long long* keys;  // [I] (depth_bits << 32 | gaussian id << 4 | quadrant mask), grouped by tile, unsorted
+    uint32_t* upay;            // [I] same order as keys: Gaussian-major instance index (point_offset_exclusive + k)
     uint32_t* point_list;      // [I] Gaussian ids, per tile sorted by (depth, id)
-    uint32_t* orig_slot;       // [I] sorted position -> slot the instance occupied before the sort
+    uint32_t* gm_index;        // [I] sorted position -> Gaussian-major instance index (where its gradient record goes)
     uint8_t* qmask;            // [I] sorted position -> 4-bit mask of the tile's 8x8 quadrants the splat can touch
     size_t bytes;
 };
@@ -79,9 +80,9 @@ inline __host__ BinView bin_view(void* base, int64_t I) {
     auto take = [&](size_t n) { char* q = p ? p + off : nullptr; off += align_up(n); return q; };
     size_t n = (size_t)(I > 0 ? I : 1);
     v.keys = (unsigned long long*)take(n * 8);
-    v.inst_slot = (uint32_t*)take(n * 4);
+    v.upay = (uint32_t*)take(n * 4);
     v.point_list = (uint32_t*)take(n * 4);
-    v.orig_slot = (uint32_t*)take(n * 4);
+    v.gm_index = (uint32_t*)take(n * 4);
     v.qmask = (uint8_t*)take(n);
     v.bytes = off;
     return v;

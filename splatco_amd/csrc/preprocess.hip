@@ -314,7 +314,7 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
                            const float* __restrict__ cov3D, const float* __restrict__ shs, KSettings ks,
                            const int32_t* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
                            const uint32_t* __restrict__ point_offsets, const uint8_t* __restrict__ clamped,
-                           const uint32_t* __restrict__ inst_slot, const float4* __restrict__ grad_rec,
+                           const float4* __restrict__ grad_rec,
                            float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
                            float* __restrict__ dL_dcolors, float* __restrict__ dL_dsh,
                            float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
@@ -332,10 +332,9 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
         uint32_t n = tiles_touched[i];
         uint32_t off = point_offsets[i] - n;
         float gmx = 0, gmy = 0, gQxx = 0, gQxy = 0, gQyy = 0;
-        for (uint32_t k = 0; k < n; ++k) {
-            uint32_t slot = inst_slot[off + k];
-            float4 r0 = grad_rec[3 * (size_t)slot], r1 = grad_rec[3 * (size_t)slot + 1],
-                   r2 = grad_rec[3 * (size_t)slot + 2];
+        for (uint32_t k = 0; k < n; ++k) {  // this Gaussian's records are contiguous, in tile order
+            const size_t slot = (size_t)off + k;
+            float4 r0 = grad_rec[3 * slot], r1 = grad_rec[3 * slot + 1], r2 = grad_rec[3 * slot + 2];
             gmx += r0.x; gmy += r0.y; gQxx += r0.z; gQxy += r0.w;
             gQyy += r1.x; gop += r1.y; gcol[0] += r1.z; gcol[1] += r1.w;
             gcol[2] += r2.x;
@@ -561,7 +560,7 @@ void launch_preprocess_backward(int64_t P, int M, const float* means3D, const fl
     if (P <= 0) return;
     preprocess_backward_kernel<<<nblk(P, PRE_BLOCK), PRE_BLOCK, 0, st>>>(
         P, M, means3D, scales, rotations, cov3D, shs, ks, radii, gv.tiles_touched, gv.point_offsets,
-        gv.clamped, bv.inst_slot, grad_rec, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh, dL_dopacity,
+        gv.clamped, grad_rec, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh, dL_dopacity,
         dL_dscales, dL_drotations, dL_dcov3D);
 }
 
