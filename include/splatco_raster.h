@@ -115,6 +115,29 @@ int scr_debug_get(int which, int64_t P, int64_t num_rendered, int32_t image_heig
                   const void* geom_buf, const void* binning_buf, const void* image_buf, void* out,
                   void* stream);
 
+/* ---- fused neural-Gaussian expansion + opacity-mask compaction: the op chain of
+ * gaussian_renderer/__init__.py:68-111 (mask = neural_opacity > 0; repeat / cat / boolean index /
+ * split; sigmoid, normalize, FMA) as one streaming pass.  Candidate c = anchor v * k + slot; kept
+ * candidates keep their order.  V anchors, k offsets per anchor, n = V*k candidates:
+ *   neural_opacity[n], color[n,3], scale_rot[n,7], offsets[n,3] (= _offset[V,k,3]),
+ *   grid_scaling[V,6], anchor[V,3]  ->  xyz[P,3], color_out[P,3], opacity[P], scaling[P,3], rot[P,4],
+ *   out_index[n] int32 (compacted index or -1), mask_out[n] uint8 (may be NULL).
+ * scr_expand_plan counts the kept candidates (stream-synchronises once, like the boolean index it
+ * replaces) and leaves workgroup offsets in `scratch` for scr_expand_run.  The backward writes every
+ * element of its outputs and uses no atomics (deterministic). */
+size_t scr_expand_scratch_bytes(int64_t n_candidates);
+int scr_expand_plan(int64_t n_candidates, const float* neural_opacity, void* scratch,
+                    int64_t* num_selected_host, void* stream);
+int scr_expand_run(int64_t V, int32_t k, const float* neural_opacity, const float* color,
+                   const float* scale_rot, const float* offsets, const float* grid_scaling,
+                   const float* anchor, const void* scratch, int32_t* out_index, uint8_t* mask_out,
+                   float* xyz, float* color_out, float* opacity, float* scaling, float* rot, void* stream);
+int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const float* offsets,
+                        const float* grid_scaling, const int32_t* out_index, const float* g_xyz,
+                        const float* g_color, const float* g_opacity, const float* g_scaling,
+                        const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
+                        float* d_offsets, float* d_grid_scaling, float* d_anchor, void* stream);
+
 /* ---- opt-in kernel timing (bench / profiling only; process-global, off by default).
  * scr_profile_enable(mask): bit i of mask selects kernel class i (SCR_PROF_*); -1 = all, 0 = off.
  * Launches of the selected classes are bracketed by hipEventRecord on the launch stream (each
@@ -125,7 +148,7 @@ int scr_debug_get(int which, int64_t P, int64_t num_rendered, int32_t image_heig
 enum {
     SCR_PROF_FILTER = 0, SCR_PROF_PREPROCESS = 1, SCR_PROF_PLAN_SCAN = 2, SCR_PROF_SCATTER = 3,
     SCR_PROF_TILE_SORT = 4, SCR_PROF_BLEND_FORWARD = 5, SCR_PROF_BLEND_BACKWARD = 6,
-    SCR_PROF_PREPROCESS_BACKWARD = 7, SCR_PROF_COUNT = 8
+    SCR_PROF_PREPROCESS_BACKWARD = 7, SCR_PROF_EXPAND = 8, SCR_PROF_EXPAND_BACKWARD = 9, SCR_PROF_COUNT = 10
 };
 int scr_profile_enable(int mask);
 int scr_profile_read(double* total_ms, int64_t* launches);

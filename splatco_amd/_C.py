@@ -15,9 +15,10 @@ SYMBOLS = [
     "scr_abi_version", "scr_last_error", "scr_geom_bytes", "scr_binning_bytes", "scr_image_bytes",
     "scr_backward_scratch_bytes", "scr_visible_filter", "scr_mark_visible", "scr_forward_plan",
     "scr_forward_run", "scr_backward", "scr_debug_get", "scr_profile_enable", "scr_profile_read",
-    "scr_profile_kernel_name",
+    "scr_profile_kernel_name", "scr_expand_scratch_bytes", "scr_expand_plan", "scr_expand_run",
+    "scr_expand_backward",
 ]
-PROF_COUNT = 8
+PROF_COUNT = 10
 ABI_VERSION = 1
 
 DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
@@ -50,7 +51,8 @@ def _load():
     if lib.scr_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH} has ABI version {lib.scr_abi_version()}, expected {ABI_VERSION}")
     lib.scr_last_error.restype = C.c_char_p
-    for f in ("scr_geom_bytes", "scr_binning_bytes", "scr_image_bytes", "scr_backward_scratch_bytes"):
+    for f in ("scr_geom_bytes", "scr_binning_bytes", "scr_image_bytes", "scr_backward_scratch_bytes",
+              "scr_expand_scratch_bytes"):
         getattr(lib, f).restype = C.c_size_t
     lib.scr_geom_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.scr_binning_bytes.argtypes = [C.c_int64]
@@ -65,6 +67,12 @@ def _load():
     lib.scr_backward.argtypes = [i64, i32, i64, vp, vp, vp, vp, vp, sp, vp, vp, vp, vp, vp, vp,
                                  vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.scr_debug_get.argtypes = [C.c_int, i64, i64, i32, i32, vp, vp, vp, vp, vp]
+    lib.scr_expand_scratch_bytes.argtypes = [C.c_int64]
+    lib.scr_expand_plan.argtypes = [i64, vp, vp, C.POINTER(C.c_int64), vp]
+    lib.scr_expand_run.argtypes = [i64, i32] + [vp] * 15
+    lib.scr_expand_backward.argtypes = [i64, i32] + [vp] * 16
+    for f in ("scr_expand_plan", "scr_expand_run", "scr_expand_backward"):
+        getattr(lib, f).restype = C.c_int
     lib.scr_profile_enable.argtypes = [C.c_int]
     lib.scr_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.scr_profile_kernel_name.argtypes = [C.c_int]

@@ -58,7 +58,8 @@ struct ProfScope {
 };
 const char* const kProfNames[SCR_PROF_COUNT] = {
     "filter_kernel", "preprocess_kernel", "plan_scan_kernel", "scatter_kernel", "tile_sort_kernel",
-    "blend_forward_kernel", "blend_backward_kernel", "preprocess_backward_kernel"};
+    "blend_forward_kernel", "blend_backward_kernel", "preprocess_backward_kernel", "expand_kernel",
+    "expand_backward_kernel"};
 }  // namespace
 
 static int check_settings(const scr_settings* s) {
@@ -223,6 +224,65 @@ int scr_debug_get(int which, int64_t P, int64_t I, int32_t H, int32_t W, const v
         return fail("unknown debug selector %d", which);
     }
     if (bytes) HIP_TRY(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// ---- fused expansion + compaction (expand.hip)
+static inline size_t expand_nwg(int64_t n) { return (size_t)((n + 1023) / 1024); }
+
+size_t scr_expand_scratch_bytes(int64_t n) { return align_up((expand_nwg(n) + 1) * 4) + 256; }
+
+int scr_expand_plan(int64_t n, const float* neural_opacity, void* scratch, int64_t* num_selected_host,
+                    void* stream) {
+    if (!num_selected_host) return fail("num_selected_host is NULL");
+    *num_selected_host = 0;
+    if (n < 0) return fail("n < 0");
+    if (n == 0) return 0;
+    if (!neural_opacity || !scratch) return fail("NULL argument");
+    if (n >= (1ll << 31)) return fail("more than 2^31 candidates");
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* wg = (uint32_t*)scratch;
+    unsigned long long* total = (unsigned long long*)((char*)scratch + align_up((expand_nwg(n) + 1) * 4));
+    { ProfScope ps_(SCR_PROF_EXPAND, st); launch_expand_count(n, neural_opacity, wg, total, st); }
+    CHECK_LAUNCH("expand_count_kernel", 0, st);
+    unsigned long long t = 0;
+    HIP_TRY(hipMemcpyAsync(&t, total, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *num_selected_host = (int64_t)t;
+    return 0;
+}
+
+int scr_expand_run(int64_t V, int32_t k, const float* neural_opacity, const float* color,
+                   const float* scale_rot, const float* offsets, const float* grid_scaling,
+                   const float* anchor, const void* scratch, int32_t* out_index, uint8_t* mask_out,
+                   float* xyz, float* color_out, float* opacity, float* scaling, float* rot, void* stream) {
+    if (V < 0 || k <= 0) return fail("bad V / k");
+    if (V == 0) return 0;
+    if (!neural_opacity || !color || !scale_rot || !offsets || !grid_scaling || !anchor || !scratch || !out_index)
+        return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_EXPAND, st);
+      launch_expand_run(V * k, k, neural_opacity, color, scale_rot, offsets, grid_scaling, anchor,
+                        (const uint32_t*)scratch, out_index, mask_out, xyz, color_out, opacity, scaling, rot, st); }
+    CHECK_LAUNCH("expand_run_kernel", 0, st);
+    return 0;
+}
+
+int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const float* offsets,
+                        const float* grid_scaling, const int32_t* out_index, const float* g_xyz,
+                        const float* g_color, const float* g_opacity, const float* g_scaling,
+                        const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
+                        float* d_offsets, float* d_grid_scaling, float* d_anchor, void* stream) {
+    if (V < 0 || k <= 0) return fail("bad V / k");
+    if (V == 0) return 0;
+    if (!scale_rot || !offsets || !grid_scaling || !out_index || !d_neural_opacity || !d_color || !d_scale_rot ||
+        !d_offsets || !d_grid_scaling || !d_anchor)
+        return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_EXPAND_BACKWARD, st);
+      launch_expand_backward(V, k, scale_rot, offsets, grid_scaling, out_index, g_xyz, g_color, g_opacity, g_scaling,
+                             g_rot, d_neural_opacity, d_color, d_scale_rot, d_offsets, d_grid_scaling, d_anchor, st); }
+    CHECK_LAUNCH("expand_backward_kernel", 0, st);
     return 0;
 }
 

@@ -219,4 +219,16 @@ void launch_preprocess_backward(int64_t P, int M, const float* means3D, const fl
                                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh, float* dL_dopacity,
                                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, hipStream_t st);
 
+void launch_expand_count(int64_t n, const float* neural_opacity, uint32_t* wg_count, unsigned long long* total,
+                         hipStream_t st);
+void launch_expand_run(int64_t n, int k, const float* neural_opacity, const float* color, const float* scale_rot,
+                       const float* offsets, const float* grid_scaling, const float* anchor,
+                       const uint32_t* wg_offset, int32_t* out_index, uint8_t* mask_out, float* xyz,
+                       float* color_out, float* opacity, float* scaling, float* rot, hipStream_t st);
+void launch_expand_backward(int64_t V, int k, const float* scale_rot, const float* offsets,
+                            const float* grid_scaling, const int32_t* out_index, const float* g_xyz,
+                            const float* g_color, const float* g_opacity, const float* g_scaling,
+                            const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
+                            float* d_offsets, float* d_grid_scaling, float* d_anchor, hipStream_t st);
+
 }  // namespace scr

@@ -1,0 +1,64 @@
+"""Fused neural-Gaussian expansion + opacity-mask compaction (host side of csrc/expand.hip).
+
+One autograd op for gaussian_renderer/__init__.py:68-111: given the MLP outputs of the V visible
+anchors (k offsets each) it returns the compacted per-Gaussian tensors the rasterizer consumes.
+Parity: against the plain torch op chain of splatco_amd.renderer (itself pinned by the golden
+fixture captured from the reference), tests/test_gpu_renderer.py.
+"""
+import ctypes as C
+
+import torch
+
+from . import _C
+from .rasterizer import _ptr, _stream
+
+
+class _ExpandCompact(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, neural_opacity, color, scale_rot, offsets, grid_scaling, anchor, k):
+        f = lambda t: t.contiguous().float()
+        neural_opacity, color, scale_rot = f(neural_opacity).reshape(-1), f(color), f(scale_rot)
+        offsets, grid_scaling, anchor = f(offsets).reshape(-1, 3), f(grid_scaling), f(anchor)
+        V, dev = anchor.shape[0], anchor.device
+        n = V * k
+        scratch = torch.empty(max(_C.lib.scr_expand_scratch_bytes(n), 1), dtype=torch.uint8, device=dev)
+        cnt = C.c_int64(0)
+        _C.check(_C.lib.scr_expand_plan(n, _ptr(neural_opacity), scratch.data_ptr(), C.byref(cnt), _stream()))
+        P = int(cnt.value)
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        xyz, col, opa, sca, rot = new(P, 3), new(P, 3), new(P, 1), new(P, 3), new(P, 4)
+        out_index = torch.empty(n, dtype=torch.int32, device=dev)
+        mask = torch.empty(n, dtype=torch.bool, device=dev)
+        if n:
+            _C.check(_C.lib.scr_expand_run(V, k, _ptr(neural_opacity), _ptr(color), _ptr(scale_rot), _ptr(offsets),
+                                           _ptr(grid_scaling), _ptr(anchor), scratch.data_ptr(), out_index.data_ptr(),
+                                           mask.data_ptr(), _ptr(xyz), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot),
+                                           _stream()))
+        ctx.save_for_backward(scale_rot, offsets, grid_scaling, out_index)
+        ctx.dims = (V, k)
+        ctx.mark_non_differentiable(mask)
+        return xyz, col, opa, sca, rot, mask
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_col, g_opa, g_sca, g_rot, _g_mask):
+        scale_rot, offsets, grid_scaling, out_index = ctx.saved_tensors
+        V, k = ctx.dims
+        dev, n = scale_rot.device, V * k
+        z = lambda t, *s: (torch.zeros(*s, dtype=torch.float32, device=dev) if t is None else t.contiguous().float())
+        P = int((out_index >= 0).sum().item()) if g_xyz is None else g_xyz.shape[0]
+        g_xyz, g_col, g_opa, g_sca, g_rot = z(g_xyz, P, 3), z(g_col, P, 3), z(g_opa, P, 1), z(g_sca, P, 3), z(g_rot, P, 4)
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        d_no, d_col, d_sr, d_off, d_gs, d_an = new(n, 1), new(n, 3), new(n, 7), new(V, k, 3), new(V, 6), new(V, 3)
+        if n:
+            _C.check(_C.lib.scr_expand_backward(V, k, _ptr(scale_rot), _ptr(offsets), _ptr(grid_scaling),
+                                                out_index.data_ptr(), _ptr(g_xyz), _ptr(g_col), _ptr(g_opa),
+                                                _ptr(g_sca), _ptr(g_rot), d_no.data_ptr(), d_col.data_ptr(),
+                                                d_sr.data_ptr(), d_off.data_ptr(), d_gs.data_ptr(), d_an.data_ptr(),
+                                                _stream()))
+        return d_no, d_col, d_sr, d_off, d_gs, d_an, None
+
+
+def expand_compact(neural_opacity, color, scale_rot, grid_offsets, grid_scaling, anchor, n_offsets):
+    """neural_opacity [V*k,1], color [V*k,3], scale_rot [V*k,7], grid_offsets [V,k,3], grid_scaling [V,6],
+    anchor [V,3]  ->  xyz, color, opacity, scaling, rot (compacted, order preserved), mask [V*k] bool."""
+    return _ExpandCompact.apply(neural_opacity, color, scale_rot, grid_offsets, grid_scaling, anchor, int(n_offsets))

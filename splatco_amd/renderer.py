@@ -12,14 +12,19 @@ import torch
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
-def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False):
-    """Anchors -> neural Gaussians (gaussian_renderer/__init__.py:18-116), same op order."""
+def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False, fused=None):
+    """Anchors -> neural Gaussians (gaussian_renderer/__init__.py:18-116), same op order.
+    fused: run the mask / compaction / post-processing block (:68-111) as the single HIP op of
+    splatco_amd.expand (default: on device tensors); False keeps the reference's torch op chain."""
     if visible_mask is None:
         visible_mask = torch.ones(pc.get_anchor.shape[0], dtype=torch.bool, device=pc.get_anchor.device)
-    feat = pc._anchor_feat[visible_mask]
-    anchor = pc.get_anchor[visible_mask]
-    grid_offsets = pc._offset[visible_mask]
-    grid_scaling = pc.get_scaling[visible_mask]
+    # `t[visible_mask]` four times (:23-29) = four mask->index conversions (each a host sync) and
+    # four sort-based index_put backwards; one nonzero + index_select gives the same rows
+    idx = visible_mask.nonzero(as_tuple=False).squeeze(1)
+    feat = pc._anchor_feat.index_select(0, idx)
+    anchor = pc.get_anchor.index_select(0, idx)
+    grid_offsets = pc._offset.index_select(0, idx)
+    grid_scaling = pc.get_scaling.index_select(0, idx)
     V, k = anchor.shape[0], pc.n_offsets
     geo_fea = pc.feat_planes.inference(
         anchor, torch.concat((feat, anchor, grid_offsets.reshape(V, -1), grid_scaling), dim=1), 0)
@@ -32,10 +37,19 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     cat_local_view_wodist = torch.cat([feat, ob_view, geo_fea], dim=1)
     neural_opacity = pc.get_opacity_mlp(cat_local_view if pc.add_opacity_dist else cat_local_view_wodist)
     neural_opacity = neural_opacity.reshape([-1, 1])
-    mask = (neural_opacity > 0.0).view(-1)
-    opacity = neural_opacity[mask]
     color = pc.get_color_mlp(cat_local_view if pc.add_color_dist else cat_local_view_wodist).reshape([V * k, 3])
     scale_rot = pc.get_cov_mlp(cat_local_view if pc.add_cov_dist else cat_local_view_wodist).reshape([V * k, 7])
+    if fused is None:
+        fused = anchor.is_cuda
+    if fused:
+        from .expand import expand_compact
+        xyz, color, opacity, scaling, rot, mask = expand_compact(neural_opacity, color, scale_rot, grid_offsets,
+                                                                 grid_scaling, anchor, k)
+        if is_training:
+            return xyz, color, opacity, scaling, rot, neural_opacity, mask
+        return xyz, color, opacity, scaling, rot
+    mask = (neural_opacity > 0.0).view(-1)
+    opacity = neural_opacity[mask]
     offsets = grid_offsets.view([-1, 3])
     # combine for parallel masking (:96-103): [scaling 6 | anchor 3] repeated k times, then one gather
     concatenated = torch.cat([grid_scaling, anchor], dim=-1)

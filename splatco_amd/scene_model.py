@@ -14,6 +14,45 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class _TallLinearFn(torch.autograd.Function):
+    """y = x W^T + b for x with millions of rows and a few dozen columns (one row per anchor).
+    Forward and dL/dx are ordinary GEMMs; the weight gradient dW = dy^T x contracts over the row
+    dimension (K ~ 10^6, output 32x99): hipBLASLt runs that as ONE tile without split-K (1.7 ms per
+    layer at 0.93 M rows on MI355X, 43 % of the anchor path).  Here the contraction is split into
+    2048-row slabs (a batched GEMM, one partial per slab) that are then summed: same math, fixed
+    summation order, ~15x faster."""
+    SLAB = 2048
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        M, c = x.shape[0], _TallLinearFn.SLAB
+        S = M // c
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = dy[S * c:].t() @ x[S * c:]
+            if S:
+                dw = dw + torch.bmm(dy[:S * c].view(S, c, -1).transpose(1, 2), x[:S * c].view(S, c, -1)).sum(0)
+        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+class TallLinear(nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) with the slab-split weight gradient."""
+
+    def forward(self, x):
+        if x.dim() == 2 and x.shape[0] >= 4 * _TallLinearFn.SLAB and x.is_cuda:
+            return _TallLinearFn.apply(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)
+
+
 class ChannelAttention(nn.Module):            # scene/grids.py:22-36
     def __init__(self, in_planes, ratio=5):
         super().__init__()
@@ -21,8 +60,10 @@ class ChannelAttention(nn.Module):            # scene/grids.py:22-36
                                        nn.Conv2d(in_planes // ratio, in_planes, 1, bias=False))
 
     def forward(self, x):
-        avg = self.sharedMLP(F.adaptive_avg_pool2d(x, 1))
-        mx = self.sharedMLP(F.adaptive_max_pool2d(x, 1))
+        # global average / max pool (AdaptiveAvgPool2d(1) / AdaptiveMaxPool2d(1)); amax instead of
+        # adaptive_max_pool2d: same value, 2.5 ms -> 0.05 ms on a [1,15,700,700] stack on MI355X
+        avg = self.sharedMLP(x.mean(dim=(2, 3), keepdim=True))
+        mx = self.sharedMLP(x.amax(dim=(2, 3), keepdim=True))
         return torch.sigmoid(avg + mx)
 
 
@@ -102,8 +143,8 @@ class FeaturePlanes(nn.Module):               # scene/gaussian_model.py:97-169
         self.models, self.CTX_models = nn.ModuleList(), nn.ModuleList()
         for i in range(self.num_levels):
             d = self.k0s[i].get_dim()
-            self.models.append(nn.Sequential(nn.BatchNorm1d(d), nn.Linear(d, out_dim)))
-            self.CTX_models.append(nn.Sequential(nn.BatchNorm1d(71), nn.Linear(71, out_dim)))
+            self.models.append(nn.Sequential(nn.BatchNorm1d(d), TallLinear(d, out_dim)))
+            self.CTX_models.append(nn.Sequential(nn.BatchNorm1d(71), TallLinear(71, out_dim)))
 
     def forward(self, x, g_fea, Q=0):
         res = []
@@ -141,12 +182,12 @@ class AnchorGaussianModel(nn.Module):
         self.feat_dim, self.n_offsets, self.appearance_dim, self.use_feat_bank = feat_dim, n_offsets, appearance_dim, use_feat_bank
         self.add_opacity_dist, self.add_cov_dist, self.add_color_dist = add_opacity_dist, add_cov_dist, add_color_dist
         od, cd, kd = int(add_opacity_dist), int(add_cov_dist), int(add_color_dist)
-        self.mlp_opacity = nn.Sequential(nn.Linear(feat_dim + 3 + od + 64, feat_dim), nn.ReLU(True),
-                                         nn.Linear(feat_dim, n_offsets), nn.Tanh())
-        self.mlp_cov = nn.Sequential(nn.Linear(feat_dim + 3 + cd + 64, feat_dim), nn.ReLU(True),
-                                     nn.Linear(feat_dim, 7 * n_offsets))
-        self.mlp_color = nn.Sequential(nn.Linear(feat_dim + 3 + kd + appearance_dim + 64, feat_dim), nn.ReLU(True),
-                                       nn.Linear(feat_dim, 3 * n_offsets), nn.Sigmoid())
+        self.mlp_opacity = nn.Sequential(TallLinear(feat_dim + 3 + od + 64, feat_dim), nn.ReLU(True),
+                                         TallLinear(feat_dim, n_offsets), nn.Tanh())
+        self.mlp_cov = nn.Sequential(TallLinear(feat_dim + 3 + cd + 64, feat_dim), nn.ReLU(True),
+                                     TallLinear(feat_dim, 7 * n_offsets))
+        self.mlp_color = nn.Sequential(TallLinear(feat_dim + 3 + kd + appearance_dim + 64, feat_dim), nn.ReLU(True),
+                                       TallLinear(feat_dim, 3 * n_offsets), nn.Sigmoid())
         self.feat_planes = GaussianLearner(plane_size, num_channels)
         self._anchor = nn.Parameter(torch.empty(0, 3))
         self._offset = nn.Parameter(torch.empty(0, n_offsets, 3))
