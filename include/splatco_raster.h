@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 1
+#define SCR_ABI_VERSION 2
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -59,7 +59,7 @@ const char* scr_last_error(void);
 
 /* ---- buffer sizes (bytes).  Buffers must be 256-byte aligned (any hipMalloc / torch allocation is). */
 size_t scr_geom_bytes(int64_t P, int32_t image_height, int32_t image_width); /* per-Gaussian state + per-tile counters */
-size_t scr_binning_bytes(int64_t num_rendered);                              /* per tile-instance lists */
+size_t scr_binning_bytes(int64_t num_rendered, int64_t max_tile_instances);  /* per tile-instance lists */
 size_t scr_image_bytes(int32_t image_height, int32_t image_width);           /* final_T + n_contrib */
 size_t scr_backward_scratch_bytes(int64_t num_rendered);                     /* per-instance gradient records */
 
@@ -75,17 +75,18 @@ int scr_mark_visible(int64_t P, const float* means3D, const float* viewmatrix, u
 /* ---- forward, phase 1: projection / culling / tile counting / offsets.
  * Exactly one of (shs, colors_precomp) and one of ((scales, rotations), cov3D_precomp) non-NULL.
  * M = SH coefficients per Gaussian (shs is [P, M, 3]); opacities is [P] (or [P,1]).
- * Writes radii_out[P] and geom_buf; returns the number of (Gaussian, tile) instances through
- * *num_rendered_host (host pointer; the call stream-synchronises once to read it). */
+ * Writes radii_out[P] and geom_buf; returns through plan_host[2] (host pointer; the call
+ * stream-synchronises once to read it) the number of (Gaussian, tile) instances and the largest
+ * per-tile instance count (it sizes the sort's grid); both go to scr_binning_bytes / scr_forward_run. */
 int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* scales,
                      const float* rotations, const float* cov3D_precomp, const float* opacities,
                      const float* shs, const float* colors_precomp, const scr_settings* settings,
-                     void* geom_buf, int32_t* radii_out, int64_t* num_rendered_host, void* stream);
+                     void* geom_buf, int32_t* radii_out, int64_t* plan_host, void* stream);
 
 /* ---- forward, phase 2: per-tile bucketing, depth sort, front-to-back blend.
  * out_color is [3, H, W] fp32.  geom_buf / binning_buf / image_buf must be kept for scr_backward. */
-int scr_forward_run(int64_t P, int64_t num_rendered, const scr_settings* settings, void* geom_buf,
-                    void* binning_buf, void* image_buf, float* out_color, void* stream);
+int scr_forward_run(int64_t P, int64_t num_rendered, int64_t max_tile_instances, const scr_settings* settings,
+                    void* geom_buf, void* binning_buf, void* image_buf, float* out_color, void* stream);
 
 /* ---- backward.  dL_dcolor is [3,H,W].  Outputs (each may be NULL when its input was NULL):
  * dL_dmeans3D[P,3], dL_dmeans2D[P,3] (d/d NDC position, z = 0: the gradient SplatCo reads back

@@ -19,7 +19,7 @@ SYMBOLS = [
     "scr_expand_backward",
 ]
 PROF_COUNT = 10
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
 
@@ -55,7 +55,7 @@ def _load():
               "scr_expand_scratch_bytes"):
         getattr(lib, f).restype = C.c_size_t
     lib.scr_geom_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
-    lib.scr_binning_bytes.argtypes = [C.c_int64]
+    lib.scr_binning_bytes.argtypes = [C.c_int64, C.c_int64]
     lib.scr_image_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.scr_backward_scratch_bytes.argtypes = [C.c_int64]
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
@@ -63,7 +63,7 @@ def _load():
     lib.scr_visible_filter.argtypes = [i64, vp, vp, vp, vp, sp, vp, vp]
     lib.scr_mark_visible.argtypes = [i64, vp, vp, vp, vp]
     lib.scr_forward_plan.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, sp, vp, vp, C.POINTER(C.c_int64), vp]
-    lib.scr_forward_run.argtypes = [i64, i64, sp, vp, vp, vp, vp, vp]
+    lib.scr_forward_run.argtypes = [i64, i64, i64, sp, vp, vp, vp, vp, vp]
     lib.scr_backward.argtypes = [i64, i32, i64, vp, vp, vp, vp, vp, sp, vp, vp, vp, vp, vp, vp,
                                  vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.scr_debug_get.argtypes = [C.c_int, i64, i64, i32, i32, vp, vp, vp, vp, vp]

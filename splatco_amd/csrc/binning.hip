@@ -58,9 +58,9 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(uint32_t nblk, uint32_t
             if (i < nblk) block_sums[i] = (uint32_t)carry + ex;
             carry += tot;
         }
-        if (threadIdx.x == 0) *total = carry;
+        if (threadIdx.x == 0) total[0] = carry;
     } else {
-        uint32_t carry = 0;
+        uint32_t carry = 0, mx = 0;
         for (uint32_t base = 0; base < tiles; base += 1024) {
             uint32_t i = base + threadIdx.x;
             uint32_t v = i < tiles ? tile_count[i] : 0u, tot;
@@ -71,6 +71,18 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(uint32_t nblk, uint32_t
                 cursor[i] = 0;
             }
             carry += tot;
+            mx = max(mx, v);
+        }
+        // largest per-tile instance count (sizes the sort's chunk grid / merge passes on the host)
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t m = 0;
+            for (int w = 0; w < 1024 / WAVE; ++w) m = max(m, lds[w]);
+            total[1] = m;
         }
     }
 }
@@ -142,81 +154,18 @@ scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec,
 }
 
 // ------------------------------------------------------------------ per-tile sort
-// Bitonic merge network in its "all ascending" form: merging two sorted runs of length k/2
-// starts with a mirrored compare (i <-> block_end - i) followed by half-cleaners at distance
-// k/4 .. 1.  Every compare-exchange puts the larger key at the larger index, so a segment of
-// arbitrary length n needs no padding: a partner index >= n is +infinity and never moves.
-// c = index of the compare-exchange inside one step (m/2 per step, m = next pow2 >= n).
-__device__ __forceinline__ void ce_indices(uint32_t c, uint32_t k, uint32_t j, bool mirror, uint32_t& i,
-                                           uint32_t& p) {
-    if (mirror) {
-        uint32_t half = k >> 1, blk = c / half, r = c - blk * half;
-        i = blk * k + r;
-        p = blk * k + k - 1 - r;
-    } else {
-        i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
-        p = i + j;
-    }
-}
-
-// One workgroup per tile sorts (key64, payload32) in LDS.  CAP: largest segment this
-// instantiation handles; segments in (LOWER, CAP] are taken, others skipped (the launcher issues
-// one launch per size class; a workgroup whose tile is not in the class exits at once).
-template <int CAP, int LOWER>
-__global__ void __launch_bounds__(256)
-tile_sort_kernel(int tiles, const uint32_t* __restrict__ ranges, const unsigned long long* __restrict__ keys,
-                 const uint32_t* __restrict__ upay, uint32_t* __restrict__ point_list,
-                 uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long* sk = (unsigned long long*)smem;  // [CAP]
-    uint32_t* sp = (uint32_t*)(smem + (size_t)CAP * 8);   // [CAP]
-    int t = xcd_tile(blockIdx.x, tiles);
-    if (t < 0) return;
-    uint32_t lo = ranges[2 * t], hi = ranges[2 * t + 1];
-    uint32_t n = hi - lo;
-    if (n <= (uint32_t)LOWER || n > (uint32_t)CAP) return;
-    uint32_t m = 1;
-    while (m < n) m <<= 1;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        sk[i] = keys[lo + i];
-        sp[i] = upay[lo + i];
-    }
-    __syncthreads();
-    for (uint32_t k = 2; k <= m; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t c = threadIdx.x; c < (m >> 1); c += 256) {
-                uint32_t i, p;
-                ce_indices(c, k, j, j == (k >> 1), i, p);
-                if (p < n) {
-                    unsigned long long a = sk[i], b = sk[p];
-                    if (a > b) {
-                        sk[i] = b;
-                        sk[p] = a;
-                        uint32_t pa = sp[i], pb = sp[p];
-                        sp[i] = pb;
-                        sp[p] = pa;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const uint32_t kl = (uint32_t)sk[i];
-        point_list[lo + i] = kl >> 4;
-        qmask[lo + i] = (uint8_t)(kl & 15u);
-        gm_index[lo + i] = sp[i];
-    }
-}
-
-// ------------------------------------------------------------------ per-tile sort, one wave per tile
-// Tiles with at most 1024 instances (the common case) are sorted by ONE wave entirely in
-// registers: lane l holds E = m/64 elements (index i = l*E + e), m = 64..1024.  The bitonic
-// network's compare-exchanges at distance j < E are register-to-register; at distance j >= E the
-// partner sits in lane l ^ (j/E) and is fetched with DPP (quad_perm for lane distance 1, 2;
-// bank-masked row_shl/row_shr for 4, 8) or v_permlane16_swap / v_permlane32_swap (16, 32).  No
-// LDS, no barriers, no s_waitcnt inside the network -- the LDS version spends most of its time in
-// 55 barrier-separated steps.  Padding elements are +inf keys and sort to the end.
+// One wave sorts up to 1024 (key64, payload32) elements entirely in registers: lane l holds
+// E = m/64 elements (index i = l*E + e), m = 64..1024.  The bitonic network's compare-exchanges at
+// distance j < E are register-to-register; at distance j >= E the partner sits in lane l ^ (j/E)
+// and is fetched with DPP (quad_perm for lane distance 1, 2; bank-masked row_shl/row_shr for 4, 8)
+// or v_permlane16_swap / v_permlane32_swap (16, 32).  No LDS, no barriers, no s_waitcnt inside the
+// network.  Padding elements are +inf keys and sort to the end.
+//   tiles with <= 1024 instances : one wave sorts the tile and writes the final lists;
+//   larger tiles                 : every 1024-chunk is sorted the same way (in place), then
+//                                  log2(chunks) rank-merge passes double the sorted run length
+//                                  (each element binary-searches its rank in the partner run;
+//                                  keys are unique, so the positions are disjoint) ping-ponging
+//                                  between two buffers; a last pass writes the final lists.
 template <int D>
 __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {  // value of lane (l ^ D)
     if constexpr (D == 1) {
@@ -284,92 +233,140 @@ __device__ __forceinline__ void bitonic_network(uint32_t (&klo)[E], uint32_t (&k
     if constexpr (K < 64 * E) bitonic_network<E, K * 2>(klo, khi, pay, lane);
 }
 
-template <int E>
-__device__ __forceinline__ void wave_sort_tile(uint32_t lo, uint32_t n, const unsigned long long* __restrict__ keys,
-                                               const uint32_t* __restrict__ upay,
-                                               uint32_t* __restrict__ point_list, uint32_t* __restrict__ gm_index,
-                                               uint8_t* __restrict__ qmask) {
+constexpr int WAVE_SORT_MAX = 1024;
+
+// Sorts the n (<= 64*E) elements at keys[0..n) / upay[0..n).  FINAL: write the tile's final lists
+// (ids, quadrant masks, Gaussian-major indices); otherwise write the sorted chunk back in place.
+template <int E, bool FINAL>
+__device__ __forceinline__ void wave_sort(uint32_t n, unsigned long long* __restrict__ keys,
+                                          uint32_t* __restrict__ upay, uint32_t* __restrict__ point_list,
+                                          uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
     const int lane = threadIdx.x & 63;
     uint32_t klo[E], khi[E], pay[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {  // coalesced load; the network does not care where an element starts
         const uint32_t i = (uint32_t)e * 64 + lane;
-        const unsigned long long k = i < n ? keys[lo + i] : ~0ull;
+        const unsigned long long k = i < n ? keys[i] : ~0ull;
         klo[e] = (uint32_t)k;
         khi[e] = (uint32_t)(k >> 32);
-        pay[e] = i < n ? upay[lo + i] : 0u;
+        pay[e] = i < n ? upay[i] : 0u;
     }
     bitonic_network<E, 2>(klo, khi, pay, lane);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const uint32_t i = (uint32_t)lane * E + e;  // sorted position
         if (i < n) {
-            point_list[lo + i] = klo[e] >> 4;
-            qmask[lo + i] = (uint8_t)(klo[e] & 15u);
-            gm_index[lo + i] = pay[e];
+            if (FINAL) {
+                point_list[i] = klo[e] >> 4;
+                qmask[i] = (uint8_t)(klo[e] & 15u);
+                gm_index[i] = pay[e];
+            } else {
+                keys[i] = ((unsigned long long)khi[e] << 32) | klo[e];
+                upay[i] = pay[e];
+            }
         }
     }
 }
 
-constexpr int WAVE_SORT_MAX = 1024;
+template <bool FINAL>
+__device__ __forceinline__ void wave_sort_any(uint32_t n, unsigned long long* keys, uint32_t* upay,
+                                              uint32_t* point_list, uint32_t* gm_index, uint8_t* qmask) {
+    if (n <= 64) wave_sort<1, FINAL>(n, keys, upay, point_list, gm_index, qmask);
+    else if (n <= 128) wave_sort<2, FINAL>(n, keys, upay, point_list, gm_index, qmask);
+    else if (n <= 256) wave_sort<4, FINAL>(n, keys, upay, point_list, gm_index, qmask);
+    else if (n <= 512) wave_sort<8, FINAL>(n, keys, upay, point_list, gm_index, qmask);
+    else wave_sort<16, FINAL>(n, keys, upay, point_list, gm_index, qmask);
+}
 
+// grid = (xcd_grid(tiles), chunks): chunk c of tile t.  Tiles with <= 1024 instances are finished
+// by their chunk 0; larger tiles get every chunk sorted in place.
 __global__ void __launch_bounds__(64)
-tile_sort_wave_kernel(int tiles, const uint32_t* __restrict__ ranges,
-                      const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ upay,
-                      uint32_t* __restrict__ point_list, uint32_t* __restrict__ gm_index,
-                      uint8_t* __restrict__ qmask) {
+tile_sort_wave_kernel(int tiles, const uint32_t* __restrict__ ranges, unsigned long long* __restrict__ keys,
+                      uint32_t* __restrict__ upay, uint32_t* __restrict__ point_list,
+                      uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
-    if (n == 0 || n > (uint32_t)WAVE_SORT_MAX) return;
-    if (n <= 64) wave_sort_tile<1>(lo, n, keys, upay, point_list, gm_index, qmask);
-    else if (n <= 128) wave_sort_tile<2>(lo, n, keys, upay, point_list, gm_index, qmask);
-    else if (n <= 256) wave_sort_tile<4>(lo, n, keys, upay, point_list, gm_index, qmask);
-    else if (n <= 512) wave_sort_tile<8>(lo, n, keys, upay, point_list, gm_index, qmask);
-    else wave_sort_tile<16>(lo, n, keys, upay, point_list, gm_index, qmask);
+    const uint32_t c0 = blockIdx.y * (uint32_t)WAVE_SORT_MAX;
+    if (c0 >= n) return;
+    if (n <= (uint32_t)WAVE_SORT_MAX) {
+        wave_sort_any<true>(n, keys + lo, upay + lo, point_list + lo, gm_index + lo, qmask + lo);
+    } else {
+        const uint32_t cnt = min((uint32_t)WAVE_SORT_MAX, n - c0);
+        wave_sort_any<false>(cnt, keys + lo + c0, upay + lo + c0, nullptr, nullptr, nullptr);
+    }
 }
 
-// Fallback for segments that do not fit the largest LDS class: the same network run in place on
-// global memory by one workgroup (rare: > 8192 instances in one 16x16 tile).  The payload is
-// sorted in place in upay.  Data stays inside one workgroup, so workgroup-scope visibility suffices
-// (__syncthreads orders this workgroup's global accesses through its own CU's L1/L2 path).
+// Merge pass over runs of length L (sorted) -> runs of length 2L.  One thread per element:
+// output position = own index in its run + rank in the partner run (lower_bound; keys unique).
+// Tiles that are already fully merged (or small) are skipped; FINAL_ONLY = false.
+// The buffer a tile's data lives in after p passes is buffer (p & 1).
+__device__ __forceinline__ uint32_t lower_bound64(const unsigned long long* __restrict__ a, uint32_t len,
+                                                  unsigned long long x) {
+    uint32_t lo = 0, hi = len;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ uint32_t merge_passes_needed(uint32_t n) {  // ceil(log2(ceil(n/1024)))
+    uint32_t chunks = (n + WAVE_SORT_MAX - 1) / WAVE_SORT_MAX, p = 0;
+    while ((1u << p) < chunks) ++p;
+    return p;
+}
+
 __global__ void __launch_bounds__(256)
-tile_sort_global_kernel(int tiles, uint32_t lower, const uint32_t* __restrict__ ranges,
-                        unsigned long long* keys, uint32_t* upay, uint32_t* __restrict__ point_list,
-                        uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
+tile_merge_pass_kernel(int tiles, uint32_t pass, const uint32_t* __restrict__ ranges,
+                       const unsigned long long* __restrict__ src_keys, const uint32_t* __restrict__ src_pay,
+                       unsigned long long* __restrict__ dst_keys, uint32_t* __restrict__ dst_pay) {
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
-    uint32_t lo = ranges[2 * t], hi = ranges[2 * t + 1];
-    uint32_t n = hi - lo;
-    if (n <= lower) return;
-    uint32_t m = 1;
-    while (m < n) m <<= 1;
-    volatile unsigned long long* sk = keys + lo;
-    volatile uint32_t* sp = upay + lo;  // payload sorted in place along with the keys
-    for (uint32_t k = 2; k <= m; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t c = threadIdx.x; c < (m >> 1); c += 256) {
-                uint32_t i, p;
-                ce_indices(c, k, j, j == (k >> 1), i, p);
-                if (p < n) {
-                    unsigned long long a = sk[i], b = sk[p];
-                    if (a > b) {
-                        sk[i] = b;
-                        sk[p] = a;
-                        uint32_t pa = sp[i], pb = sp[p];
-                        sp[i] = pb;
-                        sp[p] = pa;
-                    }
-                }
+    const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
+    if (n <= (uint32_t)WAVE_SORT_MAX || pass >= merge_passes_needed(n)) return;
+    const uint32_t L = (uint32_t)WAVE_SORT_MAX << pass;
+    const unsigned long long* sk = src_keys + lo;
+    for (uint32_t e = blockIdx.y * (uint32_t)WAVE_SORT_MAX + threadIdx.x, k = 0; k < WAVE_SORT_MAX / 256 && e < n; ++k, e += 256) {
+        const uint32_t run = e / L, pairbase = (run & ~1u) * L, inrun = e - run * L;
+        const unsigned long long x = sk[e];
+        uint32_t pos;
+        if ((run & 1u) == 0) {  // element of the left run: count right-run elements below it
+            const uint32_t rb = pairbase + L;
+            uint32_t rlen = 0;  // length of the right partner run (0: this run has no partner)
+            if (rb < n) {
+                rlen = n - rb;
+                if (rlen > L) rlen = L;
             }
-            __syncthreads();
+            pos = pairbase + inrun + lower_bound64(sk + rb, rlen, x);
+        } else {                // element of the right run: count left-run elements below it
+            pos = pairbase + inrun + lower_bound64(sk + pairbase, L, x);
         }
+        dst_keys[lo + pos] = x;
+        dst_pay[lo + pos] = src_pay[lo + e];
     }
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const uint32_t kl = (uint32_t)sk[i];
-        point_list[lo + i] = kl >> 4;
-        qmask[lo + i] = (uint8_t)(kl & 15u);
-        gm_index[lo + i] = sp[i];
+}
+
+// Final lists of the large tiles from the buffer their last merge pass wrote.
+__global__ void __launch_bounds__(256)
+tile_merge_final_kernel(int tiles, const uint32_t* __restrict__ ranges,
+                        const unsigned long long* __restrict__ keys0, const uint32_t* __restrict__ pay0,
+                        const unsigned long long* __restrict__ keys1, const uint32_t* __restrict__ pay1,
+                        uint32_t* __restrict__ point_list, uint32_t* __restrict__ gm_index,
+                        uint8_t* __restrict__ qmask) {
+    int t = xcd_tile(blockIdx.x, tiles);
+    if (t < 0) return;
+    const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
+    if (n <= (uint32_t)WAVE_SORT_MAX) return;
+    const bool odd = merge_passes_needed(n) & 1u;
+    const unsigned long long* sk = (odd ? keys1 : keys0) + lo;
+    const uint32_t* sp = (odd ? pay1 : pay0) + lo;
+    for (uint32_t e = blockIdx.y * (uint32_t)WAVE_SORT_MAX + threadIdx.x, k = 0; k < WAVE_SORT_MAX / 256 && e < n; ++k, e += 256) {
+        const uint32_t kl = (uint32_t)sk[e];
+        point_list[lo + e] = kl >> 4;
+        qmask[lo + e] = (uint8_t)(kl & 15u);
+        gm_index[lo + e] = sp[e];
     }
 }
 
@@ -395,22 +392,25 @@ void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const Bi
             bv.keys, bv.upay);
 }
 
-void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, hipStream_t st) {
+void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, int64_t max_tile_instances,
+                      hipStream_t st) {
     Grid g(ks.H, ks.W);
-    unsigned grid = (unsigned)xcd_grid(g.tiles);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tile_sort_kernel<8192, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            8192 * 12);
-        attr_set = true;
+    const unsigned gt = (unsigned)xcd_grid(g.tiles);
+    const unsigned chunks = (unsigned)((max_tile_instances + WAVE_SORT_MAX - 1) / WAVE_SORT_MAX);
+    if (chunks == 0) return;
+    tile_sort_wave_kernel<<<dim3(gt, chunks), 64, 0, st>>>(g.tiles, gv.ranges, bv.keys, bv.upay, bv.point_list,
+                                                           bv.gm_index, bv.qmask);
+    if (chunks <= 1) return;
+    unsigned passes = 0;
+    while ((1u << passes) < chunks) ++passes;
+    for (unsigned p = 0; p < passes; ++p) {
+        const bool fwd = (p & 1u) == 0;  // data of pass p lives in buffer (p & 1)
+        tile_merge_pass_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, p, gv.ranges, fwd ? bv.keys : bv.keys2,
+                                                                 fwd ? bv.upay : bv.upay2, fwd ? bv.keys2 : bv.keys,
+                                                                 fwd ? bv.upay2 : bv.upay);
     }
-    tile_sort_wave_kernel<<<grid, 64, 0, st>>>(g.tiles, gv.ranges, bv.keys, bv.upay, bv.point_list, bv.gm_index, bv.qmask);
-    tile_sort_kernel<2048, WAVE_SORT_MAX><<<grid, 256, 2048 * 12, st>>>(g.tiles, gv.ranges, bv.keys, bv.upay,
-                                                                        bv.point_list, bv.gm_index, bv.qmask);
-    tile_sort_kernel<8192, 2048><<<grid, 256, 8192 * 12, st>>>(g.tiles, gv.ranges, bv.keys, bv.upay, bv.point_list,
-                                                               bv.gm_index, bv.qmask);
-    tile_sort_global_kernel<<<grid, 256, 0, st>>>(g.tiles, 8192u, gv.ranges, bv.keys, bv.upay, bv.point_list, bv.gm_index,
-                                                  bv.qmask);
+    tile_merge_final_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, gv.ranges, bv.keys, bv.upay, bv.keys2, bv.upay2,
+                                                              bv.point_list, bv.gm_index, bv.qmask);
 }
 
 }  // namespace scr

@@ -77,7 +77,7 @@ int scr_abi_version(void) { return SCR_ABI_VERSION; }
 const char* scr_last_error(void) { return g_err; }
 
 size_t scr_geom_bytes(int64_t P, int32_t H, int32_t W) { return geom_view(nullptr, P, H, W).bytes; }
-size_t scr_binning_bytes(int64_t I) { return bin_view(nullptr, I).bytes; }
+size_t scr_binning_bytes(int64_t I, int64_t max_tile) { return bin_view(nullptr, I, max_tile).bytes; }
 size_t scr_image_bytes(int32_t H, int32_t W) { return img_view(nullptr, H, W).bytes; }
 size_t scr_backward_scratch_bytes(int64_t I) { return align_up((size_t)(I > 0 ? I : 1) * GRAD_F * 4); }
 
@@ -110,11 +110,11 @@ int scr_mark_visible(int64_t P, const float* means3D, const float* viewmatrix, u
 int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* scales,
                      const float* rotations, const float* cov3D_precomp, const float* opacities,
                      const float* shs, const float* colors_precomp, const scr_settings* settings,
-                     void* geom_buf, int32_t* radii_out, int64_t* num_rendered_host, void* stream) {
+                     void* geom_buf, int32_t* radii_out, int64_t* plan_host, void* stream) {
     if (check_settings(settings)) return 1;
     if (P < 0) return fail("P < 0");
-    if (!num_rendered_host) return fail("num_rendered_host is NULL");
-    *num_rendered_host = 0;
+    if (!plan_host) return fail("plan_host is NULL");
+    plan_host[0] = plan_host[1] = 0;
     if (!geom_buf) return fail("geom_buf is NULL");
     if ((shs != nullptr) == (colors_precomp != nullptr))
         return fail("Please provide exactly one of either SHs or precomputed colors!");
@@ -137,27 +137,28 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
     CHECK_LAUNCH("preprocess_kernel", settings->debug, st);
     { ProfScope ps_(SCR_PROF_PLAN_SCAN, st); launch_plan_scans(P, ks, gv, st); }
     CHECK_LAUNCH("plan_scan_kernel", settings->debug, st);
-    unsigned long long total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, gv.total, 8, hipMemcpyDeviceToHost, st));
+    unsigned long long total[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(total, gv.total, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (total >= (1ull << 32)) return fail("num_rendered = %llu does not fit 32-bit instance indices", total);
-    *num_rendered_host = (int64_t)total;
+    if (total[0] >= (1ull << 32)) return fail("num_rendered = %llu does not fit 32-bit instance indices", total[0]);
+    plan_host[0] = (int64_t)total[0];
+    plan_host[1] = (int64_t)total[1];
     return 0;
 }
 
-int scr_forward_run(int64_t P, int64_t I, const scr_settings* settings, void* geom_buf, void* binning_buf,
-                    void* image_buf, float* out_color, void* stream) {
+int scr_forward_run(int64_t P, int64_t I, int64_t max_tile, const scr_settings* settings, void* geom_buf,
+                    void* binning_buf, void* image_buf, float* out_color, void* stream) {
     if (check_settings(settings)) return 1;
     if (!geom_buf || !binning_buf || !image_buf || !out_color) return fail("NULL buffer");
     hipStream_t st = (hipStream_t)stream;
     KSettings ks = ksettings(settings);
     GeomView gv = geom_view(geom_buf, P, ks.H, ks.W);
-    BinView bv = bin_view(binning_buf, I);
+    BinView bv = bin_view(binning_buf, I, max_tile);
     ImgView iv = img_view(image_buf, ks.H, ks.W);
     if (I > 0) {
         { ProfScope ps_(SCR_PROF_SCATTER, st); launch_scatter(P, ks, gv, bv, st); }
         CHECK_LAUNCH("scatter_kernel", settings->debug, st);
-        { ProfScope ps_(SCR_PROF_TILE_SORT, st); launch_tile_sort(ks, gv, bv, st); }
+        { ProfScope ps_(SCR_PROF_TILE_SORT, st); launch_tile_sort(ks, gv, bv, max_tile, st); }
         CHECK_LAUNCH("tile_sort_kernel", settings->debug, st);
     }
     { ProfScope ps_(SCR_PROF_BLEND_FORWARD, st); launch_blend_forward(ks, gv, bv, iv, out_color, st); }
@@ -182,7 +183,7 @@ int scr_backward(int64_t P, int32_t M, int64_t I, const float* means3D, const fl
     hipStream_t st = (hipStream_t)stream;
     KSettings ks = ksettings(settings);
     GeomView gv = geom_view((void*)geom_buf, P, ks.H, ks.W);
-    BinView bv = bin_view((void*)binning_buf, I);
+    BinView bv = bin_view((void*)binning_buf, I, 0);  // the lists read here come first in the layout
     ImgView iv = img_view((void*)image_buf, ks.H, ks.W);
     if (I > 0) {
         { ProfScope ps_(SCR_PROF_BLEND_BACKWARD, st);
@@ -213,7 +214,7 @@ int scr_debug_get(int which, int64_t P, int64_t I, int32_t H, int32_t W, const v
         else { src = gv.rec; bytes = (size_t)P * REC_F * 4; }
     } else if (which == SCR_DBG_POINT_LIST) {
         if (!binning_buf) return fail("binning_buf is NULL");
-        src = bin_view((void*)binning_buf, I).point_list;
+        src = bin_view((void*)binning_buf, I, 0).point_list;
         bytes = (size_t)I * 4;
     } else if (which == SCR_DBG_N_CONTRIB || which == SCR_DBG_FINAL_T) {
         if (!image_buf) return fail("image_buf is NULL");

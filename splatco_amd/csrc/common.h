@@ -39,7 +39,7 @@ struct GeomView {
     uint32_t* tile_count;     // [tiles]
     uint32_t* ranges;         // [tiles][2] (start, end)
     uint32_t* cursor;         // [tiles]
-    unsigned long long* total;  // [1] number of instances (64-bit)
+    unsigned long long* total;  // [2] number of instances, largest per-tile instance count
     size_t bytes;
 };
 
@@ -58,7 +58,7 @@ inline __host__ GeomView geom_view(void* base, int64_t P, int H, int W) {
     v.tile_count = (uint32_t*)take((size_t)g.tiles * 4);
     v.ranges = (uint32_t*)take((size_t)g.tiles * 8);
     v.cursor = (uint32_t*)take((size_t)g.tiles * 4);
-    v.total = (unsigned long long*)take(8);
+    v.total = (unsigned long long*)take(16);
     v.bytes = off;
     return v;
 }
@@ -70,10 +70,12 @@ struct BinView {
     uint32_t* point_list;      // [I] Gaussian ids, per tile sorted by (depth, id)
     uint32_t* gm_index;        // [I] sorted position -> Gaussian-major instance index (where its gradient record goes)
     uint8_t* qmask;            // [I] sorted position -> 4-bit mask of the tile's 8x8 quadrants the splat can touch
+    unsigned long long* keys2;  // [I] second buffer of the merge passes (only when a tile exceeds one sort chunk)
+    uint32_t* upay2;            // [I]
     size_t bytes;
 };
 
-inline __host__ BinView bin_view(void* base, int64_t I) {
+inline __host__ BinView bin_view(void* base, int64_t I, int64_t max_tile_instances) {
     char* p = (char*)base;
     size_t off = 0;
     BinView v;
@@ -84,6 +86,9 @@ inline __host__ BinView bin_view(void* base, int64_t I) {
     v.point_list = (uint32_t*)take(n * 4);
     v.gm_index = (uint32_t*)take(n * 4);
     v.qmask = (uint8_t*)take(n);
+    const bool merge = max_tile_instances > 1024;  // WAVE_SORT_MAX
+    v.keys2 = merge ? (unsigned long long*)take(n * 8) : nullptr;
+    v.upay2 = merge ? (uint32_t*)take(n * 4) : nullptr;
     v.bytes = off;
     return v;
 }
@@ -207,7 +212,8 @@ void launch_preprocess(int64_t P, int M, const float* means3D, const float* scal
                        const KSettings& ks, const GeomView& gv, int32_t* radii, hipStream_t st);
 void launch_plan_scans(int64_t P, const KSettings& ks, const GeomView& gv, hipStream_t st);
 void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const BinView& bv, hipStream_t st);
-void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, hipStream_t st);
+void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, int64_t max_tile_instances,
+                      hipStream_t st);
 void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
                           float* out_color, hipStream_t st);
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,

@@ -79,7 +79,7 @@ def _bytes(n, device):
 
 class RasterState:
     """Per-call saved buffers (opaque to Python) + what the debug getters need."""
-    __slots__ = ("P", "M", "I", "cs", "geom", "binning", "image", "radii")
+    __slots__ = ("P", "M", "I", "max_tile", "cs", "geom", "binning", "image", "radii")
 
     def debug(self, which):
         """Integer / float intermediates for the parity tests (SCR_DBG_* selectors)."""
@@ -111,13 +111,13 @@ def rasterize_forward(cs, means3D, opacities, scales, rotations, cov3D_precomp, 
     st.image = _bytes(_C.lib.scr_image_bytes(cs.H, cs.W), dev)
     radii = torch.zeros(P, dtype=torch.int32, device=dev)
     color = torch.empty(3, cs.H, cs.W, dtype=torch.float32, device=dev)
-    n = C.c_int64(0)
+    plan = (C.c_int64 * 2)(0, 0)      # (tile instances, largest per-tile instance count)
     _C.check(_C.lib.scr_forward_plan(P, M, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
                                      _ptr(opacities), _ptr(shs), _ptr(colors_precomp), cs.ref(),
-                                     st.geom.data_ptr(), _ptr(radii), C.byref(n), _stream()))
-    st.I = int(n.value)
-    st.binning = _bytes(_C.lib.scr_binning_bytes(st.I), dev)
-    _C.check(_C.lib.scr_forward_run(P, st.I, cs.ref(), st.geom.data_ptr(), st.binning.data_ptr(),
+                                     st.geom.data_ptr(), _ptr(radii), plan, _stream()))
+    st.I, st.max_tile = int(plan[0]), int(plan[1])
+    st.binning = _bytes(_C.lib.scr_binning_bytes(st.I, st.max_tile), dev)
+    _C.check(_C.lib.scr_forward_run(P, st.I, st.max_tile, cs.ref(), st.geom.data_ptr(), st.binning.data_ptr(),
                                     st.image.data_ptr(), color.data_ptr(), _stream()))
     st.radii = radii
     return color, radii, st

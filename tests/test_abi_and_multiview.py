@@ -30,10 +30,11 @@ def test_c_abi_exports_every_declared_symbol():
     # pure size queries (no device needed): monotone, 256-byte aligned
     lib.scr_geom_bytes.restype = lib.scr_binning_bytes.restype = ctypes.c_size_t
     lib.scr_geom_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
-    lib.scr_binning_bytes.argtypes = [ctypes.c_int64]
+    lib.scr_binning_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
     a, b = lib.scr_geom_bytes(1000, 1080, 1920), lib.scr_geom_bytes(2000, 1080, 1920)
     assert 0 < a < b and a % 256 == 0
-    assert lib.scr_binning_bytes(10) % 256 == 0
+    assert lib.scr_binning_bytes(10, 5) % 256 == 0
+    assert lib.scr_binning_bytes(100000, 5000) > lib.scr_binning_bytes(100000, 500)   # merge buffers
     # the python binding loads the same symbols and refuses to run without the library
     from splatco_amd import _C
     assert set(_C.SYMBOLS) == declared
