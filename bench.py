@@ -108,11 +108,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the rasterizer has no CPU path")
+    # developer overrides to exercise the N > 1 code path on a 1-GPU box (never set by the driver):
+    # every rank on one device, gloo instead of RCCL
+    if os.environ.get("SPLATCO_BENCH_ONE_DEVICE"):
+        local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        backend = os.environ.get("SPLATCO_BENCH_BACKEND", "nccl")   # "nccl" is RCCL over xGMI on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from splatco_amd import _C
     from splatco_amd.multiview import allreduce_gradients

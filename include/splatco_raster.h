@@ -139,6 +139,16 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
                         const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
                         float* d_offsets, float* d_grid_scaling, float* d_anchor, void* stream);
 
+/* ---- backward of the tri-plane bilinear feature sampling (scene/grids.py:146-182):
+ * out[v, r] = grid_sample(plane[1,R,A,B], grid[v] = (x, y) in [-1,1], bilinear, align_corners=True,
+ * zeros padding) -- x indexes the last plane dimension (B), y the dimension A.  Given
+ * grad_out[V,R] the call overwrites grad_plane[R,A,B] with the scatter-add of the four corner
+ * weights (points are bucketed by 32x32-cell tile and accumulated in LDS; global float atomics
+ * only when a tile is flushed).  R <= 8; scratch from scr_plane_sample_scratch_bytes. */
+size_t scr_plane_sample_scratch_bytes(int64_t V, int32_t A, int32_t B);
+int scr_plane_sample_backward(int64_t V, const float* grid, int32_t R, int32_t A, int32_t B,
+                              const float* grad_out, float* grad_plane, void* scratch, void* stream);
+
 /* ---- opt-in kernel timing (bench / profiling only; process-global, off by default).
  * scr_profile_enable(mask): bit i of mask selects kernel class i (SCR_PROF_*); -1 = all, 0 = off.
  * Launches of the selected classes are bracketed by hipEventRecord on the launch stream (each
@@ -149,7 +159,8 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
 enum {
     SCR_PROF_FILTER = 0, SCR_PROF_PREPROCESS = 1, SCR_PROF_PLAN_SCAN = 2, SCR_PROF_SCATTER = 3,
     SCR_PROF_TILE_SORT = 4, SCR_PROF_BLEND_FORWARD = 5, SCR_PROF_BLEND_BACKWARD = 6,
-    SCR_PROF_PREPROCESS_BACKWARD = 7, SCR_PROF_EXPAND = 8, SCR_PROF_EXPAND_BACKWARD = 9, SCR_PROF_COUNT = 10
+    SCR_PROF_PREPROCESS_BACKWARD = 7, SCR_PROF_EXPAND = 8, SCR_PROF_EXPAND_BACKWARD = 9, SCR_PROF_PLANE_BACKWARD = 10,
+    SCR_PROF_COUNT = 11
 };
 int scr_profile_enable(int mask);
 int scr_profile_read(double* total_ms, int64_t* launches);

@@ -24,6 +24,8 @@
 
 namespace scr {
 
+typedef float v2f __attribute__((ext_vector_type(2)));  // two fp32 lanes of a packed VALU op
+
 __device__ __forceinline__ float fast_exp(float x) {  // v_exp_f32(x * log2 e)
     return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
 }
@@ -51,8 +53,10 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
                      const float4* __restrict__ rec, const float* __restrict__ bg,
                      float* __restrict__ out_color, float* __restrict__ final_T,
                      uint32_t* __restrict__ n_contrib) {
-    __shared__ float4 s0[FCHUNK], s1[FCHUNK];
-    __shared__ float2 s2[FCHUNK];
+    // pair-interleaved staging: entry q holds splats 2q and 2q+1 field by field, so that one
+    // ds_read_b128 lands (field of splat 2q, field of splat 2q+1) in adjacent registers and the
+    // per-pixel arithmetic runs as packed fp32 (v_pk_fma_f32 & co: two splats per instruction)
+    __shared__ float4 sp[5][FCHUNK / 2];  // (mx,mx',my,my') (A,A',B,B') (C,C',o,o') (r,r',g,g') (b,b',j,j')
     int t, quad;
     if (!block_to_tile_quad(blockIdx.x, tiles, t, quad)) return;
     const int lane = threadIdx.x;
@@ -94,33 +98,62 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(sel_cur);
         const int cnt = __builtin_popcountll(bal);
         if (sel_cur) {
-            uint32_t pos = lanes_below(bal);
-            s0[pos] = r0;
-            s1[pos] = r1;
-            s2[pos] = make_float2(r2x, __uint_as_float(base + lane + 1));  // contributor number
+            const uint32_t pos = lanes_below(bal), q = pos >> 1, h = pos & 1;
+            float* f0 = (float*)&sp[0][q];
+            float* f1 = (float*)&sp[1][q];
+            float* f2 = (float*)&sp[2][q];
+            float* f3 = (float*)&sp[3][q];
+            float* f4 = (float*)&sp[4][q];
+            f0[h] = r0.x; f0[2 + h] = r0.y;
+            f1[h] = r0.z; f1[2 + h] = r0.w;
+            f2[h] = r1.x; f2[2 + h] = r1.y;
+            f3[h] = r1.z; f3[2 + h] = r1.w;
+            f4[h] = r2x;  f4[2 + h] = __uint_as_float(base + lane + 1);  // contributor number
         }
         // ---- put the next chunk's gathers and the one after's mask/id loads in flight
         gather(m_next, id_next);
         load_mask_id(base + 2 * FCHUNK, m_next, id_next);
         __syncthreads();  // one-wave workgroup: orders the LDS writes above before the reads below
-        for (int k = 0; k < cnt; ++k) {
-            const float4 a = s0[k], b = s1[k];
-            const float2 c = s2[k];
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float power = __builtin_fmaf(dx, __builtin_fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy);
-            const float alpha = fminf(0.99f, b.y * fast_exp(power));
-            const bool hit = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;
-            const float test_T = T * (1.0f - alpha);
-            const bool stop = hit && (test_T < 0.0001f);
-            const bool upd = hit && !stop;
-            done = done || stop;
-            const float w = alpha * T;
-            C0 = upd ? __builtin_fmaf(b.z, w, C0) : C0;
-            C1 = upd ? __builtin_fmaf(b.w, w, C1) : C1;
-            C2 = upd ? __builtin_fmaf(c.x, w, C2) : C2;
-            T = upd ? test_T : T;
-            last = upd ? __float_as_uint(c.y) : last;
+        for (int k = 0; k < cnt; k += 2) {
+            const float4 p0 = sp[0][k >> 1], p1 = sp[1][k >> 1], p2 = sp[2][k >> 1], p3 = sp[3][k >> 1],
+                         p4 = sp[4][k >> 1];
+            const bool second = k + 1 < cnt;  // wave-uniform: the pair's second slot holds a splat
+            const v2f dx = v2f{p0.x, p0.y} - pxf, dy = v2f{p0.z, p0.w} - pyf;
+            const v2f A = {p1.x, p1.y}, B = {p1.z, p1.w}, Cq = {p2.x, p2.y}, o = {p2.z, p2.w};
+            // normative order: fma(dx, fma(A,dx,B*dy), (C*dy)*dy), both splats per instruction
+            const v2f power = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(A, dx, B * dy), (Cq * dy) * dy);
+            const v2f e2 = power * 1.4426950408889634f;
+            const v2f al = o * v2f{__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
+            const float alpha0 = fminf(0.99f, al.x), alpha1 = fminf(0.99f, al.y);
+            const bool hit0 = !(power.x > 0.0f) && !(alpha0 < 1.0f / 255.0f);
+            const bool hit1 = second && !(power.y > 0.0f) && !(alpha1 < 1.0f / 255.0f);
+            if (__builtin_amdgcn_ballot_w64(!done && (hit0 || hit1)) == 0ull) continue;
+            {   // splat 2q
+                const bool hit = hit0 && !done;
+                const float test_T = T * (1.0f - alpha0);
+                const bool stop = hit && (test_T < 0.0001f);
+                const bool upd = hit && !stop;
+                done = done || stop;
+                const float w = alpha0 * T;
+                C0 = upd ? __builtin_fmaf(p3.x, w, C0) : C0;
+                C1 = upd ? __builtin_fmaf(p3.z, w, C1) : C1;
+                C2 = upd ? __builtin_fmaf(p4.x, w, C2) : C2;
+                T = upd ? test_T : T;
+                last = upd ? __float_as_uint(p4.z) : last;
+            }
+            {   // splat 2q+1
+                const bool hit = hit1 && !done;
+                const float test_T = T * (1.0f - alpha1);
+                const bool stop = hit && (test_T < 0.0001f);
+                const bool upd = hit && !stop;
+                done = done || stop;
+                const float w = alpha1 * T;
+                C0 = upd ? __builtin_fmaf(p3.y, w, C0) : C0;
+                C1 = upd ? __builtin_fmaf(p3.w, w, C1) : C1;
+                C2 = upd ? __builtin_fmaf(p4.y, w, C2) : C2;
+                T = upd ? test_T : T;
+                last = upd ? __float_as_uint(p4.w) : last;
+            }
         }
         if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
         __syncthreads();  // reads of this chunk finished before the next chunk overwrites LDS

@@ -59,7 +59,7 @@ struct ProfScope {
 const char* const kProfNames[SCR_PROF_COUNT] = {
     "filter_kernel", "preprocess_kernel", "plan_scan_kernel", "scatter_kernel", "tile_sort_kernel",
     "blend_forward_kernel", "blend_backward_kernel", "preprocess_backward_kernel", "expand_kernel",
-    "expand_backward_kernel"};
+    "expand_backward_kernel", "plane_sample_backward_kernels"};
 }  // namespace
 
 static int check_settings(const scr_settings* s) {
@@ -284,6 +284,23 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
       launch_expand_backward(V, k, scale_rot, offsets, grid_scaling, out_index, g_xyz, g_color, g_opacity, g_scaling,
                              g_rot, d_neural_opacity, d_color, d_scale_rot, d_offsets, d_grid_scaling, d_anchor, st); }
     CHECK_LAUNCH("expand_backward_kernel", 0, st);
+    return 0;
+}
+
+// ---- tri-plane sampling backward (triplane.hip)
+size_t scr_plane_sample_scratch_bytes(int64_t V, int32_t A, int32_t B) { return triplane_scratch_bytes(V, A, B); }
+
+int scr_plane_sample_backward(int64_t V, const float* grid, int32_t R, int32_t A, int32_t B,
+                              const float* grad_out, float* grad_plane, void* scratch, void* stream) {
+    if (V < 0 || R <= 0 || A <= 1 || B <= 1) return fail("bad sizes");
+    if (!grad_plane || !scratch || (V > 0 && (!grid || !grad_out))) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    { ProfScope ps_(SCR_PROF_PLANE_BACKWARD, st);
+      rc = launch_plane_sample_backward(V, grid, R, A, B, grad_out, grad_plane, scratch, st); }
+    if (rc == 1) return fail("R = %d channels per plane exceeds the supported 8", R);
+    if (rc == 2) return fail("plane %dx%d has too many 32x32 tiles for the LDS histogram", A, B);
+    CHECK_LAUNCH("plane_sample_backward", 0, st);
     return 0;
 }
 

@@ -237,4 +237,8 @@ void launch_expand_backward(int64_t V, int k, const float* scale_rot, const floa
                             const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
                             float* d_offsets, float* d_grid_scaling, float* d_anchor, hipStream_t st);
 
+size_t triplane_scratch_bytes(int64_t V, int A, int B);
+int launch_plane_sample_backward(int64_t V, const float* grid, int R, int A, int B, const float* grad_out,
+                                 float* grad_plane, void* scratch, hipStream_t st);
+
 }  // namespace scr

@@ -91,6 +91,9 @@ class TriPlaneAttention(nn.Module):           # scene/grids.py:55-64
 
 def _sample(plane, ind_norm, cols):
     # F.grid_sample bilinear, align_corners=True, zeros padding (scene/grids.py:148-150)
+    if plane.is_cuda and plane.shape[1] <= 8 and not ind_norm.requires_grad and ind_norm.shape[2] >= 65536:
+        from .triplane import plane_sample      # same forward, tile-bucketed LDS backward (csrc/triplane.hip)
+        return plane_sample(plane, ind_norm[0, 0][:, cols])
     return F.grid_sample(plane, ind_norm[:, :, :, cols], mode="bilinear", align_corners=True).flatten(0, 2).T
 
 

@@ -123,3 +123,33 @@ def test_fused_expand_compact_matches_torch_chain():
     ref_idx = torch.nonzero(no.view(-1) > 0).view(-1)
     assert torch.equal(a[2].view(-1), no.view(-1)[ref_idx])          # order-preserving compaction
     assert torch.equal(a[1], args[1][ref_idx])
+
+
+@pytest.mark.parametrize("A,B,R", [(70, 70, 5), (133, 97, 3), (700, 700, 5)])
+def test_plane_sample_backward_matches_grid_sample(A, B, R):
+    """csrc/triplane.hip (tile-bucketed LDS scatter) == torch's grid_sample backward
+    (scene/grids.py:148-150 semantics: bilinear, align_corners=True, zeros padding), including
+    points outside the plane and on its border.  Tolerance: fp32 summation order only."""
+    import torch.nn.functional as F
+    from splatco_amd.triplane import plane_sample
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(A * 1000 + B)
+    V = 300_000
+    grid = torch.rand(V, 2, device=dev, generator=g) * 2.4 - 1.2          # ~30 % of the points leave [-1,1]
+    grid[:1000] = torch.randint(0, 2, (1000, 2), device=dev, generator=g).float() * 2 - 1   # exact corners / borders
+    grid[1000:2000, 0] = 1.0
+    grid[2000:2010] = float("nan")
+    w = torch.randn(V, R, device=dev, generator=g)
+    p1 = (torch.randn(1, R, A, B, device=dev, generator=g)).requires_grad_()
+    p2 = p1.detach().clone().requires_grad_()
+    o1 = plane_sample(p1, grid)
+    o2 = F.grid_sample(p2, grid.view(1, 1, V, 2), mode="bilinear", align_corners=True).flatten(0, 2).T
+    ok = ~torch.isnan(grid).any(dim=1)
+    assert torch.equal(o1[ok], o2[ok])
+    w = torch.where(ok[:, None], w, torch.zeros_like(w))
+    (o1[ok] * w[ok]).sum().backward()
+    (o2[ok] * w[ok]).sum().backward()
+    err = (p1.grad - p2.grad).abs().max().item()
+    ref = p2.grad.abs().max().item()
+    assert err <= 2e-5 * ref, (err, ref)
+    assert torch.isfinite(p1.grad).all()

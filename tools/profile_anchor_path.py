@@ -11,7 +11,7 @@ torch.manual_seed(0)
 pc = AnchorGaussianModel(plane_size=plane, num_channels=15).to(dev)
 pc.set_anchors(torch.rand(N, 3, device=dev) * 3.6 - 1.8, torch.randn(N, 10, 3, device=dev) * 0.5,
                torch.randn(N, 32, device=dev) * 0.5, torch.randn(N, 6, device=dev) * 0.3 - 4.5)
-pc.feat_planes.Q0 = 0; pc.train()
+pc.feat_planes.Q0 = 0; pc.train(); pc.feat_planes._feat.activate_level = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 cam = look_at_camera((0.3, -0.2, -5.5), (0, 0, 0), (0, -1, 0), math.radians(60), 1920, 1080).to(dev)
 pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
 vis = prefilter_voxel(cam, pc, pipe, torch.ones(3, device=dev))
