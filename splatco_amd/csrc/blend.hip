@@ -359,12 +359,21 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             float g[4][9];
             uint32_t jj[4];
             bool any = false;
+            // all four records first (one LDS round trip per group instead of four)
+            float4 ra[4], rb[4];
+            float2 rc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ks = k - u >= 0 ? k - u : 0;
+                ra[u] = s0[wave][ks];
+                rb[u] = s1[wave][ks];
+                rc[u] = s2[wave][ks];
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool valid = k - u >= 0;  // wave-uniform
-                const int ks = valid ? k - u : 0;
-                const float4 a = s0[wave][ks], b = s1[wave][ks];
-                const float2 c = s2[wave][ks];
+                const float4 a = ra[u], b = rb[u];
+                const float2 c = rc[u];
                 const uint32_t j = __float_as_uint(c.y);
                 const uint32_t q = base + j;  // list position; contributor number q+1
                 const float dx = a.x - pxf, dy = a.y - pyf;
@@ -372,11 +381,12 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 const float G = fast_exp(power);
                 const float alpha = fminf(0.99f, b.y * G);
                 const bool hit = valid && (q < last) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-#pragma unroll
-                for (int v = 0; v < 9; ++v) g[u][v] = 0.0f;
-                if (hit)
-                    splat_pixel_grad(ps, a, b, c.x, dx, dy, G, alpha, g[u][0], g[u][1], g[u][2], g[u][3], g[u][4],
-                                     g[u][5], g[u][6], g[u][7], g[u][8]);
+                // Branch-free: a splat that does not contribute to this pixel is carried through the
+                // back-to-front recurrences with alpha = 0, which leaves T and the colour-behind
+                // accumulator exactly as skipping it would (T / (1 - 0) = T; the accumulator folds
+                // 0 * colour); only the G-weighted sums need an explicit zero.
+                splat_pixel_grad(ps, a, b, c.x, dx, dy, hit ? G : 0.0f, hit ? alpha : 0.0f, g[u][0], g[u][1], g[u][2],
+                                 g[u][3], g[u][4], g[u][5], g[u][6], g[u][7], g[u][8]);
                 any = any || (__builtin_amdgcn_ballot_w64(hit) != 0ull);
                 jj[u] = valid ? j : 0xffffffffu;
             }
