@@ -232,6 +232,27 @@ def test_depth_ties_and_huge_tile(oracle, P):
         _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"])
 
 
+@pytest.mark.parametrize("P", [1, 63, 4097])
+def test_odd_sizes_and_giant_splats(oracle, P):
+    """P = 1, P not a multiple of any workgroup shape, and Gaussians that cover the whole image
+    (tiles_touched = every tile; long per-thread tile loops, every quadrant mask bit set)."""
+    cam = synthetic_camera(400, 304)
+    g = synthetic_gaussians(P, 400, 304, seed=21)
+    n_big = min(P, 5)
+    g["scales"][:n_big] = np.array([3.0, 2.0, 0.5], np.float32)     # hundreds of pixels across
+    g["opacities"][:n_big] = 0.3
+    st = oracle_settings(oracle, cam, g["bg"])
+    f = oracle.forward(st, g["means3D"], g["opacities"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+    assert f["tiles_touched"][:n_big].max() >= 0.5 * st.grid[0] * st.grid[1]
+    rng = np.random.default_rng(4)
+    dL = rng.standard_normal((3, 304, 400)).astype(np.float32)
+    b = oracle.backward(st, f, dL, g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+    o = _run_gpu(cam, g, dL=dL)
+    _check_forward(f, o, st)
+    if np.array_equal(o["n_contrib"], f["n_contrib"]):
+        _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"], tol=2e-4)
+
+
 def test_full_size_cfg1_1M_1080p(oracle):
     """BASELINE.json configs[1]: 1M Gaussians, 1920x1080, forward + backward, against the oracle
     (about a minute of single-thread CPU), plus size-independent properties."""
