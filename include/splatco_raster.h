@@ -149,6 +149,19 @@ size_t scr_plane_sample_scratch_bytes(int64_t V, int32_t A, int32_t B);
 int scr_plane_sample_backward(int64_t V, const float* grid, int32_t R, int32_t A, int32_t B,
                               const float* grad_out, float* grad_plane, void* scratch, void* stream);
 
+/* ---- fused L1 + SSIM image loss (train.py:192-196, utils/loss_utils.py:17-63): img1 = rendered
+ * image [C,H,W] (gets the gradient), img2 = ground truth.  Forward writes out2[0] = mean |img1-img2|
+ * and out2[1] = mean SSIM (11x11 Gaussian window, sigma 1.5, zero padding) to DEVICE memory; with
+ * with_grad != 0 it also leaves the three derivative maps in `scratch` for the backward, which
+ * computes dimg1 = g_l1 * dL1/dimg1 + g_ssim * dSSIM/dimg1 with the upstream scalars read from
+ * device memory (no host synchronisation anywhere).  Deterministic (fixed-order reductions). */
+size_t scr_l1_ssim_scratch_bytes(int32_t C, int32_t H, int32_t W, int32_t with_grad);
+int scr_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, void* scratch,
+                        int32_t with_grad, float* out2, void* stream);
+int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2,
+                         const void* scratch, const float* g_l1, const float* g_ssim, float* dimg1,
+                         void* stream);
+
 /* ---- opt-in kernel timing (bench / profiling only; process-global, off by default).
  * scr_profile_enable(mask): bit i of mask selects kernel class i (SCR_PROF_*); -1 = all, 0 = off.
  * Launches of the selected classes are bracketed by hipEventRecord on the launch stream (each
@@ -160,7 +173,7 @@ enum {
     SCR_PROF_FILTER = 0, SCR_PROF_PREPROCESS = 1, SCR_PROF_PLAN_SCAN = 2, SCR_PROF_SCATTER = 3,
     SCR_PROF_TILE_SORT = 4, SCR_PROF_BLEND_FORWARD = 5, SCR_PROF_BLEND_BACKWARD = 6,
     SCR_PROF_PREPROCESS_BACKWARD = 7, SCR_PROF_EXPAND = 8, SCR_PROF_EXPAND_BACKWARD = 9, SCR_PROF_PLANE_BACKWARD = 10,
-    SCR_PROF_COUNT = 11
+    SCR_PROF_L1_SSIM = 11, SCR_PROF_L1_SSIM_BACKWARD = 12, SCR_PROF_COUNT = 13
 };
 int scr_profile_enable(int mask);
 int scr_profile_read(double* total_ms, int64_t* launches);

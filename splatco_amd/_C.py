@@ -17,8 +17,9 @@ SYMBOLS = [
     "scr_forward_run", "scr_backward", "scr_debug_get", "scr_profile_enable", "scr_profile_read",
     "scr_profile_kernel_name", "scr_expand_scratch_bytes", "scr_expand_plan", "scr_expand_run",
     "scr_expand_backward", "scr_plane_sample_scratch_bytes", "scr_plane_sample_backward",
+    "scr_l1_ssim_scratch_bytes", "scr_l1_ssim_forward", "scr_l1_ssim_backward",
 ]
-PROF_COUNT = 11
+PROF_COUNT = 13
 ABI_VERSION = 2
 
 DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
@@ -77,6 +78,11 @@ def _load():
     lib.scr_plane_sample_scratch_bytes.restype = C.c_size_t
     lib.scr_plane_sample_backward.argtypes = [i64, vp, i32, i32, i32, vp, vp, vp, vp]
     lib.scr_plane_sample_backward.restype = C.c_int
+    lib.scr_l1_ssim_scratch_bytes.argtypes = [i32, i32, i32, i32]
+    lib.scr_l1_ssim_scratch_bytes.restype = C.c_size_t
+    lib.scr_l1_ssim_forward.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, vp]
+    lib.scr_l1_ssim_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.scr_l1_ssim_forward.restype = lib.scr_l1_ssim_backward.restype = C.c_int
     lib.scr_profile_enable.argtypes = [C.c_int]
     lib.scr_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.scr_profile_kernel_name.argtypes = [C.c_int]

@@ -59,7 +59,8 @@ struct ProfScope {
 const char* const kProfNames[SCR_PROF_COUNT] = {
     "filter_kernel", "preprocess_kernel", "plan_scan_kernel", "scatter_kernel", "tile_sort_kernel",
     "blend_forward_kernel", "blend_backward_kernel", "preprocess_backward_kernel", "expand_kernel",
-    "expand_backward_kernel", "plane_sample_backward_kernels"};
+    "expand_backward_kernel", "plane_sample_backward_kernels", "l1_ssim_forward_kernel",
+    "l1_ssim_backward_kernel"};
 }  // namespace
 
 static int check_settings(const scr_settings* s) {
@@ -301,6 +302,33 @@ int scr_plane_sample_backward(int64_t V, const float* grid, int32_t R, int32_t A
     if (rc == 1) return fail("R = %d channels per plane exceeds the supported 8", R);
     if (rc == 2) return fail("plane %dx%d has too many 32x32 tiles for the LDS histogram", A, B);
     CHECK_LAUNCH("plane_sample_backward", 0, st);
+    return 0;
+}
+
+// ---- fused L1 + SSIM loss (ssim.hip)
+size_t scr_l1_ssim_scratch_bytes(int32_t C, int32_t H, int32_t W, int32_t with_grad) {
+    return l1_ssim_scratch_bytes(C, H, W, with_grad);
+}
+
+int scr_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, void* scratch,
+                        int32_t with_grad, float* out2, void* stream) {
+    if (C <= 0 || H <= 0 || W <= 0) return fail("bad image size");
+    if (!img1 || !img2 || !scratch || !out2) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_L1_SSIM, st); launch_l1_ssim_forward(C, H, W, img1, img2, scratch, with_grad, out2, st); }
+    CHECK_LAUNCH("l1_ssim_forward_kernel", 0, st);
+    return 0;
+}
+
+int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2,
+                         const void* scratch, const float* g_l1, const float* g_ssim, float* dimg1,
+                         void* stream) {
+    if (C <= 0 || H <= 0 || W <= 0) return fail("bad image size");
+    if (!img1 || !img2 || !scratch || !g_l1 || !g_ssim || !dimg1) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_L1_SSIM_BACKWARD, st);
+      launch_l1_ssim_backward(C, H, W, img1, img2, scratch, g_l1, g_ssim, dimg1, st); }
+    CHECK_LAUNCH("l1_ssim_backward_kernel", 0, st);
     return 0;
 }
 

@@ -237,6 +237,11 @@ void launch_expand_backward(int64_t V, int k, const float* scale_rot, const floa
                             const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
                             float* d_offsets, float* d_grid_scaling, float* d_anchor, hipStream_t st);
 
+size_t l1_ssim_scratch_bytes(int C, int H, int W, int with_grad);
+void launch_l1_ssim_forward(int C, int H, int W, const float* img1, const float* img2, void* scratch,
+                            int with_grad, float* out2, hipStream_t st);
+void launch_l1_ssim_backward(int C, int H, int W, const float* img1, const float* img2, const void* scratch,
+                             const float* g_l1, const float* g_ssim, float* dimg1, hipStream_t st);
 size_t triplane_scratch_bytes(int64_t V, int A, int B);
 int launch_plane_sample_backward(int64_t V, const float* grid, int R, int A, int B, const float* grad_out,
                                  float* grad_plane, void* scratch, hipStream_t st);

@@ -42,7 +42,46 @@ def ssim(img1, img2, window_size=11, size_average=True):
     return ssim_map.mean() if size_average else ssim_map.mean(1).mean(1).mean(1)
 
 
+class _L1Ssim(torch.autograd.Function):
+    """(mean |x - y|, mean SSIM(x, y)) of two [C,H,W] device images in one fused HIP pass
+    (csrc/ssim.hip); the gradient flows to x only.  11 ms -> ~0.3 ms forward+backward at 1080p."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        from . import _C
+        from .rasterizer import _stream
+        x, y = x.contiguous().float(), y.contiguous().float()
+        C, H, W = x.shape
+        need = x.requires_grad
+        scratch = torch.empty(_C.lib.scr_l1_ssim_scratch_bytes(C, H, W, int(need)), dtype=torch.uint8, device=x.device)
+        out = torch.empty(2, dtype=torch.float32, device=x.device)
+        _C.check(_C.lib.scr_l1_ssim_forward(C, H, W, x.data_ptr(), y.data_ptr(), scratch.data_ptr(), int(need),
+                                            out.data_ptr(), _stream()))
+        ctx.save_for_backward(x, y, scratch)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ssim):
+        from . import _C
+        from .rasterizer import _stream
+        x, y, scratch = ctx.saved_tensors
+        C, H, W = x.shape
+        g_l1 = g_l1.contiguous().float().reshape(1)
+        g_ssim = g_ssim.contiguous().float().reshape(1)
+        dx = torch.empty_like(x)
+        _C.check(_C.lib.scr_l1_ssim_backward(C, H, W, x.data_ptr(), y.data_ptr(), scratch.data_ptr(),
+                                             g_l1.data_ptr(), g_ssim.data_ptr(), dx.data_ptr(), _stream()))
+        return dx, None
+
+
+def l1_ssim(image, gt_image):
+    """Fused (l1_loss, ssim) for [3,H,W] device images; falls back to the torch ops on CPU."""
+    if image.is_cuda and image.dim() == 3:
+        return _L1Ssim.apply(image, gt_image)
+    return l1_loss(image, gt_image), ssim(image, gt_image)
+
+
 def view_loss(image, gt_image, scaling, lambda_dssim=0.2):
     """Per-view training loss (train.py:192-196): 0.8 L1 + 0.2 (1 - SSIM) + 0.01 mean(prod(scaling))."""
-    return (1.0 - lambda_dssim) * l1_loss(image, gt_image) + lambda_dssim * (1.0 - ssim(image, gt_image)) + \
-        0.01 * scaling.prod(dim=1).mean()
+    l1, s = l1_ssim(image, gt_image)
+    return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - s) + 0.01 * scaling.prod(dim=1).mean()
