@@ -184,3 +184,21 @@ def test_fused_l1_ssim_matches_torch(H, W):
     l1g, sg = l1_ssim(x3, b)
     (0.8 * l1g + 0.2 * (1.0 - sg)).backward()
     assert torch.equal(x3.grad, x1.grad) and torch.equal(sg, sf)
+
+
+def test_collaborative_step_runs_and_updates_parameters():
+    """configs[3]/[4] counterpart on one rank: mv = 2 views, one backward, Adam step."""
+    from splatco_amd.train_step import collaborative_step
+    dev = torch.device("cuda:0")
+    pc, d = _model(dev)
+    pc.train()
+    cams = [look_at_camera(eye=(0.3 + 0.4 * i, -0.2, -4.5), target=(0, 0, 0), up=(0, -1, 0), FoVx=math.radians(60),
+                           width=160, height=96, uid=i).to(dev) for i in range(2)]
+    gts = [torch.rand(3, 96, 160) for _ in cams]
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
+    opt = torch.optim.Adam([p for p in pc.parameters() if p.requires_grad], lr=1e-3)
+    before = pc._anchor_feat.detach().clone()
+    loss, out, _ = collaborative_step(pc, cams, gts, pipe, torch.ones(3, device=dev), optimizer=opt)
+    assert torch.isfinite(loss) and out["render"].shape == (3, 96, 160)
+    assert not torch.equal(before, pc._anchor_feat.detach())
+    assert out["viewspace_points"].grad is not None
