@@ -114,45 +114,49 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
         gather(m_next, id_next);
         load_mask_id(base + 2 * FCHUNK, m_next, id_next);
         __syncthreads();  // one-wave workgroup: orders the LDS writes above before the reads below
-        for (int k = 0; k < cnt; k += 2) {
-            const float4 p0 = sp[0][k >> 1], p1 = sp[1][k >> 1], p2 = sp[2][k >> 1], p3 = sp[3][k >> 1],
-                         p4 = sp[4][k >> 1];
-            const bool second = k + 1 < cnt;  // wave-uniform: the pair's second slot holds a splat
-            const v2f dx = v2f{p0.x, p0.y} - pxf, dy = v2f{p0.z, p0.w} - pyf;
-            const v2f A = {p1.x, p1.y}, B = {p1.z, p1.w}, Cq = {p2.x, p2.y}, o = {p2.z, p2.w};
-            // normative order: fma(dx, fma(A,dx,B*dy), (C*dy)*dy), both splats per instruction
-            const v2f power = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(A, dx, B * dy), (Cq * dy) * dy);
-            const v2f e2 = power * 1.4426950408889634f;
-            const v2f al = o * v2f{__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
-            const float alpha0 = fminf(0.99f, al.x), alpha1 = fminf(0.99f, al.y);
-            const bool hit0 = !(power.x > 0.0f) && !(alpha0 < 1.0f / 255.0f);
-            const bool hit1 = second && !(power.y > 0.0f) && !(alpha1 < 1.0f / 255.0f);
-            if (__builtin_amdgcn_ballot_w64(!done && (hit0 || hit1)) == 0ull) continue;
-            {   // splat 2q
-                const bool hit = hit0 && !done;
-                const float test_T = T * (1.0f - alpha0);
-                const bool stop = hit && (test_T < 0.0001f);
-                const bool upd = hit && !stop;
-                done = done || stop;
-                const float w = alpha0 * T;
-                C0 = upd ? __builtin_fmaf(p3.x, w, C0) : C0;
-                C1 = upd ? __builtin_fmaf(p3.z, w, C1) : C1;
-                C2 = upd ? __builtin_fmaf(p4.x, w, C2) : C2;
-                T = upd ? test_T : T;
-                last = upd ? __float_as_uint(p4.z) : last;
+        for (int k = 0; k < cnt; k += 4) {
+            // two packed pairs per iteration: all LDS reads and both exponent chains are in flight
+            // before the sequential (front-to-back) transmittance updates
+            v2f power[2], al[2];
+            float4 p3[2], p4[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q = (k >> 1) + h;  // pair index; slots past cnt hold stale data and are masked below
+                const float4 p0 = sp[0][q], p1 = sp[1][q], p2 = sp[2][q];
+                p3[h] = sp[3][q];
+                p4[h] = sp[4][q];
+                const v2f dx = v2f{p0.x, p0.y} - pxf, dy = v2f{p0.z, p0.w} - pyf;
+                const v2f A = {p1.x, p1.y}, B = {p1.z, p1.w}, Cq = {p2.x, p2.y}, o = {p2.z, p2.w};
+                // normative order: fma(dx, fma(A,dx,B*dy), (C*dy)*dy), both splats per instruction
+                power[h] = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(A, dx, B * dy), (Cq * dy) * dy);
+                const v2f e2 = power[h] * 1.4426950408889634f;
+                al[h] = o * v2f{__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
             }
-            {   // splat 2q+1
-                const bool hit = hit1 && !done;
-                const float test_T = T * (1.0f - alpha1);
-                const bool stop = hit && (test_T < 0.0001f);
-                const bool upd = hit && !stop;
+            const float alpha[4] = {fminf(0.99f, al[0].x), fminf(0.99f, al[0].y), fminf(0.99f, al[1].x), fminf(0.99f, al[1].y)};
+            const float pw[4] = {power[0].x, power[0].y, power[1].x, power[1].y};
+            bool hit[4];
+            bool anyh = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                hit[u] = (k + u < cnt) && !(pw[u] > 0.0f) && !(alpha[u] < 1.0f / 255.0f);  // (k+u < cnt) is wave-uniform
+                anyh = anyh || hit[u];
+            }
+            if (__builtin_amdgcn_ballot_w64(!done && anyh) == 0ull) continue;
+            const float cr[4] = {p3[0].x, p3[0].y, p3[1].x, p3[1].y}, cg[4] = {p3[0].z, p3[0].w, p3[1].z, p3[1].w};
+            const float cb[4] = {p4[0].x, p4[0].y, p4[1].x, p4[1].y}, cj[4] = {p4[0].z, p4[0].w, p4[1].z, p4[1].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool h_ = hit[u] && !done;
+                const float test_T = T * (1.0f - alpha[u]);
+                const bool stop = h_ && (test_T < 0.0001f);
+                const bool upd = h_ && !stop;
                 done = done || stop;
-                const float w = alpha1 * T;
-                C0 = upd ? __builtin_fmaf(p3.y, w, C0) : C0;
-                C1 = upd ? __builtin_fmaf(p3.w, w, C1) : C1;
-                C2 = upd ? __builtin_fmaf(p4.y, w, C2) : C2;
+                const float w = alpha[u] * T;
+                C0 = upd ? __builtin_fmaf(cr[u], w, C0) : C0;
+                C1 = upd ? __builtin_fmaf(cg[u], w, C1) : C1;
+                C2 = upd ? __builtin_fmaf(cb[u], w, C2) : C2;
                 T = upd ? test_T : T;
-                last = upd ? __float_as_uint(p4.w) : last;
+                last = upd ? __float_as_uint(cj[u]) : last;
             }
         }
         if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
