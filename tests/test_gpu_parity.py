@@ -98,12 +98,16 @@ def _check_forward(f, o, st, full_ncontrib=True):
     if f["num_rendered"]:
         assert np.array_equal(o["point_offsets"].astype(np.uint64), f["point_offsets"]), "point_offsets"
         assert np.array_equal(o["point_list"], f["point_list"]), "point_list (sorted ids)"
+    # margin = the pixel's smallest relative distance of an exp()-dependent decision (alpha vs 1/255,
+    # T' vs 1e-4 -- for ANY splat of its list, not only the last) from its threshold; the spec gives
+    # exp() 2 ulp, so only pixels with margin > 1e-5 are required to take identical decisions
     safe = f["margin"] > 1e-5
     assert np.array_equal(o["n_contrib"][safe], f["n_contrib"][safe]), "n_contrib away from thresholds"
     assert (o["n_contrib"] == f["n_contrib"]).mean() >= 0.999
-    same = o["n_contrib"] == f["n_contrib"]
-    assert np.abs(o["color"] - f["color"])[:, same].max() <= 1e-4, "image max-abs"
-    assert np.abs(o["final_T"] - f["final_T"])[same].max() <= 1e-5
+    cmp_px = safe & (o["n_contrib"] == f["n_contrib"])
+    assert cmp_px.mean() >= 0.98
+    assert np.abs(o["color"] - f["color"])[:, cmp_px].max() <= 1e-4, "image max-abs"
+    assert np.abs(o["final_T"] - f["final_T"])[cmp_px].max() <= 1e-5
     assert psnr(o["color"], f["color"]) >= 80.0
 
 
