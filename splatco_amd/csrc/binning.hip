@@ -280,7 +280,10 @@ __device__ __forceinline__ void wave_sort_any(uint32_t n, unsigned long long* ke
 
 // grid = (xcd_grid(tiles), chunks): chunk c of tile t.  Tiles with <= 1024 instances are finished
 // by their chunk 0; larger tiles get every chunk sorted in place.
-__global__ void __launch_bounds__(64)
+#ifndef SCR_SORT_MIN_WAVES
+#define SCR_SORT_MIN_WAVES 1
+#endif
+__global__ void __launch_bounds__(64, SCR_SORT_MIN_WAVES)
 tile_sort_wave_kernel(int tiles, const uint32_t* __restrict__ ranges, unsigned long long* __restrict__ keys,
                       uint32_t* __restrict__ upay, uint32_t* __restrict__ point_list,
                       uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
