@@ -12,8 +12,8 @@
 //
 // HBM-bound: 56 B read per candidate (+36 B per anchor), 56 B written per kept Gaussian.
 // Compaction = wave ballot + mbcnt prefix inside a workgroup, workgroup offsets from a scan of
-// per-workgroup counts (count pass reads 4 B per candidate).  Backward is one thread per anchor
-// (its k candidates are contiguous): per-anchor sums need no atomics -> deterministic.
+// per-workgroup counts (count pass reads 4 B per candidate).  Backward is one thread per candidate;
+// the per-anchor sums over its k candidates go through LDS in slot order -> no atomics, deterministic.
 #include "common.h"
 
 namespace scr {
@@ -132,37 +132,43 @@ expand_run_kernel(int64_t n, int k, const float* __restrict__ neural_opacity, co
     }
 }
 
-// backward: one thread per anchor
-__global__ void __launch_bounds__(256)
-expand_backward_kernel(int64_t V, int k, const float* __restrict__ scale_rot, const float* __restrict__ offsets,
-                       const float* __restrict__ grid_scaling, const int32_t* __restrict__ out_index,
+// backward: one thread per CANDIDATE (coalesced per-candidate reads / writes); the per-anchor sums
+// (d grid_scaling, d anchor) of the k candidates of an anchor are added in slot order through LDS
+// -> no atomics, deterministic.  A workgroup owns `apw` consecutive anchors (32, fewer when k is
+// so large that 32 k partial records would not fit 48 KB of LDS).
+
+__global__ void __launch_bounds__(1024)
+expand_backward_kernel(int64_t V, int k, int apw, const float* __restrict__ scale_rot,
+                       const float* __restrict__ offsets, const float* __restrict__ grid_scaling,
+                       const int32_t* __restrict__ out_index,
                        const float* __restrict__ g_xyz, const float* __restrict__ g_color,
                        const float* __restrict__ g_opacity, const float* __restrict__ g_scaling,
                        const float* __restrict__ g_rot, float* __restrict__ d_neural_opacity,
                        float* __restrict__ d_color, float* __restrict__ d_scale_rot, float* __restrict__ d_offsets,
                        float* __restrict__ d_grid_scaling, float* __restrict__ d_anchor) {
-    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (v >= V) return;
-    const float* gs = grid_scaling + 6 * v;
-    float dgs[6] = {0, 0, 0, 0, 0, 0}, da[3] = {0, 0, 0};
-    for (int s = 0; s < k; ++s) {
-        const int64_t i = v * k + s;
+    extern __shared__ __attribute__((aligned(16))) float part[];  // [apw * k][9]
+    const int64_t v0 = (int64_t)blockIdx.x * apw;
+    const int nloc = (int)min((int64_t)apw, V - v0) * k;  // candidates of this workgroup
+    for (int c = threadIdx.x; c < nloc; c += blockDim.x) {
+        const int64_t i = v0 * k + c, v = i / k;
         const int32_t p = out_index[i];
+        const float* gs = grid_scaling + 6 * v;
         float dsr[7] = {0, 0, 0, 0, 0, 0, 0}, dof[3] = {0, 0, 0}, dcol[3] = {0, 0, 0}, dop = 0.0f;
+        float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // (d grid_scaling[0..5], d anchor[0..2]) of this candidate
         if (p >= 0) {
             const float* sr = scale_rot + 7 * i;
             dop = g_opacity[p];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                dcol[c] = g_color[3 * (size_t)p + c];
-                const float gx = g_xyz[3 * (size_t)p + c];
-                da[c] += gx;
-                dof[c] = gx * gs[c];
-                dgs[c] += gx * offsets[3 * i + c];
-                const float sg = 1.0f / (1.0f + __expf(-sr[c]));
-                const float gsc = g_scaling[3 * (size_t)p + c];
-                dgs[3 + c] += gsc * sg;
-                dsr[c] = gsc * gs[3 + c] * sg * (1.0f - sg);
+            for (int ch = 0; ch < 3; ++ch) {
+                dcol[ch] = g_color[3 * (size_t)p + ch];
+                const float gx = g_xyz[3 * (size_t)p + ch];
+                acc9[6 + ch] = gx;
+                dof[ch] = gx * gs[ch];
+                acc9[ch] = gx * offsets[3 * i + ch];
+                const float sg = 1.0f / (1.0f + __expf(-sr[ch]));
+                const float gsc = g_scaling[3 * (size_t)p + ch];
+                acc9[3 + ch] = gsc * sg;
+                dsr[ch] = gsc * gs[3 + ch] * sg * (1.0f - sg);
             }
             const float q0 = sr[3], q1 = sr[4], q2 = sr[5], q3 = sr[6];
             const float nrm = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
@@ -182,17 +188,25 @@ expand_backward_kernel(int64_t V, int k, const float* __restrict__ scale_rot, co
         }
         d_neural_opacity[i] = dop;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            d_color[3 * i + c] = dcol[c];
-            d_offsets[3 * i + c] = dof[c];
+        for (int ch = 0; ch < 3; ++ch) {
+            d_color[3 * i + ch] = dcol[ch];
+            d_offsets[3 * i + ch] = dof[ch];
         }
 #pragma unroll
-        for (int c = 0; c < 7; ++c) d_scale_rot[7 * i + c] = dsr[c];
+        for (int ch = 0; ch < 7; ++ch) d_scale_rot[7 * i + ch] = dsr[ch];
+#pragma unroll
+        for (int ch = 0; ch < 9; ++ch) part[c * 9 + ch] = acc9[ch];
     }
-#pragma unroll
-    for (int c = 0; c < 6; ++c) d_grid_scaling[6 * v + c] = dgs[c];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) d_anchor[3 * v + c] = da[c];
+    __syncthreads();
+    // anchor sums: thread (anchor a, component ch) adds the k candidates in slot order
+    const int na = nloc / k;
+    for (int j = threadIdx.x; j < na * 9; j += blockDim.x) {
+        const int a_ = j / 9, ch = j % 9;
+        float sum = 0.0f;
+        for (int sidx = 0; sidx < k; ++sidx) sum += part[(a_ * k + sidx) * 9 + ch];
+        if (ch < 6) d_grid_scaling[6 * (v0 + a_) + ch] = sum;
+        else d_anchor[3 * (v0 + a_) + ch - 6] = sum;
+    }
 }
 
 void launch_expand_count(int64_t n, const float* neural_opacity, uint32_t* wg_count, unsigned long long* total,
@@ -217,8 +231,10 @@ void launch_expand_backward(int64_t V, int k, const float* scale_rot, const floa
                             const float* g_color, const float* g_opacity, const float* g_scaling,
                             const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
                             float* d_offsets, float* d_grid_scaling, float* d_anchor, hipStream_t st) {
-    expand_backward_kernel<<<(unsigned)((V + 255) / 256), 256, 0, st>>>(
-        V, k, scale_rot, offsets, grid_scaling, out_index, g_xyz, g_color, g_opacity, g_scaling, g_rot,
+    const int apw = max(1, min(32, (48 * 1024) / (k * 9 * (int)sizeof(float))));
+    const int threads = min(1024, ((apw * k + 63) / 64) * 64);
+    expand_backward_kernel<<<(unsigned)((V + apw - 1) / apw), threads, (size_t)apw * k * 9 * sizeof(float), st>>>(
+        V, k, apw, scale_rot, offsets, grid_scaling, out_index, g_xyz, g_color, g_opacity, g_scaling, g_rot,
         d_neural_opacity, d_color, d_scale_rot, d_offsets, d_grid_scaling, d_anchor);
 }
 
