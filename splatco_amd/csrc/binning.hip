@@ -4,8 +4,8 @@
 // Here the same ordered lists are produced MI355X-style in two HBM passes:
 //   1. bucket:  per-tile instance counts (integer atomics fused into the preprocess kernel) ->
 //               exclusive scan -> every instance is dropped into its tile's segment
-//               (key = depth_bits << 32 | gaussian id << 4 | quadrant mask; payload = the instance's
-//               Gaussian-major index).  Slot order inside a segment is arbitrary.
+//               as ONE 16-byte record (key = depth_bits << 32 | gaussian id << 4 | quadrant mask;
+//               payload = the instance's Gaussian-major index).  Slot order inside a segment is arbitrary.
 //   2. sort:    one workgroup per tile sorts its segment by the 64-bit key in LDS (bitonic
 //               network, 160 KiB LDS lets a 8192-instance tile stay on chip).  Sorting by
 //               (depth, id) reproduces the stable (tile, depth) order of the reference semantics,
@@ -98,8 +98,7 @@ __global__ void __launch_bounds__(BIN_THREADS)
 scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec,
                const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
                uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ ranges,
-               uint32_t* __restrict__ cursor, unsigned long long* __restrict__ keys,
-               uint32_t* __restrict__ upay) {
+               uint32_t* __restrict__ cursor, uint4* __restrict__ kv) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // [tiles] when LDS_HIST
     __shared__ uint32_t lds[BIN_THREADS / WAVE + 1];
     if (LDS_HIST) {
@@ -140,15 +139,14 @@ scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec,
     for (int r = 0; r < BIN_ROUNDS; ++r) {
         if (!tts[r]) continue;
         const int64_t i = (int64_t)blockIdx.x * BIN_GPW + r * BIN_THREADS + threadIdx.x;
-        const unsigned long long key = ((unsigned long long)dbits[r] << 32) | ((uint32_t)i << 4);
+        const uint32_t klo = (uint32_t)i << 4;
         const float4 r0 = rec[3 * i], r1 = rec[3 * i + 1];
         uint32_t k = off[r];  // Gaussian-major index of this Gaussian's first instance
         for (int ty = rlo[r] >> 16; ty < (int)(rhi[r] >> 16); ++ty)
             for (int tx = rlo[r] & 0xffff; tx < (int)(rhi[r] & 0xffff); ++tx) {
                 const uint32_t t = (uint32_t)(ty * gx + tx);
                 const uint32_t slot = LDS_HIST ? atomicAdd(&hist[t], 1u) : ranges[2 * t] + atomicAdd(&cursor[t], 1u);
-                keys[slot] = key | quadrant_mask(r0, r1, tx * TILE, ty * TILE);
-                upay[slot] = k++;
+                kv[slot] = make_uint4(klo | quadrant_mask(r0, r1, tx * TILE, ty * TILE), dbits[r], k++, 0u);
             }
     }
 }
@@ -235,21 +233,20 @@ __device__ __forceinline__ void bitonic_network(uint32_t (&klo)[E], uint32_t (&k
 
 constexpr int WAVE_SORT_MAX = 1024;
 
-// Sorts the n (<= 64*E) elements at keys[0..n) / upay[0..n).  FINAL: write the tile's final lists
-// (ids, quadrant masks, Gaussian-major indices); otherwise write the sorted chunk back in place.
+// Sorts the n (<= 64*E) records at kv[0..n).  FINAL: write the tile's final lists (ids, quadrant
+// masks, Gaussian-major indices); otherwise write the sorted chunk back in place.
 template <int E, bool FINAL>
-__device__ __forceinline__ void wave_sort(uint32_t n, unsigned long long* __restrict__ keys,
-                                          uint32_t* __restrict__ upay, uint32_t* __restrict__ point_list,
+__device__ __forceinline__ void wave_sort(uint32_t n, uint4* __restrict__ kv, uint32_t* __restrict__ point_list,
                                           uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
     const int lane = threadIdx.x & 63;
     uint32_t klo[E], khi[E], pay[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {  // coalesced load; the network does not care where an element starts
         const uint32_t i = (uint32_t)e * 64 + lane;
-        const unsigned long long k = i < n ? keys[i] : ~0ull;
-        klo[e] = (uint32_t)k;
-        khi[e] = (uint32_t)(k >> 32);
-        pay[e] = i < n ? upay[i] : 0u;
+        const uint4 v = i < n ? kv[i] : make_uint4(~0u, ~0u, 0u, 0u);
+        klo[e] = v.x;
+        khi[e] = v.y;
+        pay[e] = v.z;
     }
     bitonic_network<E, 2>(klo, khi, pay, lane);
 #pragma unroll
@@ -261,21 +258,20 @@ __device__ __forceinline__ void wave_sort(uint32_t n, unsigned long long* __rest
                 qmask[i] = (uint8_t)(klo[e] & 15u);
                 gm_index[i] = pay[e];
             } else {
-                keys[i] = ((unsigned long long)khi[e] << 32) | klo[e];
-                upay[i] = pay[e];
+                kv[i] = make_uint4(klo[e], khi[e], pay[e], 0u);
             }
         }
     }
 }
 
 template <bool FINAL>
-__device__ __forceinline__ void wave_sort_any(uint32_t n, unsigned long long* keys, uint32_t* upay,
-                                              uint32_t* point_list, uint32_t* gm_index, uint8_t* qmask) {
-    if (n <= 64) wave_sort<1, FINAL>(n, keys, upay, point_list, gm_index, qmask);
-    else if (n <= 128) wave_sort<2, FINAL>(n, keys, upay, point_list, gm_index, qmask);
-    else if (n <= 256) wave_sort<4, FINAL>(n, keys, upay, point_list, gm_index, qmask);
-    else if (n <= 512) wave_sort<8, FINAL>(n, keys, upay, point_list, gm_index, qmask);
-    else wave_sort<16, FINAL>(n, keys, upay, point_list, gm_index, qmask);
+__device__ __forceinline__ void wave_sort_any(uint32_t n, uint4* kv, uint32_t* point_list, uint32_t* gm_index,
+                                              uint8_t* qmask) {
+    if (n <= 64) wave_sort<1, FINAL>(n, kv, point_list, gm_index, qmask);
+    else if (n <= 128) wave_sort<2, FINAL>(n, kv, point_list, gm_index, qmask);
+    else if (n <= 256) wave_sort<4, FINAL>(n, kv, point_list, gm_index, qmask);
+    else if (n <= 512) wave_sort<8, FINAL>(n, kv, point_list, gm_index, qmask);
+    else wave_sort<16, FINAL>(n, kv, point_list, gm_index, qmask);
 }
 
 // grid = (xcd_grid(tiles), chunks): chunk c of tile t.  Tiles with <= 1024 instances are finished
@@ -284,36 +280,29 @@ __device__ __forceinline__ void wave_sort_any(uint32_t n, unsigned long long* ke
 #define SCR_SORT_MIN_WAVES 1
 #endif
 __global__ void __launch_bounds__(64, SCR_SORT_MIN_WAVES)
-tile_sort_wave_kernel(int tiles, const uint32_t* __restrict__ ranges, unsigned long long* __restrict__ keys,
-                      uint32_t* __restrict__ upay, uint32_t* __restrict__ point_list,
-                      uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
+tile_sort_wave_kernel(int tiles, const uint32_t* __restrict__ ranges, uint4* __restrict__ kv,
+                      uint32_t* __restrict__ point_list, uint32_t* __restrict__ gm_index,
+                      uint8_t* __restrict__ qmask) {
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
     const uint32_t c0 = blockIdx.y * (uint32_t)WAVE_SORT_MAX;
     if (c0 >= n) return;
     if (n <= (uint32_t)WAVE_SORT_MAX) {
-        wave_sort_any<true>(n, keys + lo, upay + lo, point_list + lo, gm_index + lo, qmask + lo);
+        wave_sort_any<true>(n, kv + lo, point_list + lo, gm_index + lo, qmask + lo);
     } else {
         const uint32_t cnt = min((uint32_t)WAVE_SORT_MAX, n - c0);
-        wave_sort_any<false>(cnt, keys + lo + c0, upay + lo + c0, nullptr, nullptr, nullptr);
+        wave_sort_any<false>(cnt, kv + lo + c0, nullptr, nullptr, nullptr);
     }
 }
 
 // Merge pass over runs of length L (sorted) -> runs of length 2L.  One thread per element:
 // output position = own index in its run + rank in the partner run (lower_bound; keys unique).
-// Tiles that are already fully merged (or small) are skipped; FINAL_ONLY = false.
-// The buffer a tile's data lives in after p passes is buffer (p & 1).
-__device__ __forceinline__ uint32_t lower_bound64(const unsigned long long* __restrict__ a, uint32_t len,
-                                                  unsigned long long x) {
-    uint32_t lo = 0, hi = len;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (a[mid] < x) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
-}
+// Tiles that are already fully merged (or small) are skipped.  The buffer a tile's data lives in
+// after p passes is buffer (p & 1).
+//   L <= 4096: one workgroup per PAIR of runs stages the pair's keys in LDS (<= 64 KB) and searches there;
+//   larger   : the searches go to global memory (L2).
+__device__ __forceinline__ unsigned long long kv_key(uint4 v) { return ((unsigned long long)v.y << 32) | v.x; }
 
 __device__ __forceinline__ uint32_t merge_passes_needed(uint32_t n) {  // ceil(log2(ceil(n/1024)))
     uint32_t chunks = (n + WAVE_SORT_MAX - 1) / WAVE_SORT_MAX, p = 0;
@@ -322,54 +311,91 @@ __device__ __forceinline__ uint32_t merge_passes_needed(uint32_t n) {  // ceil(l
 }
 
 __global__ void __launch_bounds__(256)
-tile_merge_pass_kernel(int tiles, uint32_t pass, const uint32_t* __restrict__ ranges,
-                       const unsigned long long* __restrict__ src_keys, const uint32_t* __restrict__ src_pay,
-                       unsigned long long* __restrict__ dst_keys, uint32_t* __restrict__ dst_pay) {
+tile_merge_lds_kernel(int tiles, uint32_t pass, const uint32_t* __restrict__ ranges, const uint4* __restrict__ src,
+                      uint4* __restrict__ dst) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lk[];  // [2L] keys of the pair
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
     if (n <= (uint32_t)WAVE_SORT_MAX || pass >= merge_passes_needed(n)) return;
     const uint32_t L = (uint32_t)WAVE_SORT_MAX << pass;
-    const unsigned long long* sk = src_keys + lo;
+    const uint32_t pairbase = blockIdx.y * 2u * L;
+    if (pairbase >= n) return;
+    const uint32_t lenA = min(L, n - pairbase);
+    uint32_t lenB = 0;
+    if (pairbase + L < n) {
+        lenB = n - pairbase - L;
+        if (lenB > L) lenB = L;
+    }
+    const uint4* s = src + lo + pairbase;
+    uint4* d = dst + lo + pairbase;
+    const uint32_t tot = lenA + lenB;
+    for (uint32_t e = threadIdx.x; e < tot; e += 256) lk[e] = kv_key(s[e]);
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < tot; e += 256) {
+        const unsigned long long x = lk[e];
+        const bool left = e < lenA;
+        const unsigned long long* other = left ? lk + lenA : lk;
+        uint32_t a = 0, b = left ? lenB : lenA;  // lower_bound in the partner run
+        while (a < b) {
+            const uint32_t mid = (a + b) >> 1;
+            if (other[mid] < x) a = mid + 1;
+            else b = mid;
+        }
+        d[(left ? e : e - lenA) + a] = s[e];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+tile_merge_global_kernel(int tiles, uint32_t pass, const uint32_t* __restrict__ ranges,
+                         const uint4* __restrict__ src, uint4* __restrict__ dst) {
+    int t = xcd_tile(blockIdx.x, tiles);
+    if (t < 0) return;
+    const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
+    if (n <= (uint32_t)WAVE_SORT_MAX || pass >= merge_passes_needed(n)) return;
+    const uint32_t L = (uint32_t)WAVE_SORT_MAX << pass;
+    const uint4* sk = src + lo;
     for (uint32_t e = blockIdx.y * (uint32_t)WAVE_SORT_MAX + threadIdx.x, k = 0; k < WAVE_SORT_MAX / 256 && e < n; ++k, e += 256) {
         const uint32_t run = e / L, pairbase = (run & ~1u) * L, inrun = e - run * L;
-        const unsigned long long x = sk[e];
-        uint32_t pos;
+        const uint4 rec_ = sk[e];
+        const unsigned long long x = kv_key(rec_);
+        uint32_t base, len;
         if ((run & 1u) == 0) {  // element of the left run: count right-run elements below it
-            const uint32_t rb = pairbase + L;
-            uint32_t rlen = 0;  // length of the right partner run (0: this run has no partner)
-            if (rb < n) {
-                rlen = n - rb;
-                if (rlen > L) rlen = L;
+            base = pairbase + L;
+            len = 0;  // length of the right partner run (0: this run has no partner)
+            if (base < n) {
+                len = n - base;
+                if (len > L) len = L;
             }
-            pos = pairbase + inrun + lower_bound64(sk + rb, rlen, x);
         } else {                // element of the right run: count left-run elements below it
-            pos = pairbase + inrun + lower_bound64(sk + pairbase, L, x);
+            base = pairbase;
+            len = L;
         }
-        dst_keys[lo + pos] = x;
-        dst_pay[lo + pos] = src_pay[lo + e];
+        uint32_t a = 0, b = len;
+        while (a < b) {
+            const uint32_t mid = (a + b) >> 1;
+            if (kv_key(sk[base + mid]) < x) a = mid + 1;
+            else b = mid;
+        }
+        dst[lo + pairbase + inrun + a] = rec_;
     }
 }
 
 // Final lists of the large tiles from the buffer their last merge pass wrote.
 __global__ void __launch_bounds__(256)
-tile_merge_final_kernel(int tiles, const uint32_t* __restrict__ ranges,
-                        const unsigned long long* __restrict__ keys0, const uint32_t* __restrict__ pay0,
-                        const unsigned long long* __restrict__ keys1, const uint32_t* __restrict__ pay1,
-                        uint32_t* __restrict__ point_list, uint32_t* __restrict__ gm_index,
-                        uint8_t* __restrict__ qmask) {
+tile_merge_final_kernel(int tiles, const uint32_t* __restrict__ ranges, const uint4* __restrict__ kv0,
+                        const uint4* __restrict__ kv1, uint32_t* __restrict__ point_list,
+                        uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
     if (n <= (uint32_t)WAVE_SORT_MAX) return;
-    const bool odd = merge_passes_needed(n) & 1u;
-    const unsigned long long* sk = (odd ? keys1 : keys0) + lo;
-    const uint32_t* sp = (odd ? pay1 : pay0) + lo;
+    const uint4* sk = ((merge_passes_needed(n) & 1u) ? kv1 : kv0) + lo;
     for (uint32_t e = blockIdx.y * (uint32_t)WAVE_SORT_MAX + threadIdx.x, k = 0; k < WAVE_SORT_MAX / 256 && e < n; ++k, e += 256) {
-        const uint32_t kl = (uint32_t)sk[e];
-        point_list[lo + e] = kl >> 4;
-        qmask[lo + e] = (uint8_t)(kl & 15u);
-        gm_index[lo + e] = sp[e];
+        const uint4 v = sk[e];
+        point_list[lo + e] = v.x >> 4;
+        qmask[lo + e] = (uint8_t)(v.x & 15u);
+        gm_index[lo + e] = v.z;
     }
 }
 
@@ -388,11 +414,11 @@ void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const Bi
     if (g.tiles <= LDS_HIST_MAX_TILES)
         scatter_kernel<true><<<nb, BIN_THREADS, (size_t)g.tiles * 4, st>>>(
             P, g.gx, g.tiles, gv.rec, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor,
-            bv.keys, bv.upay);
+            bv.kv);
     else
         scatter_kernel<false><<<nb, BIN_THREADS, 0, st>>>(
             P, g.gx, g.tiles, gv.rec, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor,
-            bv.keys, bv.upay);
+            bv.kv);
 }
 
 void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, int64_t max_tile_instances,
@@ -401,19 +427,28 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
     const unsigned gt = (unsigned)xcd_grid(g.tiles);
     const unsigned chunks = (unsigned)((max_tile_instances + WAVE_SORT_MAX - 1) / WAVE_SORT_MAX);
     if (chunks == 0) return;
-    tile_sort_wave_kernel<<<dim3(gt, chunks), 64, 0, st>>>(g.tiles, gv.ranges, bv.keys, bv.upay, bv.point_list,
-                                                           bv.gm_index, bv.qmask);
+    tile_sort_wave_kernel<<<dim3(gt, chunks), 64, 0, st>>>(g.tiles, gv.ranges, bv.kv, bv.point_list, bv.gm_index, bv.qmask);
     if (chunks <= 1) return;
     unsigned passes = 0;
     while ((1u << passes) < chunks) ++passes;
-    for (unsigned p = 0; p < passes; ++p) {
-        const bool fwd = (p & 1u) == 0;  // data of pass p lives in buffer (p & 1)
-        tile_merge_pass_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, p, gv.ranges, fwd ? bv.keys : bv.keys2,
-                                                                 fwd ? bv.upay : bv.upay2, fwd ? bv.keys2 : bv.keys,
-                                                                 fwd ? bv.upay2 : bv.upay);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)tile_merge_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
     }
-    tile_merge_final_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, gv.ranges, bv.keys, bv.upay, bv.keys2, bv.upay2,
-                                                              bv.point_list, bv.gm_index, bv.qmask);
+    for (unsigned p = 0; p < passes; ++p) {
+        const uint4* src = (p & 1u) ? bv.kv2 : bv.kv;  // data of pass p lives in buffer (p & 1)
+        uint4* dst = (p & 1u) ? bv.kv : bv.kv2;
+        const unsigned L = (unsigned)WAVE_SORT_MAX << p;
+        if (L <= 4096u) {
+            const unsigned pairs = (chunks * (unsigned)WAVE_SORT_MAX + 2 * L - 1) / (2 * L);
+            tile_merge_lds_kernel<<<dim3(gt, pairs), 256, (size_t)2 * L * 8, st>>>(g.tiles, p, gv.ranges, src, dst);
+        } else {
+            tile_merge_global_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, p, gv.ranges, src, dst);
+        }
+    }
+    tile_merge_final_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, gv.ranges, bv.kv, bv.kv2, bv.point_list,
+                                                              bv.gm_index, bv.qmask);
 }
 
 }  // namespace scr

@@ -65,13 +65,13 @@ inline __host__ GeomView geom_view(void* base, int64_t P, int H, int W) {
 
 // ---- binning buffer: per (Gaussian, tile) instance lists ----
 struct BinView {
-    unsigned long long* keys;  // [I] (depth_bits << 32 | gaussian id << 4 | quadrant mask), grouped by tile, unsorted
-    uint32_t* upay;            // [I] same order as keys: Gaussian-major instance index (point_offset_exclusive + k)
+    uint4* kv;                 // [I] grouped by tile, unsorted: (key lo = gaussian id << 4 | quadrant mask,
+                               //     key hi = depth bits, payload = Gaussian-major instance index, 0) -- one
+                               //     16-byte record so the scatter issues ONE random write per instance
     uint32_t* point_list;      // [I] Gaussian ids, per tile sorted by (depth, id)
     uint32_t* gm_index;        // [I] sorted position -> Gaussian-major instance index (where its gradient record goes)
     uint8_t* qmask;            // [I] sorted position -> 4-bit mask of the tile's 8x8 quadrants the splat can touch
-    unsigned long long* keys2;  // [I] second buffer of the merge passes (only when a tile exceeds one sort chunk)
-    uint32_t* upay2;            // [I]
+    uint4* kv2;                // [I] second buffer of the merge passes (only when a tile exceeds one sort chunk)
     size_t bytes;
 };
 
@@ -81,14 +81,12 @@ inline __host__ BinView bin_view(void* base, int64_t I, int64_t max_tile_instanc
     BinView v;
     auto take = [&](size_t n) { char* q = p ? p + off : nullptr; off += align_up(n); return q; };
     size_t n = (size_t)(I > 0 ? I : 1);
-    v.keys = (unsigned long long*)take(n * 8);
-    v.upay = (uint32_t*)take(n * 4);
+    v.kv = (uint4*)take(n * 16);
     v.point_list = (uint32_t*)take(n * 4);
     v.gm_index = (uint32_t*)take(n * 4);
     v.qmask = (uint8_t*)take(n);
     const bool merge = max_tile_instances > 1024;  // WAVE_SORT_MAX
-    v.keys2 = merge ? (unsigned long long*)take(n * 8) : nullptr;
-    v.upay2 = merge ? (uint32_t*)take(n * 4) : nullptr;
+    v.kv2 = merge ? (uint4*)take(n * 16) : nullptr;
     v.bytes = off;
     return v;
 }
