@@ -211,40 +211,40 @@ __device__ __forceinline__ float fold4(float a, float b, float c, float d) {
     return __uint_as_float(q[0]) + __uint_as_float(q[1]);               // rows: A, C, B, D
 }
 
-// Per-pixel gradient of one contributing splat (back-to-front recurrences).  Not decision
-// bearing, so the compiler may contract mul+add pairs here (fewer VALU issues); the tolerance is
-// the gradient bar of the parity tests (rel-L2 <= 1e-4 vs the oracle).
+// Per-pixel gradient terms of one splat (back-to-front recurrences).  Not decision bearing, so the
+// compiler may contract mul+add pairs here (fewer VALU issues); the tolerance is the gradient bar of
+// the parity tests (rel-L2 <= 1e-4 vs the oracle).
+//
+// Everything that is constant per splat is moved out of the per-pixel work (A.5 restated):
+//   * colour enters dL/dalpha only through d = <colour, dL/dpixel>, so the "colour behind this splat"
+//     accumulator of the reference (3 channels) becomes ONE scalar recurrence on
+//     behind = <accumulated colour behind, dL/dpixel>, started at <bg, dL/dpixel> (the background is
+//     the last layer: T_final * bg), which also absorbs the separate background term;
+//   * with Y = G * dL/dalpha, the position / conic gradients are opacity- and conic-weighted
+//     combinations of the five moments  sum Y dx, sum Y dy, sum Y dx^2, sum Y dx dy, sum Y dy^2;
+//     the weights are applied once per Gaussian in preprocess_backward_kernel.
+// A wave therefore reduces, per splat: the five moments, sum Y (opacity gradient), and the three
+// colour gradients  sum alpha T dL/dpixel_c.
 struct PixState {
-    float T, T_final, bg_dot, dLp0, dLp1, dLp2;
-    float ac0, ac1, ac2, last_alpha, lc0, lc1, lc2;
+    float T, dLp0, dLp1, dLp2;
+    float behind, last_alpha, d_last;
 };
-__device__ __forceinline__ void splat_pixel_grad(PixState& s, float4 a, float4 b, float cb, float dx, float dy,
-                                                 float G, float alpha, float& g_mx, float& g_my, float& g_qxx,
-                                                 float& g_qxy, float& g_qyy, float& g_o, float& g_c0, float& g_c1,
-                                                 float& g_c2) {
+__device__ __forceinline__ void splat_pixel_grad(PixState& s, float4 b, float cb, float dx, float dy, float G,
+                                                 float alpha, float& g_x, float& g_y, float& g_xx, float& g_xy,
+                                                 float& g_yy, float& g_o, float& g_c0, float& g_c1, float& g_c2) {
 #pragma clang fp contract(fast)
-    const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);
-    s.T = s.T * rcp;  // transmittance in front of this splat
-    const float dchan = alpha * s.T;
-    const float om = 1.0f - s.last_alpha;
-    s.ac0 = s.last_alpha * s.lc0 + om * s.ac0;
-    s.ac1 = s.last_alpha * s.lc1 + om * s.ac1;
-    s.ac2 = s.last_alpha * s.lc2 + om * s.ac2;
-    s.lc0 = b.z; s.lc1 = b.w; s.lc2 = cb;
-    float dL_dalpha = (b.z - s.ac0) * s.dLp0 + (b.w - s.ac1) * s.dLp1 + (cb - s.ac2) * s.dLp2;
-    g_c0 = dchan * s.dLp0; g_c1 = dchan * s.dLp1; g_c2 = dchan * s.dLp2;
+    s.T = s.T * __builtin_amdgcn_rcpf(1.0f - alpha);  // transmittance in front of this splat
+    const float w = alpha * s.T;
+    s.behind = s.last_alpha * (s.d_last - s.behind) + s.behind;
+    const float d = b.z * s.dLp0 + b.w * s.dLp1 + cb * s.dLp2;
+    g_c0 = w * s.dLp0; g_c1 = w * s.dLp1; g_c2 = w * s.dLp2;
+    const float Y = G * (s.T * (d - s.behind));  // G * dL/dalpha  (straight-through min(0.99, .))
     s.last_alpha = alpha;
-    dL_dalpha = dL_dalpha * s.T - (s.T_final * rcp) * s.bg_dot;
-    const float dL_dG = b.y * dL_dalpha;  // straight-through min(0.99, .)
-    const float wG = dL_dG * G;
-    const float wx = wG * dx, wy = wG * dy;
-    // Q = (-2A, -B, -2C):  dG/dmean = -G Q d
-    g_mx = 2.0f * a.z * wx + a.w * wy;
-    g_my = 2.0f * b.x * wy + a.w * wx;
-    g_qxx = -0.5f * wx * dx;
-    g_qxy = -wx * dy;
-    g_qyy = -0.5f * wy * dy;
-    g_o = G * dL_dalpha;
+    s.d_last = d;
+    const float yx = Y * dx, yy = Y * dy;
+    g_x = yx; g_y = yy;
+    g_xx = yx * dx; g_xy = yx * dy; g_yy = yy * dy;
+    g_o = Y;
 }
 
 // ------------------------------------------------------------------ backward
@@ -280,16 +280,15 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
     const uint32_t last = inside ? n_contrib[pix] : 0u;
     PixState ps;
-    ps.T_final = inside ? final_T[pix] : 0.0f;
-    ps.T = ps.T_final;
+    ps.T = inside ? final_T[pix] : 0.0f;
     ps.dLp0 = ps.dLp1 = ps.dLp2 = 0.0f;
     if (inside) {
         ps.dLp0 = dL_dpix[pix];
         ps.dLp1 = dL_dpix[hw + pix];
         ps.dLp2 = dL_dpix[2 * hw + pix];
     }
-    ps.bg_dot = (bg[0] * ps.dLp0 + bg[1] * ps.dLp1) + bg[2] * ps.dLp2;
-    ps.ac0 = ps.ac1 = ps.ac2 = ps.last_alpha = ps.lc0 = ps.lc1 = ps.lc2 = 0.0f;
+    ps.behind = (bg[0] * ps.dLp0 + bg[1] * ps.dLp1) + bg[2] * ps.dLp2;
+    ps.last_alpha = ps.d_last = 0.0f;
     // per-wave largest contributor count: list positions >= it cannot matter to the wave
     uint32_t wm = last;
 #pragma unroll
@@ -342,6 +341,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     }
     for (int ci = live_top; ci >= 0; --ci) {
         const uint32_t base = (uint32_t)ci * BCH;
+        const int last_rel = (int)last - (int)base;  // entry j of the round is contributor base + j + 1
         // ---- stage this round's surviving records (wave-private, list order)
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(sel_cur);
         const int cnt = __builtin_popcountll(bal);
@@ -379,17 +379,16 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 const float4 a = ra[u], b = rb[u];
                 const float2 c = rc[u];
                 const uint32_t j = __float_as_uint(c.y);
-                const uint32_t q = base + j;  // list position; contributor number q+1
                 const float dx = a.x - pxf, dy = a.y - pyf;
                 const float power = __builtin_fmaf(dx, __builtin_fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy);
                 const float G = fast_exp(power);
                 const float alpha = fminf(0.99f, b.y * G);
-                const bool hit = valid && (q < last) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                const bool hit = valid && ((int)j < last_rel) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 // Branch-free: a splat that does not contribute to this pixel is carried through the
                 // back-to-front recurrences with alpha = 0, which leaves T and the colour-behind
                 // accumulator exactly as skipping it would (T / (1 - 0) = T; the accumulator folds
-                // 0 * colour); only the G-weighted sums need an explicit zero.
-                splat_pixel_grad(ps, a, b, c.x, dx, dy, hit ? G : 0.0f, hit ? alpha : 0.0f, g[u][0], g[u][1], g[u][2],
+                // 0 * d); only the G-weighted sums need an explicit zero.
+                splat_pixel_grad(ps, b, c.x, dx, dy, hit ? G : 0.0f, hit ? alpha : 0.0f, g[u][0], g[u][1], g[u][2],
                                  g[u][3], g[u][4], g[u][5], g[u][6], g[u][7], g[u][8]);
                 any = any || (__builtin_amdgcn_ballot_w64(hit) != 0ull);
                 jj[u] = valid ? j : 0xffffffffu;

@@ -314,7 +314,7 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
                            const float* __restrict__ cov3D, const float* __restrict__ shs, KSettings ks,
                            const int32_t* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
                            const uint32_t* __restrict__ point_offsets, const uint8_t* __restrict__ clamped,
-                           const float4* __restrict__ grad_rec,
+                           const float4* __restrict__ rec, const float4* __restrict__ grad_rec,
                            float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
                            float* __restrict__ dL_dcolors, float* __restrict__ dL_dsh,
                            float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
@@ -331,14 +331,20 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
         // ---- deterministic reduction of the per-(tile, Gaussian) records
         uint32_t n = tiles_touched[i];
         uint32_t off = point_offsets[i] - n;
-        float gmx = 0, gmy = 0, gQxx = 0, gQxy = 0, gQyy = 0;
+        float sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0;  // moments of Y = G dL/dalpha over the footprint
         for (uint32_t k = 0; k < n; ++k) {  // this Gaussian's records are contiguous, in tile order
             const size_t slot = (size_t)off + k;
             float4 r0 = grad_rec[3 * slot], r1 = grad_rec[3 * slot + 1], r2 = grad_rec[3 * slot + 2];
-            gmx += r0.x; gmy += r0.y; gQxx += r0.z; gQxy += r0.w;
-            gQyy += r1.x; gop += r1.y; gcol[0] += r1.z; gcol[1] += r1.w;
+            sx += r0.x; sy += r0.y; sxx += r0.z; sxy += r0.w;
+            syy += r1.x; gop += r1.y; gcol[0] += r1.z; gcol[1] += r1.w;
             gcol[2] += r2.x;
         }
+        // the per-splat constants the blend kernel left out: dL/dG = opacity * dL/dalpha,
+        // dG/dmean = -G Q d with Q = (-2A, -B, -2C), dG/dQ = -G/2 d d^T (Qxy counted once: factor 1)
+        const float4 ra = rec[3 * i], rb = rec[3 * i + 1];
+        const float cA = ra.z, cB = ra.w, cC = rb.x, op = rb.y;
+        const float gmx = op * (2.0f * cA * sx + cB * sy), gmy = op * (2.0f * cC * sy + cB * sx);
+        const float gQxx = -0.5f * op * sxx, gQxy = -op * sxy, gQyy = -0.5f * op * syy;
         const float* V = ks.view;
         const float* Pm = ks.proj;
         float a = ps.a, b = ps.b, c = ps.c;
@@ -560,7 +566,7 @@ void launch_preprocess_backward(int64_t P, int M, const float* means3D, const fl
     if (P <= 0) return;
     preprocess_backward_kernel<<<nblk(P, PRE_BLOCK), PRE_BLOCK, 0, st>>>(
         P, M, means3D, scales, rotations, cov3D, shs, ks, radii, gv.tiles_touched, gv.point_offsets,
-        gv.clamped, grad_rec, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh, dL_dopacity,
+        gv.clamped, gv.rec, grad_rec, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh, dL_dopacity,
         dL_dscales, dL_drotations, dL_dcov3D);
 }
 
