@@ -65,8 +65,10 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
-    bool done = !inside;
+    unsigned long long done = lanes(!inside);  // lane mask of finished pixels
     float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+    float c099 = 0.99f;
+    asm volatile("" : "+v"(c099));  // keep the clamp in a VGPR: VOP2 with a literal issues slower
     uint32_t last = 0;
 
     // software pipeline: (mask, id) two chunks ahead, gathered records one chunk ahead
@@ -88,6 +90,8 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
             r2x = rec[3 * (size_t)id + 2].x;
         }
     };
+    // slots past a chunk's count are blended with alpha 0: they must hold finite numbers
+    for (int i = lane; i < 5 * (FCHUNK / 2); i += WAVE) (&sp[0][0])[i] = make_float4(0, 0, 0, 0);
     uint32_t m0, id0;
     load_mask_id(0, m0, id0);
     gather(m0, id0);
@@ -132,34 +136,38 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
                 const v2f e2 = power[h] * 1.4426950408889634f;
                 al[h] = o * v2f{__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
             }
-            const float alpha[4] = {fminf(0.99f, al[0].x), fminf(0.99f, al[0].y), fminf(0.99f, al[1].x), fminf(0.99f, al[1].y)};
+            const float alpha[4] = {vmin(c099, al[0].x), vmin(c099, al[0].y), vmin(c099, al[1].x), vmin(c099, al[1].y)};
             const float pw[4] = {power[0].x, power[0].y, power[1].x, power[1].y};
-            bool hit[4];
-            bool anyh = false;
+            // lane masks (SGPR pairs): which pixels does splat u touch
+            unsigned long long hit[4], anyh = 0ull;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                hit[u] = (k + u < cnt) && !(pw[u] > 0.0f) && !(alpha[u] < 1.0f / 255.0f);  // (k+u < cnt) is wave-uniform
-                anyh = anyh || hit[u];
+                hit[u] = (k + u < cnt) ? (lanes(!(pw[u] > 0.0f)) & lanes(!(alpha[u] < 1.0f / 255.0f))) : 0ull;
+                anyh |= hit[u];
             }
-            if (__builtin_amdgcn_ballot_w64(!done && anyh) == 0ull) continue;
+            if ((anyh & ~done) == 0ull) continue;
             const float cr[4] = {p3[0].x, p3[0].y, p3[1].x, p3[1].y}, cg[4] = {p3[0].z, p3[0].w, p3[1].z, p3[1].w};
             const float cb[4] = {p4[0].x, p4[0].y, p4[1].x, p4[1].y}, cj[4] = {p4[0].z, p4[0].w, p4[1].z, p4[1].w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const bool h_ = hit[u] && !done;
-                const float test_T = T * (1.0f - alpha[u]);
-                const bool stop = h_ && (test_T < 0.0001f);
-                const bool upd = h_ && !stop;
-                done = done || stop;
-                const float w = alpha[u] * T;
-                C0 = upd ? __builtin_fmaf(cr[u], w, C0) : C0;
-                C1 = upd ? __builtin_fmaf(cg[u], w, C1) : C1;
-                C2 = upd ? __builtin_fmaf(cb[u], w, C2) : C2;
-                T = upd ? test_T : T;
-                last = upd ? __float_as_uint(cj[u]) : last;
+                // A pixel the splat does not touch (or a finished pixel) blends it with alpha 0, which
+                // leaves T and C bit-for-bit unchanged (T * (1 - 0), fma(c, 0 * T, C)), so only the
+                // alpha and the early stop need selects.  T never drops below 1e-4 (the update that
+                // would do so is the stop), hence test_T < 1e-4 can only fire on a touching splat.
+                const unsigned long long h = hit[u] & ~done;
+                const float a = sel(h, alpha[u], 0.0f);
+                const float test_T = T * (1.0f - a);
+                const unsigned long long stop = lanes(test_T < 0.0001f);
+                done |= stop;
+                const float w = sel(stop, 0.0f, a * T);
+                C0 = __builtin_fmaf(cr[u], w, C0);
+                C1 = __builtin_fmaf(cg[u], w, C1);
+                C2 = __builtin_fmaf(cb[u], w, C2);
+                T = sel(stop, T, test_T);
+                last = sel(h & ~stop, __float_as_uint(cj[u]), last);
             }
         }
-        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+        if (~done == 0ull) break;
         __syncthreads();  // reads of this chunk finished before the next chunk overwrites LDS
     }
     if (inside) {
@@ -253,7 +261,7 @@ constexpr int BCH = 64;  // list entries per round: one per lane of each wave
 #define SCR_BWD_ACC_BUFS 2
 #endif
 #ifndef SCR_BWD_MIN_WAVES
-#define SCR_BWD_MIN_WAVES 1
+#define SCR_BWD_MIN_WAVES 2
 #endif
 constexpr int ACC_BUFS = SCR_BWD_ACC_BUFS;  // 2: per-round sums double-buffered (one barrier per round)
 
@@ -266,7 +274,10 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                       float4* __restrict__ grad_rec) {
     __shared__ float4 s0[4][BCH], s1[4][BCH];  // wave-private compacted records of the round
     __shared__ float2 s2[4][BCH];              // (blue, position in round)
-    __shared__ float4 acc[ACC_BUFS][4][BCH][3];       // [round parity][wave]: sums per position (9 of 12 floats used)
+    // [round parity][wave]: the nine sums per position, as 16 + 16 + 4 bytes (36 B / entry keeps the
+    // workgroup under 32 KB of LDS: five workgroups per CU)
+    __shared__ float4 accA[ACC_BUFS][4][BCH], accB[ACC_BUFS][4][BCH];
+    __shared__ float accC[ACC_BUFS][4][BCH];
     __shared__ uint32_t wave_max[4];
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
@@ -289,6 +300,8 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     }
     ps.behind = (bg[0] * ps.dLp0 + bg[1] * ps.dLp1) + bg[2] * ps.dLp2;
     ps.last_alpha = ps.d_last = 0.0f;
+    float c099 = 0.99f;
+    asm volatile("" : "+v"(c099));  // keep the clamp in a VGPR: VOP2 with a literal issues slower
     // per-wave largest contributor count: list positions >= it cannot matter to the wave
     uint32_t wm = last;
 #pragma unroll
@@ -357,12 +370,12 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         // acc is double-buffered by round parity: this round's writes cannot collide with the
         // previous round's combine, so ONE barrier per round suffices (a wave reaches the writes of
         // round r+2 only after barrier B of round r+1, which every wave passes after its combine of r)
-        float4 (*accw)[BCH][3] = acc[ACC_BUFS == 2 ? (ci & 1) : 0];
+        const int par = ACC_BUFS == 2 ? (ci & 1) : 0;
         if (ACC_BUFS == 1) __syncthreads();  // A: the previous round's combine has read acc
         for (int k = cnt - 1; k >= 0; k -= 4) {  // back to front, four splats per reduction
             float g[4][9];
             uint32_t jj[4];
-            bool any = false;
+            unsigned long long any = 0ull;
             // all four records first (one LDS round trip per group instead of four)
             float4 ra[4], rb[4];
             float2 rc[4];
@@ -382,15 +395,16 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 const float dx = a.x - pxf, dy = a.y - pyf;
                 const float power = __builtin_fmaf(dx, __builtin_fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy);
                 const float G = fast_exp(power);
-                const float alpha = fminf(0.99f, b.y * G);
-                const bool hit = valid && ((int)j < last_rel) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                const float alpha = vmin(c099, b.y * G);
+                const unsigned long long hit =
+                    valid ? (lanes((int)j < last_rel) & lanes(!(power > 0.0f)) & lanes(!(alpha < 1.0f / 255.0f))) : 0ull;
                 // Branch-free: a splat that does not contribute to this pixel is carried through the
                 // back-to-front recurrences with alpha = 0, which leaves T and the colour-behind
                 // accumulator exactly as skipping it would (T / (1 - 0) = T; the accumulator folds
                 // 0 * d); only the G-weighted sums need an explicit zero.
-                splat_pixel_grad(ps, b, c.x, dx, dy, hit ? G : 0.0f, hit ? alpha : 0.0f, g[u][0], g[u][1], g[u][2],
+                splat_pixel_grad(ps, b, c.x, dx, dy, sel(hit, G, 0.0f), sel(hit, alpha, 0.0f), g[u][0], g[u][1], g[u][2],
                                  g[u][3], g[u][4], g[u][5], g[u][6], g[u][7], g[u][8]);
-                any = any || (__builtin_amdgcn_ballot_w64(hit) != 0ull);
+                any |= hit;
                 jj[u] = valid ? j : 0xffffffffu;
             }
             float r[9];
@@ -406,9 +420,9 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             const int row = lane >> 4;
             const uint32_t jw = row == 0 ? jj[0] : row == 1 ? jj[2] : row == 2 ? jj[1] : jj[3];
             if ((lane & 15) == 15 && jw != 0xffffffffu) {  // every listed position is written
-                accw[wave][jw][0] = make_float4(r[0], r[1], r[2], r[3]);
-                accw[wave][jw][1] = make_float4(r[4], r[5], r[6], r[7]);
-                accw[wave][jw][2] = make_float4(r[8], 0.0f, 0.0f, 0.0f);
+                accA[par][wave][jw] = make_float4(r[0], r[1], r[2], r[3]);
+                accB[par][wave][jw] = make_float4(r[4], r[5], r[6], r[7]);
+                accC[par][wave][jw] = r[8];
             }
         }
         __syncthreads();  // B: every wave's sums for this round are in acc
@@ -417,10 +431,14 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         if (wave < 3 && base + lane < n) {
             const uint32_t i = base + lane;
             float4 r = make_float4(0, 0, 0, 0);
-            if (((m_this >> 0) & 1u) && i < wmax0) { const float4 x = accw[0][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
-            if (((m_this >> 1) & 1u) && i < wmax1) { const float4 x = accw[1][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
-            if (((m_this >> 2) & 1u) && i < wmax2) { const float4 x = accw[2][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
-            if (((m_this >> 3) & 1u) && i < wmax3) { const float4 x = accw[3][lane][wave]; r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
+            auto part = [&](int w) {
+                return wave == 0 ? accA[par][w][lane] : wave == 1 ? accB[par][w][lane]
+                                                                  : make_float4(accC[par][w][lane], 0.0f, 0.0f, 0.0f);
+            };
+            if (((m_this >> 0) & 1u) && i < wmax0) { const float4 x = part(0); r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
+            if (((m_this >> 1) & 1u) && i < wmax1) { const float4 x = part(1); r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
+            if (((m_this >> 2) & 1u) && i < wmax2) { const float4 x = part(2); r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
+            if (((m_this >> 3) & 1u) && i < wmax3) { const float4 x = part(3); r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
             grad_rec[3 * (size_t)slot_this + wave] = r;
         }
     }

@@ -138,6 +138,28 @@ inline __host__ KSettings ksettings(const scr_settings* s) {
     return k;
 }
 
+// Per-lane select through an SGPR-pair lane mask.  hipcc usually emits the VOP2 form
+// `v_cndmask_b32_e32 ..., vcc`, which gfx950 issues at ~23 cycles per wave instruction against
+// ~4.5 for the VOP3 form with the mask in an SGPR pair (tools/exp/valu_probe2.hip), so the hot
+// loops spell the VOP3 form out.  mask bit set -> t, clear -> f.
+__device__ __forceinline__ float sel(unsigned long long mask, float t, float f) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ uint32_t sel(unsigned long long mask, uint32_t t, uint32_t f) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(mask));
+    return r;
+}
+// IEEE minNum without the canonicalising v_max the compiler puts in front of fminf's v_min
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned long long lanes(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // XCD-aware block -> tile map: consecutive tiles (which share splats) run on one XCD so their
 // record gathers hit that XCD's L2.  Blocks are observed to be dealt round-robin to the 8 XCDs;
 // the map is a speed choice only.  Returns -1 for the padding blocks.
