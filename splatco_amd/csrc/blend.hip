@@ -272,8 +272,11 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                       const float* __restrict__ bg, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                       float4* __restrict__ grad_rec) {
-    __shared__ float4 s0[4][BCH], s1[4][BCH];  // wave-private compacted records of the round
-    __shared__ float2 s2[4][BCH];              // (blue, position in round)
+    // wave-private compacted records of the round: [wave][field group][3 pad + position]; group 0/1 =
+    // the first 32 bytes of the splat record, group 2 = (blue, position in round, -, -).  A group of four
+    // reads slots k .. k+3 of each field group: one address register and immediate offsets.  The three
+    // pad slots in front stay zero (a partial last group blends them with alpha 0).
+    __shared__ float4 st[4][3][BCH + 4];
     // [round parity][wave]: the nine sums per position, as 16 + 16 + 4 bytes (36 B / entry keeps the
     // workgroup under 32 KB of LDS: five workgroups per CU)
     __shared__ float4 accA[ACC_BUFS][4][BCH], accB[ACC_BUFS][4][BCH];
@@ -307,6 +310,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) wm = max(wm, (uint32_t)__shfl_xor((int)wm, d, WAVE));
     if (lane == 0) wave_max[wave] = wm;
+    if (lane < 9) st[wave][lane / 3][lane % 3] = make_float4(0, 0, 0, 0);
     __syncthreads();
     const uint32_t wmax0 = wave_max[0], wmax1 = wave_max[1], wmax2 = wave_max[2], wmax3 = wave_max[3];
     const uint32_t max_last = max(max(wmax0, wmax1), max(wmax2, wmax3));
@@ -360,9 +364,9 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         const int cnt = __builtin_popcountll(bal);
         if (sel_cur) {
             const uint32_t pos = lanes_below(bal);
-            s0[wave][pos] = r0;
-            s1[wave][pos] = r1;
-            s2[wave][pos] = make_float2(r2x, __uint_as_float((uint32_t)lane));
+            st[wave][0][pos + 3] = r0;
+            st[wave][1][pos + 3] = r1;
+            st[wave][2][pos + 3] = make_float4(r2x, __uint_as_float((uint32_t)lane), 0.0f, 0.0f);
         }
         const uint32_t m_this = m_cur, slot_this = slot_cur;
         gather(ci - 1, m_next, id_next, slot_next);
@@ -380,11 +384,10 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             float4 ra[4], rb[4];
             float2 rc[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ks = k - u >= 0 ? k - u : 0;
-                ra[u] = s0[wave][ks];
-                rb[u] = s1[wave][ks];
-                rc[u] = s2[wave][ks];
+            for (int u = 0; u < 4; ++u) {  // entry k - u lives in slot k - u + 3
+                ra[u] = st[wave][0][k + 3 - u];
+                rb[u] = st[wave][1][k + 3 - u];
+                rc[u] = *(const float2*)&st[wave][2][k + 3 - u];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
