@@ -3,13 +3,15 @@
 // The operator family sorts all (tile | depth) 64-bit keys with a global multi-pass radix sort.
 // Here the same ordered lists are produced MI355X-style in two HBM passes:
 //   1. bucket:  per-tile instance counts (integer atomics fused into the preprocess kernel) ->
-//               exclusive scan -> every instance is dropped into its tile's segment
-//               as ONE 16-byte record (key = depth_bits << 32 | gaussian id << 4 | quadrant mask;
-//               payload = the instance's Gaussian-major index).  Slot order inside a segment is arbitrary.
-//   2. sort:    one workgroup per tile sorts its segment by the 64-bit key in LDS (bitonic
-//               network, 160 KiB LDS lets a 8192-instance tile stay on chip).  Sorting by
-//               (depth, id) reproduces the stable (tile, depth) order of the reference semantics,
-//               so point_list / ranges are bit-identical to the oracle's.
+//               exclusive scan -> every instance is dropped into its tile's segment as one 64-bit
+//               key (depth_bits << 32 | gaussian id << 4 | quadrant mask).  Slot order inside a
+//               segment is arbitrary.
+//   2. sort:    one wave per tile (per 1024-chunk of a big tile) sorts the keys in registers
+//               (bitonic network; rank-merge passes for bigger tiles).  Sorting by (depth, id)
+//               reproduces the stable (tile, depth) order of the reference semantics, so
+//               point_list / ranges are bit-identical to the oracle's.  The final write also derives
+//               each instance's Gaussian-major index (where the backward pass puts its gradient
+//               record) from the Gaussian's tile rect, so no payload travels through the sort.
 // Both passes move 8-12 B per instance once instead of 6+ radix passes over 12 B.
 #include "common.h"
 
@@ -95,10 +97,10 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(uint32_t nblk, uint32_t
 // way; the tile sort restores the canonical (depth, id) order.
 template <bool LDS_HIST>
 __global__ void __launch_bounds__(BIN_THREADS)
-scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec,
+scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec, uint2* __restrict__ gm_base,
                const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
                uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ ranges,
-               uint32_t* __restrict__ cursor, uint4* __restrict__ kv) {
+               uint32_t* __restrict__ cursor, unsigned long long* __restrict__ keys) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // [tiles] when LDS_HIST
     __shared__ uint32_t lds[BIN_THREADS / WAVE + 1];
     if (LDS_HIST) {
@@ -122,6 +124,10 @@ scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec,
             dbits[r] = __float_as_uint(r2.y);
             rlo[r] = __float_as_uint(r2.z);
             rhi[r] = __float_as_uint(r2.w);
+            // what the sort's final write needs to place an instance in Gaussian-major order: the
+            // index of the instance in tile (tx, ty) is off + (ty - y0) * rw + (tx - x0)
+            const uint32_t x0 = rlo[r] & 0xffff, y0 = rlo[r] >> 16, rw = (rhi[r] & 0xffff) - x0;
+            gm_base[i] = make_uint2(off[r] - y0 * rw - x0, rw);
             if (LDS_HIST)
                 for (int ty = rlo[r] >> 16; ty < (int)(rhi[r] >> 16); ++ty)
                     for (int tx = rlo[r] & 0xffff; tx < (int)(rhi[r] & 0xffff); ++tx) atomicAdd(&hist[ty * gx + tx], 1u);
@@ -141,18 +147,18 @@ scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec,
         const int64_t i = (int64_t)blockIdx.x * BIN_GPW + r * BIN_THREADS + threadIdx.x;
         const uint32_t klo = (uint32_t)i << 4;
         const float4 r0 = rec[3 * i], r1 = rec[3 * i + 1];
-        uint32_t k = off[r];  // Gaussian-major index of this Gaussian's first instance
+        const unsigned long long khi = (unsigned long long)dbits[r] << 32;
         for (int ty = rlo[r] >> 16; ty < (int)(rhi[r] >> 16); ++ty)
             for (int tx = rlo[r] & 0xffff; tx < (int)(rhi[r] & 0xffff); ++tx) {
                 const uint32_t t = (uint32_t)(ty * gx + tx);
                 const uint32_t slot = LDS_HIST ? atomicAdd(&hist[t], 1u) : ranges[2 * t] + atomicAdd(&cursor[t], 1u);
-                kv[slot] = make_uint4(klo | quadrant_mask(r0, r1, tx * TILE, ty * TILE), dbits[r], k++, 0u);
+                keys[slot] = khi | klo | quadrant_mask(r0, r1, tx * TILE, ty * TILE);
             }
     }
 }
 
 // ------------------------------------------------------------------ per-tile sort
-// One wave sorts up to 1024 (key64, payload32) elements entirely in registers: lane l holds
+// One wave sorts up to 1024 64-bit keys entirely in registers: lane l holds
 // E = m/64 elements (index i = l*E + e), m = 64..1024.  The bitonic network's compare-exchanges at
 // distance j < E are register-to-register; at distance j >= E the partner sits in lane l ^ (j/E)
 // and is fetched with DPP (quad_perm for lane distance 1, 2; bank-masked row_shl/row_shr for 4, 8)
@@ -178,100 +184,119 @@ __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {  // value of lane (l 
         return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x118, 0xf, 0xC, false);  // row_shr:8 -> banks 2,3
     } else if constexpr (D == 16) {
         auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // r[0] = (x0,x0,x2,x2), r[1] = (x1,x1,x3,x3)
-        return (threadIdx.x & 16) ? r[0] : r[1];
+        return sel(0xFFFF0000FFFF0000ull, r[0], r[1]);
     } else {
         auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // r[0] = (lo,lo), r[1] = (hi,hi)
-        return (threadIdx.x & 32) ? r[0] : r[1];
+        return sel(0xFFFFFFFF00000000ull, r[0], r[1]);
     }
 }
 
+// lanes l (of 64) with (l & bit) == 0; bit >= 64 -> all lanes
+constexpr unsigned long long lanes_with_bit_clear(int bit) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if ((l & bit) == 0) m |= 1ull << l;
+    return m;
+}
+
+// The direction of every compare-exchange depends only on lane bits, so the "which lanes swap the other
+// way" masks are compile-time constants: swap = lanes(a > b) ^ constant.  (Equal keys only occur between
+// two padding elements, where either outcome is the same.)
 template <int E, int K, int J>
-__device__ __forceinline__ void bitonic_step(uint32_t (&klo)[E], uint32_t (&khi)[E], uint32_t (&pay)[E], int lane) {
+__device__ __forceinline__ void bitonic_step(uint32_t (&klo)[E], uint32_t (&khi)[E], int lane) {
     if constexpr (J < E) {  // partner in the same lane
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             if ((e & J) != 0) continue;
             const int f = e | J;
-            bool asc;
-            if constexpr (K < E) asc = (e & K) == 0;
-            else asc = (lane & (K / E)) == 0;  // K == 64*E: bit outside the lane range -> ascending
+            // ascending where the K bit of the element index is clear (K == 64*E: everywhere)
+            const unsigned long long desc = K < E ? ((e & K) == 0 ? 0ull : ~0ull) : ~lanes_with_bit_clear(K / E);
             const unsigned long long a = ((unsigned long long)khi[e] << 32) | klo[e];
             const unsigned long long b = ((unsigned long long)khi[f] << 32) | klo[f];
-            const bool sw = (a > b) == asc;
-            const uint32_t t0 = klo[e], t1 = khi[e], t2 = pay[e];
-            klo[e] = sw ? klo[f] : t0; khi[e] = sw ? khi[f] : t1; pay[e] = sw ? pay[f] : t2;
-            klo[f] = sw ? t0 : klo[f]; khi[f] = sw ? t1 : khi[f]; pay[f] = sw ? t2 : pay[f];
+            const unsigned long long swm = lanes(a > b) ^ desc;
+            const uint32_t t0 = klo[e], t1 = khi[e];
+            klo[e] = sel(swm, klo[f], t0); khi[e] = sel(swm, khi[f], t1);
+            klo[f] = sel(swm, t0, klo[f]); khi[f] = sel(swm, t1, khi[f]);
         }
     } else {  // partner in lane ^ (J / E)
         constexpr int D = J / E;
-        const bool lower = (lane & D) == 0;
-        const bool asc = (lane & (K / E)) == 0;
-        const bool keep_min = lower == asc;
+        // keep the smaller key where (lower lane of the pair) == (ascending block)
+        constexpr unsigned long long keep_max = lanes_with_bit_clear(D) ^ lanes_with_bit_clear(K / E);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const uint32_t olo = lane_xor<D>(klo[e]), ohi = lane_xor<D>(khi[e]), opay = lane_xor<D>(pay[e]);
+            const uint32_t olo = lane_xor<D>(klo[e]), ohi = lane_xor<D>(khi[e]);
             const unsigned long long mine = ((unsigned long long)khi[e] << 32) | klo[e];
             const unsigned long long theirs = ((unsigned long long)ohi << 32) | olo;
-            const bool take = keep_min ? (theirs < mine) : (theirs > mine);
-            klo[e] = take ? olo : klo[e];
-            khi[e] = take ? ohi : khi[e];
-            pay[e] = take ? opay : pay[e];
+            const unsigned long long take = lanes(theirs < mine) ^ keep_max;
+            klo[e] = sel(take, olo, klo[e]);
+            khi[e] = sel(take, ohi, khi[e]);
         }
     }
 }
 
 template <int E, int K, int J>
-__device__ __forceinline__ void bitonic_stage(uint32_t (&klo)[E], uint32_t (&khi)[E], uint32_t (&pay)[E], int lane) {
-    bitonic_step<E, K, J>(klo, khi, pay, lane);
-    if constexpr (J > 1) bitonic_stage<E, K, J / 2>(klo, khi, pay, lane);
+__device__ __forceinline__ void bitonic_stage(uint32_t (&klo)[E], uint32_t (&khi)[E], int lane) {
+    bitonic_step<E, K, J>(klo, khi, lane);
+    if constexpr (J > 1) bitonic_stage<E, K, J / 2>(klo, khi, lane);
 }
 template <int E, int K>
-__device__ __forceinline__ void bitonic_network(uint32_t (&klo)[E], uint32_t (&khi)[E], uint32_t (&pay)[E], int lane) {
-    bitonic_stage<E, K, K / 2>(klo, khi, pay, lane);
-    if constexpr (K < 64 * E) bitonic_network<E, K * 2>(klo, khi, pay, lane);
+__device__ __forceinline__ void bitonic_network(uint32_t (&klo)[E], uint32_t (&khi)[E], int lane) {
+    bitonic_stage<E, K, K / 2>(klo, khi, lane);
+    if constexpr (K < 64 * E) bitonic_network<E, K * 2>(klo, khi, lane);
 }
 
 constexpr int WAVE_SORT_MAX = 1024;
 
-// Sorts the n (<= 64*E) records at kv[0..n).  FINAL: write the tile's final lists (ids, quadrant
-// masks, Gaussian-major indices); otherwise write the sorted chunk back in place.
+// What the blend kernels read per sorted instance: the Gaussian id, the quadrant mask, and the
+// instance's Gaussian-major index = (first index of the Gaussian) + (position of this tile in the
+// Gaussian's tile rect, row-major as the scatter kernel walks it), from the 8-byte gm_base entry.
+struct FinalLists {
+    const uint2* gm_base;
+    uint32_t* point_list;
+    uint32_t* gm_index;
+    uint8_t* qmask;
+    int tx, ty;  // this tile
+    __device__ __forceinline__ void write(uint32_t i, uint32_t klo) const {
+        const uint32_t id = klo >> 4;
+        const uint2 b = gm_base[id];  // 8 B per Gaussian: an XCD's band of tiles keeps its share in L2
+        point_list[i] = id;
+        qmask[i] = (uint8_t)(klo & 15u);
+        gm_index[i] = b.x + (uint32_t)ty * b.y + (uint32_t)tx;
+    }
+};
+
+// Sorts the n (<= 64*E) keys at keys[0..n).  FINAL: write the tile's final lists; otherwise write the
+// sorted chunk back in place.
 template <int E, bool FINAL>
-__device__ __forceinline__ void wave_sort(uint32_t n, uint4* __restrict__ kv, uint32_t* __restrict__ point_list,
-                                          uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
+__device__ __forceinline__ void wave_sort(uint32_t n, unsigned long long* __restrict__ keys, uint32_t lo,
+                                          const FinalLists& fl) {
     const int lane = threadIdx.x & 63;
-    uint32_t klo[E], khi[E], pay[E];
+    uint32_t klo[E], khi[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {  // coalesced load; the network does not care where an element starts
         const uint32_t i = (uint32_t)e * 64 + lane;
-        const uint4 v = i < n ? kv[i] : make_uint4(~0u, ~0u, 0u, 0u);
-        klo[e] = v.x;
-        khi[e] = v.y;
-        pay[e] = v.z;
+        const unsigned long long v = i < n ? keys[i] : ~0ull;
+        klo[e] = (uint32_t)v;
+        khi[e] = (uint32_t)(v >> 32);
     }
-    bitonic_network<E, 2>(klo, khi, pay, lane);
+    bitonic_network<E, 2>(klo, khi, lane);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const uint32_t i = (uint32_t)lane * E + e;  // sorted position
         if (i < n) {
-            if (FINAL) {
-                point_list[i] = klo[e] >> 4;
-                qmask[i] = (uint8_t)(klo[e] & 15u);
-                gm_index[i] = pay[e];
-            } else {
-                kv[i] = make_uint4(klo[e], khi[e], pay[e], 0u);
-            }
+            if (FINAL) fl.write(lo + i, klo[e]);
+            else keys[i] = ((unsigned long long)khi[e] << 32) | klo[e];
         }
     }
 }
 
 template <bool FINAL>
-__device__ __forceinline__ void wave_sort_any(uint32_t n, uint4* kv, uint32_t* point_list, uint32_t* gm_index,
-                                              uint8_t* qmask) {
-    if (n <= 64) wave_sort<1, FINAL>(n, kv, point_list, gm_index, qmask);
-    else if (n <= 128) wave_sort<2, FINAL>(n, kv, point_list, gm_index, qmask);
-    else if (n <= 256) wave_sort<4, FINAL>(n, kv, point_list, gm_index, qmask);
-    else if (n <= 512) wave_sort<8, FINAL>(n, kv, point_list, gm_index, qmask);
-    else wave_sort<16, FINAL>(n, kv, point_list, gm_index, qmask);
+__device__ __forceinline__ void wave_sort_any(uint32_t n, unsigned long long* keys, uint32_t lo, const FinalLists& fl) {
+    if (n <= 64) wave_sort<1, FINAL>(n, keys, lo, fl);
+    else if (n <= 128) wave_sort<2, FINAL>(n, keys, lo, fl);
+    else if (n <= 256) wave_sort<4, FINAL>(n, keys, lo, fl);
+    else if (n <= 512) wave_sort<8, FINAL>(n, keys, lo, fl);
+    else wave_sort<16, FINAL>(n, keys, lo, fl);
 }
 
 // grid = (xcd_grid(tiles), chunks): chunk c of tile t.  Tiles with <= 1024 instances are finished
@@ -280,19 +305,20 @@ __device__ __forceinline__ void wave_sort_any(uint32_t n, uint4* kv, uint32_t* p
 #define SCR_SORT_MIN_WAVES 1
 #endif
 __global__ void __launch_bounds__(64, SCR_SORT_MIN_WAVES)
-tile_sort_wave_kernel(int tiles, const uint32_t* __restrict__ ranges, uint4* __restrict__ kv,
-                      uint32_t* __restrict__ point_list, uint32_t* __restrict__ gm_index,
-                      uint8_t* __restrict__ qmask) {
+tile_sort_wave_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, unsigned long long* __restrict__ keys,
+                      const uint2* __restrict__ gm_base, uint32_t* __restrict__ point_list,
+                      uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
     const uint32_t c0 = blockIdx.y * (uint32_t)WAVE_SORT_MAX;
     if (c0 >= n) return;
+    const FinalLists fl{gm_base, point_list, gm_index, qmask, t % gx, t / gx};
     if (n <= (uint32_t)WAVE_SORT_MAX) {
-        wave_sort_any<true>(n, kv + lo, point_list + lo, gm_index + lo, qmask + lo);
+        wave_sort_any<true>(n, keys + lo, lo, fl);
     } else {
         const uint32_t cnt = min((uint32_t)WAVE_SORT_MAX, n - c0);
-        wave_sort_any<false>(cnt, kv + lo + c0, nullptr, nullptr, nullptr);
+        wave_sort_any<false>(cnt, keys + lo + c0, 0, fl);
     }
 }
 
@@ -302,8 +328,6 @@ tile_sort_wave_kernel(int tiles, const uint32_t* __restrict__ ranges, uint4* __r
 // after p passes is buffer (p & 1).
 //   L <= 4096: one workgroup per PAIR of runs stages the pair's keys in LDS (<= 64 KB) and searches there;
 //   larger   : the searches go to global memory (L2).
-__device__ __forceinline__ unsigned long long kv_key(uint4 v) { return ((unsigned long long)v.y << 32) | v.x; }
-
 __device__ __forceinline__ uint32_t merge_passes_needed(uint32_t n) {  // ceil(log2(ceil(n/1024)))
     uint32_t chunks = (n + WAVE_SORT_MAX - 1) / WAVE_SORT_MAX, p = 0;
     while ((1u << p) < chunks) ++p;
@@ -311,8 +335,8 @@ __device__ __forceinline__ uint32_t merge_passes_needed(uint32_t n) {  // ceil(l
 }
 
 __global__ void __launch_bounds__(256)
-tile_merge_lds_kernel(int tiles, uint32_t pass, const uint32_t* __restrict__ ranges, const uint4* __restrict__ src,
-                      uint4* __restrict__ dst) {
+tile_merge_lds_kernel(int tiles, uint32_t pass, const uint32_t* __restrict__ ranges,
+                      const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lk[];  // [2L] keys of the pair
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
@@ -327,10 +351,10 @@ tile_merge_lds_kernel(int tiles, uint32_t pass, const uint32_t* __restrict__ ran
         lenB = n - pairbase - L;
         if (lenB > L) lenB = L;
     }
-    const uint4* s = src + lo + pairbase;
-    uint4* d = dst + lo + pairbase;
+    const unsigned long long* s = src + lo + pairbase;
+    unsigned long long* d = dst + lo + pairbase;
     const uint32_t tot = lenA + lenB;
-    for (uint32_t e = threadIdx.x; e < tot; e += 256) lk[e] = kv_key(s[e]);
+    for (uint32_t e = threadIdx.x; e < tot; e += 256) lk[e] = s[e];
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < tot; e += 256) {
         const unsigned long long x = lk[e];
@@ -342,23 +366,22 @@ tile_merge_lds_kernel(int tiles, uint32_t pass, const uint32_t* __restrict__ ran
             if (other[mid] < x) a = mid + 1;
             else b = mid;
         }
-        d[(left ? e : e - lenA) + a] = s[e];
+        d[(left ? e : e - lenA) + a] = x;
     }
 }
 
 __global__ void __launch_bounds__(256)
 tile_merge_global_kernel(int tiles, uint32_t pass, const uint32_t* __restrict__ ranges,
-                         const uint4* __restrict__ src, uint4* __restrict__ dst) {
+                         const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst) {
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
     if (n <= (uint32_t)WAVE_SORT_MAX || pass >= merge_passes_needed(n)) return;
     const uint32_t L = (uint32_t)WAVE_SORT_MAX << pass;
-    const uint4* sk = src + lo;
+    const unsigned long long* sk = src + lo;
     for (uint32_t e = blockIdx.y * (uint32_t)WAVE_SORT_MAX + threadIdx.x, k = 0; k < WAVE_SORT_MAX / 256 && e < n; ++k, e += 256) {
         const uint32_t run = e / L, pairbase = (run & ~1u) * L, inrun = e - run * L;
-        const uint4 rec_ = sk[e];
-        const unsigned long long x = kv_key(rec_);
+        const unsigned long long x = sk[e];
         uint32_t base, len;
         if ((run & 1u) == 0) {  // element of the left run: count right-run elements below it
             base = pairbase + L;
@@ -374,29 +397,27 @@ tile_merge_global_kernel(int tiles, uint32_t pass, const uint32_t* __restrict__ 
         uint32_t a = 0, b = len;
         while (a < b) {
             const uint32_t mid = (a + b) >> 1;
-            if (kv_key(sk[base + mid]) < x) a = mid + 1;
+            if (sk[base + mid] < x) a = mid + 1;
             else b = mid;
         }
-        dst[lo + pairbase + inrun + a] = rec_;
+        dst[lo + pairbase + inrun + a] = x;
     }
 }
 
 // Final lists of the large tiles from the buffer their last merge pass wrote.
 __global__ void __launch_bounds__(256)
-tile_merge_final_kernel(int tiles, const uint32_t* __restrict__ ranges, const uint4* __restrict__ kv0,
-                        const uint4* __restrict__ kv1, uint32_t* __restrict__ point_list,
-                        uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
+tile_merge_final_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, const unsigned long long* __restrict__ k0,
+                        const unsigned long long* __restrict__ k1, const uint2* __restrict__ gm_base,
+                        uint32_t* __restrict__ point_list, uint32_t* __restrict__ gm_index,
+                        uint8_t* __restrict__ qmask) {
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
     if (n <= (uint32_t)WAVE_SORT_MAX) return;
-    const uint4* sk = ((merge_passes_needed(n) & 1u) ? kv1 : kv0) + lo;
-    for (uint32_t e = blockIdx.y * (uint32_t)WAVE_SORT_MAX + threadIdx.x, k = 0; k < WAVE_SORT_MAX / 256 && e < n; ++k, e += 256) {
-        const uint4 v = sk[e];
-        point_list[lo + e] = v.x >> 4;
-        qmask[lo + e] = (uint8_t)(v.x & 15u);
-        gm_index[lo + e] = v.z;
-    }
+    const unsigned long long* sk = ((merge_passes_needed(n) & 1u) ? k1 : k0) + lo;
+    const FinalLists fl{gm_base, point_list, gm_index, qmask, t % gx, t / gx};
+    for (uint32_t e = blockIdx.y * (uint32_t)WAVE_SORT_MAX + threadIdx.x, k = 0; k < WAVE_SORT_MAX / 256 && e < n; ++k, e += 256)
+        fl.write(lo + e, (uint32_t)sk[e]);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -413,12 +434,12 @@ void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const Bi
     const unsigned nb = (unsigned)((P + BIN_GPW - 1) / BIN_GPW);
     if (g.tiles <= LDS_HIST_MAX_TILES)
         scatter_kernel<true><<<nb, BIN_THREADS, (size_t)g.tiles * 4, st>>>(
-            P, g.gx, g.tiles, gv.rec, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor,
-            bv.kv);
+            P, g.gx, g.tiles, gv.rec, gv.gm_base, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor,
+            bv.keys);
     else
         scatter_kernel<false><<<nb, BIN_THREADS, 0, st>>>(
-            P, g.gx, g.tiles, gv.rec, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor,
-            bv.kv);
+            P, g.gx, g.tiles, gv.rec, gv.gm_base, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor,
+            bv.keys);
 }
 
 void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, int64_t max_tile_instances,
@@ -427,7 +448,8 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
     const unsigned gt = (unsigned)xcd_grid(g.tiles);
     const unsigned chunks = (unsigned)((max_tile_instances + WAVE_SORT_MAX - 1) / WAVE_SORT_MAX);
     if (chunks == 0) return;
-    tile_sort_wave_kernel<<<dim3(gt, chunks), 64, 0, st>>>(g.tiles, gv.ranges, bv.kv, bv.point_list, bv.gm_index, bv.qmask);
+    tile_sort_wave_kernel<<<dim3(gt, chunks), 64, 0, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.gm_base, bv.point_list,
+                                                          bv.gm_index, bv.qmask);
     if (chunks <= 1) return;
     unsigned passes = 0;
     while ((1u << passes) < chunks) ++passes;
@@ -437,8 +459,8 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
         attr_set = true;
     }
     for (unsigned p = 0; p < passes; ++p) {
-        const uint4* src = (p & 1u) ? bv.kv2 : bv.kv;  // data of pass p lives in buffer (p & 1)
-        uint4* dst = (p & 1u) ? bv.kv : bv.kv2;
+        const unsigned long long* src = (p & 1u) ? bv.keys2 : bv.keys;  // data of pass p lives in buffer (p & 1)
+        unsigned long long* dst = (p & 1u) ? bv.keys : bv.keys2;
         const unsigned L = (unsigned)WAVE_SORT_MAX << p;
         if (L <= 4096u) {
             const unsigned pairs = (chunks * (unsigned)WAVE_SORT_MAX + 2 * L - 1) / (2 * L);
@@ -447,8 +469,8 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
             tile_merge_global_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, p, gv.ranges, src, dst);
         }
     }
-    tile_merge_final_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, gv.ranges, bv.kv, bv.kv2, bv.point_list,
-                                                              bv.gm_index, bv.qmask);
+    tile_merge_final_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, bv.keys2, gv.gm_base,
+                                                              bv.point_list, bv.gm_index, bv.qmask);
 }
 
 }  // namespace scr

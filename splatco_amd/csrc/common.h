@@ -35,6 +35,8 @@ struct GeomView {
     uint32_t* tiles_touched;  // [P]
     uint32_t* point_offsets;  // [P] inclusive scan of tiles_touched (written by the scatter kernel)
     uint8_t* clamped;         // [P] bit c set when SH colour channel c was clamped at 0
+    uint2* gm_base;           // [P] (b, rw): Gaussian-major index of the instance in tile (tx, ty) = b + ty*rw + tx
+                              //     (b = first index - y0*rw - x0 mod 2^32, rw = rect width; written by the scatter kernel)
     uint32_t* block_sums;     // [ceil(P/BIN_GPW)] -> exclusive prefix after scan
     uint32_t* tile_count;     // [tiles]
     uint32_t* ranges;         // [tiles][2] (start, end)
@@ -54,6 +56,7 @@ inline __host__ GeomView geom_view(void* base, int64_t P, int H, int W) {
     v.tiles_touched = (uint32_t*)take((size_t)P * 4);
     v.point_offsets = (uint32_t*)take((size_t)P * 4);
     v.clamped = (uint8_t*)take((size_t)P);
+    v.gm_base = (uint2*)take((size_t)P * 8);
     v.block_sums = (uint32_t*)take((nblk + 1) * 4);
     v.tile_count = (uint32_t*)take((size_t)g.tiles * 4);
     v.ranges = (uint32_t*)take((size_t)g.tiles * 8);
@@ -65,13 +68,11 @@ inline __host__ GeomView geom_view(void* base, int64_t P, int H, int W) {
 
 // ---- binning buffer: per (Gaussian, tile) instance lists ----
 struct BinView {
-    uint4* kv;                 // [I] grouped by tile, unsorted: (key lo = gaussian id << 4 | quadrant mask,
-                               //     key hi = depth bits, payload = Gaussian-major instance index, 0) -- one
-                               //     16-byte record so the scatter issues ONE random write per instance
+    unsigned long long* keys;  // [I] grouped by tile, unsorted: depth bits << 32 | gaussian id << 4 | quadrant mask
     uint32_t* point_list;      // [I] Gaussian ids, per tile sorted by (depth, id)
     uint32_t* gm_index;        // [I] sorted position -> Gaussian-major instance index (where its gradient record goes)
     uint8_t* qmask;            // [I] sorted position -> 4-bit mask of the tile's 8x8 quadrants the splat can touch
-    uint4* kv2;                // [I] second buffer of the merge passes (only when a tile exceeds one sort chunk)
+    unsigned long long* keys2; // [I] second buffer of the merge passes (only when a tile exceeds one sort chunk)
     size_t bytes;
 };
 
@@ -81,12 +82,12 @@ inline __host__ BinView bin_view(void* base, int64_t I, int64_t max_tile_instanc
     BinView v;
     auto take = [&](size_t n) { char* q = p ? p + off : nullptr; off += align_up(n); return q; };
     size_t n = (size_t)(I > 0 ? I : 1);
-    v.kv = (uint4*)take(n * 16);
+    v.keys = (unsigned long long*)take(n * 8);
     v.point_list = (uint32_t*)take(n * 4);
     v.gm_index = (uint32_t*)take(n * 4);
     v.qmask = (uint8_t*)take(n);
     const bool merge = max_tile_instances > 1024;  // WAVE_SORT_MAX
-    v.kv2 = merge ? (uint4*)take(n * 16) : nullptr;
+    v.keys2 = merge ? (unsigned long long*)take(n * 8) : nullptr;
     v.bytes = off;
     return v;
 }
