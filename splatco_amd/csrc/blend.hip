@@ -181,31 +181,47 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
 }
 
 // ------------------------------------------------------------------ wave64 sums, four splats at a time
-// The nine per-splat partial sums of FOUR consecutive splats (A,B,C,D) are reduced together:
-//   v_permlane32_swap folds the wave in half   (A|B and C|D share a register: 2 swaps + 2 adds)
-//   v_permlane16_swap folds the halves again   (row 0: A, row 1: C, row 2: B, row 3: D)
-//   four DPP row_shr adds finish inside each 16-lane row -> lanes 15 / 31 / 47 / 63 hold the sums
-// = 10 instructions per value for four splats (2.5 per splat-value instead of 6), always added
-// in the same order (bit-reproducible).  The row steps are one asm block: hipcc splits the
-// builtin DPP form into v_mov_dpp + v_add pairs padded with s_nop; here the nine chains are
-// interleaved, which also covers the 2-wait-state VALU-write -> DPP-read hazard between steps.
-// The leading s_nop 1 covers the same hazard against the instruction just before the block.
-#define SCR_DPP9(ctrl)                              \
-    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\t"         \
-    "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t"         \
-    "v_add_f32_dpp %2, %2, %2 " ctrl "\n\t"         \
-    "v_add_f32_dpp %3, %3, %3 " ctrl "\n\t"         \
-    "v_add_f32_dpp %4, %4, %4 " ctrl "\n\t"         \
-    "v_add_f32_dpp %5, %5, %5 " ctrl "\n\t"         \
-    "v_add_f32_dpp %6, %6, %6 " ctrl "\n\t"         \
-    "v_add_f32_dpp %7, %7, %7 " ctrl "\n\t"         \
-    "v_add_f32_dpp %8, %8, %8 " ctrl "\n\t"
-__device__ __forceinline__ void row_sums9(float (&v)[9]) {  // lane 15 of every 16-lane row <- row sum
+// The nine per-splat partial sums of FOUR consecutive splats (A,B,C,D) are reduced together by
+// FOLDING: every step adds the two halves of TWO registers into one, so the register count halves
+// with the lane span and no lane ever carries a redundant copy:
+//   v_permlane32_swap + add : 36 -> 18 registers  (A|B and C|D share a register)
+//   v_permlane16_swap + add : 18 -> 9             (16-lane rows 0..3 hold splats A, C, B, D)
+//   two bank-masked DPP adds fold two VALUES into one register inside every row:
+//     8-lane step  (row_shl:8 -> lanes 0-7, row_shr:8 -> lanes 8-15)          : 9 -> 5
+//     4-lane step  (row_shl:4 -> banks 0,2, row_shr:4 -> banks 1,3)           : 5 -> 3
+//   two quad_perm adds finish inside each 4-lane group.
+// Result per row: v[0] = (sum0 | sum2 | sum1 | sum3), v[4] = (sum4 | sum6 | sum5 | sum7) by 4-lane
+// group, v[8] = sum8 in lanes 12-15.  20 DPP adds instead of 36 for plain row reductions, always
+// added in the same order (bit-reproducible).  The DPP part is one asm block: hipcc splits the
+// builtin DPP form into v_mov_dpp + v_add pairs padded with s_nop; here independent chains are
+// interleaved so that every DPP source was written at least two instructions earlier (the
+// 2-wait-state VALU-write -> DPP-read hazard); the leading s_nop 1 covers the instruction before the block.
+#define SCR_DPP(d, s, ctrl) "v_add_f32_dpp " d ", " s ", " s " " ctrl "\n\t"
+__device__ __forceinline__ void row_fold9(float (&v)[9]) {
     asm volatile("s_nop 1\n\t"
-                 SCR_DPP9("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                 SCR_DPP9("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                 SCR_DPP9("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                 SCR_DPP9("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 // 8-lane step: (0,1) (2,3) (4,5) (6,7) -> 0, 2, 4, 6; 8 alone (upper half only)
+                 SCR_DPP("%0", "%0", "row_shl:8 row_mask:0xf bank_mask:0x3")
+                 SCR_DPP("%2", "%2", "row_shl:8 row_mask:0xf bank_mask:0x3")
+                 SCR_DPP("%4", "%4", "row_shl:8 row_mask:0xf bank_mask:0x3")
+                 SCR_DPP("%6", "%6", "row_shl:8 row_mask:0xf bank_mask:0x3")
+                 SCR_DPP("%8", "%8", "row_shr:8 row_mask:0xf bank_mask:0xc")
+                 SCR_DPP("%0", "%1", "row_shr:8 row_mask:0xf bank_mask:0xc")
+                 SCR_DPP("%2", "%3", "row_shr:8 row_mask:0xf bank_mask:0xc")
+                 SCR_DPP("%4", "%5", "row_shr:8 row_mask:0xf bank_mask:0xc")
+                 SCR_DPP("%6", "%7", "row_shr:8 row_mask:0xf bank_mask:0xc")
+                 // 4-lane step: (0,2) -> 0, (4,6) -> 4; 8 alone (lanes 12-15 only)
+                 SCR_DPP("%0", "%0", "row_shl:4 row_mask:0xf bank_mask:0x5")
+                 SCR_DPP("%4", "%4", "row_shl:4 row_mask:0xf bank_mask:0x5")
+                 SCR_DPP("%8", "%8", "row_shr:4 row_mask:0xf bank_mask:0x8")
+                 SCR_DPP("%0", "%2", "row_shr:4 row_mask:0xf bank_mask:0xa")
+                 SCR_DPP("%4", "%6", "row_shr:4 row_mask:0xf bank_mask:0xa")
+                 // inside each 4-lane group
+                 SCR_DPP("%8", "%8", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%0", "%0", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%4", "%4", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%8", "%8", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%0", "%0", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%4", "%4", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
                  "s_nop 1"
                  : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
                    "+v"(v[8]));
@@ -305,6 +321,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     ps.last_alpha = ps.d_last = 0.0f;
     float c099 = 0.99f;
     asm volatile("" : "+v"(c099));  // keep the clamp in a VGPR: VOP2 with a literal issues slower
+    const int comp = ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1);  // which sum this lane's 4-lane group ends up with
     // per-wave largest contributor count: list positions >= it cannot matter to the wave
     uint32_t wm = last;
 #pragma unroll
@@ -414,18 +431,18 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             if (any) {
 #pragma unroll
                 for (int v = 0; v < 9; ++v) r[v] = fold4(g[0][v], g[1][v], g[2][v], g[3][v]);
-                row_sums9(r);
+                row_fold9(r);
             } else {
-#pragma unroll
-                for (int v = 0; v < 9; ++v) r[v] = 0.0f;
+                r[0] = r[4] = r[8] = 0.0f;
             }
-            // lanes 15 / 31 / 47 / 63 hold splat u = 0 / 2 / 1 / 3 of the group
+            // rows 0 / 1 / 2 / 3 hold splat u = 0 / 2 / 1 / 3 of the group; 4-lane group q of a row holds
+            // sums (0,2,1,3)[q] in r[0], (4,6,5,7)[q] in r[4], and group 3 holds sum 8 in r[8]
             const int row = lane >> 4;
             const uint32_t jw = row == 0 ? jj[0] : row == 1 ? jj[2] : row == 2 ? jj[1] : jj[3];
-            if ((lane & 15) == 15 && jw != 0xffffffffu) {  // every listed position is written
-                accA[par][wave][jw] = make_float4(r[0], r[1], r[2], r[3]);
-                accB[par][wave][jw] = make_float4(r[4], r[5], r[6], r[7]);
-                accC[par][wave][jw] = r[8];
+            if ((lane & 3) == 0 && jw != 0xffffffffu) {  // every listed position is written
+                ((float*)&accA[par][wave][jw])[comp] = r[0];
+                ((float*)&accB[par][wave][jw])[comp] = r[4];
+                if (comp == 3) accC[par][wave][jw] = r[8];
             }
         }
         __syncthreads();  // B: every wave's sums for this round are in acc
