@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 2
+#define SCR_ABI_VERSION 3
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -139,15 +139,28 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
                         const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
                         float* d_offsets, float* d_grid_scaling, float* d_anchor, void* stream);
 
-/* ---- backward of the tri-plane bilinear feature sampling (scene/grids.py:146-182):
- * out[v, r] = grid_sample(plane[1,R,A,B], grid[v] = (x, y) in [-1,1], bilinear, align_corners=True,
- * zeros padding) -- x indexes the last plane dimension (B), y the dimension A.  Given
- * grad_out[V,R] the call overwrites grad_plane[R,A,B] with the scatter-add of the four corner
- * weights (points are bucketed by 32x32-cell tile and accumulated in LDS; global float atomics
- * only when a tile is flushed).  R <= 8; scratch from scr_plane_sample_scratch_bytes. */
+/* ---- tri-plane bilinear feature sampling (scene/grids.py:146-182).  One plane sample is
+ * out[v, r] = grid_sample(plane[1,R,A,B], (gx, gy) in [-1,1], bilinear, align_corners=True, zeros
+ * padding) -- gx indexes the last plane dimension (B), gy the dimension A.
+ *
+ * scr_triplane_forward: coords[V][cstride] holds the normalised (x, y, z) of every anchor in its first
+ * three columns; the three planes xy[R,X,Y], xz[R,X,Z], yz[R,Y,Z] are sampled with the coordinate pairs
+ * of scene/grids.py:148-150 ((y,x), (z,x), (z,y)) and written to out[v*ld + col_xy/col_xz/col_yz + r], i.e.
+ * straight into the concatenated feature matrix the reference builds with torch.cat (:165,:181).
+ *
+ * scr_plane_sample_backward: given grad_out (row stride ld, R used columns: pass the column-offset
+ * pointer) and the columns (cx, cy) of coords that hold (gx, gy), overwrites grad_plane[R,A,B] with
+ * the scatter-add of the four corner weights (points are bucketed by 32x32-cell tile and
+ * accumulated in LDS; global float atomics only when a tile is flushed).  R <= 8; scratch from
+ * scr_plane_sample_scratch_bytes.  The sample positions get no gradient (the reference detaches
+ * them, scene/gaussian_model.py:210). */
+int scr_triplane_forward(int64_t V, const float* coords, int32_t cstride, const float* xy, const float* xz,
+                         const float* yz, int32_t R, int32_t X, int32_t Y, int32_t Z, float* out, int32_t ld,
+                         int32_t col_xy, int32_t col_xz, int32_t col_yz, void* stream);
 size_t scr_plane_sample_scratch_bytes(int64_t V, int32_t A, int32_t B);
-int scr_plane_sample_backward(int64_t V, const float* grid, int32_t R, int32_t A, int32_t B,
-                              const float* grad_out, float* grad_plane, void* scratch, void* stream);
+int scr_plane_sample_backward(int64_t V, const float* coords, int32_t cstride, int32_t cx, int32_t cy, int32_t R,
+                              int32_t A, int32_t B, const float* grad_out, int32_t ld, float* grad_plane,
+                              void* scratch, void* stream);
 
 /* ---- fused L1 + SSIM image loss (train.py:192-196, utils/loss_utils.py:17-63): img1 = rendered
  * image [C,H,W] (gets the gradient), img2 = ground truth.  Forward writes out2[0] = mean |img1-img2|
@@ -173,7 +186,7 @@ enum {
     SCR_PROF_FILTER = 0, SCR_PROF_PREPROCESS = 1, SCR_PROF_PLAN_SCAN = 2, SCR_PROF_SCATTER = 3,
     SCR_PROF_TILE_SORT = 4, SCR_PROF_BLEND_FORWARD = 5, SCR_PROF_BLEND_BACKWARD = 6,
     SCR_PROF_PREPROCESS_BACKWARD = 7, SCR_PROF_EXPAND = 8, SCR_PROF_EXPAND_BACKWARD = 9, SCR_PROF_PLANE_BACKWARD = 10,
-    SCR_PROF_L1_SSIM = 11, SCR_PROF_L1_SSIM_BACKWARD = 12, SCR_PROF_COUNT = 13
+    SCR_PROF_L1_SSIM = 11, SCR_PROF_L1_SSIM_BACKWARD = 12, SCR_PROF_TRIPLANE_FORWARD = 13, SCR_PROF_COUNT = 14
 };
 int scr_profile_enable(int mask);
 int scr_profile_read(double* total_ms, int64_t* launches);

@@ -16,11 +16,11 @@ SYMBOLS = [
     "scr_backward_scratch_bytes", "scr_visible_filter", "scr_mark_visible", "scr_forward_plan",
     "scr_forward_run", "scr_backward", "scr_debug_get", "scr_profile_enable", "scr_profile_read",
     "scr_profile_kernel_name", "scr_expand_scratch_bytes", "scr_expand_plan", "scr_expand_run",
-    "scr_expand_backward", "scr_plane_sample_scratch_bytes", "scr_plane_sample_backward",
+    "scr_expand_backward", "scr_plane_sample_scratch_bytes", "scr_plane_sample_backward", "scr_triplane_forward",
     "scr_l1_ssim_scratch_bytes", "scr_l1_ssim_forward", "scr_l1_ssim_backward",
 ]
-PROF_COUNT = 13
-ABI_VERSION = 2
+PROF_COUNT = 14
+ABI_VERSION = 3
 
 DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
 
@@ -76,7 +76,9 @@ def _load():
         getattr(lib, f).restype = C.c_int
     lib.scr_plane_sample_scratch_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.scr_plane_sample_scratch_bytes.restype = C.c_size_t
-    lib.scr_plane_sample_backward.argtypes = [i64, vp, i32, i32, i32, vp, vp, vp, vp]
+    lib.scr_plane_sample_backward.argtypes = [i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
+    lib.scr_triplane_forward.argtypes = [i64, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]
+    lib.scr_triplane_forward.restype = C.c_int
     lib.scr_plane_sample_backward.restype = C.c_int
     lib.scr_l1_ssim_scratch_bytes.argtypes = [i32, i32, i32, i32]
     lib.scr_l1_ssim_scratch_bytes.restype = C.c_size_t

@@ -60,7 +60,7 @@ const char* const kProfNames[SCR_PROF_COUNT] = {
     "filter_kernel", "preprocess_kernel", "plan_scan_kernel", "scatter_kernel", "tile_sort_kernel",
     "blend_forward_kernel", "blend_backward_kernel", "preprocess_backward_kernel", "expand_kernel",
     "expand_backward_kernel", "plane_sample_backward_kernels", "l1_ssim_forward_kernel",
-    "l1_ssim_backward_kernel"};
+    "l1_ssim_backward_kernel", "triplane_forward_kernel"};
 }  // namespace
 
 static int check_settings(const scr_settings* s) {
@@ -291,17 +291,35 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
 // ---- tri-plane sampling backward (triplane.hip)
 size_t scr_plane_sample_scratch_bytes(int64_t V, int32_t A, int32_t B) { return triplane_scratch_bytes(V, A, B); }
 
-int scr_plane_sample_backward(int64_t V, const float* grid, int32_t R, int32_t A, int32_t B,
-                              const float* grad_out, float* grad_plane, void* scratch, void* stream) {
+int scr_plane_sample_backward(int64_t V, const float* coords, int32_t cstride, int32_t cx, int32_t cy, int32_t R,
+                              int32_t A, int32_t B, const float* grad_out, int32_t ld, float* grad_plane,
+                              void* scratch, void* stream) {
     if (V < 0 || R <= 0 || A <= 1 || B <= 1) return fail("bad sizes");
-    if (!grad_plane || !scratch || (V > 0 && (!grid || !grad_out))) return fail("NULL argument");
+    if (cstride <= 0 || cx < 0 || cy < 0 || cx >= cstride || cy >= cstride || ld < R) return fail("bad strides");
+    if (!grad_plane || !scratch || (V > 0 && (!coords || !grad_out))) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
     int rc;
     { ProfScope ps_(SCR_PROF_PLANE_BACKWARD, st);
-      rc = launch_plane_sample_backward(V, grid, R, A, B, grad_out, grad_plane, scratch, st); }
+      rc = launch_plane_sample_backward(V, coords, cstride, cx, cy, R, A, B, grad_out, ld, grad_plane, scratch, st); }
     if (rc == 1) return fail("R = %d channels per plane exceeds the supported 8", R);
     if (rc == 2) return fail("plane %dx%d has too many 32x32 tiles for the LDS histogram", A, B);
     CHECK_LAUNCH("plane_sample_backward", 0, st);
+    return 0;
+}
+
+int scr_triplane_forward(int64_t V, const float* coords, int32_t cstride, const float* xy, const float* xz,
+                         const float* yz, int32_t R, int32_t X, int32_t Y, int32_t Z, float* out, int32_t ld,
+                         int32_t col_xy, int32_t col_xz, int32_t col_yz, void* stream) {
+    if (V < 0 || R <= 0 || X <= 1 || Y <= 1 || Z <= 1) return fail("bad sizes");
+    if (cstride < 3 || col_xy < 0 || col_xz < 0 || col_yz < 0 || col_xy + R > ld || col_xz + R > ld || col_yz + R > ld)
+        return fail("bad strides");
+    if (V > 0 && (!coords || !xy || !xz || !yz || !out)) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    { ProfScope ps_(SCR_PROF_TRIPLANE_FORWARD, st);
+      rc = launch_triplane_forward(V, coords, cstride, xy, xz, yz, R, X, Y, Z, out, ld, col_xy, col_xz, col_yz, st); }
+    if (rc == 1) return fail("R = %d channels per plane exceeds the supported 8", R);
+    CHECK_LAUNCH("triplane_forward_kernel", 0, st);
     return 0;
 }
 

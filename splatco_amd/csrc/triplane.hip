@@ -1,4 +1,7 @@
-// splatco_amd/csrc/triplane.hip -- backward of the tri-plane bilinear feature sampling (gfx950).
+// splatco_amd/csrc/triplane.hip -- tri-plane bilinear feature sampling, forward and backward (gfx950).
+//
+// Forward: one thread per anchor samples all three planes and writes its 3*R features as one
+// contiguous row segment of the caller's [V, ld] matrix (no per-plane outputs, no concatenation).
 //
 // PlaneGrid samples three learnable planes [1,R,A,B] at V anchor positions with
 // F.grid_sample(bilinear, align_corners=True, zeros padding) (scene/grids.py:146-182).  The
@@ -66,7 +69,7 @@ __device__ __forceinline__ uint32_t tp_block_scan(uint32_t v, uint32_t* lds_wave
 
 // pass 1: per-tile point counts (LDS histogram per workgroup, one global atomic per touched tile)
 __global__ void __launch_bounds__(TP_THREADS)
-tp_count_kernel(int64_t V, const float* __restrict__ grid, int A, int B, int tb, int tiles,
+tp_count_kernel(int64_t V, const float* __restrict__ coords, int cs, int cx, int cy, int A, int B, int tb, int tiles,
                 uint32_t* __restrict__ tile_count) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     for (int t = threadIdx.x; t < tiles; t += TP_THREADS) hist[t] = 0;
@@ -74,7 +77,7 @@ tp_count_kernel(int64_t V, const float* __restrict__ grid, int A, int B, int tb,
     for (int r = 0; r < TP_ROUNDS; ++r) {
         const int64_t i = (int64_t)blockIdx.x * TP_PER_WG + r * TP_THREADS + threadIdx.x;
         if (i >= V) break;
-        const int t = tp_tile_of(grid[2 * i], grid[2 * i + 1], A, B, tb);
+        const int t = tp_tile_of(coords[i * cs + cx], coords[i * cs + cy], A, B, tb);
         if (t >= 0) atomicAdd(&hist[t], 1u);
     }
     __syncthreads();
@@ -106,7 +109,7 @@ tp_scan_kernel(int tiles, const uint32_t* __restrict__ tile_count, uint32_t* __r
 
 // pass 3: point indices grouped by tile
 __global__ void __launch_bounds__(TP_THREADS)
-tp_scatter_kernel(int64_t V, const float* __restrict__ grid, int A, int B, int tb, int tiles,
+tp_scatter_kernel(int64_t V, const float* __restrict__ coords, int cs, int cx, int cy, int A, int B, int tb, int tiles,
                   const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ cursor,
                   uint32_t* __restrict__ perm) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
@@ -116,7 +119,7 @@ tp_scatter_kernel(int64_t V, const float* __restrict__ grid, int A, int B, int t
 #pragma unroll
     for (int r = 0; r < TP_ROUNDS; ++r) {
         const int64_t i = (int64_t)blockIdx.x * TP_PER_WG + r * TP_THREADS + threadIdx.x;
-        tl[r] = i < V ? tp_tile_of(grid[2 * i], grid[2 * i + 1], A, B, tb) : -1;
+        tl[r] = i < V ? tp_tile_of(coords[i * cs + cx], coords[i * cs + cy], A, B, tb) : -1;
         if (tl[r] >= 0) atomicAdd(&hist[tl[r]], 1u);
     }
     __syncthreads();
@@ -135,9 +138,9 @@ tp_scatter_kernel(int64_t V, const float* __restrict__ grid, int A, int B, int t
 
 // pass 4: one workgroup per tile accumulates its points in LDS, then flushes the tile
 __global__ void __launch_bounds__(256)
-tp_accumulate_kernel(const float* __restrict__ grid, int A, int B, int tb, int R,
+tp_accumulate_kernel(const float* __restrict__ coords, int cs, int cx, int cy, int A, int B, int tb, int R,
                      const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ perm,
-                     const float* __restrict__ grad_out /*[V][R]*/, float* __restrict__ grad_plane /*[R][A][B]*/) {
+                     const float* __restrict__ grad_out /*[V][ld]*/, int ld, float* __restrict__ grad_plane /*[R][A][B]*/) {
     __shared__ float acc[TP_MAX_R][TP_NODES * TP_NODES];
     const int t = blockIdx.x;
     const uint32_t lo = tile_start[t], hi = tile_start[t + 1];
@@ -149,7 +152,7 @@ tp_accumulate_kernel(const float* __restrict__ grid, int A, int B, int tb, int R
         const uint32_t i = perm[q];
         int a0, b0;
         float fa, fb;
-        tp_cell(grid[2 * (size_t)i], grid[2 * (size_t)i + 1], A, B, a0, b0, fa, fb);
+        tp_cell(coords[(size_t)i * cs + cx], coords[(size_t)i * cs + cy], A, B, a0, b0, fa, fb);
         // weights as torch: nw = (ix_se - ix)(iy_se - iy) ... ; corners outside the plane contribute nothing
         const float w00 = (1.0f - fa) * (1.0f - fb), w01 = (1.0f - fa) * fb, w10 = fa * (1.0f - fb), w11 = fa * fb;
         const bool va0 = a0 >= 0 && a0 < A, va1 = a0 + 1 >= 0 && a0 + 1 < A;
@@ -157,7 +160,7 @@ tp_accumulate_kernel(const float* __restrict__ grid, int A, int B, int tb, int R
         const int la = a0 - ta * TP_TILE, lb = b0 - tbb * TP_TILE;  // in [-1, 31]
         const int n00 = la * TP_NODES + lb;
         for (int r = 0; r < R; ++r) {
-            const float g = grad_out[(size_t)i * R + r];
+            const float g = grad_out[(size_t)i * ld + r];
             float* base = acc[r];
             if (va0 && vb0) unsafeAtomicAdd(base + n00, g * w00);
             if (va0 && vb1) unsafeAtomicAdd(base + n00 + 1, g * w01);
@@ -178,13 +181,83 @@ tp_accumulate_kernel(const float* __restrict__ grid, int A, int B, int tb, int R
     }
 }
 
+
+// ---- forward: out[v, col_p + r] = bilinear sample of plane p (zeros padding), weights and
+// accumulation order as torch's grid_sampler_2d (nw, ne, sw, se)
+template <int R>
+__device__ __forceinline__ void tp_sample_plane(const float* __restrict__ plane, int A, int B, float gx, float gy,
+                                                float* __restrict__ out) {
+    int a0, b0;
+    float fa, fb;
+    tp_cell(gx, gy, A, B, a0, b0, fa, fb);
+    const bool va0 = a0 >= 0 && a0 < A, va1 = a0 + 1 >= 0 && a0 + 1 < A;
+    const bool vb0 = b0 >= 0 && b0 < B, vb1 = b0 + 1 >= 0 && b0 + 1 < B;
+    // The two x-neighbours of a corner pair are adjacent in memory: one 8-byte load per (row, channel)
+    // from the pair base pb = clamp(b0, 0, B-2); a corner outside the plane (zeros padding) or not
+    // covered by the pair gets weight 0, so all 2*R loads are unconditional and in flight together.
+    // (NaN coordinates fail every test -> weights 0 -> output 0, where torch propagates NaN; the
+    // reference never samples NaN positions.)
+    const int pb = min(max(b0, 0), B - 2);
+    const float wx0 = vb0 ? 1.0f - fb : 0.0f, wx1 = vb1 ? fb : 0.0f;           // weights of columns b0, b0+1
+    const float we0 = b0 == pb ? wx0 : (b0 + 1 == pb ? wx1 : 0.0f);            // ... of columns pb, pb+1
+    const float we1 = b0 == pb + 1 ? wx0 : (b0 + 1 == pb + 1 ? wx1 : 0.0f);
+    const float wy0 = va0 ? 1.0f - fa : 0.0f, wy1 = va1 ? fa : 0.0f;
+    const float w00 = wy0 * we0, w01 = wy0 * we1, w10 = wy1 * we0, w11 = wy1 * we1;
+    const size_t n0 = (size_t)(va0 ? a0 : 0) * B + pb, n1 = (size_t)(va1 ? a0 + 1 : 0) * B + pb;
+    const size_t AB = (size_t)A * B;
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    f2u v0[R], v1[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float* pl = plane + r * AB;
+        v0[r] = *(const f2u*)(pl + n0);
+        v1[r] = *(const f2u*)(pl + n1);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)  // accumulation order of torch's grid_sampler_2d: nw, ne, sw, se
+        out[r] = ((v0[r].x * w00 + v0[r].y * w01) + v1[r].x * w10) + v1[r].y * w11;
+}
+
+template <int R>
+__global__ void __launch_bounds__(256)
+triplane_forward_kernel(int64_t V, const float* __restrict__ coords, int cs, const float* __restrict__ xy,
+                        const float* __restrict__ xz, const float* __restrict__ yz, int X, int Y, int Z,
+                        float* __restrict__ out, int ld, int col_xy, int col_xz, int col_yz) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= V) return;
+    const float x = coords[i * cs], y = coords[i * cs + 1], z = coords[i * cs + 2];
+    float* o = out + i * ld;
+    // coordinate pairs of scene/grids.py:148-150: grid x indexes the LAST plane dimension
+    tp_sample_plane<R>(xy, X, Y, y, x, o + col_xy);  // xy_plane [R,X,Y] at ind[..., [1, 0]]
+    tp_sample_plane<R>(xz, X, Z, z, x, o + col_xz);  // xz_plane [R,X,Z] at ind[..., [2, 0]]
+    tp_sample_plane<R>(yz, Y, Z, z, y, o + col_yz);  // yz_plane [R,Y,Z] at ind[..., [2, 1]]
+}
+
+int launch_triplane_forward(int64_t V, const float* coords, int cs, const float* xy, const float* xz, const float* yz,
+                            int R, int X, int Y, int Z, float* out, int ld, int col_xy, int col_xz, int col_yz,
+                            hipStream_t st) {
+    if (R > TP_MAX_R) return 1;
+    if (V <= 0) return 0;
+    const unsigned nb = (unsigned)((V + 255) / 256);
+#define SCR_TP_FWD(RR)                                                                                          \
+    case RR:                                                                                                    \
+        triplane_forward_kernel<RR><<<nb, 256, 0, st>>>(V, coords, cs, xy, xz, yz, X, Y, Z, out, ld, col_xy, col_xz, \
+                                                        col_yz);                                                \
+        break;
+    switch (R) {
+        SCR_TP_FWD(1) SCR_TP_FWD(2) SCR_TP_FWD(3) SCR_TP_FWD(4) SCR_TP_FWD(5) SCR_TP_FWD(6) SCR_TP_FWD(7) SCR_TP_FWD(8)
+    }
+#undef SCR_TP_FWD
+    return 0;
+}
+
 size_t triplane_scratch_bytes(int64_t V, int A, int B) {
     const size_t tiles = (size_t)((A + TP_TILE - 1) / TP_TILE) * ((B + TP_TILE - 1) / TP_TILE);
     return align_up((3 * tiles + 2) * 4) + align_up((size_t)(V > 0 ? V : 1) * 4);
 }
 
-int launch_plane_sample_backward(int64_t V, const float* grid, int R, int A, int B, const float* grad_out,
-                                 float* grad_plane, void* scratch, hipStream_t st) {
+int launch_plane_sample_backward(int64_t V, const float* coords, int cs, int cx, int cy, int R, int A, int B,
+                                 const float* grad_out, int ld, float* grad_plane, void* scratch, hipStream_t st) {
     if (R > TP_MAX_R) return 1;
     const int ta = (A + TP_TILE - 1) / TP_TILE, tb = (B + TP_TILE - 1) / TP_TILE, tiles = ta * tb;
     if ((size_t)tiles * 4 > 64 * 1024) return 2;  // LDS histogram of the tile counts
@@ -196,10 +269,10 @@ int launch_plane_sample_backward(int64_t V, const float* grid, int R, int A, int
     (void)hipMemsetAsync(grad_plane, 0, (size_t)R * A * B * 4, st);
     if (V <= 0) return 0;
     const unsigned nwg = (unsigned)((V + TP_PER_WG - 1) / TP_PER_WG);
-    tp_count_kernel<<<nwg, TP_THREADS, (size_t)tiles * 4, st>>>(V, grid, A, B, tb, tiles, tile_count);
+    tp_count_kernel<<<nwg, TP_THREADS, (size_t)tiles * 4, st>>>(V, coords, cs, cx, cy, A, B, tb, tiles, tile_count);
     tp_scan_kernel<<<1, 1024, 0, st>>>(tiles, tile_count, tile_start, cursor);
-    tp_scatter_kernel<<<nwg, TP_THREADS, (size_t)tiles * 4, st>>>(V, grid, A, B, tb, tiles, tile_start, cursor, perm);
-    tp_accumulate_kernel<<<tiles, 256, 0, st>>>(grid, A, B, tb, R, tile_start, perm, grad_out, grad_plane);
+    tp_scatter_kernel<<<nwg, TP_THREADS, (size_t)tiles * 4, st>>>(V, coords, cs, cx, cy, A, B, tb, tiles, tile_start, cursor, perm);
+    tp_accumulate_kernel<<<tiles, 256, 0, st>>>(coords, cs, cx, cy, A, B, tb, R, tile_start, perm, grad_out, ld, grad_plane);
     return 0;
 }
 

@@ -91,9 +91,6 @@ class TriPlaneAttention(nn.Module):           # scene/grids.py:55-64
 
 def _sample(plane, ind_norm, cols):
     # F.grid_sample bilinear, align_corners=True, zeros padding (scene/grids.py:148-150)
-    if plane.is_cuda and plane.shape[1] <= 8 and not ind_norm.requires_grad and ind_norm.shape[2] >= 65536:
-        from .triplane import plane_sample      # same forward, tile-bucketed LDS backward (csrc/triplane.hip)
-        return plane_sample(plane, ind_norm[0, 0][:, cols])
     return F.grid_sample(plane, ind_norm[:, :, :, cols], mode="bilinear", align_corners=True).flatten(0, 2).T
 
 
@@ -119,6 +116,26 @@ class PlaneGrid(nn.Module):                   # scene/grids.py:102-201
         xyz = xyz.reshape(1, 1, -1, 3)
         ind = (xyz - self.xyz_min) / (self.xyz_max - self.xyz_min) * 2 - 1
         ind = torch.cat([ind, torch.zeros_like(ind[..., [0]])], dim=-1)
+        R = self.channels // 3
+        fused = self.xy_plane.is_cuda and R <= 8 and not ind.requires_grad    # csrc/triplane.hip
+        if fused:
+            from .triplane import triplane_sample
+            ind3 = ind[0, 0, :, :3]
+            if not self.TAflag:
+                feat = triplane_sample(ind3, (self.xy_plane, self.xz_plane, self.yz_plane))
+                if Q != 0:                                          # training-time uniform noise (:159-164)
+                    feat = feat + torch.empty_like(feat).uniform_(-0.5, 0.5) * Q
+                return feat.reshape(*shape, self.channels)
+            tri = self.TA(torch.cat((self.xy_plane, self.xz_plane, self.yz_plane), dim=1))   # every call (:166-168)
+            xyA, xzA, yzA = torch.chunk(tri, 3, dim=1)
+            # column order of :181: xy, xyA, xz, xzA, yz, yzA
+            feat = triplane_sample(ind3, (self.xy_plane, self.xz_plane, self.yz_plane, xyA, xzA, yzA),
+                                   cols=(0, 2 * R, 4 * R, R, 3 * R, 5 * R))
+            if Q != 0:                                              # noise on the plain samples only
+                noise = torch.zeros_like(feat).view(-1, 3, 2, R)
+                noise[:, :, 0].uniform_(-0.5, 0.5)
+                feat = feat + noise.view_as(feat) * Q
+            return feat.reshape(*shape, self.channels * 2)
         xy, xz, yz = _sample(self.xy_plane, ind, [1, 0]), _sample(self.xz_plane, ind, [2, 0]), _sample(self.yz_plane, ind, [2, 1])
         if Q != 0:                                              # training-time uniform noise (:159-164)
             xy = xy + torch.empty_like(xy).uniform_(-0.5, 0.5) * Q
