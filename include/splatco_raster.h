@@ -147,6 +147,8 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
  * three columns; the three planes xy[R,X,Y], xz[R,X,Z], yz[R,Y,Z] are sampled with the coordinate pairs
  * of scene/grids.py:148-150 ((y,x), (z,x), (z,y)) and written to out[v*ld + col_xy/col_xz/col_yz + r], i.e.
  * straight into the concatenated feature matrix the reference builds with torch.cat (:165,:181).
+ * channel_last = 0: planes in the reference's layout [R,A,B]; 1: caller passes [A,B,R] copies (one or two
+ * cache lines per sampled row instead of R; pays off when the planes exceed the L2).
  *
  * scr_plane_sample_backward: given grad_out (row stride ld, R used columns: pass the column-offset
  * pointer) and the columns (cx, cy) of coords that hold (gx, gy), overwrites grad_plane[R,A,B] with
@@ -155,8 +157,8 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
  * scr_plane_sample_scratch_bytes.  The sample positions get no gradient (the reference detaches
  * them, scene/gaussian_model.py:210). */
 int scr_triplane_forward(int64_t V, const float* coords, int32_t cstride, const float* xy, const float* xz,
-                         const float* yz, int32_t R, int32_t X, int32_t Y, int32_t Z, float* out, int32_t ld,
-                         int32_t col_xy, int32_t col_xz, int32_t col_yz, void* stream);
+                         const float* yz, int32_t R, int32_t X, int32_t Y, int32_t Z, int32_t channel_last, float* out,
+                         int32_t ld, int32_t col_xy, int32_t col_xz, int32_t col_yz, void* stream);
 size_t scr_plane_sample_scratch_bytes(int64_t V, int32_t A, int32_t B);
 int scr_plane_sample_backward(int64_t V, const float* coords, int32_t cstride, int32_t cx, int32_t cy, int32_t R,
                               int32_t A, int32_t B, const float* grad_out, int32_t ld, float* grad_plane,

@@ -77,7 +77,7 @@ def _load():
     lib.scr_plane_sample_scratch_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.scr_plane_sample_scratch_bytes.restype = C.c_size_t
     lib.scr_plane_sample_backward.argtypes = [i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
-    lib.scr_triplane_forward.argtypes = [i64, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]
+    lib.scr_triplane_forward.argtypes = [i64, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]
     lib.scr_triplane_forward.restype = C.c_int
     lib.scr_plane_sample_backward.restype = C.c_int
     lib.scr_l1_ssim_scratch_bytes.argtypes = [i32, i32, i32, i32]

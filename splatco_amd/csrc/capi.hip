@@ -308,8 +308,8 @@ int scr_plane_sample_backward(int64_t V, const float* coords, int32_t cstride, i
 }
 
 int scr_triplane_forward(int64_t V, const float* coords, int32_t cstride, const float* xy, const float* xz,
-                         const float* yz, int32_t R, int32_t X, int32_t Y, int32_t Z, float* out, int32_t ld,
-                         int32_t col_xy, int32_t col_xz, int32_t col_yz, void* stream) {
+                         const float* yz, int32_t R, int32_t X, int32_t Y, int32_t Z, int32_t channel_last, float* out,
+                         int32_t ld, int32_t col_xy, int32_t col_xz, int32_t col_yz, void* stream) {
     if (V < 0 || R <= 0 || X <= 1 || Y <= 1 || Z <= 1) return fail("bad sizes");
     if (cstride < 3 || col_xy < 0 || col_xz < 0 || col_yz < 0 || col_xy + R > ld || col_xz + R > ld || col_yz + R > ld)
         return fail("bad strides");
@@ -317,7 +317,7 @@ int scr_triplane_forward(int64_t V, const float* coords, int32_t cstride, const 
     hipStream_t st = (hipStream_t)stream;
     int rc;
     { ProfScope ps_(SCR_PROF_TRIPLANE_FORWARD, st);
-      rc = launch_triplane_forward(V, coords, cstride, xy, xz, yz, R, X, Y, Z, out, ld, col_xy, col_xz, col_yz, st); }
+      rc = launch_triplane_forward(V, coords, cstride, xy, xz, yz, R, X, Y, Z, channel_last, out, ld, col_xy, col_xz, col_yz, st); }
     if (rc == 1) return fail("R = %d channels per plane exceeds the supported 8", R);
     CHECK_LAUNCH("triplane_forward_kernel", 0, st);
     return 0;

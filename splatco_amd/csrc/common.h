@@ -267,7 +267,7 @@ size_t triplane_scratch_bytes(int64_t V, int A, int B);
 int launch_plane_sample_backward(int64_t V, const float* coords, int cs, int cx, int cy, int R, int A, int B,
                                  const float* grad_out, int ld, float* grad_plane, void* scratch, hipStream_t st);
 int launch_triplane_forward(int64_t V, const float* coords, int cs, const float* xy, const float* xz, const float* yz,
-                             int R, int X, int Y, int Z, float* out, int ld, int col_xy, int col_xz, int col_yz,
-                             hipStream_t st);
+                             int R, int X, int Y, int Z, int channel_last, float* out, int ld, int col_xy, int col_xz,
+                             int col_yz, hipStream_t st);
 
 }  // namespace scr

@@ -218,7 +218,36 @@ __device__ __forceinline__ void tp_sample_plane(const float* __restrict__ plane,
         out[r] = ((v0[r].x * w00 + v0[r].y * w01) + v1[r].x * w10) + v1[r].y * w11;
 }
 
+// channel-last planes [A][B][R]: the two x-neighbours of a row are 2*R consecutive floats -> one or two
+// cache lines per row instead of R (random gathers from planes of tens of MB are bound by the number of
+// lines requested from L2 / Infinity Cache, not by bytes)
 template <int R>
+__device__ __forceinline__ void tp_sample_plane_cl(const float* __restrict__ plane, int A, int B, float gx, float gy,
+                                                   float* __restrict__ out) {
+    int a0, b0;
+    float fa, fb;
+    tp_cell(gx, gy, A, B, a0, b0, fa, fb);
+    const bool va0 = a0 >= 0 && a0 < A, va1 = a0 + 1 >= 0 && a0 + 1 < A;
+    const bool vb0 = b0 >= 0 && b0 < B, vb1 = b0 + 1 >= 0 && b0 + 1 < B;
+    const int pb = min(max(b0, 0), B - 2);
+    const float wx0 = vb0 ? 1.0f - fb : 0.0f, wx1 = vb1 ? fb : 0.0f;
+    const float we0 = b0 == pb ? wx0 : (b0 + 1 == pb ? wx1 : 0.0f);
+    const float we1 = b0 == pb + 1 ? wx0 : (b0 + 1 == pb + 1 ? wx1 : 0.0f);
+    const float wy0 = va0 ? 1.0f - fa : 0.0f, wy1 = va1 ? fa : 0.0f;
+    const float w00 = wy0 * we0, w01 = wy0 * we1, w10 = wy1 * we0, w11 = wy1 * we1;
+    const float* p0 = plane + ((size_t)(va0 ? a0 : 0) * B + pb) * R;
+    const float* p1 = plane + ((size_t)(va1 ? a0 + 1 : 0) * B + pb) * R;
+    float v0[2 * R], v1[2 * R];
+#pragma unroll
+    for (int k = 0; k < 2 * R; ++k) {
+        v0[k] = p0[k];
+        v1[k] = p1[k];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[r] = ((v0[r] * w00 + v0[R + r] * w01) + v1[r] * w10) + v1[R + r] * w11;
+}
+
+template <int R, bool CL>
 __global__ void __launch_bounds__(256)
 triplane_forward_kernel(int64_t V, const float* __restrict__ coords, int cs, const float* __restrict__ xy,
                         const float* __restrict__ xz, const float* __restrict__ yz, int X, int Y, int Z,
@@ -228,21 +257,31 @@ triplane_forward_kernel(int64_t V, const float* __restrict__ coords, int cs, con
     const float x = coords[i * cs], y = coords[i * cs + 1], z = coords[i * cs + 2];
     float* o = out + i * ld;
     // coordinate pairs of scene/grids.py:148-150: grid x indexes the LAST plane dimension
-    tp_sample_plane<R>(xy, X, Y, y, x, o + col_xy);  // xy_plane [R,X,Y] at ind[..., [1, 0]]
-    tp_sample_plane<R>(xz, X, Z, z, x, o + col_xz);  // xz_plane [R,X,Z] at ind[..., [2, 0]]
-    tp_sample_plane<R>(yz, Y, Z, z, y, o + col_yz);  // yz_plane [R,Y,Z] at ind[..., [2, 1]]
+    if (CL) {
+        tp_sample_plane_cl<R>(xy, X, Y, y, x, o + col_xy);
+        tp_sample_plane_cl<R>(xz, X, Z, z, x, o + col_xz);
+        tp_sample_plane_cl<R>(yz, Y, Z, z, y, o + col_yz);
+    } else {
+        tp_sample_plane<R>(xy, X, Y, y, x, o + col_xy);  // xy_plane [R,X,Y] at ind[..., [1, 0]]
+        tp_sample_plane<R>(xz, X, Z, z, x, o + col_xz);  // xz_plane [R,X,Z] at ind[..., [2, 0]]
+        tp_sample_plane<R>(yz, Y, Z, z, y, o + col_yz);  // yz_plane [R,Y,Z] at ind[..., [2, 1]]
+    }
 }
 
 int launch_triplane_forward(int64_t V, const float* coords, int cs, const float* xy, const float* xz, const float* yz,
-                            int R, int X, int Y, int Z, float* out, int ld, int col_xy, int col_xz, int col_yz,
-                            hipStream_t st) {
+                            int R, int X, int Y, int Z, int channel_last, float* out, int ld, int col_xy, int col_xz,
+                            int col_yz, hipStream_t st) {
     if (R > TP_MAX_R) return 1;
     if (V <= 0) return 0;
     const unsigned nb = (unsigned)((V + 255) / 256);
 #define SCR_TP_FWD(RR)                                                                                          \
     case RR:                                                                                                    \
-        triplane_forward_kernel<RR><<<nb, 256, 0, st>>>(V, coords, cs, xy, xz, yz, X, Y, Z, out, ld, col_xy, col_xz, \
-                                                        col_yz);                                                \
+        if (channel_last)                                                                                       \
+            triplane_forward_kernel<RR, true><<<nb, 256, 0, st>>>(V, coords, cs, xy, xz, yz, X, Y, Z, out, ld, col_xy,   \
+                                                                  col_xz, col_yz);                               \
+        else                                                                                                    \
+            triplane_forward_kernel<RR, false><<<nb, 256, 0, st>>>(V, coords, cs, xy, xz, yz, X, Y, Z, out, ld, col_xy,  \
+                                                                   col_xz, col_yz);                              \
         break;
     switch (R) {
         SCR_TP_FWD(1) SCR_TP_FWD(2) SCR_TP_FWD(3) SCR_TP_FWD(4) SCR_TP_FWD(5) SCR_TP_FWD(6) SCR_TP_FWD(7) SCR_TP_FWD(8)

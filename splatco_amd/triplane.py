@@ -16,6 +16,7 @@ from .rasterizer import _stream
 
 # (column of ind holding grid-x -> last plane dim, column holding grid-y) for xy / xz / yz (scene/grids.py:148-150)
 _PAIRS = ((1, 0), (2, 0), (2, 1))
+CHANNEL_LAST_MIN_POINTS = 262144
 
 
 class _TriPlaneSample(torch.autograd.Function):
@@ -26,13 +27,17 @@ class _TriPlaneSample(torch.autograd.Function):
         V, R = ind.shape[0], planes[0].shape[1]
         ld = R * len(planes)
         out = torch.empty(V, ld, dtype=torch.float32, device=ind.device)
-        planes = [p.contiguous() for p in planes]
+        # random gathers are bound by the number of cache lines requested: for many points the planes are
+        # first copied to channel-last [A,B,R] (a streaming pass), which cuts the lines per sampled row from R to 1-2
+        cl = 1 if V >= CHANNEL_LAST_MIN_POINTS else 0
         for t in range(0, len(planes), 3):
             xy, xz, yz = planes[t:t + 3]
             X, Y, Z = xy.shape[2], xy.shape[3], xz.shape[3]
             assert xz.shape[2] == X and yz.shape[2] == Y and yz.shape[3] == Z, "plane shapes do not form a tri-plane"
+            xy, xz, yz = ((p.permute(0, 2, 3, 1) if cl else p).contiguous() for p in (xy, xz, yz))
             _C.check(_C.lib.scr_triplane_forward(V, ind.data_ptr(), ind.stride(0), xy.data_ptr(), xz.data_ptr(), yz.data_ptr(),
-                                                 R, X, Y, Z, out.data_ptr(), ld, cols[t], cols[t + 1], cols[t + 2], _stream()))
+                                                 R, X, Y, Z, cl, out.data_ptr(), ld, cols[t], cols[t + 1], cols[t + 2],
+                                                 _stream()))
         ctx.save_for_backward(ind)
         ctx.cols, ctx.shapes = cols, [tuple(p.shape) for p in planes]
         return out

@@ -155,8 +155,9 @@ def test_plane_sample_backward_matches_grid_sample(A, B, R):
     assert torch.isfinite(p1.grad).all()
 
 
+@pytest.mark.parametrize("V", [200_000, 300_000])   # below / above triplane.CHANNEL_LAST_MIN_POINTS (both plane layouts)
 @pytest.mark.parametrize("TA", [False, True])
-def test_triplane_forward_backward_matches_grid_sample(TA):
+def test_triplane_forward_backward_matches_grid_sample(TA, V):
     """csrc/triplane.hip fused three-plane forward (written straight into the concatenated feature
     matrix) and strided LDS backward == the grid_sample / cat formulation of scene/grids.py:146-182,
     for the plain and the attention (TA) grid; PlaneGrid golden fixture on the GPU as well."""
@@ -167,7 +168,6 @@ def test_triplane_forward_backward_matches_grid_sample(TA):
     pg = PlaneGrid(15, ws, [-2.0] * 3, [2.0] * 3, TAflag=TA).to(dev)
     ref = PlaneGrid(15, ws, [-2.0] * 3, [2.0] * 3, TAflag=TA).to(dev)
     ref.load_state_dict(pg.state_dict())
-    V = 200_000
     xyz = torch.rand(V, 3, device=dev) * 4.6 - 2.3             # some anchors leave the [-2,2] box
     xyz[:500] = torch.randint(0, 2, (500, 3), device=dev).float() * 4 - 2   # exact corners / borders
     out = pg(xyz)
