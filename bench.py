@@ -198,6 +198,14 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC-derived bytes per launch, if measured
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(dom)
+        # VALU issue view of the same kernel: wave64 VALU instructions per launch (PMC SQ_INSTS_VALU, if
+        # measured) x 2 issue cycles (SIMD-32) over the SIMD-cycles of its launch at the 2.4 GHz peak clock
+        valu = None
+        vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
+        if os.path.exists(vpath):
+            n_inst = json.load(open(vpath)).get(dom)
+            if n_inst:
+                valu = {"insts_per_launch": n_inst, "issue_frac": n_inst * 2.0 / (256 * 4 * 2.4e9 * kern[dom] * 1e-3)}
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": METRIC, "value": world * P / (elapsed / args.steps) / 1e6, "unit": "Msplats/s",
@@ -212,7 +220,7 @@ def main():
                            f", RCCL all-reduce(SUM) of {P}x14 fp32 per-Gaussian grads per step" if world > 1 else "")},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ab, "avg_launch_ms": kern[dom],
+                         "algorithmic_bytes_per_launch": ab, "avg_launch_ms": kern[dom], "valu": valu,
                          "note": "blend kernels are FP32-VALU/exp-issue bound at this density (SURVEY.md 8d); "
                                  "the HBM fraction is reported as the contract asks"},
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])},

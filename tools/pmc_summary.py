@@ -44,7 +44,14 @@ def main(out_txt, out_json, dirs):
                 line += f" FETCH_SIZE {c['FETCH_SIZE']:10.0f} KB  WRITE_SIZE {c['WRITE_SIZE']:10.0f} KB  -> traffic {t / 1e6:8.1f} MB/launch"
             rest = "  ".join(f"{n}={v:.3g}" for n, v in sorted(c.items()) if n not in ("FETCH_SIZE", "WRITE_SIZE"))
             f.write(line + ("  " + rest if rest else "") + "\n")
+    insts = {}
+    for k in acc:
+        if "SQ_INSTS_VALU" in acc[k]:
+            key = "tile_sort_kernel" if k.startswith("tile_sort") or k.startswith("tile_merge") else k
+            insts[key] = insts.get(key, 0) + int(acc[k]["SQ_INSTS_VALU"][0] / acc[k]["SQ_INSTS_VALU"][1])
     json.dump(traffic, open(out_json, "w"), indent=1, sort_keys=True)
+    if insts:
+        json.dump(insts, open(out_json.replace("hbm_traffic", "valu_insts"), "w"), indent=1, sort_keys=True)
     print(open(out_txt).read())
 
 
