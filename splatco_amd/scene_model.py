@@ -214,10 +214,14 @@ class AnchorGaussianModel(nn.Module):
         self._anchor_feat = nn.Parameter(torch.empty(0, feat_dim))
         self._scaling = nn.Parameter(torch.empty(0, 6))
         self._rotation = nn.Parameter(torch.empty(0, 4), requires_grad=False)   # requires_grad False in the reference
+        self._opacity = nn.Parameter(torch.empty(0, 1), requires_grad=False)    # carried, never read by render()
         self.rotation_activation = F.normalize
 
-    def set_anchors(self, anchor, offset, anchor_feat, scaling, rotation=None):
+    def set_anchors(self, anchor, offset, anchor_feat, scaling, rotation=None, opacity=None):
         N = anchor.shape[0]
+        if opacity is None:                                  # inverse_sigmoid(0.1), scene/gaussian_model.py:493
+            opacity = torch.full((N, 1), -2.1972246, device=anchor.device)
+        self._opacity = nn.Parameter(opacity.float(), requires_grad=False)
         self._anchor = nn.Parameter(anchor.float())
         self._offset = nn.Parameter(offset.float())
         self._anchor_feat = nn.Parameter(anchor_feat.float())

@@ -18,6 +18,8 @@ Fixtures (all float32 / int, a few hundred KB in total):
                  appearance_dim=0, Q0=0, train and eval variants, activate_level 0 and 2
                  (gaussian_renderer/__init__.py:18-116) + every state_dict it needs
   training_statis.npz  GaussianModel.training_statis on small seeded masks (scene/gaussian_model.py:761-782)
+  densify.npz    GaussianModel.adjust_anchor (anchor_growing + prune_anchor, optimizer state surgery) and
+                 compute_curvature on small seeded models (scene/gaussian_model.py:784-997,1092-1110)
 """
 import argparse
 import importlib.util
@@ -220,6 +222,81 @@ def make_neural_gaussians():
                         offset_gradient_accum=f32(pc.offset_gradient_accum), offset_denom=f32(pc.offset_denom))
 
 
+def make_densify():
+    """GaussianModel.adjust_anchor / anchor_growing / prune_anchor / compute_curvature
+    (scene/gaussian_model.py:784-997,1092-1110) on a small seeded model, CPU.  The reference hard-codes
+    device='cuda' in torch.zeros / torch.ones calls and takes scatter_max from torch_scatter: both are
+    patched (device kwarg dropped; scatter_max restated with scatter_reduce amax)."""
+    import scene.gaussian_model as gm
+
+    def drop_cuda(fn):
+        def wrapped(*a, **k):
+            if str(k.get("device", "")).startswith("cuda"):
+                k.pop("device")
+            return fn(*a, **k)
+        return wrapped
+
+    torch.zeros, torch.ones = drop_cuda(torch.zeros), drop_cuda(torch.ones)
+
+    def scatter_max(src, index, dim=0):
+        out = torch.zeros(int(index.max()) + 1, src.shape[1], dtype=src.dtype)
+        out = out.scatter_reduce(0, index, src, "amax", include_self=False)
+        return out, None
+
+    gm.scatter_max = scatter_max
+    out = {}
+    for case, (iteration, N) in enumerate(((1700, 60), (1600, 48))):
+        k, F_ = 4, 8
+        pc = gm.GaussianModel.__new__(gm.GaussianModel)
+        torch.nn.Module.__init__(pc) if isinstance(pc, torch.nn.Module) else None
+        pc.n_offsets, pc.feat_dim, pc.voxel_size = k, F_, 0.01
+        pc.update_depth, pc.update_init_factor, pc.update_hierachy_factor = 3, 16, 4
+        pc.scaling_activation = torch.exp
+        g = torch.Generator().manual_seed(11 + case)
+        anchor = torch.round((torch.rand(N, 3, generator=g) * 2 - 1) / 0.16) * 0.16      # on the coarsest grid
+        params = {"anchor": anchor, "offset": torch.randn(N, k, 3, generator=g) * 0.5,
+                  "anchor_feat": torch.randn(N, F_, generator=g), "opacity": torch.full((N, 1), -2.1972246),
+                  "scaling": torch.randn(N, 6, generator=g) * 0.5 - 2.0, "rotation": torch.randn(N, 4, generator=g)}
+        for name, v in params.items():
+            setattr(pc, "_" + name, torch.nn.Parameter(v.clone()))
+        groups = [{"params": [getattr(pc, "_" + name)], "lr": 1e-3, "name": name} for name in params]
+        pc.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        # one optimizer step so that exp_avg / exp_avg_sq exist (except for "rotation": state-less branch)
+        for name in params:
+            if name != "rotation":
+                getattr(pc, "_" + name).grad = torch.randn(getattr(pc, "_" + name).shape, generator=g)
+        pc.optimizer.step()
+        pc.offset_gradient_accum = torch.rand(N * k, 1, generator=g) * 0.05
+        pc.offset_denom = torch.randint(0, 90, (N * k, 1), generator=g).float()
+        pc.opacity_accum = torch.rand(N, 1, generator=g) * 2.0
+        pc.anchor_demon = torch.randint(60, 120, (N, 1), generator=g).float()
+        pre = f"c{case}."
+        out[pre + "iteration"], out[pre + "n_offsets"] = np.int64(iteration), np.int64(k)
+        for name in params:
+            out[pre + "in." + name] = f32(getattr(pc, "_" + name))
+            st = pc.optimizer.state.get(getattr(pc, "_" + name), None)
+            if st is not None:
+                out[pre + "in.exp_avg." + name], out[pre + "in.exp_avg_sq." + name] = f32(st["exp_avg"]), f32(st["exp_avg_sq"])
+        for name in ("offset_gradient_accum", "offset_denom", "opacity_accum", "anchor_demon"):
+            out[pre + "in." + name] = f32(getattr(pc, name))
+        torch.manual_seed(100 + case)                     # the random pick of anchor_growing (:844)
+        out[pre + "seed"] = np.int64(100 + case)
+        if iteration == 1600:
+            out[pre + "curvature"] = f32(pc.compute_curvature(pc.get_anchor))
+        with torch.no_grad():                             # train.py:243 runs the densification block under no_grad
+            pc.adjust_anchor(iteration=iteration, check_interval=100, success_threshold=0.8, grad_threshold=0.0002,
+                             min_opacity=0.005)
+        for name in params:
+            out[pre + "out." + name] = f32(getattr(pc, "_" + name))
+            st = pc.optimizer.state.get(getattr(pc, "_" + name), None)
+            if st is not None:
+                out[pre + "out.exp_avg." + name], out[pre + "out.exp_avg_sq." + name] = f32(st["exp_avg"]), f32(st["exp_avg_sq"])
+        for name in ("offset_gradient_accum", "offset_denom", "opacity_accum", "anchor_demon", "max_radii2D"):
+            out[pre + "out." + name] = f32(getattr(pc, name))
+        print("densify case", case, "anchors", N, "->", pc._anchor.shape[0])
+    np.savez_compressed(os.path.join(OUT, "densify.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
@@ -227,5 +304,6 @@ if __name__ == "__main__":
     make_losses()
     make_planegrid()
     make_neural_gaussians()
+    make_densify()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
