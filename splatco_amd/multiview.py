@@ -65,18 +65,88 @@ def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = N
     return bucket
 
 
+def align_images(*imgs):                                        # train.py:79-96
+    h, w = min(i.shape[1] for i in imgs), min(i.shape[2] for i in imgs)
+    return tuple(i[:, :h, :w] for i in imgs)
+
+
+def pair_consistency(gen1, real1, gen2, real2):
+    """Cross-view consistency term of one view pair (train.py:208-217):
+    ssim(real1, real2) * |mean |(real1 - real2) - (gen1 - gen2)||  if the two ground-truth views are alike
+    (SSIM > 0.6), else 0."""
+    from .losses import l1_loss, ssim
+    gen1, gen2, real1, real2 = align_images(gen1, gen2, real1, real2)
+    s = ssim(real1, real2)
+    if not bool(s > 0.6):
+        return None
+    return s * torch.abs(l1_loss(real1 - real2, gen1 - gen2))
+
+
+def consistency_loss(local: Sequence, weight: float = 0.05):
+    """Sum over ALL view pairs of pair_consistency, times `weight` (train.py:201-239), in the sharded
+    setting: `local` = [(global view index, rendered image, gt image), ...] of this rank.  The rendered
+    and ground-truth images of the other ranks are all-gathered as constants; a pair with one remote
+    view is evaluated on both owning ranks, each differentiating its own image only, so the gradients
+    summed over ranks equal those of the single-process pairwise sum.  Returns (term to add to this
+    rank's loss before backward, this rank's share of the loss VALUE -- cross-rank pairs count half)."""
+    rank, world = world_info()
+    items = [(int(i), g, r, True) for i, g, r in local]
+    if world > 1:
+        mine = [(int(i), g.detach(), r.detach()) for i, g, r in local]
+        everyone = [None] * world
+        dist.all_gather_object(everyone, [(i, tuple(g.shape)) for i, g, _ in mine])
+        for src in range(world):
+            for i, shape in everyone[src]:
+                if src == rank:
+                    g, r = next((g, r) for j, g, r in mine if j == i)
+                    pair = torch.stack([g, r]).contiguous()
+                else:
+                    pair = torch.empty((2,) + shape, dtype=local[0][1].dtype if local else torch.float32,
+                                       device=local[0][1].device if local else None)
+                dist.broadcast(pair, src=src)
+                if src != rank:
+                    items.append((i, pair[0], pair[1], False))
+    items.sort(key=lambda t: t[0])
+    grad_term, value = None, 0.0
+    for a in range(len(items)):
+        for b in range(a + 1, len(items)):
+            (_, g1, r1, own1), (_, g2, r2, own2) = items[a], items[b]
+            if not (own1 or own2):
+                continue
+            t = pair_consistency(g1, r1, g2, r2)
+            if t is None:
+                continue
+            grad_term = t if grad_term is None else grad_term + t
+            value = value + t.detach() * (1.0 if (own1 and own2) else 0.5)
+    if grad_term is None:
+        return None, value
+    return weight * grad_term, weight * value
+
+
 def multiview_step(views: Sequence, params: Sequence[torch.Tensor],
-                   render_loss: Callable[[object], torch.Tensor], bucket: torch.Tensor = None):
+                   render_loss: Callable[[object], torch.Tensor], bucket: torch.Tensor = None,
+                   consistency_weight: float = 0.0):
     """One collaborative step: this rank renders its shard of `views`, sums the per-view losses,
     runs ONE backward (as train.py:240 does) and all-reduces the gradients.  After the call every
     rank holds d(sum over ALL views of loss)/d(params) -- identical to the sequential mv loop.
-    Returns (local loss sum, bucket)."""
+    With consistency_weight > 0 (train.py: 0.05 for update_from < iteration < update_until)
+    `render_loss(view)` must return (loss, rendered image, gt image) and the pairwise cross-view term is
+    added (see consistency_loss).  Returns (local loss sum, bucket)."""
     for p in params:
         p.grad = None
     total = None
-    for v in shard_views(views):
+    rank, world = world_info()
+    rendered = []
+    for k, v in enumerate(shard_views(views)):
         loss = render_loss(v)
+        if consistency_weight:
+            loss, img, gt = loss
+            rendered.append((rank + k * world, img, gt))
         total = loss if total is None else total + loss
+    if consistency_weight:
+        term, _ = consistency_loss(rendered, consistency_weight)
+        if term is not None:
+            total = term if total is None else total + term
     if total is not None:
         total.backward()
     bucket = allreduce_gradients(params, bucket)

@@ -86,6 +86,30 @@ for a, p in zip(sharded, params):
     assert torch.allclose(a, p.grad, rtol=1e-10, atol=1e-12), (rank, (a - p.grad).abs().max())
 tl = loss.clone(); dist.all_reduce(tl)
 assert torch.allclose(tl, total.detach(), rtol=1e-12)
+# ---- with the cross-view consistency term (train.py:201-239): views alike enough for SSIM > 0.6
+from splatco_amd.multiview import pair_consistency
+gts = [(target + 0.02 * i).clamp(0, 1) for i in range(4)]
+def render_loss3(cam):
+    m, o, s, r, c = params
+    img, _, _ = torch_ref.rasterize(24, 32, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.tensor(g["bg"]),
+                                    1.0, cam.world_view_transform, cam.full_proj_transform, 1, cam.camera_center,
+                                    m, o, s, r, None, None, c)
+    return (img - gts[cam.uid]).abs().mean(), img, gts[cam.uid]
+multiview_step(views, params, render_loss3, consistency_weight=0.05)
+sharded = [p.grad.clone() for p in params]
+for p in params: p.grad = None
+outs = [render_loss3(v) for v in views]
+total = sum(o[0] for o in outs)
+npairs = 0
+for i in range(4):
+    for j in range(i + 1, 4):
+        t_ = pair_consistency(outs[i][1], outs[i][2], outs[j][1], outs[j][2])
+        if t_ is not None:
+            total = total + 0.05 * t_; npairs += 1
+assert npairs == 6
+total.backward()
+for a, p in zip(sharded, params):
+    assert torch.allclose(a, p.grad, rtol=1e-9, atol=1e-12), (rank, (a - p.grad).abs().max())
 # a rank with no gradient for a parameter still takes part
 extra = torch.zeros(5, dtype=torch.float64, requires_grad=True)
 if rank == 0: extra.grad = torch.ones(5, dtype=torch.float64)
