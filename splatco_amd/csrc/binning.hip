@@ -451,6 +451,12 @@ void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const Bi
     if (P <= 0) return;
     Grid g(ks.H, ks.W);
     const unsigned nb = (unsigned)((P + BIN_GPW - 1) / BIN_GPW);
+    static bool big_lds = false;
+    if (!big_lds) {  // histograms beyond the default 64 KB dynamic-LDS limit (gfx950 has 160 KB per CU)
+        (void)hipFuncSetAttribute((const void*)scatter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_HIST_MAX_TILES * 4);
+        big_lds = true;
+    }
     if (g.tiles <= LDS_HIST_MAX_TILES)
         scatter_kernel<true><<<nb, BIN_THREADS, (size_t)g.tiles * 4, st>>>(
             P, g.gx, g.tiles, gv.rec, gv.gm_base, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor,

@@ -16,7 +16,10 @@ constexpr int PRE_BLOCK = 256;          // Gaussians per preprocess-backward wor
 constexpr int BIN_THREADS = 1024;       // threads of a preprocess / scatter workgroup
 constexpr int BIN_ROUNDS = 4;           // Gaussians per thread
 constexpr int BIN_GPW = BIN_THREADS * BIN_ROUNDS;  // Gaussians per preprocess / scatter workgroup
-constexpr int LDS_HIST_MAX_TILES = 16000;          // per-tile LDS histogram (4 B / tile) must fit 64 KB
+#ifndef SCR_LDS_HIST_MAX_TILES
+#define SCR_LDS_HIST_MAX_TILES 40000
+#endif
+constexpr int LDS_HIST_MAX_TILES = SCR_LDS_HIST_MAX_TILES;  // per-tile LDS histogram (4 B / tile) in the CU's 160 KB of LDS (4K images: 32400 tiles)
 constexpr int ID_BITS = 28;             // sort key = depth:32 | id:28 | quadrant mask:4  ->  P < 2^28
 constexpr int REC_F = 12;               // floats per splat record (48 B, three float4)
 constexpr int GRAD_F = 12;              // floats per per-instance gradient record (9 used)

@@ -547,6 +547,12 @@ void launch_preprocess(int64_t P, int M, const float* means3D, const float* scal
                        const KSettings& ks, const GeomView& gv, int32_t* radii, hipStream_t st) {
     if (P <= 0) return;
     Grid g(ks.H, ks.W);
+    static bool big_lds = false;
+    if (!big_lds) {  // histograms beyond the default 64 KB dynamic-LDS limit (gfx950 has 160 KB per CU)
+        (void)hipFuncSetAttribute((const void*)preprocess_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_HIST_MAX_TILES * 4);
+        big_lds = true;
+    }
     if (g.tiles <= LDS_HIST_MAX_TILES)
         preprocess_kernel<true><<<nblk(P, BIN_GPW), BIN_THREADS, (size_t)g.tiles * 4, st>>>(
             P, M, means3D, scales, rotations, cov3D, opacities, shs, colors, ks, g.tiles, gv.rec, gv.tiles_touched,

@@ -132,14 +132,17 @@ def test_visible_filter_bit_exact(oracle):
         assert np.array_equal(vis.cpu().numpy(), oracle.mark_visible(st, g["means3D"]))
 
 
-@pytest.mark.parametrize("scene", ["small_offaxis", "cfg0_10k_400x400", "ragged_130x70", "many_tiles_2064x2050"])
+@pytest.mark.parametrize("scene", ["small_offaxis", "cfg0_10k_400x400", "ragged_130x70", "many_tiles_2064x2050",
+                                   "huge_tiles_3360x3104"])
 def test_forward_backward_colors_path(oracle, scene):
     if scene == "small_offaxis":
         cam, g = small_scene(P=400, W=96, H=64, spread=1.5)
     elif scene == "cfg0_10k_400x400":
         cam, g = synthetic_camera(400, 400), synthetic_gaussians(10_000, 400, 400, 0)
-    elif scene == "many_tiles_2064x2050":  # > 16000 tiles: the global-atomic counting fallback
+    elif scene == "many_tiles_2064x2050":  # 16641 tiles: per-tile LDS histogram beyond the default 64 KB of dynamic LDS
         cam, g = synthetic_camera(2064, 2050), synthetic_gaussians(20_000, 2064, 2050, 9)
+    elif scene == "huge_tiles_3360x3104":  # 40740 tiles > LDS_HIST_MAX_TILES: the global-atomic counting fallback
+        cam, g = synthetic_camera(3360, 3104), synthetic_gaussians(20_000, 3360, 3104, 10)
     else:  # image size not a multiple of the tile size
         cam, g = synthetic_camera(130, 70), synthetic_gaussians(1500, 130, 70, 4)
     st = oracle_settings(oracle, cam, g["bg"])
