@@ -32,6 +32,25 @@ def shard_views(views: Sequence, rank: int = None, world: int = None) -> List:
     return list(views[rank::world])
 
 
+def _shared_arena(params):
+    """If every parameter has a contiguous gradient and the gradients tile one gap-free range of one
+    storage (the rasterizer's backward allocates them that way), return that range as a flat tensor."""
+    grads = [p.grad for p in params]
+    if any(g is None or not g.is_contiguous() or g.dtype != grads[0].dtype for g in grads):
+        return None
+    st = grads[0].untyped_storage()
+    if any(g.untyped_storage().data_ptr() != st.data_ptr() for g in grads):
+        return None
+    order = sorted(grads, key=lambda g: g.storage_offset())
+    pos = order[0].storage_offset()
+    for g in order:
+        if g.storage_offset() != pos:
+            return None
+        pos += g.numel()
+    start = order[0].storage_offset()
+    return torch.empty(0, dtype=grads[0].dtype, device=grads[0].device).set_(st, start, (pos - start,))
+
+
 def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = None) -> torch.Tensor:
     """SUM-all-reduce the .grad of every tensor in `params` through one flat bucket, in place.
     Parameters without a gradient on this rank contribute zeros (a rank whose views do not see
@@ -39,6 +58,11 @@ def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = N
     params = [p for p in params if p is not None and p.requires_grad]
     if not params:
         return bucket
+    arena = _shared_arena(params)
+    if arena is not None:      # the gradients already sit side by side in one buffer: reduce it in place
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(arena, op=dist.ReduceOp.SUM)
+        return arena
     n = sum(p.numel() for p in params)
     dev, dt = params[0].device, params[0].dtype
     if bucket is None or bucket.numel() != n or bucket.device != dev:

@@ -158,13 +158,20 @@ class _RasterizeGaussians(torch.autograd.Function):
         means3D, scales, rotations, cov3D, sh, colors, opacities = ctx.saved_tensors
         dev, P, cs = means3D.device, st.P, st.cs
         g = _dev_f32(grad_out_color, "grad_out_color")
-        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
-        g_means3D, g_means2D, g_op = new(P, 3), new(P, 3), new(P, 1)
-        g_col = new(P, 3) if colors is not None else None
-        g_sh = new(P, st.M, 3) if sh is not None else None
-        g_scales = new(P, 3) if cov3D is None else None
-        g_rot = new(P, 4) if cov3D is None else None
-        g_cov = new(P, 6) if cov3D is not None else None
+        # All per-Gaussian gradients are carved from ONE arena, parameter gradients first and adjacent
+        # (means2D, a per-view statistic, last): when the operator's inputs are leaves their .grad tensors
+        # alias the arena, and multiview.allreduce_gradients reduces it in place without packing copies.
+        widths = [3, 3 if colors is not None else 0, 3 * st.M if sh is not None else 0, 1,
+                  3 if cov3D is None else 0, 4 if cov3D is None else 0, 6 if cov3D is not None else 0, 3]
+        arena = torch.empty(P * sum(widths), dtype=torch.float32, device=dev)
+        parts, off = [], 0
+        for w in widths:
+            parts.append(arena[off:off + P * w].view(P, w) if w else None)
+            off += P * w
+        g_means3D, g_col, g_sh, g_op, g_scales, g_rot, g_cov, g_means2D = parts
+        if g_sh is not None:
+            g_sh = g_sh.view(P, st.M, 3)
+        del arena, parts
         scratch = _bytes(_C.lib.scr_backward_scratch_bytes(st.I), dev)
         _C.check(_C.lib.scr_backward(P, st.M, st.I, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D),
                                      _ptr(sh), cs.ref(), st.radii.data_ptr(), st.geom.data_ptr(),

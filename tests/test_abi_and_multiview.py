@@ -116,6 +116,17 @@ if rank == 0: extra.grad = torch.ones(5, dtype=torch.float64)
 from splatco_amd.multiview import allreduce_gradients
 allreduce_gradients([extra])
 assert torch.equal(extra.grad, torch.ones(5, dtype=torch.float64))
+# gradients that already tile one buffer (the rasterizer's backward arena) are reduced in place, no packing
+arena = torch.arange(12, dtype=torch.float64) * (rank + 1)
+a_, b_, c_ = (torch.zeros(n, dtype=torch.float64, requires_grad=True) for n in (5, 3, 4))
+b_.grad, a_.grad, c_.grad = arena[0:3], arena[3:8], arena[8:12]          # adjacent, not in parameter order
+ptr = a_.grad.data_ptr()
+out = allreduce_gradients([a_, b_, c_])
+assert out.data_ptr() == arena.data_ptr() and out.numel() == 12 and a_.grad.data_ptr() == ptr
+assert torch.equal(arena, torch.arange(12, dtype=torch.float64) * 3)
+c_.grad = torch.ones(4, dtype=torch.float64)                               # a stranger breaks the tiling: packed path
+allreduce_gradients([a_, b_, c_])
+assert torch.equal(c_.grad, torch.full((4,), 2.0, dtype=torch.float64)) and torch.equal(a_.grad, torch.arange(3, 8, dtype=torch.float64) * 6)
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''

@@ -245,3 +245,27 @@ def test_collaborative_step_runs_and_updates_parameters():
     assert torch.isfinite(loss) and out["render"].shape == (3, 96, 160)
     assert not torch.equal(before, pc._anchor_feat.detach())
     assert out["viewspace_points"].grad is not None
+
+
+def test_backward_gradients_share_one_arena():
+    """The operator's backward carves all per-Gaussian gradients from one buffer with the parameter
+    gradients adjacent, so the sharded mv step all-reduces them in place (multiview._shared_arena)."""
+    from splatco_amd import rasterizer as R
+    from splatco_amd.multiview import _shared_arena, allreduce_gradients
+    from splatco_amd.synthetic import synthetic_camera, synthetic_gaussians
+    dev = torch.device("cuda:0")
+    cam, g = synthetic_camera(160, 96), synthetic_gaussians(3000, 160, 96, 2)
+    rs = R.GaussianRasterizationSettings(96, 160, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.tensor(g["bg"], device=dev),
+                                         1.0, cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), 1,
+                                         cam.camera_center.to(dev), False, False)
+    t = lambda a: torch.tensor(a, device=dev, requires_grad=True)
+    m, o, s, r, c = t(g["means3D"]), t(g["opacities"]), t(g["scales"]), t(g["rotations"]), t(g["colors"])
+    m2d = torch.zeros(3000, 3, device=dev, requires_grad=True)
+    img, _ = R.GaussianRasterizer(rs)(means3D=m, means2D=m2d, opacities=o, colors_precomp=c, scales=s, rotations=r)
+    img.square().sum().backward()
+    arena = _shared_arena([m, o, s, r, c])
+    assert arena is not None and arena.numel() == 3000 * 14
+    before = [p.grad.clone() for p in (m, o, s, r, c)]
+    assert allreduce_gradients([m, o, s, r, c]).data_ptr() == arena.data_ptr()     # world size 1: nothing moves
+    assert all(torch.equal(a, p.grad) for a, p in zip(before, (m, o, s, r, c)))
+    assert m2d.grad is not None and m2d.grad.shape == (3000, 3)
