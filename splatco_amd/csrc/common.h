@@ -13,8 +13,14 @@ constexpr int TILE_PIX = TILE * TILE;   // 256
 constexpr int WAVE = 64;                // CDNA wavefront
 constexpr int NUM_XCD = 8;
 constexpr int PRE_BLOCK = 256;          // Gaussians per preprocess-backward workgroup
-constexpr int BIN_THREADS = 1024;       // threads of a preprocess / scatter workgroup
-constexpr int BIN_ROUNDS = 4;           // Gaussians per thread
+#ifndef SCR_BIN_THREADS
+#define SCR_BIN_THREADS 1024
+#endif
+#ifndef SCR_BIN_ROUNDS
+#define SCR_BIN_ROUNDS 4
+#endif
+constexpr int BIN_THREADS = SCR_BIN_THREADS;  // threads of a preprocess / scatter workgroup
+constexpr int BIN_ROUNDS = SCR_BIN_ROUNDS;    // Gaussians per thread
 constexpr int BIN_GPW = BIN_THREADS * BIN_ROUNDS;  // Gaussians per preprocess / scatter workgroup
 #ifndef SCR_LDS_HIST_MAX_TILES
 #define SCR_LDS_HIST_MAX_TILES 40000

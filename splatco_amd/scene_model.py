@@ -13,6 +13,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+FUSE_NORM_LINEAR = True      # FeaturePlanes: fold the train-mode BatchNorms into their Linears (see _NormLinearFn)
+
 
 class _TallLinearFn(torch.autograd.Function):
     """y = x W^T + b for x with millions of rows and a few dozen columns (one row per anchor).
@@ -51,6 +53,106 @@ class TallLinear(nn.Linear):
         if x.dim() == 2 and x.shape[0] >= 4 * _TallLinearFn.SLAB and x.is_cuda:
             return _TallLinearFn.apply(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)
+
+
+def _tall_contract(a, b):
+    """a^T b for two matrices with millions of rows (slab-split, fixed summation order; see _TallLinearFn)."""
+    M, c = a.shape[0], _TallLinearFn.SLAB
+    S = M // c
+    out = a[S * c:].t() @ b[S * c:]
+    if S:
+        out = out + torch.bmm(a[:S * c].view(S, c, -1).transpose(1, 2), b[:S * c].view(S, c, -1)).sum(0)
+    return out
+
+
+def _col_var_mean(x):
+    """Biased variance and mean of every column of a tall matrix, two-level (per 2048-row slab, then Chan's
+    combination).  torch.var_mean(x, dim=0) on ROCm takes 150 ms for [4.6 M, 71] fp32 (0.5 ms for 60 columns)
+    and loses 3 digits; this is 0.45 ms for either width (tools/exp/colstats_probe.py)."""
+    V, d = x.shape
+    c = _TallLinearFn.SLAB
+    S = V // c
+    if S == 0:
+        return torch.var_mean(x, dim=0, unbiased=False)
+    v_s, m_s = torch.var_mean(x[:S * c].view(S, c, d), dim=1, unbiased=False)
+    r = V - S * c
+    tot = m_s.sum(0) * c
+    if r:
+        v_r, m_r = torch.var_mean(x[S * c:], dim=0, unbiased=False)
+        tot = tot + m_r * r
+    mean = tot / V
+    acc = c * (v_s + (m_s - mean) ** 2).sum(0)
+    if r:
+        acc = acc + r * (v_r + (m_r - mean) ** 2)
+    return acc / V, mean
+
+
+class _NormLinearFn(torch.autograd.Function):
+    """y = xhat G^T + c with xhat = (x - mean(x)) / sqrt(var(x) + eps), the batch statistics taken over
+    the rows (BatchNorm1d in training mode without its affine part, folded into G and c by the caller).
+
+    Train-mode BatchNorm followed by Linear is linear in xhat, so the normalised copy of x is never
+    materialised: forward = one statistics pass + ONE GEMM with column-scaled weights; backward =
+    one tall contraction dy^T x (from which the weight gradient AND both BatchNorm reduction terms
+    follow on 32 x d matrices), one GEMM dy G' and one fused multiply-add pass.  x has one row per
+    anchor (millions) and d <= 131 columns, so every saved pass over [V, d] counts.
+    Also returns (mean, biased var) for the running-statistics update."""
+
+    @staticmethod
+    def forward(ctx, x, G, c, eps):
+        var, mean = _col_var_mean(x)
+        inv = torch.rsqrt(var + eps)
+        Gs = G * inv                                   # scale columns
+        y = torch.addmm(c - Gs @ mean, x, Gs.t())
+        ctx.save_for_backward(x, G, mean, inv)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, G, mean, inv = ctx.saved_tensors
+        V = x.shape[0]
+        dy = dy.contiguous()
+        sdy = dy.sum(0)
+        H = (_tall_contract(dy, x) - sdy[:, None] * mean) * inv            # dy^T xhat            [out, d]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            u = G.t() @ sdy                                                  # sum_v dxhat          [d]
+            w = (G * H).sum(0)                                               # sum_v dxhat * xhat   [d]
+            k1 = -(inv * inv) * w / V
+            k0 = -inv * u / V - mean * k1
+            dx = torch.addmm(k0, dy, G * inv)
+            dx.addcmul_(x, k1)
+        return dx, H, sdy, None
+
+
+def _norm_linear(x, bns, linears):
+    """sum_i Linear_i(BatchNorm_i(x_i)) where x = cat_i(x_i) column-wise (bns[i] normalises its own column
+    block; pass the same block twice -- offsets repeat -- is not supported) OR every BatchNorm_i sees the
+    whole x (len(bns) == len(linears), all of width x.shape[1]).  Updates the running statistics as
+    nn.BatchNorm1d.forward does in training mode."""
+    d = x.shape[1]
+    shared = all(bn.num_features == d for bn in bns)
+    if shared:      # same input through every pair: the folded weights simply add up
+        G = sum(lin.weight * bn.weight for bn, lin in zip(bns, linears))
+        c = sum(lin.weight @ bn.bias + lin.bias for bn, lin in zip(bns, linears))
+    else:
+        assert sum(bn.num_features for bn in bns) == d
+        G = torch.cat([lin.weight * bn.weight for bn, lin in zip(bns, linears)], dim=1)
+        c = sum(lin.weight @ bn.bias + lin.bias for bn, lin in zip(bns, linears))
+    assert all(bn.eps == bns[0].eps for bn in bns)
+    y, mean, var = _NormLinearFn.apply(x, G, c, bns[0].eps)
+    with torch.no_grad():
+        n, off = x.shape[0], 0
+        for bn in bns:
+            m, v = (mean, var) if shared else (mean[off:off + bn.num_features], var[off:off + bn.num_features])
+            off += 0 if shared else bn.num_features
+            if bn.track_running_stats and bn.training:
+                bn.num_batches_tracked += 1
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - mom).add_(m, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(v * (n / max(n - 1, 1)), alpha=mom)
+    return y
 
 
 class ChannelAttention(nn.Module):            # scene/grids.py:22-36
@@ -167,6 +269,13 @@ class FeaturePlanes(nn.Module):               # scene/gaussian_model.py:97-169
             self.CTX_models.append(nn.Sequential(nn.BatchNorm1d(71), TallLinear(71, out_dim)))
 
     def forward(self, x, g_fea, Q=0):
+        L = self.activate_level + 1
+        if FUSE_NORM_LINEAR and all(m[0].training for m in list(self.models[:L]) + list(self.CTX_models[:L])):
+            # sum_i cat(Linear(BN(feat_i)), Linear(BN(g_fea))) is linear in the normalised inputs: two GEMMs
+            feats = torch.cat([self.k0s[i](x, Q) for i in range(L)], dim=1) if L > 1 else self.k0s[0](x, Q)
+            a = _norm_linear(feats, [self.models[i][0] for i in range(L)], [self.models[i][1] for i in range(L)])
+            b = _norm_linear(g_fea, [self.CTX_models[i][0] for i in range(L)], [self.CTX_models[i][1] for i in range(L)])
+            return torch.cat((a, b), dim=1)
         res = []
         for i in range(self.activate_level + 1):
             feat = self.k0s[i](x, Q)

@@ -109,3 +109,41 @@ def test_training_statis():
                           torch.tensor(d["anchor_visible_mask"]))
     for got, name in zip(out, ["opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"]):
         np.testing.assert_allclose(got.numpy(), d[name], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("level", [0, 2])
+def test_fused_norm_linear_matches_batchnorm_linear_chain(level):
+    """FeaturePlanes with the train-mode BatchNorms folded into their Linears (_NormLinearFn: no normalised
+    copy, analytic backward) == the module-by-module chain of scene/gaussian_model.py:149-169: outputs,
+    every parameter gradient, the input gradient and the running statistics, in float64."""
+    import splatco_amd.scene_model as sm
+    torch.manual_seed(level)
+    a = sm.FeaturePlanes([16, 16, 16], torch.tensor([-2.0] * 3), torch.tensor([2.0] * 3), feat_dim=15).double()
+    b = sm.FeaturePlanes([16, 16, 16], torch.tensor([-2.0] * 3), torch.tensor([2.0] * 3), feat_dim=15).double()
+    with torch.no_grad():
+        for p in a.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    b.load_state_dict(a.state_dict())
+    a.activate_level = b.activate_level = level
+    x = torch.rand(5000, 3, dtype=torch.float64) * 3.6 - 1.8
+    g1 = torch.randn(5000, 71, dtype=torch.float64, requires_grad=True)
+    g2 = g1.detach().clone().requires_grad_()
+    w = torch.randn(5000, 64, dtype=torch.float64)
+    sm.FUSE_NORM_LINEAR = True
+    ya = a(x, g1)
+    sm.FUSE_NORM_LINEAR = False
+    try:
+        yb = b(x, g2)
+    finally:
+        sm.FUSE_NORM_LINEAR = True
+    assert torch.allclose(ya, yb, rtol=1e-10, atol=1e-12)
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    assert torch.allclose(g1.grad, g2.grad, rtol=1e-8, atol=1e-12)
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None or not p.grad.abs().any(), n
+        else:
+            assert torch.allclose(p.grad, q.grad, rtol=1e-7, atol=1e-11), (n, (p.grad - q.grad).abs().max())
+    for (n, p), (_, q) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.allclose(p.double(), q.double(), rtol=1e-10, atol=1e-12), n
