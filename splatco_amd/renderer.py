@@ -12,6 +12,21 @@ import torch
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
+def _mlp_heads(pc, x):
+    """mlp_opacity / mlp_color / mlp_cov (scene/gaussian_model.py:315-337) on a shared input."""
+    heads = (pc.get_opacity_mlp, pc.get_color_mlp, pc.get_cov_mlp)
+    first = [h[0] for h in heads]
+    if not all(isinstance(h, torch.nn.Sequential) and isinstance(h[0], torch.nn.Linear) and isinstance(h[1], torch.nn.ReLU)
+               for h in heads) or len({f.out_features for f in first}) != 1:
+        return tuple(h(x) for h in heads)
+    from .scene_model import TallLinear
+    w = torch.cat([f.weight for f in first], dim=0)
+    b = torch.cat([f.bias for f in first], dim=0)
+    hdn = torch.relu_(TallLinear.apply_weights(x, w, b))
+    n = first[0].out_features
+    return tuple(h[2:](hdn[:, i * n:(i + 1) * n]) for i, h in enumerate(heads))
+
+
 def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False, fused=None):
     """Anchors -> neural Gaussians (gaussian_renderer/__init__.py:18-116), same op order.
     fused: run the mask / compaction / post-processing block (:68-111) as the single HIP op of
@@ -33,12 +48,20 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     ob_view = ob_view / ob_dist
     if getattr(pc, "use_feat_bank", False) or getattr(pc, "appearance_dim", 0) > 0:
         raise NotImplementedError("feature bank / appearance embedding are off on the benchmarked path")
-    cat_local_view = torch.cat([feat, ob_view, ob_dist, geo_fea], dim=1)
-    cat_local_view_wodist = torch.cat([feat, ob_view, geo_fea], dim=1)
-    neural_opacity = pc.get_opacity_mlp(cat_local_view if pc.add_opacity_dist else cat_local_view_wodist)
+    if not (pc.add_opacity_dist or pc.add_color_dist or pc.add_cov_dist):
+        # the three heads read the same [V, 99] input (:62-93 with the default flags): their first layers run
+        # as ONE GEMM with stacked weights (one pass over the input instead of three, forward and backward)
+        cat_local_view_wodist = torch.cat([feat, ob_view, geo_fea], dim=1)
+        neural_opacity, color, scale_rot = _mlp_heads(pc, cat_local_view_wodist)
+    else:
+        cat_local_view = torch.cat([feat, ob_view, ob_dist, geo_fea], dim=1)
+        cat_local_view_wodist = torch.cat([feat, ob_view, geo_fea], dim=1)
+        neural_opacity = pc.get_opacity_mlp(cat_local_view if pc.add_opacity_dist else cat_local_view_wodist)
+        color = pc.get_color_mlp(cat_local_view if pc.add_color_dist else cat_local_view_wodist)
+        scale_rot = pc.get_cov_mlp(cat_local_view if pc.add_cov_dist else cat_local_view_wodist)
     neural_opacity = neural_opacity.reshape([-1, 1])
-    color = pc.get_color_mlp(cat_local_view if pc.add_color_dist else cat_local_view_wodist).reshape([V * k, 3])
-    scale_rot = pc.get_cov_mlp(cat_local_view if pc.add_cov_dist else cat_local_view_wodist).reshape([V * k, 7])
+    color = color.reshape([V * k, 3])
+    scale_rot = scale_rot.reshape([V * k, 7])
     if fused is None:
         fused = anchor.is_cuda
     if fused:

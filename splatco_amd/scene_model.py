@@ -49,10 +49,14 @@ class _TallLinearFn(torch.autograd.Function):
 class TallLinear(nn.Linear):
     """nn.Linear (same parameters / state_dict keys) with the slab-split weight gradient."""
 
-    def forward(self, x):
+    @staticmethod
+    def apply_weights(x, weight, bias):
         if x.dim() == 2 and x.shape[0] >= 4 * _TallLinearFn.SLAB and x.is_cuda:
-            return _TallLinearFn.apply(x, self.weight, self.bias)
-        return F.linear(x, self.weight, self.bias)
+            return _TallLinearFn.apply(x, weight, bias)
+        return F.linear(x, weight, bias)
+
+    def forward(self, x):
+        return TallLinear.apply_weights(x, self.weight, self.bias)
 
 
 def _tall_contract(a, b):
