@@ -267,11 +267,10 @@ struct FinalLists {
 
 // Sorts the n (<= 64*E) keys at keys[0..n).  FINAL: write the tile's final lists; otherwise write the
 // sorted chunk back in place.
-template <int E, bool FINAL>
-__device__ __forceinline__ void wave_sort(uint32_t n, unsigned long long* __restrict__ keys, uint32_t lo,
-                                          const FinalLists& fl, uint32_t* __restrict__ tr) {
+template <int E>
+__device__ __forceinline__ void wave_sort_regs(uint32_t n, const unsigned long long* __restrict__ keys,
+                                               uint32_t (&klo)[E], uint32_t (&khi)[E]) {
     const int lane = threadIdx.x & 63;
-    uint32_t klo[E], khi[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {  // coalesced load; the network does not care where an element starts
         const uint32_t i = (uint32_t)e * 64 + lane;
@@ -279,7 +278,15 @@ __device__ __forceinline__ void wave_sort(uint32_t n, unsigned long long* __rest
         klo[e] = (uint32_t)v;
         khi[e] = (uint32_t)(v >> 32);
     }
-    bitonic_network<E, 2>(klo, khi, lane);
+    bitonic_network<E, 2>(klo, khi, lane);  // sorted position of (lane, e) is lane * E + e
+}
+
+template <int E, bool FINAL>
+__device__ __forceinline__ void wave_sort(uint32_t n, unsigned long long* __restrict__ keys, uint32_t lo,
+                                          const FinalLists& fl, uint32_t* __restrict__ tr) {
+    const int lane = threadIdx.x & 63;
+    uint32_t klo[E], khi[E];
+    wave_sort_regs<E>(n, keys, klo, khi);
     // Sorted position of (lane, e) is lane * E + e: storing from here would put the 64 lanes of one store
     // instruction E words apart (one partial HBM sector each; measured 7.6x write amplification).  The
     // wave transposes through its 4 KB of LDS instead, so that store s covers positions s*64 .. s*64+63.
@@ -317,8 +324,7 @@ __device__ __forceinline__ void wave_sort_any(uint32_t n, unsigned long long* ke
     else wave_sort<16, FINAL>(n, keys, lo, fl, tr);
 }
 
-// grid = (xcd_grid(tiles), chunks): chunk c of tile t.  Tiles with <= 1024 instances are finished
-// by their chunk 0; larger tiles get every chunk sorted in place.
+// Tiles with <= 1024 instances: one wave sorts the tile and writes its final lists.
 #ifndef SCR_SORT_MIN_WAVES
 #define SCR_SORT_MIN_WAVES 1
 #endif
@@ -329,114 +335,166 @@ tile_sort_wave_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, un
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
-    const uint32_t c0 = blockIdx.y * (uint32_t)WAVE_SORT_MAX;
-    if (c0 >= n) return;
+    if (n == 0 || n > (uint32_t)WAVE_SORT_MAX) return;
     const FinalLists fl{gm_base, point_list, gm_index, qmask, t % gx, t / gx};
     __shared__ uint32_t tr[WAVE_SORT_MAX + 64];  // the wave's transposition buffer (wave_sort)
-    if (n <= (uint32_t)WAVE_SORT_MAX) {
-        wave_sort_any<true>(n, keys + lo, lo, fl, tr);
-    } else {
-        const uint32_t cnt = min((uint32_t)WAVE_SORT_MAX, n - c0);
-        wave_sort_any<false>(cnt, keys + lo + c0, 0, fl, tr);
-    }
+    wave_sort_any<true>(n, keys + lo, lo, fl, tr);
 }
 
-// Merge pass over runs of length L (sorted) -> runs of length 2L.  One thread per element:
-// output position = own index in its run + rank in the partner run (lower_bound; keys unique).
-// Tiles that are already fully merged (or small) are skipped.  The buffer a tile's data lives in
-// after p passes is buffer (p & 1).
-//   L <= 4096: one workgroup per PAIR of runs stages the pair's keys in LDS (<= 64 KB) and searches there;
-//   larger   : the searches go to global memory (L2).
-__device__ __forceinline__ uint32_t merge_passes_needed(uint32_t n) {  // ceil(log2(ceil(n/1024)))
-    uint32_t chunks = (n + WAVE_SORT_MAX - 1) / WAVE_SORT_MAX, p = 0;
-    while ((1u << p) < chunks) ++p;
-    return p;
-}
-
+// Tiles with more than 1024 instances: a four-wave workgroup sorts a chunk of up to 4096 keys on chip --
+// every wave sorts 1024 keys in registers, the four sorted runs meet in LDS and two rank-merge passes
+// (each key binary-searches its rank in the partner run; keys are unique) make one run of them.  A tile
+// of up to 4096 instances is finished here (final lists written); a larger tile gets its 4096-chunks
+// sorted in place and goes on to the global merge passes.
+constexpr int WG_SORT_MAX = 4096;
+__device__ __forceinline__ int wg_slot(int p) { return p + (p >> 4); }  // 16 keys of a lane start 17 slots apart
 __global__ void __launch_bounds__(256)
-tile_merge_lds_kernel(int tiles, uint32_t pass, const uint32_t* __restrict__ ranges,
-                      const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long lk[];  // [2L] keys of the pair
-    int t = xcd_tile(blockIdx.x, tiles);
-    if (t < 0) return;
-    const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
-    if (n <= (uint32_t)WAVE_SORT_MAX || pass >= merge_passes_needed(n)) return;
-    const uint32_t L = (uint32_t)WAVE_SORT_MAX << pass;
-    const uint32_t pairbase = blockIdx.y * 2u * L;
-    if (pairbase >= n) return;
-    const uint32_t lenA = min(L, n - pairbase);
-    uint32_t lenB = 0;
-    if (pairbase + L < n) {
-        lenB = n - pairbase - L;
-        if (lenB > L) lenB = L;
-    }
-    const unsigned long long* s = src + lo + pairbase;
-    unsigned long long* d = dst + lo + pairbase;
-    const uint32_t tot = lenA + lenB;
-    for (uint32_t e = threadIdx.x; e < tot; e += 256) lk[e] = s[e];
-    __syncthreads();
-    for (uint32_t e = threadIdx.x; e < tot; e += 256) {
-        const unsigned long long x = lk[e];
-        const bool left = e < lenA;
-        const unsigned long long* other = left ? lk + lenA : lk;
-        uint32_t a = 0, b = left ? lenB : lenA;  // lower_bound in the partner run
-        while (a < b) {
-            const uint32_t mid = (a + b) >> 1;
-            if (other[mid] < x) a = mid + 1;
-            else b = mid;
-        }
-        d[(left ? e : e - lenA) + a] = x;
-    }
-}
-
-__global__ void __launch_bounds__(256)
-tile_merge_global_kernel(int tiles, uint32_t pass, const uint32_t* __restrict__ ranges,
-                         const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst) {
-    int t = xcd_tile(blockIdx.x, tiles);
-    if (t < 0) return;
-    const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
-    if (n <= (uint32_t)WAVE_SORT_MAX || pass >= merge_passes_needed(n)) return;
-    const uint32_t L = (uint32_t)WAVE_SORT_MAX << pass;
-    const unsigned long long* sk = src + lo;
-    for (uint32_t e = blockIdx.y * (uint32_t)WAVE_SORT_MAX + threadIdx.x, k = 0; k < WAVE_SORT_MAX / 256 && e < n; ++k, e += 256) {
-        const uint32_t run = e / L, pairbase = (run & ~1u) * L, inrun = e - run * L;
-        const unsigned long long x = sk[e];
-        uint32_t base, len;
-        if ((run & 1u) == 0) {  // element of the left run: count right-run elements below it
-            base = pairbase + L;
-            len = 0;  // length of the right partner run (0: this run has no partner)
-            if (base < n) {
-                len = n - base;
-                if (len > L) len = L;
-            }
-        } else {                // element of the right run: count left-run elements below it
-            base = pairbase;
-            len = L;
-        }
-        uint32_t a = 0, b = len;
-        while (a < b) {
-            const uint32_t mid = (a + b) >> 1;
-            if (sk[base + mid] < x) a = mid + 1;
-            else b = mid;
-        }
-        dst[lo + pairbase + inrun + a] = x;
-    }
-}
-
-// Final lists of the large tiles from the buffer their last merge pass wrote.
-__global__ void __launch_bounds__(256)
-tile_merge_final_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, const unsigned long long* __restrict__ k0,
-                        const unsigned long long* __restrict__ k1, const uint2* __restrict__ gm_base,
-                        uint32_t* __restrict__ point_list, uint32_t* __restrict__ gm_index,
-                        uint8_t* __restrict__ qmask) {
+tile_sort_wg_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, unsigned long long* __restrict__ keys,
+                    const uint2* __restrict__ gm_base, uint32_t* __restrict__ point_list,
+                    uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
+    __shared__ unsigned long long buf[WG_SORT_MAX + WG_SORT_MAX / 16];  // 34 KB: four workgroups per CU
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
     if (n <= (uint32_t)WAVE_SORT_MAX) return;
-    const unsigned long long* sk = ((merge_passes_needed(n) & 1u) ? k1 : k0) + lo;
-    const FinalLists fl{gm_base, point_list, gm_index, qmask, t % gx, t / gx};
-    for (uint32_t e = blockIdx.y * (uint32_t)WAVE_SORT_MAX + threadIdx.x, k = 0; k < WAVE_SORT_MAX / 256 && e < n; ++k, e += 256)
-        fl.write(lo + e, (uint32_t)sk[e]);
+    const uint32_t c0 = blockIdx.y * (uint32_t)WG_SORT_MAX;
+    if (c0 >= n) return;
+    const uint32_t cnt = min((uint32_t)WG_SORT_MAX, n - c0);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long* chunk = keys + lo + c0;
+    {   // ---- every wave sorts its 1024 keys (missing keys are +inf padding, they stay at the end)
+        const uint32_t w0 = (uint32_t)wave * WAVE_SORT_MAX;
+        const uint32_t wn = w0 < cnt ? min((uint32_t)WAVE_SORT_MAX, cnt - w0) : 0u;
+        uint32_t klo[16], khi[16];
+        wave_sort_regs<16>(wn, chunk + w0, klo, khi);
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            buf[wg_slot((int)w0 + lane * 16 + e)] = ((unsigned long long)khi[e] << 32) | klo[e];
+    }
+    __syncthreads();
+    // ---- rank merges in LDS: runs of L -> 2L (padding keys compare equal: their ranks would collide, so a
+    // padding key keeps its position -- all padding sits at the end of the last runs and stays there)
+    // One buffer: a thread reads its 16 keys, finds their places while everybody still sees the old runs,
+    // and the moves happen after a barrier.
+    for (uint32_t L = WAVE_SORT_MAX; L < (uint32_t)WG_SORT_MAX && L < cnt; L <<= 1) {
+        unsigned long long x[WG_SORT_MAX / 256];
+        uint32_t pos[WG_SORT_MAX / 256];
+#pragma unroll
+        for (int k = 0; k < WG_SORT_MAX / 256; ++k) {
+            const uint32_t e = threadIdx.x + 256u * k;
+            x[k] = buf[wg_slot((int)e)];
+            pos[k] = e;
+            if (x[k] != ~0ull) {
+                const uint32_t run = e / L, base = (run ^ 1u) * L, inrun = e - run * L;
+                uint32_t a = 0, b = L;  // lower_bound in the partner run (padding there is +inf: never below x)
+                while (a < b) {
+                    const uint32_t mid = (a + b) >> 1;
+                    if (buf[wg_slot((int)(base + mid))] < x[k]) a = mid + 1;
+                    else b = mid;
+                }
+                pos[k] = (run & ~1u) * L + inrun + a;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < WG_SORT_MAX / 256; ++k) buf[wg_slot((int)pos[k])] = x[k];
+        __syncthreads();
+    }
+    const unsigned long long* src = buf;
+    // ---- out: final lists (the whole tile was this chunk) or the sorted chunk back in place
+    if (n <= (uint32_t)WG_SORT_MAX) {
+        const FinalLists fl{gm_base, point_list, gm_index, qmask, t % gx, t / gx};
+        for (uint32_t e = threadIdx.x; e < cnt; e += 256) fl.write(lo + e, (uint32_t)src[wg_slot((int)e)]);
+    } else {
+        for (uint32_t e = threadIdx.x; e < cnt; e += 256) chunk[e] = src[wg_slot((int)e)];
+    }
+}
+
+// Merge pass over sorted runs of length L = 4096 << pass -> runs of length 2L, for tiles above 4096
+// instances (data of pass p lives in buffer (p & 1); tiles that are already fully merged are skipped).
+// Merge path: every workgroup produces one 4096-key segment of the merged output.  Two lanes find where
+// the segment's first and last diagonal cut the two runs (one binary search each over global memory --
+// per workgroup, not per key), the at most 4096 input keys between the cuts are staged in LDS as two
+// short runs, rank-merged there (each key binary-searches its rank in the other run; keys are unique)
+// and streamed out coalesced.
+__device__ __forceinline__ uint32_t merge_passes_needed(uint32_t n) {  // ceil(log2(ceil(n/4096)))
+    uint32_t chunks = (n + WG_SORT_MAX - 1) / WG_SORT_MAX, p = 0;
+    while ((1u << p) < chunks) ++p;
+    return p;
+}
+
+// number of A-keys among the first s keys of merge(A[0..la), B[0..lb))
+__device__ __forceinline__ uint32_t merge_path_cut(const unsigned long long* __restrict__ A, uint32_t la,
+                                                   const unsigned long long* __restrict__ B, uint32_t lb, uint32_t s) {
+    uint32_t lo = s > lb ? s - lb : 0u, hi = min(s, la);
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (A[mid] < B[s - mid - 1]) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256)
+tile_merge_path_kernel(int tiles, int gx, uint32_t pass, const uint32_t* __restrict__ ranges,
+                       const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst,
+                       const uint2* __restrict__ gm_base, uint32_t* __restrict__ point_list,
+                       uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
+    __shared__ unsigned long long buf[WG_SORT_MAX];
+    __shared__ uint32_t cut[2];
+    int t = xcd_tile(blockIdx.x, tiles);
+    if (t < 0) return;
+    const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
+    if (n <= (uint32_t)WG_SORT_MAX || pass >= merge_passes_needed(n)) return;
+    const uint32_t L = (uint32_t)WG_SORT_MAX << pass;
+    const uint32_t e0 = blockIdx.y * (uint32_t)WG_SORT_MAX;
+    if (e0 >= n) return;
+    const uint32_t pairbase = e0 / (2u * L) * (2u * L);
+    const uint32_t lenA = min(L, n - pairbase);
+    const uint32_t lenB = n - pairbase > L ? min(L, n - pairbase - L) : 0u;
+    const uint32_t s0 = e0 - pairbase, s1 = min(s0 + (uint32_t)WG_SORT_MAX, lenA + lenB);
+    const unsigned long long* A = src + lo + pairbase;
+    const unsigned long long* B = A + L;
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 128) {  // lane 0 of waves 0 and 1: the two cuts, concurrently
+        const int w = threadIdx.x >> 6;
+        cut[w] = merge_path_cut(A, lenA, B, lenB, w ? s1 : s0);
+    }
+    __syncthreads();
+    const uint32_t i0 = cut[0], na = cut[1] - i0, j0 = s0 - i0, nb = (s1 - s0) - na;
+    for (uint32_t e = threadIdx.x; e < na; e += 256) buf[e] = A[i0 + e];
+    for (uint32_t e = threadIdx.x; e < nb; e += 256) buf[na + e] = B[j0 + e];
+    __syncthreads();
+    unsigned long long x[WG_SORT_MAX / 256];
+    uint32_t pos[WG_SORT_MAX / 256];
+#pragma unroll
+    for (int k = 0; k < WG_SORT_MAX / 256; ++k) {
+        const uint32_t e = threadIdx.x + 256u * k;
+        pos[k] = 0xffffffffu;
+        if (e < na + nb) {
+            x[k] = buf[e];
+            const bool left = e < na;
+            const unsigned long long* other = left ? buf + na : buf;
+            uint32_t a = 0, b = left ? nb : na;  // lower_bound in the other run
+            while (a < b) {
+                const uint32_t mid = (a + b) >> 1;
+                if (other[mid] < x[k]) a = mid + 1;
+                else b = mid;
+            }
+            pos[k] = (left ? e : e - na) + a;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < WG_SORT_MAX / 256; ++k)
+        if (pos[k] != 0xffffffffu) buf[pos[k]] = x[k];
+    __syncthreads();
+    if (pass + 1 == merge_passes_needed(n)) {  // the tile's last pass writes the final lists directly
+        const FinalLists fl{gm_base, point_list, gm_index, qmask, t % gx, t / gx};
+        for (uint32_t e = threadIdx.x; e < na + nb; e += 256) fl.write(lo + pairbase + s0 + e, (uint32_t)buf[e]);
+    } else {
+        unsigned long long* out = dst + lo + pairbase + s0;
+        for (uint32_t e = threadIdx.x; e < na + nb; e += 256) out[e] = buf[e];
+    }
 }
 
 // ------------------------------------------------------------------ launchers
@@ -471,31 +529,22 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
                       hipStream_t st) {
     Grid g(ks.H, ks.W);
     const unsigned gt = (unsigned)xcd_grid(g.tiles);
-    const unsigned chunks = (unsigned)((max_tile_instances + WAVE_SORT_MAX - 1) / WAVE_SORT_MAX);
-    if (chunks == 0) return;
-    tile_sort_wave_kernel<<<dim3(gt, chunks), 64, 0, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.gm_base, bv.point_list,
-                                                          bv.gm_index, bv.qmask);
+    if (max_tile_instances <= 0) return;
+    tile_sort_wave_kernel<<<gt, 64, 0, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.gm_base, bv.point_list, bv.gm_index,
+                                             bv.qmask);
+    if (max_tile_instances <= WAVE_SORT_MAX) return;
+    const unsigned chunks = (unsigned)((max_tile_instances + WG_SORT_MAX - 1) / WG_SORT_MAX);
+    tile_sort_wg_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.gm_base, bv.point_list,
+                                                         bv.gm_index, bv.qmask);
     if (chunks <= 1) return;
     unsigned passes = 0;
     while ((1u << passes) < chunks) ++passes;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tile_merge_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        attr_set = true;
-    }
     for (unsigned p = 0; p < passes; ++p) {
         const unsigned long long* src = (p & 1u) ? bv.keys2 : bv.keys;  // data of pass p lives in buffer (p & 1)
         unsigned long long* dst = (p & 1u) ? bv.keys : bv.keys2;
-        const unsigned L = (unsigned)WAVE_SORT_MAX << p;
-        if (L <= 4096u) {
-            const unsigned pairs = (chunks * (unsigned)WAVE_SORT_MAX + 2 * L - 1) / (2 * L);
-            tile_merge_lds_kernel<<<dim3(gt, pairs), 256, (size_t)2 * L * 8, st>>>(g.tiles, p, gv.ranges, src, dst);
-        } else {
-            tile_merge_global_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, p, gv.ranges, src, dst);
-        }
+        tile_merge_path_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, g.gx, p, gv.ranges, src, dst, gv.gm_base,
+                                                                 bv.point_list, bv.gm_index, bv.qmask);
     }
-    tile_merge_final_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, bv.keys2, gv.gm_base,
-                                                              bv.point_list, bv.gm_index, bv.qmask);
 }
 
 }  // namespace scr
