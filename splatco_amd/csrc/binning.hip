@@ -6,8 +6,8 @@
 //               exclusive scan -> every instance is dropped into its tile's segment as one 64-bit
 //               key (depth_bits << 32 | gaussian id << 4 | quadrant mask).  Slot order inside a
 //               segment is arbitrary.
-//   2. sort:    one wave per tile (per 1024-chunk of a big tile) sorts the keys in registers
-//               (bitonic network; rank-merge passes for bigger tiles).  Sorting by (depth, id)
+//   2. sort:    one wave per tile sorts up to 1024 keys in registers (bitonic network), a four-wave
+//               workgroup up to 4096 through LDS; bigger tiles add merge-path passes.  Sorting by (depth, id)
 //               reproduces the stable (tile, depth) order of the reference semantics, so
 //               point_list / ranges are bit-identical to the oracle's.  The final write also derives
 //               each instance's Gaussian-major index (where the backward pass puts its gradient
@@ -165,11 +165,11 @@ scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec, uin
 // or v_permlane16_swap / v_permlane32_swap (16, 32).  No LDS, no barriers, no s_waitcnt inside the
 // network.  Padding elements are +inf keys and sort to the end.
 //   tiles with <= 1024 instances : one wave sorts the tile and writes the final lists;
-//   larger tiles                 : every 1024-chunk is sorted the same way (in place), then
-//                                  log2(chunks) rank-merge passes double the sorted run length
-//                                  (each element binary-searches its rank in the partner run;
-//                                  keys are unique, so the positions are disjoint) ping-ponging
-//                                  between two buffers; a last pass writes the final lists.
+//   up to 4096                   : a four-wave workgroup -- each wave sorts 1024 keys this way, the runs are
+//                                  rank-merged in LDS (tile_sort_wg_kernel);
+//   larger tiles                 : every 4096-chunk is sorted like that (in place), then log2(chunks)
+//                                  merge-path passes double the sorted run length, ping-ponging between
+//                                  two buffers; a tile's last pass writes its final lists.
 template <int D>
 __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {  // value of lane (l ^ D)
     if constexpr (D == 1) {
