@@ -16,11 +16,24 @@ from splatco_amd.renderer import prefilter_voxel, render
 from splatco_amd.scene_model import AnchorGaussianModel
 
 
-def main(N=5_000_000, plane=2800, iters=3):
+def morton_order(xyz, lo=-2.0, hi=2.0, bits=10):
+    """Permutation that sorts points along a Z-order curve (developer probe of anchor-order locality)."""
+    q = ((xyz - lo) / (hi - lo) * (2 ** bits - 1)).clamp(0, 2 ** bits - 1).long()
+    code = torch.zeros(xyz.shape[0], dtype=torch.long, device=xyz.device)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return torch.argsort(code)
+
+
+def main(N=5_000_000, plane=2800, iters=3, sort_anchors=False):
     dev = torch.device("cuda:0")
     torch.manual_seed(2)
     pc = AnchorGaussianModel(plane_size=plane, num_channels=15).to(dev)
-    pc.set_anchors(torch.rand(N, 3, device=dev) * 4 - 2, torch.randn(N, 10, 3, device=dev) * 0.5,
+    anchors = torch.rand(N, 3, device=dev) * 4 - 2
+    if sort_anchors:
+        anchors = anchors[morton_order(anchors)]
+    pc.set_anchors(anchors, torch.randn(N, 10, 3, device=dev) * 0.5,
                    torch.randn(N, 32, device=dev) * 0.5, torch.randn(N, 6, device=dev) * 0.3 - 5.0)
     pc.feat_planes.Q0 = 0
     pc.feat_planes._feat.activate_level = 2
@@ -59,4 +72,8 @@ def main(N=5_000_000, plane=2800, iters=3):
 
 
 if __name__ == "__main__":
+    if "--sorted" in sys.argv:
+        sys.argv.remove("--sorted")
+        main(*[int(a) for a in sys.argv[1:]], sort_anchors=True)
+        sys.exit(0)
     main(*(int(a) for a in sys.argv[1:]))
