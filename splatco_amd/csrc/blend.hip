@@ -2,16 +2,17 @@
 //
 // Decomposition (wave64-first): a 16x16 tile is four 8x8-pixel quadrants, ONE WAVE PER QUADRANT,
 // one pixel per lane.  The tile's depth-sorted splat list carries a 4-bit quadrant mask per
-// instance (written by the sort kernel, common.h quadrant_mask): a wave walks only the splats that
-// can reach its quadrant (about a third of the list at the benchmark density), compacted with
+// instance (computed by the scatter kernel, common.h quadrant_mask, carried in the sort key): a wave walks
+// only the splats that can reach its quadrant (about a third of the list at the benchmark density), compacted with
 // wave ballots + mbcnt prefix counts.  Splat records (48 B) are gathered once per surviving
 // (wave, splat) into LDS and then read back with conflict-free broadcast ds_read_b128.
 //
 // Forward: waves are independent -> one-wave workgroups, no barriers; the next chunk's masks,
 // ids and records are in flight while the current chunk is blended.
-// Backward: the four waves of a tile share one workgroup.  Per (tile, Gaussian) gradients are
-// reduced on chip -- DPP row shifts / row broadcasts inside the wave, one LDS slot per
-// (wave, splat), a fixed-order add over the waves that took part -- and written ONCE as a 48-byte
+// Backward: the four waves of a tile share one workgroup.  Per (tile, Gaussian) gradient moments are
+// reduced on chip -- a folding reduction inside the wave (permlane swaps, then bank-masked DPP adds that
+// pack two values per register), one LDS slot per (wave, splat), a fixed-order add over the waves that
+// took part -- and written ONCE as a 48-byte
 // record at the instance's Gaussian-major index (so the per-Gaussian reduction reads its records
 // contiguously).  No floating-point atomics:
 // results are bit-reproducible.  The per-Gaussian sum over tiles happens in
