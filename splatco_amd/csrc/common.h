@@ -188,48 +188,62 @@ inline __host__ int xcd_grid(int tiles) { return ((tiles + NUM_XCD - 1) / NUM_XC
 // difference between this bound and the per-pixel evaluation.  Dropping such a splat cannot
 // change any result (it would be skipped by every pixel anyway), so lists, n_contrib and images
 // stay bit-identical to the un-culled semantics.  NaNs compare false -> kept.
-__device__ inline uint32_t quadrant_mask(float4 r0, float4 r1, int tile_x0, int tile_y0) {
-    const float mx = r0.x, my = r0.y;
-    const float a = -r0.z, b = -r0.w, c = -r1.x;  // q = a dx^2 + b dx dy + c dy^2, a,c > 0
-    const float o = r1.y;
-    const float thr = __logf(255.0f * o) + 0.01f;  // q above this -> alpha < 1/255 (with margin)
-    // the bound below needs a finite, positive-definite form; anything else is simply kept
-    if (!(a > 0.0f && c > 0.0f && 4.0f * a * c - b * b > 0.0f) || !(mx - mx == 0.0f) || !(my - my == 0.0f) ||
-        !(thr - thr == 0.0f))
-        return 0xfu;
-    uint32_t mask = 0;
+// Conservative sub-tile culling.  A splat contributes to a pixel only where its quadratic form
+// q(d) = a dx^2 + b dx dy + c dy^2 stays below thr = ln(255 * opacity) (alpha >= 1/255); a pixel box can be
+// skipped when the exact minimum of q over the box exceeds thr by more than the rounding of the terms.
+struct SplatForm {
+    float mx, my, a, b, c, thr;
+    bool ok;  // finite and positive definite; anything else is simply kept everywhere
+};
+__device__ inline SplatForm splat_form(float4 r0, float4 r1) {
+    SplatForm f;
+    f.mx = r0.x; f.my = r0.y;
+    f.a = -r0.z; f.b = -r0.w; f.c = -r1.x;  // q = a dx^2 + b dx dy + c dy^2, a,c > 0
+    f.thr = __logf(255.0f * r1.y) + 0.01f;  // q above this -> alpha < 1/255 (with margin)
+    f.ok = (f.a > 0.0f && f.c > 0.0f && 4.0f * f.a * f.c - f.b * f.b > 0.0f) && (f.mx - f.mx == 0.0f) &&
+           (f.my - f.my == 0.0f) && (f.thr - f.thr == 0.0f);
+    return f;
+}
+// can the splat reach a pixel of [x0, x0+ex] x [y0, y0+ey] (inclusive pixel coordinates)?
+__device__ inline bool box_reachable(const SplatForm& f, float x0, float y0, float ex, float ey) {
+    if (!f.ok) return true;
+    const float a = f.a, b = f.b, c = f.c;
+    // d = mean - pixel
+    const float dxl = f.mx - (x0 + ex), dxh = f.mx - x0, dyl = f.my - (y0 + ey), dyh = f.my - y0;
+    float qmin, mag;
+    if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) {
+        qmin = 0.0f;
+        mag = 0.0f;
+    } else {
+        qmin = 3.0e38f;
+        mag = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float x0 = (float)(tile_x0 + (q & 1) * 8), y0 = (float)(tile_y0 + (q >> 1) * 8);
-        // d = mean - pixel, pixel in [x0, x0+7] x [y0, y0+7]
-        const float dxl = mx - (x0 + 7.0f), dxh = mx - x0, dyl = my - (y0 + 7.0f), dyh = my - y0;
-        float qmin, mag;
-        if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) {
-            qmin = 0.0f;
-            mag = 0.0f;
-        } else {
-            qmin = 3.0e38f;
-            mag = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // edges: dx = dxl, dx = dxh (free dy), dy = dyl, dy = dyh (free dx)
-                const bool xe = e < 2;
-                const float fix = e == 0 ? dxl : e == 1 ? dxh : e == 2 ? dyl : dyh;
-                const float kf = xe ? a : c, kv = xe ? c : a;  // q = kf fix^2 + b fix v + kv v^2
-                const float lo = xe ? dyl : dxl, hi = xe ? dyh : dxh;
-                float v = -b * fix / (2.0f * kv);
-                v = fminf(hi, fmaxf(lo, v));
-                const float t0 = kf * fix * fix, t1 = b * fix * v, t2 = kv * v * v;
-                const float qe = t0 + t1 + t2;
-                if (qe < qmin) {
-                    qmin = qe;
-                    mag = fabsf(t0) + fabsf(t1) + fabsf(t2);
-                }
+        for (int e = 0; e < 4; ++e) {
+            // edges: dx = dxl, dx = dxh (free dy), dy = dyl, dy = dyh (free dx)
+            const bool xe = e < 2;
+            const float fix = e == 0 ? dxl : e == 1 ? dxh : e == 2 ? dyl : dyh;
+            const float kf = xe ? a : c, kv = xe ? c : a;  // q = kf fix^2 + b fix v + kv v^2
+            const float lo = xe ? dyl : dxl, hi = xe ? dyh : dxh;
+            float v = -b * fix / (2.0f * kv);
+            v = fminf(hi, fmaxf(lo, v));
+            const float t0 = kf * fix * fix, t1 = b * fix * v, t2 = kv * v * v;
+            const float qe = t0 + t1 + t2;
+            if (qe < qmin) {
+                qmin = qe;
+                mag = fabsf(t0) + fabsf(t1) + fabsf(t2);
             }
         }
-        const bool cull = qmin > thr + 1.0e-5f * mag;
-        if (!cull) mask |= 1u << q;
     }
+    return !(qmin > f.thr + 1.0e-5f * mag);
+}
+
+__device__ inline uint32_t quadrant_mask(float4 r0, float4 r1, int tile_x0, int tile_y0) {
+    const SplatForm f = splat_form(r0, r1);
+    if (!f.ok) return 0xfu;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (box_reachable(f, (float)(tile_x0 + (q & 1) * 8), (float)(tile_y0 + (q >> 1) * 8), 7.0f, 7.0f)) mask |= 1u << q;
     return mask;
 }
 

@@ -18,5 +18,6 @@ _C.lib.scr_debug_stats(out, 1)
 img, radii = rast(means3D=t(g["means3D"]), means2D=torch.zeros(P, 3, device=d), opacities=t(g["opacities"]), colors_precomp=t(g["colors"]), scales=t(g["scales"]), rotations=t(g["rotations"]))
 torch.cuda.synchronize()
 _C.lib.scr_debug_stats(out, 0)
-it, zero, lanes, groups, zgroups = out[0], out[1], out[2], out[3], out[4]
-print(f"(wave,splat) iterations {it}; zero-hit {zero} ({100*zero/it:.1f} %); mean hit lanes {lanes/it:.1f} of 64; groups {groups}, skipped {zgroups} ({100*zgroups/groups:.1f} %)")
+it = out[0]
+print(f"(wave,splat) iterations {it}; top/bottom halves: sum of max {out[1]} ({100*out[1]/it:.1f} %), half-entries {out[2]} ({out[2]/it:.2f} per entry); "
+      f"left/right halves: sum of max {out[3]} ({100*out[3]/it:.1f} %), half-entries {out[4]} ({out[4]/it:.2f} per entry)")
