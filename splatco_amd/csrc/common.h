@@ -193,7 +193,8 @@ inline __host__ int xcd_grid(int tiles) { return ((tiles + NUM_XCD - 1) / NUM_XC
 // skipped when the exact minimum of q over the box exceeds thr by more than the rounding of the terms.
 struct SplatForm {
     float mx, my, a, b, c, thr;
-    bool ok;  // finite and positive definite; anything else is simply kept everywhere
+    float vy, vx;  // minimiser slopes along an edge: dy* = vy * dx on a vertical edge, dx* = vx * dy on a horizontal one
+    bool ok;       // finite and positive definite; anything else is simply kept everywhere
 };
 __device__ inline SplatForm splat_form(float4 r0, float4 r1) {
     SplatForm f;
@@ -202,6 +203,11 @@ __device__ inline SplatForm splat_form(float4 r0, float4 r1) {
     f.thr = __logf(255.0f * r1.y) + 0.01f;  // q above this -> alpha < 1/255 (with margin)
     f.ok = (f.a > 0.0f && f.c > 0.0f && 4.0f * f.a * f.c - f.b * f.b > 0.0f) && (f.mx - f.mx == 0.0f) &&
            (f.my - f.my == 0.0f) && (f.thr - f.thr == 0.0f);
+    // one division per direction and Gaussian instead of one per edge: q is stationary at the minimiser, so
+    // the last-bit difference to (-b * fix) / (2 k) moves the edge minimum by a second-order amount, far
+    // inside the margins below
+    f.vy = -f.b / (2.0f * f.c);
+    f.vx = -f.b / (2.0f * f.a);
     return f;
 }
 // can the splat reach a pixel of [x0, x0+ex] x [y0, y0+ey] (inclusive pixel coordinates)?
@@ -224,7 +230,7 @@ __device__ inline bool box_reachable(const SplatForm& f, float x0, float y0, flo
             const float fix = e == 0 ? dxl : e == 1 ? dxh : e == 2 ? dyl : dyh;
             const float kf = xe ? a : c, kv = xe ? c : a;  // q = kf fix^2 + b fix v + kv v^2
             const float lo = xe ? dyl : dxl, hi = xe ? dyh : dxh;
-            float v = -b * fix / (2.0f * kv);
+            float v = (xe ? f.vy : f.vx) * fix;
             v = fminf(hi, fmaxf(lo, v));
             const float t0 = kf * fix * fix, t1 = b * fix * v, t2 = kv * v * v;
             const float qe = t0 + t1 + t2;
