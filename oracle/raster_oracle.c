@@ -71,6 +71,22 @@ typedef struct {
 
 int orc_real_size(void) { return (int)sizeof(real); }
 
+/* Optional multi-threaded build (-fopenmp -DORC_OMP, libraster_oracle_f32_omp.so): used ONLY for the timed
+   cpu_baseline of bench.py, so that the baseline runs on all host cores.  Loops over Gaussians / tiles are
+   split across threads; the per-Gaussian sums of the blend backward become atomic adds (their order, and so
+   the last bits, then vary from run to run -- the parity tests use the serial build, where these macros
+   expand to nothing and the code is the scalar restatement as before). */
+#ifdef ORC_OMP
+#include <omp.h>
+#define ORC_PARALLEL_FOR _Pragma("omp parallel for schedule(dynamic, 8)")
+#define ORC_ATOMIC _Pragma("omp atomic")
+int orc_threads(void) { return omp_get_max_threads(); }
+#else
+#define ORC_PARALLEL_FOR
+#define ORC_ATOMIC
+int orc_threads(void) { return 1; }
+#endif
+
 /* ---------------------------------------------------------------- SH (utils/sh_utils.py:57-112) */
 static const real SH_C0 = R(0.28209479177387814);
 static const real SH_C1 = R(0.4886025119029199);
@@ -199,6 +215,7 @@ void orc_preprocess(int P, int M, const float* means3D, const float* scales, con
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const real tanfovx = st->tanfovx, tanfovy = st->tanfovy;
     const real fx = (real)W / (R(2.0) * tanfovx), fy = (real)H / (R(2.0) * tanfovy);
+    ORC_PARALLEL_FOR
     for (int i = 0; i < P; ++i) {
         if (radii) radii[i] = 0;
         if (tiles_touched) tiles_touched[i] = 0;
@@ -298,6 +315,24 @@ static void merge_sort_kv(kv_t* a, kv_t* tmp, size_t n) { /* stable, bottom-up *
     }
 }
 
+#ifdef ORC_OMP
+/* Threaded build: the same stable order, found per tile -- a stable counting pass groups the pairs by
+   tile (the high key word), then every tile's segment is merge-sorted on its own thread. */
+static void sort_kv_by_tile(kv_t* a, kv_t* tmp, size_t n, int tiles) {
+    size_t* start = (size_t*)calloc((size_t)tiles + 1, sizeof(size_t));
+    for (size_t k = 0; k < n; ++k) ++start[(a[k].key >> 32) + 1];
+    for (int t = 0; t < tiles; ++t) start[t + 1] += start[t];
+    size_t* cur = (size_t*)malloc((size_t)tiles * sizeof(size_t));
+    memcpy(cur, start, (size_t)tiles * sizeof(size_t));
+    for (size_t k = 0; k < n; ++k) tmp[cur[a[k].key >> 32]++] = a[k];
+    ORC_PARALLEL_FOR
+    for (int t = 0; t < tiles; ++t) merge_sort_kv(tmp + start[t], a + start[t], start[t + 1] - start[t]);
+    memcpy(a, tmp, n * sizeof(kv_t));
+    free(cur);
+    free(start);
+}
+#endif
+
 /* pass 1: offsets = inclusive scan(tiles_touched); returns I = offsets[P-1] */
 int64_t orc_scan(int P, const uint32_t* tiles_touched, uint64_t* offsets) {
     uint64_t s = 0;
@@ -311,21 +346,33 @@ void orc_bin(int P, const uint32_t* tiles_touched, const int32_t* rect, const fl
              uint32_t* ranges /*[gx*gy][2]*/) {
     kv_t* kv = (kv_t*)malloc((size_t)(I > 0 ? I : 1) * sizeof(kv_t));
     kv_t* tmp = (kv_t*)malloc((size_t)(I > 0 ? I : 1) * sizeof(kv_t));
+    /* emit in Gaussian order: Gaussian i owns the slots [first[i], first[i] + tiles_touched[i]) */
+    size_t* first = (size_t*)malloc((size_t)(P > 0 ? P : 1) * sizeof(size_t));
     size_t n = 0;
+    for (int i = 0; i < P; ++i) { first[i] = n; n += tiles_touched[i]; }
+    ORC_PARALLEL_FOR
     for (int i = 0; i < P; ++i) {
         if (!tiles_touched[i]) continue;
         uint32_t dbits;
         memcpy(&dbits, depth32 + i, 4);
+        size_t k = first[i];
         for (int y = rect[4 * i + 1]; y < rect[4 * i + 3]; ++y)
             for (int x = rect[4 * i]; x < rect[4 * i + 2]; ++x) {
-                kv[n].key = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
-                kv[n].id = (uint32_t)i;
-                ++n;
+                kv[k].key = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
+                kv[k].id = (uint32_t)i;
+                ++k;
             }
     }
+    free(first);
+#ifdef ORC_OMP
+    sort_kv_by_tile(kv, tmp, n, gx * gy);
+#else
     merge_sort_kv(kv, tmp, n);
+#endif
     memset(ranges, 0, (size_t)gx * gy * 2 * sizeof(uint32_t));
-    for (size_t k = 0; k < n; ++k) {
+    ORC_PARALLEL_FOR
+    for (long long kk = 0; kk < (long long)n; ++kk) {
+        const size_t k = (size_t)kk;
         keys_sorted[k] = kv[k].key;
         ids_sorted[k] = kv[k].id;
         uint32_t tile = (uint32_t)(kv[k].key >> 32);
@@ -346,8 +393,10 @@ void orc_blend_forward(int H, int W, const uint32_t* ranges, const uint32_t* ids
                        real* out_color /*[3][H][W]*/, real* final_T /*[H][W]*/,
                        uint32_t* n_contrib /*[H][W]*/, real* margin /*[H][W] or NULL*/) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    for (int ty = 0; ty < gy; ++ty)
-        for (int tx = 0; tx < gx; ++tx) {
+    ORC_PARALLEL_FOR
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        {
+            const int ty = tile / gx, tx = tile % gx;
             uint32_t lo = ranges[2 * (ty * gx + tx)], hi = ranges[2 * (ty * gx + tx) + 1];
             for (int ly = 0; ly < TILE; ++ly)
                 for (int lx = 0; lx < TILE; ++lx) {
@@ -389,6 +438,7 @@ void orc_blend_forward(int H, int W, const uint32_t* ranges, const uint32_t* ids
                     if (margin) margin[pix] = mg;
                 }
         }
+    }
 }
 
 /* ---------------------------------------------------------------- A.5 blend backward */
@@ -405,8 +455,10 @@ void orc_blend_backward(int H, int W, const uint32_t* ranges, const uint32_t* id
     memset(dL_dconic, 0, sizeof(real) * 3 * (size_t)P);
     memset(dL_dopacity, 0, sizeof(real) * (size_t)P);
     memset(dL_dcolor, 0, sizeof(real) * 3 * (size_t)P);
-    for (int ty = 0; ty < gy; ++ty)
-        for (int tx = 0; tx < gx; ++tx) {
+    ORC_PARALLEL_FOR
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        {
+            const int ty = tile / gx, tx = tile % gx;
             uint32_t lo = ranges[2 * (ty * gx + tx)];
             for (int ly = 0; ly < TILE; ++ly)
                 for (int lx = 0; lx < TILE; ++lx) {
@@ -440,6 +492,7 @@ void orc_blend_backward(int H, int W, const uint32_t* ranges, const uint32_t* id
                             accum[ch] = last_alpha * last_col[ch] + (R(1.0) - last_alpha) * accum[ch];
                             last_col[ch] = c;
                             dL_dalpha += (c - accum[ch]) * dLp[ch];
+                            ORC_ATOMIC
                             dL_dcolor[3 * g + ch] += dchan * dLp[ch];
                         }
                         dL_dalpha *= T;
@@ -450,15 +503,22 @@ void orc_blend_backward(int H, int W, const uint32_t* ranges, const uint32_t* id
                         real gdx = G * dx, gdy = G * dy;
                         real dG_ddx = -gdx * Qxx - gdy * Qxy;
                         real dG_ddy = -gdy * Qyy - gdx * Qxy;
+                        ORC_ATOMIC
                         dL_dmean2D[2 * g] += dL_dG * dG_ddx;
+                        ORC_ATOMIC
                         dL_dmean2D[2 * g + 1] += dL_dG * dG_ddy;
+                        ORC_ATOMIC
                         dL_dconic[3 * g] += R(-0.5) * gdx * dx * dL_dG;
+                        ORC_ATOMIC
                         dL_dconic[3 * g + 1] += -gdx * dy * dL_dG;
+                        ORC_ATOMIC
                         dL_dconic[3 * g + 2] += R(-0.5) * gdy * dy * dL_dG;
+                        ORC_ATOMIC
                         dL_dopacity[g] += G * dL_dalpha;
                     }
                 }
         }
+    }
 }
 
 /* ---------------------------------------------------------------- A.5 preprocess backward */
@@ -476,6 +536,7 @@ void orc_preprocess_backward(int P, int M, const float* means3D, const float* sc
     const real fx = (real)W / (R(2.0) * tanfovx), fy = (real)H / (R(2.0) * tanfovy);
     const float* V = st->viewmatrix;
     const float* Pm = st->projmatrix;
+    ORC_PARALLEL_FOR
     for (int i = 0; i < P; ++i) {
         for (int k = 0; k < 3; ++k) { dL_dmeans3D[3 * i + k] = 0; dL_dmeans2D_out[3 * i + k] = 0; }
         if (dL_dscales) for (int k = 0; k < 3; ++k) dL_dscales[3 * i + k] = 0;

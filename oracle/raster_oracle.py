@@ -66,7 +66,7 @@ class Settings:
 
 def build(force=False):
     """(Re)build both oracle libraries with oracle/Makefile (gcc only)."""
-    names = ["libraster_oracle_f32.so", "libraster_oracle_f64.so"]
+    names = ["libraster_oracle_f32.so", "libraster_oracle_f64.so", "libraster_oracle_f32_omp.so"]
     src = os.path.join(_HERE, "raster_oracle.c")
     stale = force or any(
         not os.path.exists(os.path.join(_HERE, n)) or
@@ -76,10 +76,22 @@ def build(force=False):
 
 
 _LIBS = {}
+_THREADED = False
+
+
+def use_threads(on):
+    """Route the fp32 calls to the OpenMP build (all host cores; atomic gradient sums, so the last bits
+    vary from run to run).  For bench.py's timed cpu_baseline only -- the parity tests use the serial build."""
+    global _THREADED
+    _THREADED = bool(on)
+
+
+def threads():
+    return int(_lib().orc_threads())
 
 
 def _lib(f64=False):
-    key = "f64" if f64 else "f32"
+    key = "f64" if f64 else ("f32_omp" if _THREADED else "f32")
     if key not in _LIBS:
         build()
         lib = C.CDLL(os.path.join(_HERE, f"libraster_oracle_{key}.so"))
