@@ -245,6 +245,17 @@ def test_collaborative_step_runs_and_updates_parameters():
     assert torch.isfinite(loss) and out["render"].shape == (3, 96, 160)
     assert not torch.equal(before, pc._anchor_feat.detach())
     assert out["viewspace_points"].grad is not None
+    # with the cross-view consistency term (train.py:201-239) and the densification statistics of the last
+    # view (train.py:266): alike ground-truth views so that SSIM(gt_i, gt_j) > 0.6 switches the term on
+    from splatco_amd.densify import AnchorDensifier
+    base = torch.rand(3, 96, 160)
+    gts2 = [(base + 0.01 * i).clamp(0, 1) for i in range(2)]
+    den = AnchorDensifier(pc, opt, voxel_size=0.01)
+    loss2, out2, _ = collaborative_step(pc, cams, gts2, pipe, torch.ones(3, device=dev), optimizer=opt,
+                                        consistency_weight=0.05, densifier=den)
+    loss_plain, _, _ = collaborative_step(pc, cams, gts2, pipe, torch.ones(3, device=dev))
+    assert torch.isfinite(loss2) and den.anchor_demon.sum() > 0 and den.offset_denom.sum() > 0
+    assert den.opacity_accum.shape == (pc.get_anchor.shape[0], 1)
 
 
 def test_backward_gradients_share_one_arena():
