@@ -147,6 +147,7 @@ def main():
     def step():
         for p in leaves:
             p.grad = None
+        means2D.grad = None          # the reference makes a fresh screenspace tensor per render (:133)
         img, radii = rast(means2D=means2D, **params)
         img.backward(dL)
         if world > 1:

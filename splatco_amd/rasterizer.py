@@ -109,7 +109,7 @@ def rasterize_forward(cs, means3D, opacities, scales, rotations, cov3D_precomp, 
     st.P, st.M, st.cs = P, M, cs
     st.geom = _bytes(_C.lib.scr_geom_bytes(P, cs.H, cs.W), dev)
     st.image = _bytes(_C.lib.scr_image_bytes(cs.H, cs.W), dev)
-    radii = torch.zeros(P, dtype=torch.int32, device=dev)
+    radii = torch.empty(P, dtype=torch.int32, device=dev)      # every entry is written by preprocess_kernel
     color = torch.empty(3, cs.H, cs.W, dtype=torch.float32, device=dev)
     plan = (C.c_int64 * 2)(0, 0)      # (tile instances, largest per-tile instance count)
     _C.check(_C.lib.scr_forward_plan(P, M, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
@@ -231,7 +231,7 @@ class GaussianRasterizer(nn.Module):
             scales, rotations = _dev_f32(scales, "scales"), _dev_f32(rotations, "rotations")
             cov3D_precomp = _dev_f32(cov3D_precomp, "cov3D_precomp")
             P = means3D.shape[0]
-            radii = torch.zeros(P, dtype=torch.int32, device=means3D.device)
+            radii = torch.empty(P, dtype=torch.int32, device=means3D.device)  # filter_kernel writes every entry
             if P:
                 _C.check(_C.lib.scr_visible_filter(P, means3D.data_ptr(), _ptr(scales), _ptr(rotations),
                                                    _ptr(cov3D_precomp), cs.ref(), radii.data_ptr(), _stream()))
