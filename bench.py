@@ -181,10 +181,27 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = _C.profile_read()
     _C.profile_enable(False)
+    allreduce_info = None
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # bookkeeping (outside the timed region): the gradient all-reduce on its own, SURVEY.md 8(e)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            bucket = allreduce_gradients(leaves)
+        e1.record()
+        torch.cuda.synchronize()
+        ar = torch.tensor([e0.elapsed_time(e1) / 5], device=dev, dtype=torch.float64)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        nbytes = bucket.numel() * bucket.element_size()
+        allreduce_info = {"bytes": nbytes, "ms": float(ar.item()),
+                          "algbw_GBps": nbytes / (float(ar.item()) * 1e-3) / 1e9,
+                          "busbw_GBps": nbytes / (float(ar.item()) * 1e-3) / 1e9 * 2 * (world - 1) / world,
+                          "xgmi_link_peak_GBps": 153.0}
 
     if rank == 0:
         # instance count of this view (the units the blend / sort kernels process)
@@ -231,6 +248,8 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])},
             "hbm_gbs_all_kernels": sum(algorithmic_bytes(k, P, I, npix) for k in kern) / (sum(kern.values()) * 1e-3) / 1e9,
         }
+        if allreduce_info is not None:
+            out["allreduce"] = allreduce_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["psnr_match_db"] = cpu_baseline(g, cam, dev)
         print(json.dumps(out))
