@@ -23,8 +23,10 @@ def _mlp_heads(pc, x):
     w = torch.cat([f.weight for f in first], dim=0)
     b = torch.cat([f.bias for f in first], dim=0)
     hdn = torch.relu_(TallLinear.apply_weights(x, w, b))
-    n = first[0].out_features
-    return tuple(h[2:](hdn[:, i * n:(i + 1) * n]) for i, h in enumerate(heads))
+    # split, not three slices: its backward is one concatenation of the three hidden gradients, where a slice's
+    # backward materialises a zero-padded [V, 96] tensor per head and sums them
+    parts = hdn.split(first[0].out_features, dim=1)
+    return tuple(h[2:](x_) for h, x_ in zip(heads, parts))
 
 
 def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False, fused=None):
