@@ -116,7 +116,8 @@ class _NormLinearFn(torch.autograd.Function):
     def backward(ctx, dy, _dm, _dv):
         x, G, mean, inv = ctx.saved_tensors
         V = x.shape[0]
-        dy = dy.contiguous()
+        if dy.stride(1) != 1:      # a column block of a wider gradient (row stride > width) is fine for every op below
+            dy = dy.contiguous()
         sdy = dy.sum(0)
         H = (_tall_contract(dy, x) - sdy[:, None] * mean) * inv            # dy^T xhat            [out, d]
         dx = None
