@@ -27,8 +27,17 @@ namespace scr {
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // two fp32 lanes of a packed VALU op
 
-__device__ __forceinline__ float fast_exp(float x) {  // v_exp_f32(x * log2 e)
-    return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+// exp(x) = 2^(x log2 e) on the v_exp_f32 unit.  The product x * log2 e is rounded to 24 bits, an error of up to
+// |x| 2^-24 in the exponent -- 3e-7 relative on G at the alpha = 1/255 end.  That looks harmless, but the
+// transmittance is a product of (1 - alpha) factors, which amplifies a relative error of alpha by
+// alpha / (1 - alpha) (up to 99): in opaque scenes with thousand-entry tile lists the gradients ended up
+// 1e-4 off where libm's expf gives 1e-5 (tools/exp/diag_stress.py 32 18).  The residual of the product is exact
+// in one fma and 2^e = 1 + e ln 2 to first order, so three more VALU operations restore the accuracy of expf.
+__device__ __forceinline__ float fast_exp(float x) {
+    const float p = x * 1.4426950408889634f;
+    const float e = __builtin_fmaf(x, 1.4426950408889634f, -p);  // exact residual of the product
+    const float g = __builtin_amdgcn_exp2f(p);
+    return __builtin_fmaf(g, e * 0.6931471805599453f, g);
 }
 
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long ballot) {  // popcount of lower lanes
@@ -134,8 +143,7 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
                 const v2f A = {p1.x, p1.y}, B = {p1.z, p1.w}, Cq = {p2.x, p2.y}, o = {p2.z, p2.w};
                 // normative order: fma(dx, fma(A,dx,B*dy), (C*dy)*dy), both splats per instruction
                 power[h] = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(A, dx, B * dy), (Cq * dy) * dy);
-                const v2f e2 = power[h] * 1.4426950408889634f;
-                al[h] = o * v2f{__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
+                al[h] = o * v2f{fast_exp(power[h].x), fast_exp(power[h].y)};
             }
             const float alpha[4] = {vmin(c099, al[0].x), vmin(c099, al[0].y), vmin(c099, al[1].x), vmin(c099, al[1].y)};
             const float pw[4] = {power[0].x, power[0].y, power[1].x, power[1].y};

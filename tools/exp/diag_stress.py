@@ -20,10 +20,10 @@ o = _run_gpu(cam, g, scale_modifier=sm, dL=dL)
 print("scale_modifier", sm, "P", len(g["means3D"]), "n_contrib equal", np.array_equal(o["n_contrib"], f["n_contrib"]))
 for k in ("means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"):
     print(f"{k:15s} gpu-vs-f64 {rel_l2(o['grads'][k], b64[k]):.3e}  o32-vs-f64 {rel_l2(b[k], b64[k]):.3e}  gpu-vs-o32 {rel_l2(o['grads'][k], b[k]):.3e}")
-for k in ("means3D", "scales"):
-    eg = np.abs(o["grads"][k] - b64[k]).sum(1); eo = np.abs(b[k] - b64[k]).sum(1)
+for k in (sys.argv[3:] or ["means3D", "scales"]):
+    eg = np.abs(o["grads"][k] - b64[k]).reshape(len(b64[k]), -1).sum(1); eo = np.abs(b[k] - b64[k]).reshape(len(b64[k]), -1).sum(1)
     top = np.argsort(-eg)[:5]
     print(k, "norm", np.abs(b64[k]).sum(), "top offenders:")
     for i in top:
         s = g["scales"][i] * sm
-        print(f"  id {i} err_gpu {eg[i]:.3e} err_o32 {eo[i]:.3e} |g64| {np.abs(b64[k][i]).sum():.3e} scales {s} aniso {s.max()/s.min():.0f} radius {f['radii'][i]} tiles {f['tiles_touched'][i]} op {g['opacities'][i,0]:.3f} m2d gpu {o['grads']['means2D'][i]} o32 {b['means2D'][i]} f64 {b64['means2D'][i]}")
+        print(f"  id {i} err_gpu {eg[i]:.3e} err_o32 {eo[i]:.3e} |g64| {np.abs(b64[k][i]).sum():.3e} gpu {o['grads'][k][i]} o32 {b[k][i]} f64 {b64[k][i]} scales {s} aniso {s.max()/s.min():.0f} radius {f['radii'][i]} tiles {f['tiles_touched'][i]} op {g['opacities'][i,0]:.3f} m2d gpu {o['grads']['means2D'][i]} o32 {b['means2D'][i]} f64 {b64['means2D'][i]}")
