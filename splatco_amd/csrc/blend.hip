@@ -31,13 +31,14 @@ typedef float v2f __attribute__((ext_vector_type(2)));  // two fp32 lanes of a p
 // |x| 2^-24 in the exponent -- 3e-7 relative on G at the alpha = 1/255 end.  That looks harmless, but the
 // transmittance is a product of (1 - alpha) factors, which amplifies a relative error of alpha by
 // alpha / (1 - alpha) (up to 99): in opaque scenes with thousand-entry tile lists the gradients ended up
-// 1e-4 off where libm's expf gives 1e-5 (tools/exp/diag_stress.py 32 18).  The residual of the product is exact
-// in one fma and 2^e = 1 + e ln 2 to first order, so three more VALU operations restore the accuracy of expf.
+// 1e-4 off where libm's expf gives 1e-5 (tools/exp/diag_stress.py 32 18).
+// What the rounding dropped is x - p ln 2 (one fma, exact up to its own rounding) and exp of that is 1 + it to
+// first order, so two more VALU operations restore the accuracy of expf.
 __device__ __forceinline__ float fast_exp(float x) {
     const float p = x * 1.4426950408889634f;
-    const float e = __builtin_fmaf(x, 1.4426950408889634f, -p);  // exact residual of the product
     const float g = __builtin_amdgcn_exp2f(p);
-    return __builtin_fmaf(g, e * 0.6931471805599453f, g);
+    const float r = __builtin_fmaf(-p, 0.6931471805599453f, x);  // x - p ln 2: the part of x that 2^p misses
+    return __builtin_fmaf(g, r, g);
 }
 
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long ballot) {  // popcount of lower lanes
