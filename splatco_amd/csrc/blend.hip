@@ -267,13 +267,16 @@ __device__ __forceinline__ void splat_pixel_grad(PixState& s, float4 b, float cb
                                                  float alpha, float& g_x, float& g_y, float& g_xx, float& g_xy,
                                                  float& g_yy, float& g_o, float& g_c0, float& g_c1, float& g_c2) {
 #pragma clang fp contract(fast)
-    // transmittance in front of this splat: T / (1 - alpha) with v_rcp_f32 + one Newton step.  The recurrence
-    // runs over hundreds of splats per pixel and its rounding is what ill-conditioned (needle-like, hundreds of
-    // tiles) Gaussians amplify; the refinement is free here and measurably closer to fp64 than the bare rcp.
+    // transmittance in front of this splat: T / (1 - alpha), correctly rounded as the division of the reference
+    // arithmetic is -- v_rcp_f32, one Newton step, and one residual correction of the quotient (four fmas
+    // instead of the ten-instruction IEEE sequence).  The recurrence runs over hundreds to thousands of splats
+    // per pixel; its accumulated rounding is what the conic gradients of needle-like or deeply buried
+    // Gaussians amplify (tools/exp/diag_stress.py), so the last half ulp per step is worth 2 % of the kernel.
     const float om = 1.0f - alpha;
     float r = __builtin_amdgcn_rcpf(om);
     r = __builtin_fmaf(__builtin_fmaf(-om, r, 1.0f), r, r);
-    s.T = s.T * r;
+    const float q = s.T * r;
+    s.T = __builtin_fmaf(__builtin_fmaf(-q, om, s.T), r, q);
     const float w = alpha * s.T;
     s.behind = s.last_alpha * (s.d_last - s.behind) + s.behind;
     const float d = b.z * s.dLp0 + b.w * s.dLp1 + cb * s.dLp2;
