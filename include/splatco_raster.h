@@ -75,8 +75,9 @@ int scr_mark_visible(int64_t P, const float* means3D, const float* viewmatrix, u
 /* ---- forward, phase 1: projection / culling / tile counting / offsets.
  * Exactly one of (shs, colors_precomp) and one of ((scales, rotations), cov3D_precomp) non-NULL.
  * M = SH coefficients per Gaussian (shs is [P, M, 3]); opacities is [P] (or [P,1]).
- * Writes radii_out[P] and geom_buf; returns through plan_host[2] (host pointer; the call
- * stream-synchronises once to read it) the number of (Gaussian, tile) instances and the largest
+ * Writes radii_out[P] and geom_buf; returns through plan_host[2] (host pointer; the call waits for
+ * the two numbers -- the scan kernel posts them to a pinned mailbox this thread polls, with a stream
+ * synchronisation as fallback) the number of (Gaussian, tile) instances and the largest
  * per-tile instance count (it sizes the sort's grid); both go to scr_binning_bytes / scr_forward_run. */
 int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* scales,
                      const float* rotations, const float* cov3D_precomp, const float* opacities,

@@ -49,7 +49,11 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(uint32_t nblk, uint32_t
                                                          unsigned long long* __restrict__ total,
                                                          uint32_t tiles, const uint32_t* __restrict__ tile_count,
                                                          uint32_t* __restrict__ ranges,
-                                                         uint32_t* __restrict__ cursor) {
+                                                         uint32_t* __restrict__ cursor,
+                                                         volatile unsigned long long* mailbox,
+                                                         unsigned long long seq) {
+    // mailbox (optional): four words of pinned host memory the GPU can write -- (I, seq, max tile count, seq).
+    // The host spins on the two stamps instead of sleeping in a stream synchronisation.
     __shared__ uint32_t lds[1024 / WAVE + 1];
     if (blockIdx.x == 0) {
         unsigned long long carry = 0;
@@ -60,7 +64,14 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(uint32_t nblk, uint32_t
             if (i < nblk) block_sums[i] = (uint32_t)carry + ex;
             carry += tot;
         }
-        if (threadIdx.x == 0) total[0] = carry;
+        if (threadIdx.x == 0) {
+            total[0] = carry;
+            if (mailbox) {
+                mailbox[0] = carry;
+                __threadfence_system();
+                mailbox[1] = seq;
+            }
+        }
     } else {
         uint32_t carry = 0, mx = 0;
         for (uint32_t base = 0; base < tiles; base += 1024) {
@@ -85,6 +96,11 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(uint32_t nblk, uint32_t
             uint32_t m = 0;
             for (int w = 0; w < 1024 / WAVE; ++w) m = max(m, lds[w]);
             total[1] = m;
+            if (mailbox) {
+                mailbox[2] = m;
+                __threadfence_system();
+                mailbox[3] = seq;
+            }
         }
     }
 }
@@ -498,11 +514,12 @@ tile_merge_path_kernel(int tiles, int gx, uint32_t pass, const uint32_t* __restr
 }
 
 // ------------------------------------------------------------------ launchers
-void launch_plan_scans(int64_t P, const KSettings& ks, const GeomView& gv, hipStream_t st) {
+void launch_plan_scans(int64_t P, const KSettings& ks, const GeomView& gv, unsigned long long* mailbox,
+                       unsigned long long seq, hipStream_t st) {
     Grid g(ks.H, ks.W);
     uint32_t nb = (uint32_t)((P + BIN_GPW - 1) / BIN_GPW);
     plan_scan_kernel<<<2, 1024, 0, st>>>(nb, gv.block_sums, gv.total, (uint32_t)g.tiles, gv.tile_count,
-                                         gv.ranges, gv.cursor);
+                                         gv.ranges, gv.cursor, mailbox, seq);
 }
 
 void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const BinView& bv, hipStream_t st) {

@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include "common.h"
+#include <chrono>
+#include <cstring>
 
 using namespace scr;
 
@@ -62,6 +64,33 @@ const char* const kProfNames[SCR_PROF_COUNT] = {
     "expand_backward_kernel", "plane_sample_backward_kernels", "l1_ssim_forward_kernel",
     "l1_ssim_backward_kernel", "triplane_forward_kernel"};
 }  // namespace
+
+// pinned host memory the GPU writes and the host polls (scr_forward_plan); per host thread, lives for the process
+struct Mailbox {
+    volatile unsigned long long* host = nullptr;
+    unsigned long long* dev = nullptr;
+    unsigned long long seq = 0;
+};
+static Mailbox& mailbox() {
+    thread_local Mailbox mb;
+    thread_local bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && h) {
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
+                memset(h, 0, 64);
+                mb.host = (volatile unsigned long long*)h;
+                mb.dev = (unsigned long long*)d;
+            } else {
+                (void)hipHostFree(h);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    return mb;
+}
 
 static int check_settings(const scr_settings* s) {
     if (!s) return fail("settings is NULL");
@@ -136,11 +165,35 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
       launch_preprocess(P, M, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, ks, gv,
                         radii_out, st); }
     CHECK_LAUNCH("preprocess_kernel", settings->debug, st);
-    { ProfScope ps_(SCR_PROF_PLAN_SCAN, st); launch_plan_scans(P, ks, gv, st); }
+    // The two counts come back through a small pinned, device-visible mailbox (one per host thread, created on
+    // first use): the scan kernel posts them with a sequence stamp and this thread spins on the stamp.  A blocking
+    // hipStreamSynchronize + 16-byte copy costs a copy launch and, worse, a wake-up of the sleeping thread, which
+    // on a busy host is anywhere between 10 and 200 us of idle GPU in the middle of every forward pass.
+    Mailbox& mb = mailbox();
+    const unsigned long long seq = ++mb.seq;
+    { ProfScope ps_(SCR_PROF_PLAN_SCAN, st); launch_plan_scans(P, ks, gv, mb.dev, seq, st); }
     CHECK_LAUNCH("plan_scan_kernel", settings->debug, st);
     unsigned long long total[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(total, gv.total, 16, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    bool posted = false;
+    if (mb.host) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (mb.host[1] == seq && mb.host[3] == seq) {
+                total[0] = mb.host[0];
+                total[1] = mb.host[2];
+                posted = true;
+                break;
+            }
+            if ((spins & 1023u) == 1023u) {
+                if (hipStreamQuery(st) != hipErrorNotReady) break;  // finished (or failed) without a visible post
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
+            }
+        }
+    }
+    if (!posted) {  // no mailbox, or its writes are not visible on this system: the classic read-back
+        HIP_TRY(hipMemcpyAsync(total, gv.total, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     if (total[0] >= (1ull << 32)) return fail("num_rendered = %llu does not fit 32-bit instance indices", total[0]);
     plan_host[0] = (int64_t)total[0];
     plan_host[1] = (int64_t)total[1];

@@ -260,7 +260,8 @@ void launch_mark_visible(int64_t P, const float* means3D, const float* view, uin
 void launch_preprocess(int64_t P, int M, const float* means3D, const float* scales, const float* rotations,
                        const float* cov3D, const float* opacities, const float* shs, const float* colors,
                        const KSettings& ks, const GeomView& gv, int32_t* radii, hipStream_t st);
-void launch_plan_scans(int64_t P, const KSettings& ks, const GeomView& gv, hipStream_t st);
+void launch_plan_scans(int64_t P, const KSettings& ks, const GeomView& gv, unsigned long long* mailbox,
+                       unsigned long long seq, hipStream_t st);
 void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const BinView& bv, hipStream_t st);
 void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, int64_t max_tile_instances,
                       hipStream_t st);
