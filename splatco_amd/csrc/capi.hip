@@ -92,6 +92,20 @@ static Mailbox& mailbox() {
     return mb;
 }
 
+// spin until the kernel(s) of this call have posted stamp `seq` (slot 1, and slot 3 when `two`); false when the
+// stream finished without a visible post (caller falls back to a copy + stream synchronisation)
+static bool mailbox_wait(Mailbox& mb, unsigned long long seq, bool two, hipStream_t st) {
+    if (!mb.host) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (mb.host[1] == seq && (!two || mb.host[3] == seq)) return true;
+        if ((spins & 1023u) == 1023u) {
+            if (hipStreamQuery(st) != hipErrorNotReady) return mb.host[1] == seq && (!two || mb.host[3] == seq);
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return false;
+        }
+    }
+}
+
 static int check_settings(const scr_settings* s) {
     if (!s) return fail("settings is NULL");
     if (s->image_height <= 0 || s->image_width <= 0) return fail("image size must be positive");
@@ -174,21 +188,10 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
     { ProfScope ps_(SCR_PROF_PLAN_SCAN, st); launch_plan_scans(P, ks, gv, mb.dev, seq, st); }
     CHECK_LAUNCH("plan_scan_kernel", settings->debug, st);
     unsigned long long total[2] = {0, 0};
-    bool posted = false;
-    if (mb.host) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spins = 0;; ++spins) {
-            if (mb.host[1] == seq && mb.host[3] == seq) {
-                total[0] = mb.host[0];
-                total[1] = mb.host[2];
-                posted = true;
-                break;
-            }
-            if ((spins & 1023u) == 1023u) {
-                if (hipStreamQuery(st) != hipErrorNotReady) break;  // finished (or failed) without a visible post
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
-            }
-        }
+    const bool posted = mailbox_wait(mb, seq, true, st);
+    if (posted) {
+        total[0] = mb.host[0];
+        total[1] = mb.host[2];
     }
     if (!posted) {  // no mailbox, or its writes are not visible on this system: the classic read-back
         HIP_TRY(hipMemcpyAsync(total, gv.total, 16, hipMemcpyDeviceToHost, st));
@@ -298,11 +301,17 @@ int scr_expand_plan(int64_t n, const float* neural_opacity, void* scratch, int64
     hipStream_t st = (hipStream_t)stream;
     uint32_t* wg = (uint32_t*)scratch;
     unsigned long long* total = (unsigned long long*)((char*)scratch + align_up((expand_nwg(n) + 1) * 4));
-    { ProfScope ps_(SCR_PROF_EXPAND, st); launch_expand_count(n, neural_opacity, wg, total, st); }
+    Mailbox& mb = mailbox();
+    const unsigned long long seq = ++mb.seq;
+    { ProfScope ps_(SCR_PROF_EXPAND, st); launch_expand_count(n, neural_opacity, wg, total, mb.dev, seq, st); }
     CHECK_LAUNCH("expand_count_kernel", 0, st);
     unsigned long long t = 0;
-    HIP_TRY(hipMemcpyAsync(&t, total, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (mailbox_wait(mb, seq, false, st)) {
+        t = mb.host[0];
+    } else {
+        HIP_TRY(hipMemcpyAsync(&t, total, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     *num_selected_host = (int64_t)t;
     return 0;
 }

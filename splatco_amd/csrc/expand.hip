@@ -44,7 +44,8 @@ expand_count_kernel(int64_t n, const float* __restrict__ neural_opacity, uint32_
 
 // pass 2 (one workgroup): exclusive scan of the workgroup counts, total to *total
 __global__ void __launch_bounds__(1024) expand_scan_kernel(uint32_t nwg, uint32_t* __restrict__ wg_count,
-                                                           unsigned long long* __restrict__ total) {
+                                                           unsigned long long* __restrict__ total,
+                                                           volatile unsigned long long* mailbox, unsigned long long seq) {
     __shared__ uint32_t lds[1024 / WAVE];
     unsigned long long carry = 0;
     for (uint32_t base = 0; base < nwg; base += 1024) {
@@ -70,7 +71,14 @@ __global__ void __launch_bounds__(1024) expand_scan_kernel(uint32_t nwg, uint32_
         carry += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) {
+        *total = carry;
+        if (mailbox) {  // pinned host words the caller polls (capi.hip): value, then the stamp
+            mailbox[0] = carry;
+            __threadfence_system();
+            mailbox[1] = seq;
+        }
+    }
 }
 
 // pass 3: expand + compact
@@ -210,10 +218,10 @@ expand_backward_kernel(int64_t V, int k, int apw, const float* __restrict__ scal
 }
 
 void launch_expand_count(int64_t n, const float* neural_opacity, uint32_t* wg_count, unsigned long long* total,
-                         hipStream_t st) {
+                         unsigned long long* mailbox, unsigned long long seq, hipStream_t st) {
     const uint32_t nwg = (uint32_t)((n + EXP_PER_WG - 1) / EXP_PER_WG);
     expand_count_kernel<<<nwg, EXP_THREADS, 0, st>>>(n, neural_opacity, wg_count);
-    expand_scan_kernel<<<1, 1024, 0, st>>>(nwg, wg_count, total);
+    expand_scan_kernel<<<1, 1024, 0, st>>>(nwg, wg_count, total, mailbox, seq);
 }
 
 void launch_expand_run(int64_t n, int k, const float* neural_opacity, const float* color, const float* scale_rot,
