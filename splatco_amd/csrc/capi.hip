@@ -99,6 +99,9 @@ static bool mailbox_wait(Mailbox& mb, unsigned long long seq, bool two, hipStrea
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
         if (mb.host[1] == seq && (!two || mb.host[3] == seq)) return true;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
         if ((spins & 1023u) == 1023u) {
             if (hipStreamQuery(st) != hipErrorNotReady) return mb.host[1] == seq && (!two || mb.host[3] == seq);
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return false;
