@@ -238,17 +238,15 @@ class PlaneGrid(nn.Module):                   # scene/grids.py:102-201
             # column order of :181: xy, xyA, xz, xzA, yz, yzA
             feat = triplane_sample(ind3, (self.xy_plane, self.xz_plane, self.yz_plane, xyA, xzA, yzA),
                                    cols=(0, 2 * R, 4 * R, R, 3 * R, 5 * R))
-            if Q != 0:                                              # noise on the plain samples only
-                noise = torch.zeros_like(feat).view(-1, 3, 2, R)
-                noise[:, :, 0].uniform_(-0.5, 0.5)
-                feat = feat + noise.view_as(feat) * Q
+            # no noise reaches the attention grid's output whatever Q is: the reference builds the noised
+            # concatenation at :159-164 and then overwrites it at :174-181 with the un-noised samples
             return feat.reshape(*shape, self.channels * 2)
         xy, xz, yz = _sample(self.xy_plane, ind, [1, 0]), _sample(self.xz_plane, ind, [2, 0]), _sample(self.yz_plane, ind, [2, 1])
-        if Q != 0:                                              # training-time uniform noise (:159-164)
-            xy = xy + torch.empty_like(xy).uniform_(-0.5, 0.5) * Q
-            xz = xz + torch.empty_like(xz).uniform_(-0.5, 0.5) * Q
-            yz = yz + torch.empty_like(yz).uniform_(-0.5, 0.5) * Q
         if not self.TAflag:
+            if Q != 0:                                          # training-time uniform noise (:159-164), plain grids only
+                xy = xy + torch.empty_like(xy).uniform_(-0.5, 0.5) * Q
+                xz = xz + torch.empty_like(xz).uniform_(-0.5, 0.5) * Q
+                yz = yz + torch.empty_like(yz).uniform_(-0.5, 0.5) * Q
             return torch.cat([xy, xz, yz], dim=-1).reshape(*shape, self.channels)
         tri = self.TA(torch.cat((self.xy_plane, self.xz_plane, self.yz_plane), dim=1))   # every call (:166-168)
         xyA, xzA, yzA = torch.chunk(tri, 3, dim=1)

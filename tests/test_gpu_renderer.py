@@ -192,10 +192,34 @@ def test_plane_grid_golden_on_gpu(name, ta):
     dev = torch.device("cuda:0")
     pg = PlaneGrid(15, [24, 24, 24], [-2.0, -2.0, -2.0], [2.0, 2.0, 2.0], TAflag=ta)
     pre = name + "."
-    pg.load_state_dict({k[len(pre):]: torch.tensor(d[k]) for k in d.files if k.startswith(pre) and not k.endswith(".out")})
+    pg.load_state_dict({k[len(pre):]: torch.tensor(d[k]) for k in d.files if k.startswith(pre) and ".out" not in k})
     with torch.no_grad():
         y = pg.to(dev)(torch.tensor(d["xyz"], device=dev), 0)
     np.testing.assert_allclose(y.cpu().numpy(), d[f"{name}.out"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,ta", [("plain", False), ("ta", True)])
+def test_plane_grid_training_noise_on_gpu(name, ta):
+    """Q = 0.03 (the training setting, scene/gaussian_model.py:187,213) through the fused kernel: the attention
+    grid's output equals its Q = 0 output bit for bit (scene/grids.py:160-181 discards the noised samples), a
+    plain grid's differs by at most 0.5 Q per element and is uniformly spread."""
+    from splatco_amd.scene_model import PlaneGrid
+    d = np.load(os.path.join(GOLD, "planegrid.npz"))
+    dev = torch.device("cuda:0")
+    pg = PlaneGrid(15, [24, 24, 24], [-2.0, -2.0, -2.0], [2.0, 2.0, 2.0], TAflag=ta)
+    pre = name + "."
+    pg.load_state_dict({k[len(pre):]: torch.tensor(d[k]) for k in d.files if k.startswith(pre) and ".out" not in k})
+    pg = pg.to(dev)
+    xyz = torch.tensor(d["xyz"], device=dev)
+    with torch.no_grad():
+        y0, yq = pg(xyz, 0), pg(xyz, 0.03)
+    if ta:
+        assert torch.equal(y0, yq)
+    else:
+        diff = (yq - y0).abs()
+        assert 0 < diff.max().item() <= 0.5 * 0.03 * (1 + 1e-5)
+        assert abs(diff.mean().item() - 0.25 * 0.03) < 0.02 * 0.03     # E|U(-0.5, 0.5)| = 0.25
+    np.testing.assert_allclose(y0.cpu().numpy(), d[f"{name}.out"], rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("H,W", [(64, 64), (70, 133), (1080, 1920)])

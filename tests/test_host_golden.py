@@ -44,7 +44,7 @@ def test_losses():
 
 
 def _load_prefixed(module, d, prefix):
-    sd = {k[len(prefix):]: torch.tensor(d[k]) for k in d.files if k.startswith(prefix) and not k.endswith(".out")}
+    sd = {k[len(prefix):]: torch.tensor(d[k]) for k in d.files if k.startswith(prefix) and ".out" not in k}
     missing, unexpected = module.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected
     assert all("num_batches_tracked" in m for m in missing), missing
@@ -60,6 +60,32 @@ def test_planegrid(name, ta):
         y = pg(torch.tensor(d["xyz"]), 0)
     assert y.shape == (1000, 30 if ta else 15)
     np.testing.assert_allclose(y.numpy(), d[f"{name}.out"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,ta", [("plain", False), ("ta", True)])
+def test_planegrid_training_noise(name, ta):
+    """Training passes Q = GaussianLearner.Q0 = 0.03 (scene/gaussian_model.py:187,213).  The reference's
+    attention grid builds the noised concatenation and then overwrites it with the un-noised samples
+    (scene/grids.py:160-181): its output carries NO noise; a plain grid adds U(-0.5, 0.5) * Q per sample.
+    The fixture holds the reference's own outputs for Q = 0.03 with the CPU generator seeded with 7."""
+    from splatco_amd.scene_model import PlaneGrid
+    d = _npz("planegrid.npz")
+    pg = PlaneGrid(15, [24, 24, 24], [-2.0, -2.0, -2.0], [2.0, 2.0, 2.0], TAflag=ta)
+    _load_prefixed(pg, d, name + ".")
+    xyz = torch.tensor(d["xyz"])
+    with torch.no_grad():
+        y0 = pg(xyz, 0)
+        torch.manual_seed(7)
+        yq = pg(xyz, 0.03)
+    if ta:
+        assert np.array_equal(d["ta.out_q003"], d["ta.out"])          # the reference itself: no noise
+        assert torch.equal(yq, y0)                                      # bit for bit
+    else:
+        # same draws in the same order (xy, xz, yz) from the same generator state: the reference's numbers
+        np.testing.assert_allclose(yq.numpy(), d["plain.out_q003"], rtol=1e-5, atol=1e-6)
+        diff = (yq - y0).abs()
+        assert 0 < diff.max() <= 0.5 * 0.03 * (1 + 1e-5) and diff.mean() > 0.2 * 0.03
+    assert yq.shape == y0.shape
 
 
 def _model_from_fixture(d):

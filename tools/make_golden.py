@@ -139,6 +139,11 @@ def make_planegrid():
             y = pg(xyz, 0)
         out.update(sd_np(f"{name}.", pg))
         out[f"{name}.out"] = f32(y)
+        # training-time plane noise (GaussianLearner.Q0 = 0.03, scene/gaussian_model.py:187,213): CPU generator
+        # seeded with 7 right before the call
+        torch.manual_seed(7)
+        with torch.no_grad():
+            out[f"{name}.out_q003"] = f32(pg(xyz, 0.03))
     np.savez_compressed(os.path.join(OUT, "planegrid.npz"), **out)
 
 
