@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 3
+#define SCR_ABI_VERSION 4
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -177,6 +177,27 @@ int scr_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img1, cons
 int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2,
                          const void* scratch, const float* g_l1, const float* g_ssim, float* dimg1,
                          void* stream);
+
+/* ---- densification statistics: GaussianModel.training_statis (scene/gaussian_model.py:761-782), the consumer of
+ * dL_dmeans2D (train.py:264-266), over the V visible anchors of one view (k offsets each), in two steps so that the
+ * sharded --mv step can broadcast the increments between them:
+ *   scr_statis_compute: neural_opacity[V*k], out_index[V*k] (scr_expand_run's compaction index, -1 = not selected),
+ *     update_filter[P] uint8 (radii > 0), viewspace_grad[P][grad_stride] (columns 0,1 = dL_dmeans2D.xy)
+ *     -> inc_opacity[V] = sum_slot max(neural_opacity, 0);  inc_grad[V*k] = |grad.xy| of the rendered selected
+ *     candidates, -1 elsewhere.
+ *   scr_statis_apply: visible_index[V] int64 (anchor of every visible row) + the increments -> the four accumulators
+ *     opacity_accum[N], anchor_demon[N], offset_gradient_accum[N*k], offset_denom[N*k] are updated in place.
+ * No atomics: every (anchor, slot) belongs to one thread; bit-reproducible. */
+int scr_statis_compute(int64_t V, int32_t k, const float* neural_opacity, const int32_t* out_index,
+                       const uint8_t* update_filter, const float* viewspace_grad, int32_t grad_stride,
+                       float* inc_opacity, float* inc_grad, void* stream);
+int scr_statis_apply(int64_t V, int32_t k, const int64_t* visible_index, const float* inc_opacity, const float* inc_grad,
+                     float* opacity_accum, float* anchor_demon, float* offset_gradient_accum, float* offset_denom,
+                     void* stream);
+
+/* ---- measurement aid: a float4 grid-stride copy of `bytes` bytes (src -> dst, device pointers).  bench.py times it to
+ * quote the HBM bandwidth a streaming kernel reaches on the box next to the 8 TB/s datasheet figure. */
+int scr_copy_probe(const void* src, void* dst, size_t bytes, void* stream);
 
 /* ---- opt-in kernel timing (bench / profiling only; process-global, off by default).
  * scr_profile_enable(mask): bit i of mask selects kernel class i (SCR_PROF_*); -1 = all, 0 = off.

@@ -18,9 +18,10 @@ SYMBOLS = [
     "scr_profile_kernel_name", "scr_expand_scratch_bytes", "scr_expand_plan", "scr_expand_run",
     "scr_expand_backward", "scr_plane_sample_scratch_bytes", "scr_plane_sample_backward", "scr_triplane_forward",
     "scr_l1_ssim_scratch_bytes", "scr_l1_ssim_forward", "scr_l1_ssim_backward",
+    "scr_statis_compute", "scr_statis_apply", "scr_copy_probe",
 ]
 PROF_COUNT = 14
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
 
@@ -85,6 +86,11 @@ def _load():
     lib.scr_l1_ssim_forward.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, vp]
     lib.scr_l1_ssim_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.scr_l1_ssim_forward.restype = lib.scr_l1_ssim_backward.restype = C.c_int
+    lib.scr_statis_compute.argtypes = [i64, i32, vp, vp, vp, vp, i32, vp, vp, vp]
+    lib.scr_statis_apply.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.scr_statis_compute.restype = lib.scr_statis_apply.restype = C.c_int
+    lib.scr_copy_probe.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.scr_copy_probe.restype = C.c_int
     lib.scr_profile_enable.argtypes = [C.c_int]
     lib.scr_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.scr_profile_kernel_name.argtypes = [C.c_int]

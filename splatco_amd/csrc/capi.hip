@@ -65,6 +65,11 @@ const char* const kProfNames[SCR_PROF_COUNT] = {
     "l1_ssim_backward_kernel", "triplane_forward_kernel"};
 }  // namespace
 
+// float4 grid-stride copy: measures the HBM bandwidth a streaming kernel can reach on this device (bench.py)
+__global__ void __launch_bounds__(256) copy_probe_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 // pinned host memory the GPU writes and the host polls (scr_forward_plan); per host thread, lives for the process
 struct Mailbox {
     volatile unsigned long long* host = nullptr;
@@ -412,6 +417,42 @@ int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, con
     { ProfScope ps_(SCR_PROF_L1_SSIM_BACKWARD, st);
       launch_l1_ssim_backward(C, H, W, img1, img2, scratch, g_l1, g_ssim, dimg1, st); }
     CHECK_LAUNCH("l1_ssim_backward_kernel", 0, st);
+    return 0;
+}
+
+// ---- densification statistics (densify.hip)
+int scr_statis_compute(int64_t V, int32_t k, const float* neural_opacity, const int32_t* out_index,
+                       const uint8_t* update_filter, const float* viewspace_grad, int32_t grad_stride,
+                       float* inc_opacity, float* inc_grad, void* stream) {
+    if (V < 0 || k <= 0 || grad_stride < 2) return fail("bad V / k / grad_stride");
+    if (V == 0) return 0;
+    if (!neural_opacity || !out_index || !inc_opacity || !inc_grad) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    launch_statis_compute(V, k, neural_opacity, out_index, update_filter, viewspace_grad, grad_stride, inc_opacity,
+                          inc_grad, st);
+    CHECK_LAUNCH("statis_compute_kernel", 0, st);
+    return 0;
+}
+
+int scr_statis_apply(int64_t V, int32_t k, const int64_t* visible_index, const float* inc_opacity, const float* inc_grad,
+                     float* opacity_accum, float* anchor_demon, float* offset_gradient_accum, float* offset_denom,
+                     void* stream) {
+    if (V < 0 || k <= 0) return fail("bad V / k");
+    if (V == 0) return 0;
+    if (!visible_index || !inc_opacity || !inc_grad || !opacity_accum || !anchor_demon || !offset_gradient_accum ||
+        !offset_denom)
+        return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    launch_statis_apply(V, k, visible_index, inc_opacity, inc_grad, opacity_accum, anchor_demon, offset_gradient_accum,
+                        offset_denom, st);
+    CHECK_LAUNCH("statis_apply_kernel", 0, st);
+    return 0;
+}
+
+int scr_copy_probe(const void* src, void* dst, size_t bytes, void* stream) {
+    if (!src || !dst || bytes < 16) return fail("NULL argument");
+    copy_probe_kernel<<<256 * 16, 256, 0, (hipStream_t)stream>>>((const float4*)src, (float4*)dst, bytes / 16);
+    CHECK_LAUNCH("copy_probe_kernel", 0, (hipStream_t)stream);
     return 0;
 }
 

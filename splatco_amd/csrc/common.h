@@ -288,6 +288,13 @@ void launch_expand_backward(int64_t V, int k, const float* scale_rot, const floa
                             const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
                             float* d_offsets, float* d_grid_scaling, float* d_anchor, hipStream_t st);
 
+void launch_statis_compute(int64_t V, int k, const float* neural_opacity, const int32_t* out_index,
+                           const uint8_t* update_filter, const float* grad, int gstride, float* inc_opacity,
+                           float* inc_grad, hipStream_t st);
+void launch_statis_apply(int64_t V, int k, const int64_t* visible_index, const float* inc_opacity, const float* inc_grad,
+                         float* opacity_accum, float* anchor_demon, float* offset_gradient_accum, float* offset_denom,
+                         hipStream_t st);
+
 size_t l1_ssim_scratch_bytes(int C, int H, int W, int with_grad);
 void launch_l1_ssim_forward(int C, int H, int W, const float* img1, const float* img2, void* scratch,
                             int with_grad, float* out2, hipStream_t st);

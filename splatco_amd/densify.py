@@ -14,7 +14,6 @@ Fixture: tests/golden/densify.npz (captured from the reference's own Python by t
 import torch
 from torch import nn
 
-from .stats import training_statis as _training_statis
 
 # optimizer param-group name -> model attribute (scene/gaussian_model.py:520-531)
 _PARAMS = {"anchor": "_anchor", "offset": "_offset", "anchor_feat": "_anchor_feat", "opacity": "_opacity",
@@ -58,8 +57,15 @@ class AnchorDensifier:
     parameters + their Adam state in place of `adjust_anchor`."""
 
     def __init__(self, model, optimizer, voxel_size=0.001, update_depth=3, update_init_factor=16,
-                 update_hierachy_factor=4):
+                 update_hierachy_factor=4, seed=None):
+        """seed: draw the random candidate picks of anchor_growing (:843-844, torch.rand_like on the global
+        generator in the reference) from a private generator seeded with it -- every rank of the sharded --mv step
+        passes the same seed, so that the replicas grow identical anchor sets."""
         self.model, self.optimizer = model, optimizer
+        self.generator = None
+        if seed is not None:
+            self.generator = torch.Generator(device=model._anchor.device)
+            self.generator.manual_seed(int(seed))
         self.voxel_size, self.update_depth = voxel_size, update_depth
         self.update_init_factor, self.update_hierachy_factor = update_init_factor, update_hierachy_factor
         self.n_offsets, self.feat_dim = model.n_offsets, model.feat_dim
@@ -72,9 +78,16 @@ class AnchorDensifier:
 
     # ---- :761-782
     def training_statis(self, viewspace_point_tensor, opacity, update_filter, offset_selection_mask, anchor_visible_mask):
-        _training_statis(self.opacity_accum, self.anchor_demon, self.offset_gradient_accum, self.offset_denom,
-                         self.n_offsets, viewspace_point_tensor.grad, opacity, update_filter, offset_selection_mask,
-                         anchor_visible_mask)
+        from . import stats
+        stats.training_statis(self.opacity_accum, self.anchor_demon, self.offset_gradient_accum, self.offset_denom,
+                              self.n_offsets, viewspace_point_tensor.grad, opacity, update_filter, offset_selection_mask,
+                              anchor_visible_mask)
+
+    def apply_statis(self, visible_index, inc_opacity, inc_grad):
+        """Adds one view's increments (stats.statis_increments, possibly computed on another rank)."""
+        from . import stats
+        stats.statis_apply(self.opacity_accum, self.anchor_demon, self.offset_gradient_accum, self.offset_denom,
+                           self.n_offsets, visible_index, inc_opacity, inc_grad)
 
     # ---- optimizer surgery (:738-759, 784-818)
     def _groups(self):
@@ -120,7 +133,11 @@ class AnchorDensifier:
         for i in range(self.update_depth):
             cur_threshold = threshold * ((self.update_hierachy_factor // 2) ** i)
             candidate_mask = (grads >= cur_threshold) & offset_mask
-            rand_mask = torch.rand_like(candidate_mask.float()) > (0.5 ** (i + 1))     # random pick (:844)
+            if self.generator is None:
+                rand = torch.rand_like(candidate_mask.float())
+            else:
+                rand = torch.rand(candidate_mask.shape, device=candidate_mask.device, generator=self.generator)
+            rand_mask = rand > (0.5 ** (i + 1))                                          # random pick (:844)
             candidate_mask = candidate_mask & rand_mask
             length_inc = m._anchor.shape[0] * k - init_length
             if length_inc == 0:

@@ -36,11 +36,11 @@ class _ExpandCompact(torch.autograd.Function):
                                            _stream()))
         ctx.save_for_backward(scale_rot, offsets, grid_scaling, out_index)
         ctx.dims = (V, k)
-        ctx.mark_non_differentiable(mask)
-        return xyz, col, opa, sca, rot, mask
+        ctx.mark_non_differentiable(mask, out_index)
+        return xyz, col, opa, sca, rot, mask, out_index
 
     @staticmethod
-    def backward(ctx, g_xyz, g_col, g_opa, g_sca, g_rot, _g_mask):
+    def backward(ctx, g_xyz, g_col, g_opa, g_sca, g_rot, _g_mask, _g_index):
         scale_rot, offsets, grid_scaling, out_index = ctx.saved_tensors
         V, k = ctx.dims
         dev, n = scale_rot.device, V * k
@@ -61,4 +61,9 @@ class _ExpandCompact(torch.autograd.Function):
 def expand_compact(neural_opacity, color, scale_rot, grid_offsets, grid_scaling, anchor, n_offsets):
     """neural_opacity [V*k,1], color [V*k,3], scale_rot [V*k,7], grid_offsets [V,k,3], grid_scaling [V,6],
     anchor [V,3]  ->  xyz, color, opacity, scaling, rot (compacted, order preserved), mask [V*k] bool."""
-    return _ExpandCompact.apply(neural_opacity, color, scale_rot, grid_offsets, grid_scaling, anchor, int(n_offsets))
+    *out, mask, out_index = _ExpandCompact.apply(neural_opacity, color, scale_rot, grid_offsets, grid_scaling, anchor,
+                                                 int(n_offsets))
+    # the compaction index rides along with the mask: the densification statistics (stats.selection_index) need the
+    # position of every selected candidate among the Gaussians and would otherwise recompute it with a prefix sum
+    mask._scr_out_index = out_index
+    return (*out, mask)

@@ -51,20 +51,40 @@ def _shared_arena(params):
     return torch.empty(0, dtype=grads[0].dtype, device=grads[0].device).set_(st, start, (pos - start,))
 
 
+def _agree(flag: bool, signature: int, device) -> bool:
+    """True only if `flag` is True and `signature` identical on EVERY rank (one 12-byte MIN all-reduce).  The
+    in-place and the packed path move the same number of elements in different orders, so a split decision -- or
+    two ranks whose gradients tile their buffers in different orders -- would sum misaligned data silently."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return flag
+    t = torch.tensor([1 if flag else 0, signature, -signature], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t[0].item()) and int(t[1].item()) == -int(t[2].item())
+
+
 def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = None) -> torch.Tensor:
     """SUM-all-reduce the .grad of every tensor in `params` through one flat bucket, in place.
     Parameters without a gradient on this rank contribute zeros (a rank whose views do not see
-    an anchor still takes part).  Returns the bucket (reusable)."""
+    an anchor still takes part).  Returns the bucket (reusable).  Every rank must pass the same
+    parameters in the same order.  (The training step uses GradArena instead: no packing at all.)"""
     params = [p for p in params if p is not None and p.requires_grad]
     if not params:
         return bucket
+    dev, dt = params[0].device, params[0].dtype
     arena = _shared_arena(params)
-    if arena is not None:      # the gradients already sit side by side in one buffer: reduce it in place
+    # the gradients already sit side by side in one buffer (the rasterizer's backward allocates them that way):
+    # reduce that buffer in place -- provided EVERY rank is in that situation with the same layout (which
+    # parameter sits where), otherwise all ranks pack in the caller's parameter order
+    sig = 0
+    if arena is not None:
+        order = sorted(range(len(params)), key=lambda i: params[i].grad.storage_offset())
+        for i in order:
+            sig = (sig * 1000003 + i + 1) % (1 << 61)
+    if _agree(arena is not None, sig, dev):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(arena, op=dist.ReduceOp.SUM)
         return arena
     n = sum(p.numel() for p in params)
-    dev, dt = params[0].device, params[0].dtype
     if bucket is None or bucket.numel() != n or bucket.device != dev:
         bucket = torch.empty(n, dtype=dt, device=dev)
     off = 0
@@ -89,6 +109,111 @@ def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = N
     return bucket
 
 
+class GradArena:
+    """ONE persistent flat buffer (fp32 in the product) that IS the .grad of every parameter of the training step.
+
+    The per-anchor parameters of a SplatCo scene carry 71 floats of gradient per anchor (anchor 3 + offset 30 +
+    feature 32 + scaling 6, scene/gaussian_model.py:502-507): 1.42 GB at 5 M anchors, 5.68 GB at 20 M.  Packing them
+    into a bucket and unpacking after the collective would copy that twice per step.  Here every p.grad is a view
+    of the arena from the start: autograd accumulates into it in place (AccumulateGrad adds into an existing
+    .grad), the collective runs on slices of the same memory, and the optimiser reads the reduced values where
+    they are.  Per step: zero() -> backward -> reduce() -> optimizer.step().
+
+    The exchange is issued in pieces (one per parameter, large parameters split into `chunk_bytes` pieces, every
+    piece an independent collective that RCCL can spread over the xGMI links), either
+      * from post-accumulate hooks, as soon as autograd has finished a parameter's gradient -- the tail of the
+        backward pass (MLP weights and planes finish before the per-anchor tensors) overlaps the transfers; or
+      * all at once by reduce() when hooks are off.
+    mode "all_reduce": dist.all_reduce(SUM) per piece.  mode "rs_ag": reduce_scatter_tensor + all_gather_into_tensor
+    on a piece padded to a multiple of the world size (on the point-to-point xGMI mesh every rank then owns 1/world
+    of the sum and all 7 links carry traffic in both phases).
+    Every rank must build the arena from the same parameters in the same order (the layout is that order)."""
+
+    def __init__(self, params: Sequence[torch.Tensor], chunk_bytes: int = 256 << 20, mode: str = "all_reduce",
+                 overlap: bool = True):
+        self.params = [p for p in params if p is not None and p.requires_grad]
+        assert self.params, "no trainable parameters"
+        assert mode in ("all_reduce", "rs_ag")
+        dev = self.params[0].device
+        dt = self.params[0].dtype
+        assert all(p.dtype == dt and p.device == dev for p in self.params)
+        self.itemsize = self.params[0].element_size()
+        self.mode, self.overlap = mode, overlap
+        rank, world = world_info()
+        self.world = world
+        align = 64 * max(world, 1)                       # elements: every parameter starts on a 256-byte, world-divisible boundary
+        self.offsets, total = [], 0
+        for p in self.params:
+            self.offsets.append(total)
+            total += (p.numel() + align - 1) // align * align
+        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
+        chunk = max(align, chunk_bytes // self.itemsize // align * align)
+        self.pieces = []                                  # per parameter: [(start, stop) of padded pieces]
+        for o, p in zip(self.offsets, self.params):
+            end = o + (p.numel() + align - 1) // align * align
+            self.pieces.append([(a, min(a + chunk, end)) for a in range(o, end, chunk)])
+        self._work, self._handles, self._pending = [], [], []
+        self._fired = [False] * len(self.params)
+        self.bind()
+        if overlap and world > 1:
+            for i, p in enumerate(self.params):
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def bind(self):
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def zero(self):
+        """Start of a step: clear the arena and make sure every .grad still aliases it."""
+        self.flat.zero_()
+        self._fired = [False] * len(self.params)
+        self.bind()
+
+    def _issue(self, i):
+        for a, b in self.pieces[i]:
+            piece = self.flat[a:b]
+            if self.mode == "all_reduce":
+                self._work.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
+            else:                                         # phase 1 now, phase 2 (the gather) from reduce()
+                n = (b - a) // self.world
+                mine = piece[dist.get_rank() * n:(dist.get_rank() + 1) * n]
+                self._work.append(dist.reduce_scatter_tensor(mine, piece, op=dist.ReduceOp.SUM, async_op=True))
+                self._pending.append((piece, mine))
+
+    def _make_hook(self, i):
+        def hook(param):
+            if param.grad is not self.views[i] and param.grad.data_ptr() != self.views[i].data_ptr():
+                self.views[i].copy_(param.grad)           # autograd replaced the tensor (never seen; kept correct)
+                param.grad = self.views[i]
+            self._fired[i] = True
+            self._issue(i)
+        return hook
+
+    def reduce(self):
+        """SUM over ranks of everything in the arena; returns when the reduced gradients are usable on the current
+        stream.  Parameters whose hook did not fire (no gradient on this rank: zeros) are exchanged now."""
+        if self.world > 1:
+            for i in range(len(self.params)):
+                if not (self.overlap and self._fired[i]):
+                    self._issue(i)
+            for w in self._work:
+                w.wait()
+            self._work = [dist.all_gather_into_tensor(piece, mine, async_op=True) for piece, mine in self._pending]
+            for w in self._work:
+                w.wait()
+            self._work, self._pending = [], []
+        return self.flat
+
+    def nbytes(self):
+        return self.flat.numel() * self.itemsize
+
+    def close(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
 def align_images(*imgs):                                        # train.py:79-96
     h, w = min(i.shape[1] for i in imgs), min(i.shape[2] for i in imgs)
     return tuple(i[:, :h, :w] for i in imgs)
@@ -106,7 +231,7 @@ def pair_consistency(gen1, real1, gen2, real2):
     return s * torch.abs(l1_loss(real1 - real2, gen1 - gen2))
 
 
-def consistency_loss(local: Sequence, weight: float = 0.05):
+def consistency_loss(local: Sequence, weight: float = 0.05, device=None):
     """Sum over ALL view pairs of pair_consistency, times `weight` (train.py:201-239), in the sharded
     setting: `local` = [(global view index, rendered image, gt image), ...] of this rank.  The rendered
     and ground-truth images of the other ranks are all-gathered as constants; a pair with one remote
@@ -115,7 +240,12 @@ def consistency_loss(local: Sequence, weight: float = 0.05):
     rank's loss before backward, this rank's share of the loss VALUE -- cross-rank pairs count half)."""
     rank, world = world_info()
     items = [(int(i), g, r, True) for i, g, r in local]
+    if device is None and local:
+        device = local[0][1].device
     if world > 1:
+        if device is None:
+            raise ValueError("consistency_loss: a rank without local views must pass device= (the collectives need "
+                             "buffers on the communicator's device)")
         mine = [(int(i), g.detach(), r.detach()) for i, g, r in local]
         everyone = [None] * world
         dist.all_gather_object(everyone, [(i, tuple(g.shape)) for i, g, _ in mine])
@@ -125,8 +255,7 @@ def consistency_loss(local: Sequence, weight: float = 0.05):
                     g, r = next((g, r) for j, g, r in mine if j == i)
                     pair = torch.stack([g, r]).contiguous()
                 else:
-                    pair = torch.empty((2,) + shape, dtype=local[0][1].dtype if local else torch.float32,
-                                       device=local[0][1].device if local else None)
+                    pair = torch.empty((2,) + shape, dtype=local[0][1].dtype if local else torch.float32, device=device)
                 dist.broadcast(pair, src=src)
                 if src != rank:
                     items.append((i, pair[0], pair[1], False))

@@ -29,10 +29,11 @@ def _mlp_heads(pc, x):
     return tuple(h[2:](x_) for h, x_ in zip(heads, parts))
 
 
-def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False, fused=None):
+def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False, expand=None):
     """Anchors -> neural Gaussians (gaussian_renderer/__init__.py:18-116), same op order.
-    fused: run the mask / compaction / post-processing block (:68-111) as the single HIP op of
-    splatco_amd.expand (default: on device tensors); False keeps the reference's torch op chain."""
+    The mask / compaction / post-processing block (:68-111) is the single HIP op of splatco_amd.expand
+    (device tensors only, no CPU path).  expand: test hook -- a callable with expand_compact's signature
+    (tests/torch_restatements.py holds the torch op chain the kernel is checked against)."""
     if visible_mask is None:
         visible_mask = torch.ones(pc.get_anchor.shape[0], dtype=torch.bool, device=pc.get_anchor.device)
     # `t[visible_mask]` four times (:23-29) = four mask->index conversions (each a host sync) and
@@ -64,28 +65,13 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     neural_opacity = neural_opacity.reshape([-1, 1])
     color = color.reshape([V * k, 3])
     scale_rot = scale_rot.reshape([V * k, 7])
-    if fused is None:
-        fused = anchor.is_cuda
-    if fused:
-        from .expand import expand_compact
-        xyz, color, opacity, scaling, rot, mask = expand_compact(neural_opacity, color, scale_rot, grid_offsets,
-                                                                 grid_scaling, anchor, k)
-        if is_training:
-            return xyz, color, opacity, scaling, rot, neural_opacity, mask
-        return xyz, color, opacity, scaling, rot
-    mask = (neural_opacity > 0.0).view(-1)
-    opacity = neural_opacity[mask]
-    offsets = grid_offsets.view([-1, 3])
-    # combine for parallel masking (:96-103): [scaling 6 | anchor 3] repeated k times, then one gather
-    concatenated = torch.cat([grid_scaling, anchor], dim=-1)
-    concatenated_repeated = concatenated.unsqueeze(1).expand(V, k, 9).reshape(V * k, 9)
-    concatenated_all = torch.cat([concatenated_repeated, color, scale_rot, offsets], dim=-1)
-    masked = concatenated_all[mask]
-    scaling_repeat, repeat_anchor, color, scale_rot, offsets = masked.split([6, 3, 3, 7, 3], dim=-1)
-    scaling = scaling_repeat[:, 3:] * torch.sigmoid(scale_rot[:, :3])
-    rot = pc.rotation_activation(scale_rot[:, 3:7])
-    offsets = offsets * scaling_repeat[:, :3]
-    xyz = repeat_anchor + offsets
+    if expand is None:
+        if not anchor.is_cuda:
+            raise RuntimeError("generate_neural_gaussians needs device tensors: the expansion / compaction step is a "
+                               "HIP kernel (csrc/expand.hip) and has no CPU path")
+        from .expand import expand_compact as expand
+    xyz, color, opacity, scaling, rot, mask = expand(neural_opacity, color, scale_rot, grid_offsets, grid_scaling,
+                                                     anchor, k)
     if is_training:
         return xyz, color, opacity, scaling, rot, neural_opacity, mask
     return xyz, color, opacity, scaling, rot

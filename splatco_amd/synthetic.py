@@ -47,3 +47,39 @@ def synthetic_gaussians(P, width, height, seed=0, fovx_deg=60.0):
     f32 = np.float32
     return dict(means3D=means.astype(f32), scales=scales.astype(f32), rotations=q.astype(f32),
                 opacities=opac.astype(f32), colors=col.astype(f32), bg=np.ones(3, f32))
+
+
+# ---- anchor scenes of BASELINE.json configs[2..4]
+ANCHOR_CONFIGS = {
+    # name: (anchors, views = mv, seed)
+    "cfg2": (5_000_000, 1, 1),
+    "cfg3": (5_000_000, 4, 2),
+    "cfg4": (20_000_000, 8, 3),
+}
+
+
+def synthetic_anchor_model(N, seed, device, plane_size=2800, num_channels=15, activate_level=2, n_offsets=10):
+    """N anchors uniform in [-2,2]^3 (the tri-plane's fixed box, scene/gaussian_model.py:185), k = 10 offsets,
+    32 features, tri-plane features at `plane_size` with levels 0..activate_level active, seeded MLP / plane
+    weights, plane noise off (Q0 = 0, as render.py:79).  Everything is drawn from torch generators seeded with
+    `seed` (weights on the host, the per-anchor tensors on `device`)."""
+    import torch
+    from .scene_model import AnchorGaussianModel
+    torch.manual_seed(seed)                                   # module initialisers (host generator)
+    pc = AnchorGaussianModel(plane_size=plane_size, num_channels=num_channels, n_offsets=n_offsets).to(device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    r = lambda *s: torch.rand(*s, device=device, generator=g)
+    n = lambda *s: torch.randn(*s, device=device, generator=g)
+    pc.set_anchors(r(N, 3) * 4 - 2, n(N, n_offsets, 3) * 0.5, n(N, 32) * 0.5, n(N, 6) * 0.3 - 5.0)
+    pc.feat_planes.Q0 = 0
+    pc.feat_planes._feat.activate_level = activate_level
+    pc.train()
+    return pc
+
+
+def synthetic_views(n, width=1920, height=1080, fovx_deg=60.0):
+    """n cameras outside the [-2,2]^3 box looking at its centre (view i is shifted sideways by 0.3 i)."""
+    from .cameras import look_at_camera
+    return [look_at_camera((0.5 + 0.3 * i, -0.4, -6.0), (0.0, 0.0, 0.0), (0.0, -1.0, 0.0), math.radians(fovx_deg),
+                           width, height, uid=i) for i in range(n)]

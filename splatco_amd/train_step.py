@@ -3,27 +3,69 @@ for the multi-view configurations of BASELINE.json (configs[3], configs[4]): ren
 shard of the mv views, per-view loss 0.8 L1 + 0.2 (1 - SSIM) + 0.01 mean(prod scaling) summed over
 views (train.py:192-198), optionally the pairwise cross-view consistency term (train.py:201-239, weight
 0.05 for update_from < iteration < update_until), ONE backward (train.py:240), SUM all-reduce of the
-gradients, the densification statistics of the last view (train.py:266) and the optimizer step
-(train.py:310-312).  Learning-rate schedules, the key-point pruning of train.py:219-236, logging and
-checkpoints are out of scope."""
+gradients, the densification statistics of the LAST view of the mv loop (train.py:264-266) on every rank,
+and the optimizer step (train.py:310-312).  Learning-rate schedules, the key-point pruning of
+train.py:219-236, logging and checkpoints are out of scope."""
 import torch
+import torch.distributed as dist
 
 from .losses import view_loss
-from .multiview import allreduce_gradients, consistency_loss, shard_views, world_info
+from .multiview import GradArena, allreduce_gradients, consistency_loss, shard_views, world_info
 from .renderer import prefilter_voxel, render
 
 
-def collaborative_step(pc, views, gt_images, pipe, bg_color, optimizer=None, bucket=None,
-                       consistency_weight=0.0, densifier=None):
-    """views / gt_images: the identically ordered mv view list every rank holds; gt_images[i] is the
-    [3,H,W] target of views[i] (host or device).  densifier: a splatco_amd.densify.AnchorDensifier whose
-    accumulators are fed from this rank's LAST rendered view (the reference uses the last view of the mv
-    loop, train.py:266; with sharded views the caller applies them on the rank that owns it).
-    Returns (local loss sum, last render dict, bucket)."""
-    params = [p for p in pc.parameters() if p.requires_grad]
-    for p in params:
-        p.grad = None
+def sync_densification_stats(densifier, n_views, out, vis, device):
+    """training_statis of the mv loop's LAST view (train.py:264-266 uses the variables the final loop pass left
+    behind) applied on EVERY rank, so that the replicas keep identical accumulators and adjust_anchor (which every
+    rank runs with an identically seeded generator) grows / prunes the same anchors everywhere.
+
+    View mv-1 is rendered by rank (mv-1) % world as its last local view.  That rank computes the view's compact
+    increments (stats.statis_increments: V + V*k floats, V = visible anchors) and broadcasts them with the visible
+    anchor indices; every rank applies them (stats.statis_apply).  One header + two payload broadcasts; ~48 bytes per
+    visible anchor instead of re-rendering the view or shipping the four accumulators (88 bytes per anchor)."""
+    from . import stats
     rank, world = world_info()
+    owner = (n_views - 1) % world if n_views > 0 else 0
+    k = densifier.n_offsets
+    if rank == owner:
+        if out is None:
+            raise RuntimeError("the rank that owns the last view rendered nothing")
+        with torch.no_grad():
+            inc_op, inc_g = stats.statis_increments(k, out["viewspace_points"].grad, out["neural_opacity"],
+                                                    out["visibility_filter"], out["selection_mask"])
+            vis_idx = vis.nonzero(as_tuple=False).squeeze(1)
+    if world > 1:
+        head = torch.tensor([vis_idx.numel() if rank == owner else 0], dtype=torch.int64, device=device)
+        dist.broadcast(head, src=owner)
+        V = int(head.item())
+        if rank != owner:
+            vis_idx = torch.empty(V, dtype=torch.int64, device=device)
+            payload = torch.empty(V + V * k, dtype=torch.float32, device=device)
+        else:
+            payload = torch.cat([inc_op, inc_g])
+        dist.broadcast(vis_idx, src=owner)
+        dist.broadcast(payload, src=owner)
+        inc_op, inc_g = payload[:V], payload[V:]
+    with torch.no_grad():
+        densifier.apply_statis(vis_idx, inc_op, inc_g)
+
+
+def collaborative_step(pc, views, gt_images, pipe, bg_color, optimizer=None, bucket=None,
+                       consistency_weight=0.0, densifier=None, arena=None):
+    """views / gt_images: the identically ordered mv view list every rank holds; gt_images[i] is the
+    [3,H,W] target of views[i] (host or device).  densifier: a splatco_amd.densify.AnchorDensifier; its
+    accumulators receive the statistics of the LAST view of the list on every rank (sync_densification_stats).
+    arena: a multiview.GradArena over the trainable parameters (gradients live in one persistent buffer that is
+    all-reduced in place, piecewise, overlapping the tail of the backward pass); without it the gradients are
+    packed into `bucket`.  Returns (local loss sum, last render dict, bucket or arena buffer)."""
+    params = arena.params if arena is not None else [p for p in pc.parameters() if p.requires_grad]
+    if arena is not None:
+        arena.zero()
+    else:
+        for p in params:
+            p.grad = None
+    rank, world = world_info()
+    device = params[0].device
     total, out, vis, rendered = None, None, None, []
     for k, (cam, gt) in enumerate(zip(shard_views(views), shard_views(gt_images))):
         vis = prefilter_voxel(cam, pc, pipe, bg_color)
@@ -34,16 +76,17 @@ def collaborative_step(pc, views, gt_images, pipe, bg_color, optimizer=None, buc
         if consistency_weight:
             rendered.append((rank + k * world, out["render"], gt))
     if consistency_weight:
-        term, _ = consistency_loss(rendered, consistency_weight)
+        term, _ = consistency_loss(rendered, consistency_weight, device=device)
         if term is not None:
             total = term if total is None else total + term
     if total is not None:
         total.backward()
-    bucket = allreduce_gradients(params, bucket)
-    if densifier is not None and out is not None:
-        with torch.no_grad():
-            densifier.training_statis(out["viewspace_points"], out["neural_opacity"], out["visibility_filter"],
-                                      out["selection_mask"], vis)
+    if arena is not None:
+        bucket = arena.reduce()
+    else:
+        bucket = allreduce_gradients(params, bucket)
+    if densifier is not None:
+        sync_densification_stats(densifier, len(views), out, vis, device)
     if optimizer is not None:
         optimizer.step()
     return (total.detach() if total is not None else None), out, bucket

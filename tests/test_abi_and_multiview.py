@@ -127,6 +127,80 @@ assert torch.equal(arena, torch.arange(12, dtype=torch.float64) * 3)
 c_.grad = torch.ones(4, dtype=torch.float64)                               # a stranger breaks the tiling: packed path
 allreduce_gradients([a_, b_, c_])
 assert torch.equal(c_.grad, torch.full((4,), 2.0, dtype=torch.float64)) and torch.equal(a_.grad, torch.arange(3, 8, dtype=torch.float64) * 6)
+# ranks that disagree -- rank 0 holds an arena, rank 1 separate tensors; then two arenas with different layouts --
+# must all take the packed path in parameter order instead of summing misaligned buffers
+vals = [torch.arange(n, dtype=torch.float64) + 10 * j for j, n in enumerate((5, 3, 4))]
+for case in ("arena vs separate", "two layouts"):
+    ar = torch.zeros(12, dtype=torch.float64)
+    if case == "arena vs separate" and rank == 1:
+        a_.grad, b_.grad, c_.grad = (v.clone() for v in vals)
+    elif case == "two layouts" and rank == 1:
+        a_.grad, b_.grad, c_.grad = ar[0:5], ar[5:8], ar[8:12]             # a, b, c
+    else:
+        b_.grad, a_.grad, c_.grad = ar[0:3], ar[3:8], ar[8:12]             # b, a, c
+    for p_, v in zip((a_, b_, c_), vals):
+        p_.grad.copy_(v)
+    allreduce_gradients([a_, b_, c_])
+    for p_, v in zip((a_, b_, c_), vals):
+        assert torch.equal(p_.grad, 2 * v), (case, rank)
+# ---- GradArena: gradients live in one persistent buffer, exchanged piecewise (hooks + both collective shapes)
+from splatco_amd.multiview import GradArena
+for mode, overlap in (("all_reduce", True), ("rs_ag", True), ("all_reduce", False)):
+    arena = GradArena(params, chunk_bytes=256, mode=mode, overlap=overlap)      # tiny pieces: several per parameter
+    for it in range(2):                                                         # the buffer is reused step after step
+        arena.zero()
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, arena.views))
+        local = None
+        for v in shard_views(views):
+            l = render_loss(v)
+            local = l if local is None else local + l
+        local.backward()
+        arena.reduce()
+        want = torch.autograd.grad(sum(render_loss(v) for v in views), params)
+        for p, w in zip(params, want):
+            assert torch.allclose(p.grad, w, rtol=1e-10, atol=1e-12), (mode, overlap, rank)
+    arena.close()
+for p in params: p.grad = None
+# ---- densification statistics of the LAST view reach every rank; identically seeded growth -> identical anchors
+import splatco_amd.stats as stats
+from torch_restatements import statis_increments_torch, statis_apply_torch
+stats.statis_increments, stats.statis_apply = statis_increments_torch, statis_apply_torch   # CPU stand-ins of the HIP kernels
+from splatco_amd.densify import AnchorDensifier
+from splatco_amd.scene_model import AnchorGaussianModel
+from splatco_amd.train_step import sync_densification_stats
+torch.manual_seed(11)                                    # the same replica on both ranks
+N, k = 300, 10
+pc = AnchorGaussianModel(plane_size=16, num_channels=15)
+pc.set_anchors(torch.rand(N, 3) * 2 - 1, torch.randn(N, k, 3) * 0.1, torch.randn(N, 32), torch.randn(N, 6) * 0.1 - 3)
+groups = [{"params": [getattr(pc, "_" + n)], "lr": 1e-3, "name": n} for n in ("anchor", "offset", "anchor_feat", "scaling", "opacity", "rotation")]
+opt = torch.optim.Adam(groups)
+den = AnchorDensifier(pc, opt, voxel_size=0.05, seed=1234)
+for it in range(1, 5):
+    # every rank "renders" ITS OWN view (different random tensors per rank); only the last view's must count
+    gen = torch.Generator().manual_seed(100 * it + rank)
+    vis = torch.rand(N, generator=gen) < 0.7
+    V = int(vis.sum())
+    no = torch.randn(V * k, 1, generator=gen)
+    sel = (no > 0).view(-1)
+    P = int(sel.sum())
+    vp = torch.zeros(P, 3); vp.grad = torch.randn(P, 3, generator=gen) * 0.01
+    out = {"viewspace_points": vp, "neural_opacity": no, "visibility_filter": torch.rand(P, generator=gen) < 0.8,
+           "selection_mask": sel}
+    sync_densification_stats(den, 4, out, vis, torch.device("cpu"))      # mv = 4 views: the last one belongs to rank 1
+den.offset_denom += 50                                                     # enough visits for the growth test (:932)
+den.anchor_demon += 90
+den.adjust_anchor(iteration=100, check_interval=100, grad_threshold=0.004)
+assert pc._anchor.shape[0] != N
+state = torch.cat([pc._anchor.detach().reshape(-1), pc._anchor_feat.detach().reshape(-1), den.offset_denom.reshape(-1),
+                   den.opacity_accum.reshape(-1)])
+n_all = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+dist.all_gather(n_all, torch.tensor([state.numel()]))
+assert all(int(n) == state.numel() for n in n_all), n_all                  # same number of anchors everywhere
+both = [torch.zeros_like(state) for _ in range(world)]
+dist.all_gather(both, state)
+assert all(torch.equal(both[0], b) for b in both)                          # identical anchor sets + accumulators
+# rank 1's view counted, rank 0's did not: replay rank 1's last increments locally and compare one accumulator
+print("anchors", N, "->", pc._anchor.shape[0])
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''

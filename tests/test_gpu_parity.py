@@ -5,7 +5,10 @@ Bars (SURVEY.md 8c / BASELINE.md 2):
     n_contrib: bit-exact wherever no exp()-dependent decision of the pixel lies within 1e-5
     (relative) of its threshold (the spec allows exp() 2 ulp), and >= 99.9 % of pixels overall;
   * image: max-abs <= 1e-4 and PSNR(build, oracle) >= 80 dB (utils/image_utils.py:17-19);
-  * gradients: rel-L2 <= 1e-4 per tensor vs the fp32 oracle; bit-reproducible run to run.
+  * gradients: rel-L2 <= 1e-4 per tensor vs the fp32 oracle, checked UNCONDITIONALLY: pixels whose
+    n_contrib differs from the oracle's (exp() within 2 ulp of a threshold: at most 0.1 % of the image, the
+    count is printed) get dL/dpixel = 0 on BOTH sides, everything else is compared;
+    bit-reproducible run to run.
 """
 import math
 
@@ -13,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import oracle_settings, psnr, rel_l2, small_scene
+from util import oracle_settings, psnr, rel_l2, small_scene, stress_scene
 from splatco_amd.synthetic import synthetic_camera, synthetic_gaussians
 
 pytestmark = pytest.mark.gpu
@@ -39,8 +42,14 @@ def _t(a, grad=False):
     return None if a is None else torch.tensor(np.asarray(a), dtype=torch.float32, device=_dev(), requires_grad=grad)
 
 
-def _run_gpu(cam, g, scale_modifier=1.0, sh_degree=1, shs=None, cov=None, dL=None, debug=False):
-    """Forward (+ backward when dL is given) through the operator; returns numpy results."""
+EXCUSED_MAX = 1e-3     # largest fraction of pixels whose n_contrib may differ from the oracle's (threshold pixels)
+
+
+def _run_gpu(cam, g, scale_modifier=1.0, sh_degree=1, shs=None, cov=None, dL=None, debug=False, ref=None):
+    """Forward (+ backward when dL is given) through the operator; returns numpy results.
+    ref: the oracle's forward results.  Pixels whose n_contrib differs from ref's are EXCUSED from the gradient
+    comparison by zeroing dL/dpixel there (out["dL_eff"] is what the backward ran on -- the oracle's backward must
+    be given the same array); their count is bounded and reported."""
     from splatco_amd import rasterizer as R
     from splatco_amd import _C
     rs = _settings(cam, g["bg"], scale_modifier, sh_degree, debug)
@@ -71,11 +80,20 @@ def _run_gpu(cam, g, scale_modifier=1.0, sh_degree=1, shs=None, cov=None, dL=Non
         out["point_offsets"] = st.debug(_C.DBG_POINT_OFFSETS).cpu().numpy().view(np.uint32)
         out["point_list"] = st.debug(_C.DBG_POINT_LIST).cpu().numpy().view(np.uint32)
     if grad:
+        dL_eff = np.array(dL, dtype=np.float32, copy=True)
+        if ref is not None:
+            excused = out["n_contrib"] != ref["n_contrib"]
+            dL_eff[:, excused] = 0.0
+            out["excused"] = int(excused.sum())
+            print(f"[parity] pixels excused from the gradient comparison (n_contrib differs at a threshold): "
+                  f"{out['excused']} of {excused.size} ({excused.mean():.2e})")
+            assert excused.mean() <= EXCUSED_MAX, f"{out['excused']} pixels differ in n_contrib"
+        out["dL_eff"] = dL_eff
         rast = R.GaussianRasterizer(rs)
         img, rad2 = rast(means3D=m, means2D=m2d, opacities=o, shs=sh, colors_precomp=c, scales=s, rotations=r,
                          cov3D_precomp=cv)
         assert torch.equal(rad2, radii) and torch.equal(img, color)  # deterministic forward
-        (img * _t(dL)).sum().backward()
+        (img * _t(dL_eff)).sum().backward()
         gr = dict(means3D=m.grad, means2D=m2d.grad, opacities=o.grad)
         if cov is None:
             gr.update(scales=s.grad, rotations=r.grad)
@@ -105,16 +123,23 @@ def _check_forward(f, o, st, full_ncontrib=True):
     assert np.array_equal(o["n_contrib"][safe], f["n_contrib"][safe]), "n_contrib away from thresholds"
     assert (o["n_contrib"] == f["n_contrib"]).mean() >= 0.999
     cmp_px = safe & (o["n_contrib"] == f["n_contrib"])
+    print(f"[parity] image compared on {cmp_px.mean():.4%} of the pixels ({(~safe).sum()} within 1e-5 of an exp() "
+          f"threshold, {(o['n_contrib'] != f['n_contrib']).sum()} with a different n_contrib)")
     assert cmp_px.mean() >= 0.98
     assert np.abs(o["color"] - f["color"])[:, cmp_px].max() <= 1e-4, "image max-abs"
     assert np.abs(o["final_T"] - f["final_T"])[cmp_px].max() <= 1e-5
     assert psnr(o["color"], f["color"]) >= 80.0
 
 
-def _check_grads(gg, b, names, tol=1e-4):
+GRAD_TOL = 1e-4       # rel-L2 per gradient tensor vs the fp32 oracle
+
+
+def _check_grads(gg, b, names, tol=GRAD_TOL):
+    errs = {n: rel_l2(gg[n], b[n]) for n in names}
+    print("[parity] gradient rel-L2 vs the fp32 oracle: " + ", ".join(f"{n} {e:.2e}" for n, e in errs.items()))
     for n in names:
         assert gg[n].shape == b[n].shape, n
-        assert rel_l2(gg[n], b[n]) <= tol, (n, rel_l2(gg[n], b[n]))
+        assert errs[n] <= tol, (n, errs[n])
 
 
 def test_visible_filter_bit_exact(oracle):
@@ -149,14 +174,13 @@ def test_forward_backward_colors_path(oracle, scene):
     f = oracle.forward(st, g["means3D"], g["opacities"], g["scales"], g["rotations"], colors_precomp=g["colors"])
     rng = np.random.default_rng(1)
     dL = rng.standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
-    b = oracle.backward(st, f, dL, g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
-    o = _run_gpu(cam, g, dL=dL)
+    o = _run_gpu(cam, g, dL=dL, ref=f)
     _check_forward(f, o, st)
-    if np.array_equal(o["n_contrib"], f["n_contrib"]):
-        _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"])
+    b = oracle.backward(st, f, o["dL_eff"], g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+    _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"])
     assert np.all(o["grads"]["means2D"][:, 2] == 0)
     # determinism: a second run is bit-identical (no floating-point atomics anywhere)
-    o2 = _run_gpu(cam, g, dL=dL)
+    o2 = _run_gpu(cam, g, dL=dL, ref=f)
     for k in o["grads"]:
         assert np.array_equal(o["grads"][k], o2["grads"][k]), k
     assert np.array_equal(o["color"], o2["color"])
@@ -170,21 +194,19 @@ def test_sh_and_cov_paths(oracle):
     for deg in (0, 1, 2, 3):
         st = oracle_settings(oracle, cam, g["bg"], scale_modifier=0.9, sh_degree=deg)
         f = oracle.forward(st, g["means3D"], g["opacities"], g["scales"], g["rotations"], shs=shs)
-        b = oracle.backward(st, f, dL, g["means3D"], g["scales"], g["rotations"], shs=shs)
-        o = _run_gpu(cam, g, scale_modifier=0.9, sh_degree=deg, shs=shs, dL=dL)
+        o = _run_gpu(cam, g, scale_modifier=0.9, sh_degree=deg, shs=shs, dL=dL, ref=f)
         _check_forward(f, o, st)
-        if np.array_equal(o["n_contrib"], f["n_contrib"]):
-            _check_grads(o["grads"], b, ["means3D", "means2D", "sh", "opacities", "scales", "rotations"])
+        b = oracle.backward(st, f, o["dL_eff"], g["means3D"], g["scales"], g["rotations"], shs=shs)
+        _check_grads(o["grads"], b, ["means3D", "means2D", "sh", "opacities", "scales", "rotations"])
     A = rng.standard_normal((300, 3, 3)) * 0.15
     S = A @ A.transpose(0, 2, 1) + 1e-3 * np.eye(3)
     cov = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).astype(np.float32)
     st = oracle_settings(oracle, cam, g["bg"])
     f = oracle.forward(st, g["means3D"], g["opacities"], cov3D_precomp=cov, colors_precomp=g["colors"])
-    b = oracle.backward(st, f, dL, g["means3D"], cov3D_precomp=cov, colors_precomp=g["colors"])
-    o = _run_gpu(cam, g, cov=cov, dL=dL)
+    o = _run_gpu(cam, g, cov=cov, dL=dL, ref=f)
     _check_forward(f, o, st)
-    if np.array_equal(o["n_contrib"], f["n_contrib"]):
-        _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "cov3D_precomp"])
+    b = oracle.backward(st, f, o["dL_eff"], g["means3D"], cov3D_precomp=cov, colors_precomp=g["colors"])
+    _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "cov3D_precomp"])
 
 
 def test_edge_cases(oracle):
@@ -232,11 +254,10 @@ def test_depth_ties_and_huge_tile(oracle, P):
     f = oracle.forward(st, g["means3D"], g["opacities"], g["scales"], g["rotations"], colors_precomp=g["colors"])
     assert (f["ranges"][:, 1].astype(np.int64) - f["ranges"][:, 0]).max() > 0.9 * P
     dL = rng.standard_normal((3, 64, 96)).astype(np.float32)
-    b = oracle.backward(st, f, dL, g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
-    o = _run_gpu(cam, g, dL=dL)
+    o = _run_gpu(cam, g, dL=dL, ref=f)
     _check_forward(f, o, st)
-    if np.array_equal(o["n_contrib"], f["n_contrib"]):
-        _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"])
+    b = oracle.backward(st, f, o["dL_eff"], g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+    _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"])
 
 
 @pytest.mark.parametrize("P", [1, 63, 4097])
@@ -253,11 +274,10 @@ def test_odd_sizes_and_giant_splats(oracle, P):
     assert f["tiles_touched"][:n_big].max() >= 0.5 * st.grid[0] * st.grid[1]
     rng = np.random.default_rng(4)
     dL = rng.standard_normal((3, 304, 400)).astype(np.float32)
-    b = oracle.backward(st, f, dL, g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
-    o = _run_gpu(cam, g, dL=dL)
+    o = _run_gpu(cam, g, dL=dL, ref=f)
     _check_forward(f, o, st)
-    if np.array_equal(o["n_contrib"], f["n_contrib"]):
-        _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"], tol=2e-4)
+    b = oracle.backward(st, f, o["dL_eff"], g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+    _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"])
 
 
 def test_full_size_cfg1_1M_1080p(oracle):
@@ -269,7 +289,7 @@ def test_full_size_cfg1_1M_1080p(oracle):
     f = oracle.forward(st, g["means3D"], g["opacities"], g["scales"], g["rotations"], colors_precomp=g["colors"])
     rng = np.random.default_rng(1)
     dL = rng.standard_normal((3, H, W)).astype(np.float32)
-    o = _run_gpu(cam, g, dL=dL)
+    o = _run_gpu(cam, g, dL=dL, ref=f)
     _check_forward(f, o, st)
     # properties: sortedness of every tile list by (depth, id); checksum of per-tile ids
     depth = f["depth"].astype(np.float32).view(np.uint32).astype(np.uint64)
@@ -280,10 +300,81 @@ def test_full_size_cfg1_1M_1080p(oracle):
     same_tile = tile_of[1:] == tile_of[:-1]
     assert np.all(key[1:][same_tile] > key[:-1][same_tile])
     del full
-    b = oracle.backward(st, f, dL, g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
-    # n_contrib may differ on a handful of threshold pixels; their gradient share is far below tol
-    _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"], tol=2e-4)
+    b = oracle.backward(st, f, o["dL_eff"], g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+    _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"])
     # linearity of the backward in dL/dcolor: grads(2*dL) == 2*grads(dL) exactly (power-of-two scale)
-    o2 = _run_gpu(cam, g, dL=2 * dL)
+    o2 = _run_gpu(cam, g, dL=2 * dL, ref=f)
     for k in ("means3D", "opacities", "colors_precomp"):
         assert np.array_equal(o2["grads"][k], 2 * o["grads"][k]), k
+
+
+STRESS_NAMES = ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"]
+
+
+def _fp64_with_fp32_decisions(oracle, st, f, g):
+    """The fp64 oracle evaluated on the fp32 oracle's integer decisions (visibility, tile lists, sort order): fp64
+    values of every per-Gaussian quantity, blended over the fp32 lists.  (An independent fp64 forward rounds depths
+    and radii differently in rare cases and would then describe another piecewise-smooth branch of the function.)"""
+    pre = oracle.preprocess(st, g["means3D"], g["scales"], g["rotations"], None, g["opacities"].reshape(-1), None,
+                            g["colors"], f64=True)
+    other = (pre["radii"] > 0) != (f["radii"] > 0)          # culled on one side only: take the fp32 row
+    for k in ("xy", "depth", "cov3D", "conic_opacity", "rgb"):
+        pre[k][other] = f[k][other]
+    for k in ("radii", "tiles_touched", "rect", "clamped"):
+        pre[k] = f[k]
+    bins = {k: f[k] for k in ("point_offsets", "num_rendered", "keys_sorted", "point_list", "ranges")}
+    out = dict(pre)
+    out.update(bins)
+    out.update(oracle.blend_forward(st, pre, bins, f64=True))
+    return out
+
+
+def stress_case(oracle, rng):
+    """One randomised scene against the oracle.  Forward: the bars of _check_forward.  Gradients, per tensor:
+    rel-L2 <= 1e-4 vs the fp32 oracle.  A tensor that misses that bar passes only with fp64 EVIDENCE that the scene
+    is ill-conditioned in binary32 itself (needle-like Gaussians whose per-tile sums cancel): against the fp64
+    oracle evaluated on the same decisions, the device result must be within 3x of the fp32 oracle's OWN distance
+    to fp64 -- i.e. as accurate as the scalar fp32 restatement of the reference arithmetic is.  Pixels whose
+    n_contrib differs between any two of the three are excused on all sides (bounded, printed).
+    Returns a report line; raises AssertionError otherwise."""
+    cam, g, sm = stress_scene(rng)
+    st = oracle_settings(oracle, cam, g["bg"], scale_modifier=sm)
+    args = (g["means3D"], g["opacities"], g["scales"], g["rotations"])
+    f = oracle.forward(st, *args, colors_precomp=g["colors"])
+    dL = rng.standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
+    o = _run_gpu(cam, g, scale_modifier=sm, dL=dL, ref=f)
+    _check_forward(f, o, st)
+    dL_eff = o["dL_eff"]
+    b = oracle.backward(st, f, dL_eff, g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+    e32 = {k: rel_l2(o["grads"][k], b[k]) for k in STRESS_NAMES}
+    worst = max(e32.values())
+    note = ""
+    if worst > GRAD_TOL:
+        f64 = _fp64_with_fp32_decisions(oracle, st, f, g)
+        more = (f64["n_contrib"] != f["n_contrib"]) & (dL_eff != 0).any(axis=0)
+        if more.any():       # threshold pixels of the fp64 blend: excuse them on all three sides and redo
+            assert (more.sum() + o["excused"]) / more.size <= EXCUSED_MAX
+            dL2 = dL.copy()
+            dL2[:, (o["n_contrib"] != f["n_contrib"]) | (f64["n_contrib"] != f["n_contrib"])] = 0.0
+            o = _run_gpu(cam, g, scale_modifier=sm, dL=dL2)
+            dL_eff = o["dL_eff"]
+            b = oracle.backward(st, f, dL_eff, g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+            e32 = {k: rel_l2(o["grads"][k], b[k]) for k in STRESS_NAMES}
+        b64 = oracle.backward(st, f64, dL_eff, g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"], f64=True)
+        for k in STRESS_NAMES:
+            if e32[k] > GRAD_TOL:
+                e_gpu, e_o32 = rel_l2(o["grads"][k], b64[k]), rel_l2(b[k], b64[k])
+                note += f" {k}: {e32[k]:.1e} vs fp32, device {e_gpu:.1e} / fp32 oracle {e_o32:.1e} vs fp64;"
+                assert e_gpu <= 3.0 * e_o32, (k, "vs fp64: device", e_gpu, "fp32 oracle", e_o32)
+    ranges = f["ranges"]
+    return (f"P={g['means3D'].shape[0]} {cam.image_width}x{cam.image_height} I={f['num_rendered']} "
+            f"max tile={(ranges[:, 1].astype(np.int64) - ranges[:, 0]).max()} vis={(f['radii'] > 0).sum()} "
+            f"worst grad {worst:.1e}" + (" ILL-CONDITIONED" + note if note else ""))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4])
+def test_randomised_stress_scenes(oracle, seed):
+    """50 seeded scenes of the randomised stress set (tools/stress_parity.py runs more of the same)."""
+    rng = np.random.default_rng(seed)
+    for it in range(10):
+        print(f"[stress {seed}/{it}] " + stress_case(oracle, rng))

@@ -24,6 +24,7 @@ def _model(dev):
 def test_prefilter_and_render_contract(oracle):
     from splatco_amd.renderer import prefilter_voxel, render
     from splatco_amd.stats import training_statis
+    from torch_restatements import training_statis_torch
     dev = torch.device("cuda:0")
     pc, d = _model(dev)
     cam = look_at_camera(eye=(0.3, -0.2, -4.5), target=(0, 0, 0), up=(0, -1, 0), FoVx=math.radians(60), width=200,
@@ -60,8 +61,12 @@ def test_prefilter_and_render_contract(oracle):
     N, k = 512, pc.n_offsets
     acc = [torch.zeros(N, 1, device=dev), torch.zeros(N, 1, device=dev), torch.zeros(N * k, 1, device=dev),
            torch.zeros(N * k, 1, device=dev)]
+    acc_t = [a.clone() for a in acc]
     training_statis(*acc, k, g, out["neural_opacity"], out["visibility_filter"], out["selection_mask"], vis)
+    training_statis_torch(*acc_t, k, g, out["neural_opacity"], out["visibility_filter"], out["selection_mask"], vis)
     assert acc[3].sum() == out["visibility_filter"].sum()
+    assert torch.equal(acc[1], acc_t[1]) and torch.equal(acc[3], acc_t[3])
+    assert torch.allclose(acc[0], acc_t[0], rtol=1e-6, atol=0) and torch.allclose(acc[2], acc_t[2], rtol=1e-6, atol=0)
     # image equals the oracle's rendering of the same neural Gaussians
     from splatco_amd.renderer import generate_neural_gaussians
     with torch.no_grad():
@@ -80,9 +85,10 @@ def test_prefilter_and_render_contract(oracle):
 
 def test_fused_expand_compact_matches_torch_chain():
     """The fused HIP expansion + compaction op == the reference's torch op chain
-    (gaussian_renderer/__init__.py:68-111, restated in splatco_amd.renderer and pinned by the golden
+    (gaussian_renderer/__init__.py:68-111, restated in tests/torch_restatements.py and pinned by the golden
     fixture): identical mask / order, values to 1e-6, every gradient to rel-L2 1e-5; deterministic."""
     from splatco_amd.renderer import generate_neural_gaussians
+    from torch_restatements import expand_torch_chain
     dev = torch.device("cuda:0")
     res = {}
     for fused in (False, True):
@@ -90,7 +96,7 @@ def test_fused_expand_compact_matches_torch_chain():
         pc.train()
         cam = types.SimpleNamespace(camera_center=torch.tensor(d["camera_center"], device=dev), uid=0)
         vis = torch.tensor(d["visible_mask"], device=dev)
-        out = generate_neural_gaussians(cam, pc, vis, is_training=True, fused=fused)
+        out = generate_neural_gaussians(cam, pc, vis, is_training=True, expand=None if fused else expand_torch_chain)
         xyz, color, opacity, scaling, rot, neural_opacity, mask = out
         g = torch.Generator(device=dev).manual_seed(3)
         loss = sum((t * torch.randn(t.shape, device=dev, generator=g)).sum() for t in (xyz, color, opacity, scaling, rot))
@@ -304,3 +310,45 @@ def test_backward_gradients_share_one_arena():
     assert allreduce_gradients([m, o, s, r, c]).data_ptr() == arena.data_ptr()     # world size 1: nothing moves
     assert all(torch.equal(a, p.grad) for a, p in zip(before, (m, o, s, r, c)))
     assert m2d.grad is not None and m2d.grad.shape == (3000, 3)
+
+
+def test_training_statis_kernel_golden_and_random():
+    """csrc/densify.hip (GaussianModel.training_statis, scene/gaussian_model.py:761-782) against the reference's own
+    numbers (tests/golden/training_statis.npz) and, on a larger random case accumulated over three views, against the
+    torch restatement; bit-reproducible."""
+    from splatco_amd.stats import statis_apply, statis_increments, training_statis
+    from torch_restatements import training_statis_torch
+    dev = torch.device("cuda:0")
+    d = np.load(os.path.join(GOLD, "training_statis.npz"))
+    k = int(d["n_offsets"])
+    Nn = d["anchor_visible_mask"].shape[0]
+    t = lambda n: torch.tensor(d[n], device=dev)
+    acc = [torch.zeros(Nn, 1, device=dev), torch.zeros(Nn, 1, device=dev), torch.zeros(Nn * k, 1, device=dev),
+           torch.zeros(Nn * k, 1, device=dev)]
+    training_statis(*acc, k, t("viewspace_grad"), t("neural_opacity"), t("update_filter"), t("offset_selection_mask"),
+                    t("anchor_visible_mask"))
+    for got, name in zip(acc, ["opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"]):
+        np.testing.assert_allclose(got.cpu().numpy(), d[name], rtol=1e-6, atol=1e-7, err_msg=name)
+    g = torch.Generator(device=dev).manual_seed(5)
+    N, k = 200_003, 10
+    a1 = [torch.rand(N, 1, device=dev, generator=g), torch.rand(N, 1, device=dev, generator=g).round(),
+          torch.rand(N * k, 1, device=dev, generator=g), torch.rand(N * k, 1, device=dev, generator=g).round()]
+    a2 = [a.clone() for a in a1]
+    a3 = [a.clone() for a in a1]
+    for view in range(3):
+        vis = torch.rand(N, device=dev, generator=g) < 0.6
+        V = int(vis.sum())
+        no = torch.randn(V * k, 1, device=dev, generator=g)
+        sel = (no > 0).view(-1)
+        P = int(sel.sum())
+        upd = torch.rand(P, device=dev, generator=g) < 0.7
+        grad = torch.randn(P, 3, device=dev, generator=g)
+        training_statis(*a1, k, grad, no, upd, sel, vis)
+        training_statis_torch(*a2, k, grad, no, upd, sel, vis)
+        inc = statis_increments(k, grad, no, upd, sel)                  # the two-step form of the sharded step
+        statis_apply(*a3, k, vis.nonzero().squeeze(1), *inc)
+    for x, y, z in zip(a1, a2, a3):
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-6)
+        assert torch.equal(x, z)
+    with pytest.raises(RuntimeError):
+        training_statis(*[a.cpu() for a in a1], k, grad.cpu(), no.cpu(), upd.cpu(), sel.cpu(), vis.cpu())

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from torch_restatements import expand_torch_chain, training_statis_torch
+
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -111,7 +113,12 @@ def test_generate_neural_gaussians(level, training):
     pc.train(training)
     cam = types.SimpleNamespace(camera_center=torch.tensor(d["camera_center"]), uid=0)
     with torch.no_grad():
-        res = generate_neural_gaussians(cam, pc, torch.tensor(d["visible_mask"]), is_training=training)
+        # CPU: the host-side op chain of the product + the torch restatement of the expansion step (the product's
+        # expansion is a HIP kernel, checked against the same fixture in tests/test_gpu_renderer.py)
+        res = generate_neural_gaussians(cam, pc, torch.tensor(d["visible_mask"]), is_training=training,
+                                        expand=expand_torch_chain)
+        with pytest.raises(RuntimeError):
+            generate_neural_gaussians(cam, pc, torch.tensor(d["visible_mask"]), is_training=training)   # no CPU path
     names = ["xyz", "color", "opacity", "scaling", "rot", "neural_opacity", "mask"][:len(res)]
     tag = f"L{level}_{'train' if training else 'eval'}"
     assert len(res) == (7 if training else 5)
@@ -124,8 +131,9 @@ def test_generate_neural_gaussians(level, training):
             np.testing.assert_allclose(v.numpy(), want, rtol=2e-5, atol=2e-6, err_msg=n)
 
 
-def test_training_statis():
-    from splatco_amd.stats import training_statis
+def test_training_statis_restatement():
+    """The torch restatement (checker of csrc/densify.hip in test_gpu_renderer.py) against the reference's numbers."""
+    training_statis = training_statis_torch
     d = _npz("training_statis.npz")
     k = int(d["n_offsets"])
     Nn = d["anchor_visible_mask"].shape[0]

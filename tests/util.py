@@ -43,3 +43,30 @@ def psnr(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     mse = ((a - b) ** 2).reshape(a.shape[0], -1).mean(1)
     return float(np.mean(20 * np.log10(1.0 / np.sqrt(np.maximum(mse, 1e-300)))))
+
+
+def stress_scene(rng):
+    """One randomised scene of the stress set: image sizes 17..700 px, 1..30 k Gaussians, random camera, anisotropy
+    up to 300:1, optional dense clump (thousands of instances in one tile -> workgroup sort / merge passes), skewed
+    opacity distributions, scale modifiers.  Returns (camera, gaussians, scale_modifier)."""
+    W, H = int(rng.integers(17, 700)), int(rng.integers(17, 500))
+    P = int(rng.integers(1, 30000))
+    eye = rng.uniform(-1, 1, 3) + np.array([0, 0, -rng.uniform(2.5, 7)])
+    cam = look_at_camera(eye, rng.uniform(-0.3, 0.3, 3), (rng.uniform(-0.2, 0.2), -1.0, rng.uniform(-0.2, 0.2)),
+                         math.radians(rng.uniform(30, 100)), W, H)
+    spread = rng.uniform(0.3, 3.0)
+    means = rng.normal(0, spread, (P, 3))
+    if rng.random() < 0.3:                       # a dense clump -> large tiles / merge passes
+        k = P // 2
+        means[:k] = rng.normal(0, 0.03, (k, 3)) + rng.uniform(-0.5, 0.5, 3)
+    smax = rng.choice([0.02, 0.1, 0.6, 3.0])
+    scales = np.exp(rng.uniform(math.log(smax / 300), math.log(smax), (P, 3)))   # extreme anisotropy included
+    q = rng.standard_normal((P, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q *= rng.uniform(0.7, 1.3, (P, 1))
+    op = rng.uniform(0.0, 1.0, (P, 1)) ** rng.choice([0.3, 1.0, 3.0])
+    col = rng.uniform(0, 1, (P, 3))
+    f = np.float32
+    g = dict(means3D=means.astype(f), scales=scales.astype(f), rotations=q.astype(f), opacities=op.astype(f),
+             colors=col.astype(f), bg=rng.uniform(0, 1, 3).astype(f))
+    return cam, g, float(rng.choice([0.5, 1.0, 1.7]))

@@ -4,7 +4,7 @@ import sys
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests"); sys.path.insert(0, "tools")
 from oracle import raster_oracle as orc
-from stress_parity import scene
+from util import stress_scene as scene
 from test_gpu_parity import _run_gpu
 from util import oracle_settings, rel_l2
 seed, idx = int(sys.argv[1]), int(sys.argv[2])

@@ -16,7 +16,7 @@ cam = look_at_camera((0.3, -0.2, -5.5), (0, 0, 0), (0, -1, 0), math.radians(60),
 pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
 vis = prefilter_voxel(cam, pc, pipe, torch.ones(3, device=dev))
 def step():
-    out = generate_neural_gaussians(cam, pc, vis, is_training=True, fused=True)
+    out = generate_neural_gaussians(cam, pc, vis, is_training=True)
     sum(t.sum() for t in out[:5]).backward()
 step(); torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity

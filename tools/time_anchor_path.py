@@ -10,6 +10,8 @@ import torch
 sys.path.insert(0, ".")
 from splatco_amd.cameras import look_at_camera
 from splatco_amd.renderer import generate_neural_gaussians, prefilter_voxel
+sys.path.insert(0, 'tests')
+from torch_restatements import expand_torch_chain
 from splatco_amd.scene_model import AnchorGaussianModel
 
 
@@ -38,11 +40,11 @@ def main(N=1_000_000, plane=700):
     print(f"N={N} visible={int(vis.sum())}  prefilter_voxel {t_pre:.3f} ms")
     for fused in (False, True):
         def fwd_bwd():
-            out = generate_neural_gaussians(cam, pc, vis, is_training=True, fused=fused)
+            out = generate_neural_gaussians(cam, pc, vis, is_training=True, expand=None if fused else expand_torch_chain)
             sum(t.sum() for t in out[:5]).backward()
         def fwd():
             with torch.no_grad():
-                generate_neural_gaussians(cam, pc, vis, is_training=True, fused=fused)
+                generate_neural_gaussians(cam, pc, vis, is_training=True, expand=None if fused else expand_torch_chain)
         print(f"  fused={fused}: forward {timeit(fwd):.2f} ms  forward+backward {timeit(fwd_bwd):.2f} ms  "
               f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
         torch.cuda.reset_peak_memory_stats()
