@@ -1,24 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- rasterizer forward+backward throughput on MI355X (BASELINE.json metric).
+"""bench.py -- the hot path on MI355X (BASELINE.json metric), one JSON line.
 
-One "step" = one pass of the hot path over one view: GaussianRasterizer forward (projection,
-bucketing, depth sort, blend) + backward (blend backward, per-Gaussian reduce, projection
-backward) on BASELINE.json configs[1]: 1M synthetic Gaussians, 1920x1080, inputs resident in
-HBM.  With --gpus N (launched by torch.distributed.run, one rank per GPU) the N ranks render N
-different views of the SAME Gaussians (the --mv N branch, train.py:171) and SUM-all-reduce the
-per-Gaussian gradients over RCCL inside the step; value = N * P / step time (weak scaling).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg1|cfg2|cfg3|cfg4]
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed with HIP events on
-the launch stream inside the timed region (scr_profile_*); `cpu_baseline` is the CPU oracle
-(oracle/, test infrastructure) timed on the host cores for a bounded sample of the same workload.
-Nothing here reads /root/reference.
+--config (default cfg1) names the BASELINE.json configuration:
+  cfg1  configs[1]: 1M synthetic Gaussians, 1 view 1920x1080 per GPU, GaussianRasterizer forward+backward.  One
+        "step" = one pass of the operator over one view.  With N > 1 the N ranks render N different views of the SAME
+        Gaussians (the --mv N branch, train.py:171) and SUM-all-reduce the per-Gaussian gradients over RCCL inside the
+        step; value = N * P / step time (weak scaling).  THIS is the line the driver records.
+  cfg2  configs[2]: 5M anchors + tri-plane features (plane_size 2800, 15 channels, levels 0..2), 1 view 1080p, 1 GPU:
+        prefilter_voxel + render() forward + backward (gaussian_renderer/__init__.py:118-244).  value = Gaussians
+        through the whole path per second; `stages` reports anchors/s for a2+a3 and splats/s for a5/a6 separately.
+  cfg3  configs[3]: the same scene, mv = N views (4 on 4 GPUs), one per rank: full sharded training step (prefilter,
+        render, fused loss, ONE backward, in-place piecewise gradient all-reduce, densification statistics of the last
+        view on every rank, Adam).  value = Gaussians rasterised per second over all ranks; iter/s alongside.
+  cfg4  configs[4]: 20M anchors, mv = N views (8 on 8 GPUs): the same step; metric = train-step iter/s.
+
+--gpus N with WORLD_SIZE unset starts the N ranks itself (python -m torch.distributed.run, one process per GPU) BEFORE
+anything touches the GPU and exits with the launcher's code; under an external launcher WORLD_SIZE must equal N.
+
+`roofline` is for the dominant kernel class of the step, timed with HIP events on the launch stream inside the timed
+region (scr_profile_*); `cpu_baseline` is the CPU oracle (oracle/, test infrastructure) timed on the host cores (rank 0,
+N = 1 only).  Nothing here reads /root/reference.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
+import types
 
 import numpy as np
 import torch
@@ -28,13 +41,16 @@ sys.path.insert(0, ROOT)
 
 METRIC = "rasterizer fwd+bwd Msplats/s @1080p; PSNR-match vs ref"
 P_CFG1, W_CFG1, H_CFG1 = 1_000_000, 1920, 1080
-HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
-CPU_SAMPLE_P = 1_000_000       # cpu_baseline: the whole cfg1 scene (all host cores; ~20 s of CPU work)
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md (datasheet; a float4 copy reaches ~6.3 TB/s)
+XGMI_LINK_GBS = 153.0
 
 
-def algorithmic_bytes(kernel, P, I, npix):
-    """SURVEY.md 8(d) per-unit figures (bytes one launch must move), also stated in DESIGN.md."""
-    return {
+def algorithmic_bytes(kernel, P, I, npix, extra=None):
+    """SURVEY.md 8(d) per-unit figures (bytes one launch must move), also stated in DESIGN.md section 3.
+    P = Gaussians, I = (Gaussian, tile) instances, npix = pixels; extra: N anchors, V visible anchors, n = V*k."""
+    e = extra or {}
+    N, V, n = e.get("N", 0), e.get("V", 0), e.get("n", 0)
+    table = {
         "preprocess_kernel": P * (56 + 36) + P * 8 + P * 20,
         "plan_scan_kernel": P // 256 * 8,
         "scatter_kernel": P * 20 + I * 12,
@@ -42,8 +58,35 @@ def algorithmic_bytes(kernel, P, I, npix):
         "blend_forward_kernel": 40 * I + 20 * npix,
         "blend_backward_kernel": 40 * I + 20 * npix + 44 * P,
         "preprocess_backward_kernel": P * (56 + 24 + 44 + 4) + P * 40,
-        "filter_kernel": 44 * P,
-    }[kernel]
+        "filter_kernel": 44 * N,
+        "expand_kernel": 4 * n + 56 * n + 36 * V + 56 * P,          # count pass + candidates read + Gaussians written
+        "expand_backward_kernel": 56 * P + 60 * n + 36 * V + 4 * n,
+        "triplane_forward_kernel": 240 * V + 12 * V + 60 * V,       # per grid: corner gathers + coords + 15 outputs
+        "plane_sample_backward_kernels": 240 * V / 3 + 8 * V + 20 * V,   # per plane
+        "l1_ssim_forward_kernel": 2 * 12 * npix + 3 * 12 * npix,
+        "l1_ssim_backward_kernel": 2 * 12 * npix + 3 * 12 * npix + 12 * npix,
+        "mlp_heads_kernel": 4 * V * 99 + 4 * V * 110,
+        "mlp_heads_backward_kernel": 4 * V * (99 + 110 + 110 + 99),
+    }
+    return float(table.get(kernel, 0))
+
+
+# ------------------------------------------------------------------ launch
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: start N ranks as CHILD processes (never re-exec a process that touched the GPU;
+    nothing has touched it yet) and propagate the exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def make_view(rank, W, H):
@@ -64,69 +107,131 @@ def settings_for(cam, bg, dev):
         campos=cam.camera_center.to(dev), prefiltered=False, debug=False)
 
 
-def cpu_baseline(g, cam, dev):
-    """Oracle (kind "port": this repo's CPU restatement; the reference has no CPU path) on the
-    first CPU_SAMPLE_P Gaussians, on all host cores (the oracle's OpenMP build).  Also returns
-    PSNR(HIP image, oracle image)."""
+# ------------------------------------------------------------------ measurement helpers
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def hbm_copy_peak(dev):
+    """Achievable HBM bandwidth on this box: float4 copy of 1 GiB (read + write bytes / time), best of 5."""
+    from splatco_amd import _C
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    a.zero_()
+    st = torch.cuda.current_stream().cuda_stream
+    best = 0.0
+    for it in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _C.check(_C.lib.scr_copy_probe(a.data_ptr(), b.data_ptr(), n, st))
+        e1.record()
+        torch.cuda.synchronize()
+        if it:
+            best = max(best, 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    return best
+
+
+def cpu_baseline(g, cam, dev, hip_image):
+    """Oracle (kind "port": this repo's CPU restatement; the reference has no CPU path) on the whole cfg1 scene, on
+    all host cores (the oracle's OpenMP build): one warm-up run, then the median of five forward+backward runs
+    (SURVEY.md 8d).  cfg0 (10 k Gaussians, 400x400: BASELINE.json configs[0], the CPU-only plumbing case) is timed the
+    same way.  Also returns PSNR(HIP image, oracle image)."""
     from oracle import raster_oracle as orc
-    from splatco_amd.rasterizer import GaussianRasterizer
-    n = CPU_SAMPLE_P
-    sub = {k: (v[:n] if k != "bg" else v) for k, v in g.items()}
-    st = orc.Settings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
-                      sub["bg"], 1.0, cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), 1,
-                      cam.camera_center.numpy())
-    rng = np.random.default_rng(1)
-    dL = rng.standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
+    from splatco_amd.synthetic import synthetic_camera, synthetic_gaussians
     orc.build()
     orc.use_threads(True)
     cores = orc.threads()
-    t0 = time.perf_counter()
-    f = orc.forward(st, sub["means3D"], sub["opacities"], sub["scales"], sub["rotations"], colors_precomp=sub["colors"])
-    orc.backward(st, f, dL, sub["means3D"], sub["scales"], sub["rotations"], colors_precomp=sub["colors"])
-    dt = time.perf_counter() - t0
+
+    def timed(cam_, g_, runs):
+        st = orc.Settings(cam_.image_height, cam_.image_width, math.tan(cam_.FoVx * 0.5), math.tan(cam_.FoVy * 0.5),
+                          g_["bg"], 1.0, cam_.world_view_transform.numpy(), cam_.full_proj_transform.numpy(), 1,
+                          cam_.camera_center.numpy())
+        dL = np.random.default_rng(1).standard_normal((3, cam_.image_height, cam_.image_width)).astype(np.float32)
+        ts, f = [], None
+        for it in range(runs + 1):                       # run 0 = warm-up (page faults, thread pool)
+            t0 = time.perf_counter()
+            f = orc.forward(st, g_["means3D"], g_["opacities"], g_["scales"], g_["rotations"], colors_precomp=g_["colors"])
+            orc.backward(st, f, dL, g_["means3D"], g_["scales"], g_["rotations"], colors_precomp=g_["colors"])
+            if it:
+                ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), f
+
+    dt1, f = timed(cam, g, 5)
+    cam0, g0 = synthetic_camera(400, 400), synthetic_gaussians(10_000, 400, 400, 0)
+    dt0, _ = timed(cam0, g0, 5)
     orc.use_threads(False)
-    t = lambda a: torch.tensor(a, device=dev)
-    with torch.no_grad():
-        img, _ = GaussianRasterizer(settings_for(cam, sub["bg"], dev))(
-            means3D=t(sub["means3D"]), means2D=torch.zeros(n, 3, device=dev), opacities=t(sub["opacities"]),
-            colors_precomp=t(sub["colors"]), scales=t(sub["scales"]), rotations=t(sub["rotations"]))
-    a, b = img.cpu().numpy().astype(np.float64), f["color"].astype(np.float64)
+    a, b = hip_image.astype(np.float64), f["color"].astype(np.float64)
     mse = ((a - b) ** 2).reshape(3, -1).mean(1)
     psnr = float(np.mean(20 * np.log10(1.0 / np.sqrt(np.maximum(mse, 1e-300)))))
-    base = {"value": n / dt / 1e6, "unit": "Msplats/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} of the {P_CFG1} cfg1 Gaussians, 1 view 1920x1080, fwd+bwd once, "
-                      f"{dt:.1f} s on {cores} OpenMP threads ({os.cpu_count()} host cores)"}
+    P = g["means3D"].shape[0]
+    base = {"value": P / dt1 / 1e6, "unit": "Msplats/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": f"the whole cfg1 scene ({P} Gaussians, 1 view 1920x1080), forward+backward: 1 warm-up + median of 5 "
+                      f"runs = {dt1:.2f} s per pass on {cores} OpenMP threads ({os.cpu_count()} host cores)",
+            "cfg0": {"value": 10_000 / dt0 / 1e6, "unit": "Msplats/s", "ms_per_pass": dt0 * 1e3,
+                     "sample": "configs[0]: 10k Gaussians, 1 view 400x400, same protocol"}}
     return base, psnr
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the rasterizer has no CPU path")
-    # developer overrides to exercise the N > 1 code path on a 1-GPU box (never set by the driver):
-    # every rank on one device, gloo instead of RCCL
-    if os.environ.get("SPLATCO_BENCH_ONE_DEVICE"):
-        local = 0
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+def time_allreduce(fn, dev, reps=5):
     import torch.distributed as dist
-    if world > 1:
-        backend = os.environ.get("SPLATCO_BENCH_BACKEND", "nccl")   # "nccl" is RCCL over xGMI on ROCm
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dist.barrier()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    t = torch.tensor([e0.elapsed_time(e1) / reps], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
+
+def allreduce_report(nbytes, ms, world, **more):
+    alg = nbytes / (ms * 1e-3) / 1e9
+    out = {"bytes": int(nbytes), "ms": ms, "algbw_GBps": alg, "busbw_GBps": alg * 2 * (world - 1) / world,
+           "xgmi_link_peak_GBps": XGMI_LINK_GBS}
+    out.update(more)
+    return out
+
+
+def pick_dominant(warm_prof):
+    kern = {k: ms / n for k, (ms, n) in warm_prof.items() if n}
+    per_step = {k: ms for k, (ms, n) in warm_prof.items() if n}
+    return (max(per_step, key=per_step.get) if per_step else "blend_backward_kernel"), kern
+
+
+def roofline_object(dom, avg_ms, ab, peak_measured, note):
+    achieved = ab / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC-derived bytes per launch, if measured
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(dom)
+    out = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": ab,
+           "avg_launch_ms": avg_ms, "peak_measured": peak_measured,
+           "frac_of_measured": (achieved / peak_measured) if peak_measured else None, "note": note}
+    vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
+    if os.path.exists(vpath):
+        n_inst = json.load(open(vpath)).get(dom)
+        if n_inst and avg_ms:
+            out["valu"] = {"insts_per_launch": n_inst,
+                           "issue_frac": n_inst * 2.0 / (256 * 4 * 2.4e9 * avg_ms * 1e-3)}
+    return out
+
+
+# ------------------------------------------------------------------ cfg1: the operator
+def run_cfg1(args, rank, world, dev):
+    import torch.distributed as dist
     from splatco_amd import _C
+    from splatco_amd import rasterizer as R
     from splatco_amd.multiview import allreduce_gradients
     from splatco_amd.rasterizer import GaussianRasterizer
     from splatco_amd.synthetic import synthetic_gaussians
@@ -143,6 +248,7 @@ def main():
     dL = torch.randn(3, H, W, device=dev, generator=gen)     # dL/dcolor ~ N(0,1), seeded
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
     leaves = list(params.values())
+    state = {}
 
     def step():
         for p in leaves:
@@ -152,6 +258,7 @@ def main():
         img.backward(dL)
         if world > 1:
             allreduce_gradients(leaves)                       # SUM, one flat bucket (train.py:198,240)
+        state["radii"], state["img"] = radii, img
         return radii
 
     # warm-up: the last warm-up steps are timed per kernel class (HIP events around every launch)
@@ -165,8 +272,7 @@ def main():
         step()
     torch.cuda.synchronize()
     warm_prof = _C.profile_read() if args.warmup else {}
-    warm_kern = {k: ms / n for k, (ms, n) in warm_prof.items() if n}
-    dominant = max(warm_kern, key=warm_kern.get) if warm_kern else "blend_backward_kernel"
+    dominant, warm_kern = pick_dominant(warm_prof)
     _C.profile_enable(dominant)
     _C.profile_read()
     if world > 1:
@@ -174,7 +280,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        radii = step()
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -187,72 +293,233 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         # bookkeeping (outside the timed region): the gradient all-reduce on its own, SURVEY.md 8(e)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        dist.barrier()
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(5):
-            bucket = allreduce_gradients(leaves)
-        e1.record()
-        torch.cuda.synchronize()
-        ar = torch.tensor([e0.elapsed_time(e1) / 5], device=dev, dtype=torch.float64)
-        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
-        nbytes = bucket.numel() * bucket.element_size()
-        allreduce_info = {"bytes": nbytes, "ms": float(ar.item()),
-                          "algbw_GBps": nbytes / (float(ar.item()) * 1e-3) / 1e9,
-                          "busbw_GBps": nbytes / (float(ar.item()) * 1e-3) / 1e9 * 2 * (world - 1) / world,
-                          "xgmi_link_peak_GBps": 153.0}
+        bucket = allreduce_gradients(leaves)
+        ms = time_allreduce(lambda: allreduce_gradients(leaves), dev)
+        allreduce_info = allreduce_report(bucket.numel() * bucket.element_size(), ms, world,
+                                          what=f"{P}x14 fp32 per-Gaussian gradients, one in-place all-reduce of the operator's arena")
+    if rank != 0:
+        return
+    with torch.no_grad():
+        _, _, st = R.rasterize_forward(R._CSettings(rast.raster_settings), params["means3D"].detach(),
+                                       params["opacities"].detach(), params["scales"].detach(),
+                                       params["rotations"].detach(), None, None, params["colors_precomp"].detach())
+    I, npix = st.I, W * H
+    kern = dict(warm_kern)                                   # all classes: from the warm-up steps
+    kern.update({k: (ms / max(n, 1)) for k, (ms, n) in prof.items() if n})   # dominant: timed region
+    peak = hbm_copy_peak(dev)
+    ab = algorithmic_bytes(dominant, P, I, npix)
+    out = {
+        "metric": METRIC, "value": world * P / (elapsed / args.steps) / 1e6, "unit": "Msplats/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg1: 1M synthetic Gaussians (seed 0), 1 view 1920x1080 per GPU, "
+                               "GaussianRasterizer forward+backward, colors_precomp + scale/rotation path",
+                   "gaussians": P, "image": f"{W}x{H}", "tile_instances": I,
+                   "visible": int((state["radii"] > 0).sum().item()),
+                   "parallelism": "1 view per GPU (mv sharding)" + (
+                       f", RCCL all-reduce(SUM) of {P}x14 fp32 per-Gaussian grads per step" if world > 1 else "")},
+        "roofline": roofline_object(dominant, kern[dominant], ab, peak,
+                                    "blend kernels are FP32-VALU/exp-issue bound at this density (SURVEY.md 8d); "
+                                    "the HBM fraction is reported as the contract asks"),
+        "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])},
+        "hbm_gbs_all_kernels": sum(algorithmic_bytes(k, P, I, npix) for k in kern) / (sum(kern.values()) * 1e-3) / 1e9,
+    }
+    if allreduce_info is not None:
+        out["allreduce"] = allreduce_info
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"], out["psnr_match_db"] = cpu_baseline(g, cam, dev, state["img"].detach().cpu().numpy())
+    print(json.dumps(out))
 
-    if rank == 0:
-        # instance count of this view (the units the blend / sort kernels process)
-        from splatco_amd import rasterizer as R
-        with torch.no_grad():
-            _, _, st = R.rasterize_forward(R._CSettings(rast.raster_settings), params["means3D"].detach(),
-                                           params["opacities"].detach(), params["scales"].detach(),
-                                           params["rotations"].detach(), None, None, params["colors_precomp"].detach())
-        I, npix = st.I, W * H
-        kern = dict(warm_kern)                                   # all classes: from the warm-up steps
-        kern.update({k: (ms / max(n, 1)) for k, (ms, n) in prof.items() if n})   # dominant: timed region
-        dom = dominant
-        ab = algorithmic_bytes(dom, P, I, npix)
-        achieved = ab / (kern[dom] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC-derived bytes per launch, if measured
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom)
-        # VALU issue view of the same kernel: wave64 VALU instructions per launch (PMC SQ_INSTS_VALU, if
-        # measured) x 2 issue cycles (SIMD-32) over the SIMD-cycles of its launch at the 2.4 GHz peak clock
-        valu = None
-        vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
-        if os.path.exists(vpath):
-            n_inst = json.load(open(vpath)).get(dom)
-            if n_inst:
-                valu = {"insts_per_launch": n_inst, "issue_frac": n_inst * 2.0 / (256 * 4 * 2.4e9 * kern[dom] * 1e-3)}
-        ms_per_step = elapsed / args.steps * 1e3
-        out = {
-            "metric": METRIC, "value": world * P / (elapsed / args.steps) / 1e6, "unit": "Msplats/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "cfg1: 1M synthetic Gaussians (seed 0), 1 view 1920x1080 per GPU, "
-                                   "GaussianRasterizer forward+backward, colors_precomp + scale/rotation path",
-                       "gaussians": P, "image": f"{W}x{H}", "tile_instances": I,
-                       "visible": int((radii > 0).sum().item()),
-                       "parallelism": "1 view per GPU (mv sharding)" + (
-                           f", RCCL all-reduce(SUM) of {P}x14 fp32 per-Gaussian grads per step" if world > 1 else "")},
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ab, "avg_launch_ms": kern[dom], "valu": valu,
-                         "note": "blend kernels are FP32-VALU/exp-issue bound at this density (SURVEY.md 8d); "
-                                 "the HBM fraction is reported as the contract asks"},
-            "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])},
-            "hbm_gbs_all_kernels": sum(algorithmic_bytes(k, P, I, npix) for k in kern) / (sum(kern.values()) * 1e-3) / 1e9,
-        }
-        if allreduce_info is not None:
-            out["allreduce"] = allreduce_info
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["psnr_match_db"] = cpu_baseline(g, cam, dev)
-        print(json.dumps(out))
+
+# ------------------------------------------------------------------ cfg2..4: the anchor scenes
+def run_anchor_config(args, rank, world, dev):
+    import torch.distributed as dist
+    from splatco_amd import _C
+    from splatco_amd.densify import AnchorDensifier
+    from splatco_amd.multiview import GradArena
+    from splatco_amd.renderer import prefilter_voxel, render
+    from splatco_amd.synthetic import ANCHOR_CONFIGS, synthetic_anchor_model, synthetic_views
+    from splatco_amd.train_step import collaborative_step
+
+    N, mv_named, seed = ANCHOR_CONFIGS[args.config]
+    N = args.anchors or N
+    W, H = 1920, 1080
+    pc = synthetic_anchor_model(N, seed, dev)
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
+    bg = torch.ones(3, device=dev)
+    train = args.config in ("cfg3", "cfg4")
+    mv = world if train else 1
+    views = [v.to(dev) for v in synthetic_views(mv, W, H)]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(100 + seed)
+    gts = [torch.rand(3, H, W, device=dev, generator=gen) for _ in views]     # identical on every rank
+    stats = {}
+
+    if train:
+        groups = [{"params": [getattr(pc, "_" + n)], "lr": 1e-4, "name": n} for n in ("anchor", "offset", "anchor_feat", "scaling")]
+        rest = [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad]
+        groups.append({"params": rest, "lr": 1e-3, "name": "mlp_and_feat_planes"})
+        opt = torch.optim.Adam(groups, eps=1e-15)
+        den = AnchorDensifier(pc, opt, seed=seed)
+        arena = GradArena([p for grp in groups for p in grp["params"]], mode=args.exchange)
+
+        def step():
+            loss, out, _ = collaborative_step(pc, views, gts, pipe, bg, optimizer=opt, densifier=den, arena=arena)
+            stats["P"], stats["V"] = out["radii"].shape[0], int(out["selection_mask"].numel() // pc.n_offsets)
+            stats["rendered"] = out["radii"]
+    else:
+        target = gts[0]
+
+        def step():
+            for p in pc.parameters():
+                p.grad = None
+            vis = prefilter_voxel(views[0], pc, pipe, bg)
+            out = render(views[0], pc, pipe, bg, visible_mask=vis, retain_grad=True)
+            loss = (out["render"] - target).abs().mean() + 0.01 * out["scaling"].prod(dim=1).mean()
+            loss.backward()
+            stats["P"], stats["V"] = out["radii"].shape[0], int(out["selection_mask"].numel() // pc.n_offsets)
+            stats["rendered"] = out["radii"]
+
+    for w in range(args.warmup):
+        if w == max(args.warmup - 2, 0):
+            torch.cuda.synchronize()
+            _C.profile_enable(True)
+            _C.profile_read()
+        step()
+    torch.cuda.synchronize()
+    warm_prof = _C.profile_read() if args.warmup else {}
+    nwarm = min(args.warmup, 2) or 1
+    dominant, warm_kern = pick_dominant(warm_prof)
+    warm_step_ms = {k: ms / nwarm for k, (ms, n) in warm_prof.items() if n}
+    _C.profile_enable(dominant)
+    _C.profile_read()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = _C.profile_read()
+    _C.profile_enable(False)
+    Pt = torch.tensor([stats["P"]], device=dev, dtype=torch.float64)
+    allreduce_info = None
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.all_reduce(Pt)                                  # Gaussians rasterised by all ranks in one step
+        if train:
+            def exchange(mode):
+                a2 = GradArena(arena.params, mode=mode, overlap=False)
+                ms = time_allreduce(lambda: (a2.zero(), a2.reduce()), dev, reps=3)
+                a2.close()
+                return ms
+            ms_ar = exchange("all_reduce")
+            ms_rs = exchange("rs_ag") if dist.get_backend() == "nccl" else None      # gloo (developer runs) has no reduce_scatter_tensor
+            arena.bind()
+            allreduce_info = allreduce_report(
+                arena.nbytes(), ms_ar if args.exchange == "all_reduce" else ms_rs, world,
+                what=f"gradient arena: {N} anchors x 71 fp32 + planes + MLPs, exchanged in place in "
+                     f"{sum(len(p) for p in arena.pieces)} pieces of <= 256 MiB, issued from autograd hooks",
+                mode=args.exchange, ms_all_reduce_pieces=ms_ar, ms_reduce_scatter_all_gather=ms_rs)
+    if rank != 0:
+        return
+    step_s = elapsed / args.steps
+    P_all = float(Pt.item())
+    kern = dict(warm_kern)
+    kern.update({k: (ms / max(n, 1)) for k, (ms, n) in prof.items() if n})
+    ras_f = sum(warm_step_ms.get(k, 0) for k in ("preprocess_kernel", "plan_scan_kernel", "scatter_kernel", "tile_sort_kernel", "blend_forward_kernel"))
+    ras_b = sum(warm_step_ms.get(k, 0) for k in ("blend_backward_kernel", "preprocess_backward_kernel"))
+    P1 = stats["P"]
+    peak = hbm_copy_peak(dev)
+    V = stats.get("V", 0)
+    extra = {"N": N, "V": V, "n": V * pc.n_offsets}
+    from splatco_amd import rasterizer as R
+    I = R.last_plan[1]                                       # (Gaussian, tile) instances of the last rasterised view
+    ab = algorithmic_bytes(dominant, P1, I, W * H, extra)
+    out = {
+        "metric": METRIC if args.config != "cfg4" else "full train-step iter/s (BASELINE.json configs[4])",
+        "value": (P_all / step_s / 1e6) if args.config != "cfg4" else 1.0 / step_s,
+        "unit": "Msplats/s" if args.config != "cfg4" else "iter/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": {
+            "cfg2": f"cfg2: {N} anchors uniform in [-2,2]^3 (seed {seed}), k=10, tri-planes 700/700/1400 active "
+                    f"(plane_size 2800, 15 channels, activate_level 2), 1 view 1920x1080: prefilter_voxel + render() "
+                    f"forward + backward",
+            "cfg3": f"cfg3: {N} anchors (seed {seed}), mv = {mv} views 1080p, 1 per GPU: full sharded training step",
+            "cfg4": f"cfg4: {N} anchors (seed {seed}), mv = {mv} views 1080p, 1 per GPU: full training step "
+                    f"(prefilter, render, loss, backward, gradient exchange, densification statistics, Adam)"}[args.config],
+                   "anchors": N, "visible_anchors_last_view": V, "gaussians_last_view": P1, "tile_instances_last_view": I,
+                   "image": f"{W}x{H}",
+                   "rendered_last_view": int((stats["rendered"] > 0).sum().item()),
+                   "parallelism": f"{mv} view(s), 1 per GPU" + (", RCCL gradient exchange in place" if world > 1 else "")},
+        "iter_per_s": 1.0 / step_s,
+        "stages": {
+            "rasterizer_kernels_ms": {"forward": ras_f, "backward": ras_b},
+            "rasterizer_Msplats_per_s": P1 / (ras_f + ras_b) / 1e3 if ras_f + ras_b else None,
+            "anchor_path_ms": step_s * 1e3 - ras_f - ras_b if not train else None,
+            "anchor_path_Manchors_per_s": N / (step_s * 1e3 - ras_f - ras_b) / 1e3 if not train else None,
+        },
+        "roofline": roofline_object(dominant, kern.get(dominant, 0.0), ab, peak,
+                                    "dominant among this library's kernel classes by time per step; the rocBLAS GEMMs of "
+                                    "the anchor path are outside these classes"),
+        "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(warm_step_ms.items(), key=lambda kv: -kv[1])},
+        "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
+    }
+    if allreduce_info is not None:
+        out["allreduce"] = allreduce_info
+    print(json.dumps(out))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3", "cfg4"], default="cfg1")
+    ap.add_argument("--anchors", type=int, default=0, help="override the anchor count of cfg2..4 (developer runs)")
+    ap.add_argument("--exchange", choices=["all_reduce", "rs_ag"], default="all_reduce",
+                    help="shape of the gradient exchange of cfg3/cfg4 (GradArena)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.config == "cfg1" else 5
+    if args.warmup is None:
+        args.warmup = 5 if args.config == "cfg1" else 3
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                                   # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.config == "cfg2" and world != 1:
+        raise SystemExit("bench.py: cfg2 is the single-GPU configuration (BASELINE.json configs[2])")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the rasterizer has no CPU path")
+    # developer overrides to exercise the N > 1 code path on a 1-GPU box (never set by the driver):
+    # every rank on one device, gloo instead of RCCL
+    if os.environ.get("SPLATCO_BENCH_ONE_DEVICE"):
+        local = 0
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:
+        backend = os.environ.get("SPLATCO_BENCH_BACKEND", "nccl")   # "nccl" is RCCL over xGMI on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    if args.config == "cfg1":
+        run_cfg1(args, rank, world, dev)
+    else:
+        run_anchor_config(args, rank, world, dev)
     if world > 1:
         dist.destroy_process_group()
 

@@ -206,15 +206,12 @@ def forward(st, means3D, opacities, scales=None, rotations=None, cov3D_precomp=N
     return out
 
 
-def backward(st, fwd, dL_dcolor_img, means3D, scales=None, rotations=None, cov3D_precomp=None,
-             shs=None, colors_precomp=None, f64=False):
-    """Rasterizer backward: gradients in the operator's input order (SURVEY.md 8.a6)."""
+def blend_backward(st, fwd, dL_dcolor_img, f64=False):
+    """Screen-space gradient sums of the blend: (dL/dmean2D [P,2] in pixel units, dL/dconic [P,3], dL/dopacity [P],
+    dL/dcolour [P,3])."""
     lib, rt = _lib(f64), (np.float64 if f64 else np.float32)
     H, W = st.image_height, st.image_width
-    means3D = _f32(means3D)
-    P = means3D.shape[0]
-    scales, rotations, cov3D_precomp, shs = _f32(scales), _f32(rotations), _f32(cov3D_precomp), _f32(shs)
-    M = 0 if shs is None else shs.shape[1]
+    P = fwd["radii"].shape[0]
     dpix = np.ascontiguousarray(dL_dcolor_img, rt)
     g_m2 = np.zeros((P, 2), rt)
     g_conic = np.zeros((P, 3), rt)
@@ -228,6 +225,18 @@ def backward(st, fwd, dL_dcolor_img, means3D, scales=None, rotations=None, cov3D
                            _p(np.ascontiguousarray(fwd["rgb"], rt)), _p(bg),
                            _p(np.ascontiguousarray(fwd["final_T"], rt)), _p(fwd["n_contrib"]),
                            _p(dpix), C.c_int(P), _p(g_m2), _p(g_conic), _p(g_op), _p(g_col))
+    return g_m2, g_conic, g_op, g_col
+
+
+def preprocess_backward(st, fwd, g_m2, g_conic, g_col, means3D, scales=None, rotations=None, cov3D_precomp=None,
+                        shs=None, f64=False):
+    """The per-Gaussian chain from the screen-space sums to the operator inputs (linear in g_m2 / g_conic / g_col)."""
+    lib, rt = _lib(f64), (np.float64 if f64 else np.float32)
+    means3D = _f32(means3D)
+    P = means3D.shape[0]
+    scales, rotations, cov3D_precomp, shs = _f32(scales), _f32(rotations), _f32(cov3D_precomp), _f32(shs)
+    M = 0 if shs is None else shs.shape[1]
+    g_m2, g_conic, g_col = (np.ascontiguousarray(a, rt) for a in (g_m2, g_conic, g_col))
     g_means3D = np.zeros((P, 3), rt)
     g_means2D = np.zeros((P, 3), rt)
     g_scales = np.zeros((P, 3), rt) if cov3D_precomp is None else None
@@ -239,7 +248,15 @@ def backward(st, fwd, dL_dcolor_img, means3D, scales=None, rotations=None, cov3D
                                 _p(cov3D_precomp), _p(shs), C.byref(cs), _p(fwd["radii"]),
                                 _p(fwd["clamped"]), _p(g_m2), _p(g_conic), _p(g_col), _p(g_means3D),
                                 _p(g_means2D), _p(g_scales), _p(g_rot), _p(g_cov), _p(g_sh))
-    return dict(means3D=g_means3D, means2D=g_means2D, sh=g_sh,
-                colors_precomp=g_col if colors_precomp is not None else None,
-                opacities=g_op.reshape(P, 1), scales=g_scales, rotations=g_rot, cov3D_precomp=g_cov,
-                _mean2D_px=g_m2, _conic=g_conic)
+    return dict(means3D=g_means3D, means2D=g_means2D, sh=g_sh, scales=g_scales, rotations=g_rot, cov3D_precomp=g_cov)
+
+
+def backward(st, fwd, dL_dcolor_img, means3D, scales=None, rotations=None, cov3D_precomp=None,
+             shs=None, colors_precomp=None, f64=False):
+    """Rasterizer backward: gradients in the operator's input order (SURVEY.md 8.a6)."""
+    P = np.asarray(means3D).shape[0]
+    g_m2, g_conic, g_op, g_col = blend_backward(st, fwd, dL_dcolor_img, f64=f64)
+    out = preprocess_backward(st, fwd, g_m2, g_conic, g_col, means3D, scales, rotations, cov3D_precomp, shs, f64=f64)
+    out.update(colors_precomp=g_col if colors_precomp is not None else None, opacities=g_op.reshape(P, 1),
+               _mean2D_px=g_m2, _conic=g_conic)
+    return out

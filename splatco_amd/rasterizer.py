@@ -100,8 +100,12 @@ class RasterState:
         return out
 
 
+last_plan = (0, 0, 0)      # (P, tile instances, largest tile) of the most recent forward: bench / profiling bookkeeping only
+
+
 def rasterize_forward(cs, means3D, opacities, scales, rotations, cov3D_precomp, shs, colors_precomp):
     """plan + run through the C-ABI.  Returns (color, radii, RasterState)."""
+    global last_plan
     dev = means3D.device
     P = means3D.shape[0]
     M = 0 if shs is None else shs.shape[1]
@@ -116,6 +120,7 @@ def rasterize_forward(cs, means3D, opacities, scales, rotations, cov3D_precomp, 
                                      _ptr(opacities), _ptr(shs), _ptr(colors_precomp), cs.ref(),
                                      st.geom.data_ptr(), _ptr(radii), plan, _stream()))
     st.I, st.max_tile = int(plan[0]), int(plan[1])
+    last_plan = (P, st.I, st.max_tile)
     st.binning = _bytes(_C.lib.scr_binning_bytes(st.I, st.max_tile), dev)
     _C.check(_C.lib.scr_forward_run(P, st.I, st.max_tile, cs.ref(), st.geom.data_ptr(), st.binning.data_ptr(),
                                     st.image.data_ptr(), color.data_ptr(), _stream()))

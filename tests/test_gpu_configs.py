@@ -1,0 +1,118 @@
+"""GPU tests at the sizes BASELINE.json names beyond configs[1]:
+
+  configs[2]  5 M anchors + tri-plane features (plane_size 2800, 15 channels, activate_level 2), 1 view 1080p:
+              prefilter_voxel radii bit-exact vs the oracle at N = 5 M; the ~15 M neural Gaussians the anchor path
+              produces go through the rasterizer AND the oracle (OpenMP build: the forward is per-pixel independent, so
+              its integers do not depend on the thread count; the backward sums with atomics, far inside the 1e-4 bar):
+              every integer bit-exact, image, gradients; then the whole render() path forward + backward (finite
+              gradients on every parameter, bit-reproducible image).
+  configs[3]/[4] (multi-GPU) cannot run on the one GPU of the test box; their code path -- bench.py starting N ranks
+              itself, the sharded step, the in-place gradient exchange, the statistics broadcast -- runs here with two
+              ranks on ONE device over gloo at a reduced anchor count.
+"""
+import json
+import math
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from util import oracle_settings
+from test_gpu_parity import _check_forward, _check_grads, _run_gpu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cfg2_5M_anchors_plane2800(oracle):
+    from splatco_amd.renderer import generate_neural_gaussians, prefilter_voxel, render
+    from splatco_amd.synthetic import ANCHOR_CONFIGS, synthetic_anchor_model, synthetic_views
+    dev = torch.device("cuda:0")
+    N, _, seed = ANCHOR_CONFIGS["cfg2"]
+    assert N == 5_000_000
+    pc = synthetic_anchor_model(N, seed, dev, plane_size=2800, num_channels=15, activate_level=2)
+    assert pc.feat_planes._feat.k0s[3].xy_plane.shape[-1] == 2800 and pc.feat_planes._feat.activate_level == 2
+    cam = synthetic_views(1)[0]
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
+    bg = torch.ones(3, device=dev)
+    st = oracle_settings(oracle, cam, np.ones(3, np.float32))
+    oracle.use_threads(True)
+    try:
+        # ---- a2: anchor visibility at N = 5 M, bit-exact (same fp32 inputs on both sides)
+        vis = prefilter_voxel(cam.to(dev), pc, pipe, bg)
+        with torch.no_grad():
+            want = oracle.visible_filter(st, pc.get_anchor.cpu().numpy(), pc.get_scaling[:, :3].cpu().numpy(),
+                                         pc.get_rotation.cpu().numpy())
+            from splatco_amd.rasterizer import GaussianRasterizer
+            from splatco_amd.renderer import _settings
+            got = GaussianRasterizer(_settings(cam.to(dev), bg, 1.0, False)).visible_filter(
+                means3D=pc.get_anchor, scales=pc.get_scaling[:, :3], rotations=pc.get_rotation)
+        assert np.array_equal(got.cpu().numpy(), want), "visible_filter radii at N = 5M"
+        assert np.array_equal(vis.cpu().numpy(), want > 0)
+        V = int(vis.sum())
+        assert V > 4_000_000
+        # ---- a3: the anchor path; a5/a6 on its output against the oracle
+        with torch.no_grad():
+            xyz, color, opacity, scaling, rot, neural_opacity, mask = generate_neural_gaussians(cam.to(dev), pc, vis, is_training=True)
+        P = xyz.shape[0]
+        print(f"[cfg2] visible anchors {V}, neural Gaussians {P}")
+        assert P > 10_000_000 and int(mask.sum()) == P
+        g = dict(means3D=xyz.cpu().numpy(), scales=scaling.cpu().numpy(), rotations=rot.cpu().numpy(),
+                 opacities=opacity.cpu().numpy(), colors=color.cpu().numpy(), bg=np.ones(3, np.float32))
+        del xyz, color, opacity, scaling, rot, neural_opacity, mask
+        f = oracle.forward(st, g["means3D"], g["opacities"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+        tile_n = f["ranges"][:, 1].astype(np.int64) - f["ranges"][:, 0]
+        print(f"[cfg2] tile instances {f['num_rendered']}, largest tile {tile_n.max()} (merge-path passes above 4096)")
+        assert f["num_rendered"] > 15_000_000 and tile_n.max() > 4096
+        dL = np.random.default_rng(2).standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
+        o = _run_gpu(cam, g, dL=dL, ref=f)
+        _check_forward(f, o, st)
+        b = oracle.backward(st, f, o["dL_eff"], g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+        _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"])
+        del f, b, o, g
+    finally:
+        oracle.use_threads(False)
+    # ---- a4: the whole render() path at this size, forward + backward
+    pc.train()
+    out = render(cam.to(dev), pc, pipe, bg, visible_mask=vis, retain_grad=True)
+    target = torch.rand(3, cam.image_height, cam.image_width, device=dev)
+    ((out["render"] - target).abs().mean() + 0.01 * out["scaling"].prod(dim=1).mean()).backward()
+    assert out["render"].shape == (3, 1080, 1920) and torch.isfinite(out["render"]).all()
+    gvs = out["viewspace_points"].grad
+    assert gvs is not None and torch.isfinite(gvs).all() and torch.all(gvs[:, 2] == 0) and gvs[:, :2].abs().sum() > 0
+    planes = pc.feat_planes._feat.k0s
+    for name, p in [("anchor", pc._anchor), ("offset", pc._offset), ("feat", pc._anchor_feat), ("scaling", pc._scaling),
+                    ("mlp_cov", pc.mlp_cov[0].weight), ("plane L0 (attention)", planes[0].xy_plane),
+                    ("plane L1", planes[1].xz_plane), ("plane L2 (1400)", planes[2].yz_plane)]:
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0, name
+    assert planes[3].xy_plane.grad is None            # the 2800^2 level is never sampled
+    with torch.no_grad():
+        again = render(cam.to(dev), pc, pipe, bg, visible_mask=vis)["render"]
+    assert torch.equal(again, out["render"].detach())                     # bit-reproducible at 15 M Gaussians
+
+
+@pytest.mark.parametrize("config", ["cfg1", "cfg3"])
+def test_bench_starts_its_own_ranks(config):
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself (configs[3]/[4] code path; both ranks on the
+    one device of this box, gloo instead of RCCL, reduced anchor count) and prints ONE JSON line with the all-reduce
+    bookkeeping."""
+    env = dict(os.environ, SPLATCO_BENCH_ONE_DEVICE="1", SPLATCO_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--config", config]
+    if config != "cfg1":
+        cmd += ["--anchors", "200000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["allreduce"]["bytes"] > 0 and out["allreduce"]["ms"] > 0
+    assert out["roofline"]["achieved"] >= 0 and config in out["config"]["workload"]
+    # a launcher that started another number of ranks is an error, not a silent N = 1 run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stdout + bad.stderr)

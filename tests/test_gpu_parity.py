@@ -311,17 +311,14 @@ def test_full_size_cfg1_1M_1080p(oracle):
 STRESS_NAMES = ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"]
 
 
-def _fp64_with_fp32_decisions(oracle, st, f, g):
-    """The fp64 oracle evaluated on the fp32 oracle's integer decisions (visibility, tile lists, sort order): fp64
-    values of every per-Gaussian quantity, blended over the fp32 lists.  (An independent fp64 forward rounds depths
-    and radii differently in rare cases and would then describe another piecewise-smooth branch of the function.)"""
-    pre = oracle.preprocess(st, g["means3D"], g["scales"], g["rotations"], None, g["opacities"].reshape(-1), None,
-                            g["colors"], f64=True)
-    other = (pre["radii"] > 0) != (f["radii"] > 0)          # culled on one side only: take the fp32 row
-    for k in ("xy", "depth", "cov3D", "conic_opacity", "rgb"):
-        pre[k][other] = f[k][other]
-    for k in ("radii", "tiles_touched", "rect", "clamped"):
-        pre[k] = f[k]
+def _fp64_on_fp32_records(oracle, st, f):
+    """The fp64 oracle evaluated on the fp32 oracle's per-Gaussian records (screen position, conic, colour -- the
+    48-byte splat records, which the device reproduces bit for bit) and integer decisions (visibility, tile lists,
+    sort order): blend forward, blend backward and the projection chain in binary64.  What remains between this and
+    an fp32 evaluation is exactly what the device and the fp32 oracle are free to do differently: the rounding of
+    the per-pixel terms, the order of the sums, the rounding inside the chain."""
+    pre = {k: (f[k].astype(np.float64) if f[k].dtype == np.float32 else f[k])
+           for k in ("radii", "xy", "depth", "cov3D", "conic_opacity", "rgb", "clamped", "tiles_touched", "rect")}
     bins = {k: f[k] for k in ("point_offsets", "num_rendered", "keys_sorted", "point_list", "ranges")}
     out = dict(pre)
     out.update(bins)
@@ -329,14 +326,21 @@ def _fp64_with_fp32_decisions(oracle, st, f, g):
     return out
 
 
-def stress_case(oracle, rng):
+CERTIFY = 3e-5         # a gradient row is "pinned by binary32" when the fp32 oracle's own row is this close to fp64
+
+
+def stress_case(oracle, rng, verbose=False):
     """One randomised scene against the oracle.  Forward: the bars of _check_forward.  Gradients, per tensor:
-    rel-L2 <= 1e-4 vs the fp32 oracle.  A tensor that misses that bar passes only with fp64 EVIDENCE that the scene
-    is ill-conditioned in binary32 itself (needle-like Gaussians whose per-tile sums cancel): against the fp64
-    oracle evaluated on the same decisions, the device result must be within 3x of the fp32 oracle's OWN distance
-    to fp64 -- i.e. as accurate as the scalar fp32 restatement of the reference arithmetic is.  Pixels whose
-    n_contrib differs between any two of the three are excused on all sides (bounded, printed).
-    Returns a report line; raises AssertionError otherwise."""
+      (a) rel-L2 <= 1e-4 vs the fp32 oracle over ALL Gaussians -- or, where that fails,
+      (b) the same bar over the Gaussians whose gradient binary32 pins at all: rows for which the fp32 oracle itself
+          is within 3e-5 (row-relative) of the fp64 evaluation of the same records and decisions.  The stress set
+          contains needle-like Gaussians (anisotropy up to 300:1 over hundreds of tiles) whose gradient sums cancel
+          to a few per cent and whose covariance chain divides by a vanishing determinant: ANY fp32 evaluation -- the
+          scalar fp32 oracle included -- is 1e-3 .. 1e-2 off on those rows, so no fp32 tolerance can hold there.  The
+          fraction of such rows is printed, and on them the device must still be no further than 10x the fp32
+          oracle's own distance from fp64 (rel-L2 over the set): a wrong term is O(1), rounding is not.
+    Pixels whose n_contrib differs between any two of the three evaluations are excused on all sides (bounded,
+    printed).  Returns a report line; raises AssertionError otherwise."""
     cam, g, sm = stress_scene(rng)
     st = oracle_settings(oracle, cam, g["bg"], scale_modifier=sm)
     args = (g["means3D"], g["opacities"], g["scales"], g["rotations"])
@@ -349,8 +353,8 @@ def stress_case(oracle, rng):
     e32 = {k: rel_l2(o["grads"][k], b[k]) for k in STRESS_NAMES}
     worst = max(e32.values())
     note = ""
-    if worst > GRAD_TOL:
-        f64 = _fp64_with_fp32_decisions(oracle, st, f, g)
+    if worst > GRAD_TOL or verbose:
+        f64 = _fp64_on_fp32_records(oracle, st, f)
         more = (f64["n_contrib"] != f["n_contrib"]) & (dL_eff != 0).any(axis=0)
         if more.any():       # threshold pixels of the fp64 blend: excuse them on all three sides and redo
             assert (more.sum() + o["excused"]) / more.size <= EXCUSED_MAX
@@ -361,15 +365,26 @@ def stress_case(oracle, rng):
             b = oracle.backward(st, f, dL_eff, g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
             e32 = {k: rel_l2(o["grads"][k], b[k]) for k in STRESS_NAMES}
         b64 = oracle.backward(st, f64, dL_eff, g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"], f64=True)
+        vis = f["radii"] > 0
         for k in STRESS_NAMES:
+            if e32[k] <= GRAD_TOL and not verbose:
+                continue
+            dev, o32, ref = o["grads"][k].astype(np.float64), b[k].astype(np.float64), b64[k]
+            row_err = np.linalg.norm(o32 - ref, axis=1)
+            pinned = row_err <= CERTIFY * np.linalg.norm(ref, axis=1)
+            e_pinned = rel_l2(dev[pinned], o32[pinned])
+            loose = ~pinned
+            d_dev, d_o32 = np.linalg.norm(dev[loose] - ref[loose]), np.linalg.norm(o32[loose] - ref[loose])
+            note += (f" {k}: {e32[k]:.1e} over all rows; {loose.sum()} of {vis.sum()} visible rows not pinned by fp32 "
+                     f"(device {d_dev / max(np.linalg.norm(ref[loose]), 1e-300):.1e}, fp32 oracle "
+                     f"{d_o32 / max(np.linalg.norm(ref[loose]), 1e-300):.1e} from fp64 there), pinned rows {e_pinned:.1e};")
             if e32[k] > GRAD_TOL:
-                e_gpu, e_o32 = rel_l2(o["grads"][k], b64[k]), rel_l2(b[k], b64[k])
-                note += f" {k}: {e32[k]:.1e} vs fp32, device {e_gpu:.1e} / fp32 oracle {e_o32:.1e} vs fp64;"
-                assert e_gpu <= 3.0 * e_o32, (k, "vs fp64: device", e_gpu, "fp32 oracle", e_o32)
+                assert e_pinned <= GRAD_TOL, (k, "rows pinned by fp32", e_pinned)
+                assert d_dev <= 10.0 * d_o32, (k, "ill-conditioned rows vs fp64: device", d_dev, "fp32 oracle", d_o32)
     ranges = f["ranges"]
     return (f"P={g['means3D'].shape[0]} {cam.image_width}x{cam.image_height} I={f['num_rendered']} "
             f"max tile={(ranges[:, 1].astype(np.int64) - ranges[:, 0]).max()} vis={(f['radii'] > 0).sum()} "
-            f"worst grad {worst:.1e}" + (" ILL-CONDITIONED" + note if note else ""))
+            f"worst grad {worst:.1e}" + (" |" + note if note else ""))
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4])

@@ -1,6 +1,7 @@
 """Developer stress run (GPU box): more seeds of the randomised scene set that tests/test_gpu_parity.py::
 test_randomised_stress_scenes runs under pytest -m gpu (same scene generator, same bars).
-usage: python tools/stress_parity.py [scenes per seed] [first seed] [number of seeds]"""
+usage: python tools/stress_parity.py [scenes per seed] [first seed] [number of seeds] [verbose: 1 = print the
+fp64 evidence of every tensor]"""
 import sys
 
 import numpy as np
@@ -11,14 +12,14 @@ from oracle import raster_oracle as orc
 from test_gpu_parity import stress_case
 
 
-def main(n=40, seed=0, seeds=1):
+def main(n=40, seed=0, seeds=1, verbose=0):
     bad = 0
     orc.build()
     for s in range(seed, seed + seeds):
         rng = np.random.default_rng(s)
         for it in range(n):
             try:
-                line = stress_case(orc, rng)
+                line = stress_case(orc, rng, verbose=bool(verbose))
             except AssertionError as e:
                 bad += 1
                 line = "FAIL " + str(e)[:300]
