@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 4
+#define SCR_ABI_VERSION 5
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -178,6 +178,29 @@ int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, con
                          const void* scratch, const float* g_l1, const float* g_ssim, float* dimg1,
                          void* stream);
 
+/* ---- the three MLP heads of generate_neural_gaussians (gaussian_renderer/__init__.py:58-93 with the default flags,
+ * scene/gaussian_model.py:315-337) as one fp32-MFMA kernel per direction, for the reference's layer sizes
+ * (feat 32, geo_fea 64, hidden 32 per head, n_offsets 10):
+ *   x = cat(feat[V,32], (anchor - campos) / |anchor - campos|, geo_fea[V,64])       (never materialised)
+ *   out_opacity[V,10] = tanh(W2o relu(W1[0:32] x + b1[0:32]) + b2o);  out_color[V,30] = sigmoid(... [32:64] ...);
+ *   out_cov[V,70] = W2v relu(W1[64:96] x + b1[64:96]) + b2v
+ * w1[96,99] / b1[96] are the three first layers stacked (opacity, colour, cov).  hidden_save (opaque,
+ * scr_mlp_heads_hidden_bytes) keeps the hidden layer for the backward pass.  The backward overwrites every output:
+ * d_feat[V,32], d_anchor[V,3] (through ob_view), d_geo[V,64] and the parameter gradients; weight-gradient partial
+ * sums go through `partial` (scr_mlp_heads_partial_bytes) and are added in a fixed order (bit-reproducible). */
+size_t scr_mlp_heads_hidden_bytes(int64_t V);
+size_t scr_mlp_heads_partial_bytes(int64_t V);
+int scr_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,
+                          const float* w1, const float* b1, const float* w2o, const float* b2o, const float* w2c,
+                          const float* b2c, const float* w2v, const float* b2v, void* hidden_save, float* out_opacity,
+                          float* out_color, float* out_cov, void* stream);
+int scr_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,
+                           const float* w1, const float* w2o, const float* w2c, const float* w2v, const void* hidden_save,
+                           const float* out_opacity, const float* out_color, const float* g_opacity, const float* g_color,
+                           const float* g_cov, void* partial, float* d_feat, float* d_anchor, float* d_geo, float* d_w1,
+                           float* d_b1, float* d_w2o, float* d_b2o, float* d_w2c, float* d_b2c, float* d_w2v, float* d_b2v,
+                           void* stream);
+
 /* ---- densification statistics: GaussianModel.training_statis (scene/gaussian_model.py:761-782), the consumer of
  * dL_dmeans2D (train.py:264-266), over the V visible anchors of one view (k offsets each), in two steps so that the
  * sharded --mv step can broadcast the increments between them:
@@ -210,7 +233,8 @@ enum {
     SCR_PROF_FILTER = 0, SCR_PROF_PREPROCESS = 1, SCR_PROF_PLAN_SCAN = 2, SCR_PROF_SCATTER = 3,
     SCR_PROF_TILE_SORT = 4, SCR_PROF_BLEND_FORWARD = 5, SCR_PROF_BLEND_BACKWARD = 6,
     SCR_PROF_PREPROCESS_BACKWARD = 7, SCR_PROF_EXPAND = 8, SCR_PROF_EXPAND_BACKWARD = 9, SCR_PROF_PLANE_BACKWARD = 10,
-    SCR_PROF_L1_SSIM = 11, SCR_PROF_L1_SSIM_BACKWARD = 12, SCR_PROF_TRIPLANE_FORWARD = 13, SCR_PROF_COUNT = 14
+    SCR_PROF_L1_SSIM = 11, SCR_PROF_L1_SSIM_BACKWARD = 12, SCR_PROF_TRIPLANE_FORWARD = 13, SCR_PROF_MLP_HEADS = 14,
+    SCR_PROF_MLP_HEADS_BACKWARD = 15, SCR_PROF_COUNT = 16
 };
 int scr_profile_enable(int mask);
 int scr_profile_read(double* total_ms, int64_t* launches);

@@ -62,7 +62,7 @@ const char* const kProfNames[SCR_PROF_COUNT] = {
     "filter_kernel", "preprocess_kernel", "plan_scan_kernel", "scatter_kernel", "tile_sort_kernel",
     "blend_forward_kernel", "blend_backward_kernel", "preprocess_backward_kernel", "expand_kernel",
     "expand_backward_kernel", "plane_sample_backward_kernels", "l1_ssim_forward_kernel",
-    "l1_ssim_backward_kernel", "triplane_forward_kernel"};
+    "l1_ssim_backward_kernel", "triplane_forward_kernel", "mlp_heads_kernel", "mlp_heads_backward_kernel"};
 }  // namespace
 
 // float4 grid-stride copy: measures the HBM bandwidth a streaming kernel can reach on this device (bench.py)
@@ -417,6 +417,47 @@ int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, con
     { ProfScope ps_(SCR_PROF_L1_SSIM_BACKWARD, st);
       launch_l1_ssim_backward(C, H, W, img1, img2, scratch, g_l1, g_ssim, dimg1, st); }
     CHECK_LAUNCH("l1_ssim_backward_kernel", 0, st);
+    return 0;
+}
+
+// ---- MLP heads (mlp_heads.hip)
+size_t scr_mlp_heads_hidden_bytes(int64_t V) { return mlp_heads_hidden_bytes(V > 0 ? V : 1); }
+size_t scr_mlp_heads_partial_bytes(int64_t V) { return mlp_heads_partial_bytes(V > 0 ? V : 1); }
+
+int scr_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,
+                          const float* w1, const float* b1, const float* w2o, const float* b2o, const float* w2c,
+                          const float* b2c, const float* w2v, const float* b2v, void* hidden_save, float* out_opacity,
+                          float* out_color, float* out_cov, void* stream) {
+    if (V < 0) return fail("V < 0");
+    if (V == 0) return 0;
+    if (!feat || !anchor || !campos || !geo || !w1 || !b1 || !w2o || !b2o || !w2c || !b2c || !w2v || !b2v || !hidden_save ||
+        !out_opacity || !out_color || !out_cov)
+        return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_MLP_HEADS, st);
+      launch_mlp_heads_forward(V, feat, anchor, campos, geo, w1, b1, w2o, b2o, w2c, b2c, w2v, b2v, hidden_save, out_opacity,
+                               out_color, out_cov, st); }
+    CHECK_LAUNCH("mlp_heads_forward_kernel", 0, st);
+    return 0;
+}
+
+int scr_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,
+                           const float* w1, const float* w2o, const float* w2c, const float* w2v, const void* hidden_save,
+                           const float* out_opacity, const float* out_color, const float* g_opacity, const float* g_color,
+                           const float* g_cov, void* partial, float* d_feat, float* d_anchor, float* d_geo, float* d_w1,
+                           float* d_b1, float* d_w2o, float* d_b2o, float* d_w2c, float* d_b2c, float* d_w2v, float* d_b2v,
+                           void* stream) {
+    if (V <= 0) return fail("V <= 0");
+    if (!feat || !anchor || !campos || !geo || !w1 || !w2o || !w2c || !w2v || !hidden_save || !out_opacity || !out_color ||
+        !g_opacity || !g_color || !g_cov || !partial || !d_feat || !d_anchor || !d_geo || !d_w1 || !d_b1 || !d_w2o || !d_b2o ||
+        !d_w2c || !d_b2c || !d_w2v || !d_b2v)
+        return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_MLP_HEADS_BACKWARD, st);
+      launch_mlp_heads_backward(V, feat, anchor, campos, geo, w1, w2o, w2c, w2v, hidden_save, out_opacity, out_color, g_opacity,
+                                g_color, g_cov, partial, d_feat, d_anchor, d_geo, d_w1, d_b1, d_w2o, d_b2o, d_w2c, d_b2c, d_w2v,
+                                d_b2v, st); }
+    CHECK_LAUNCH("mlp_heads_backward_kernel", 0, st);
     return 0;
 }
 

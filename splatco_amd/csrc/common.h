@@ -295,6 +295,19 @@ void launch_statis_apply(int64_t V, int k, const int64_t* visible_index, const f
                          float* opacity_accum, float* anchor_demon, float* offset_gradient_accum, float* offset_denom,
                          hipStream_t st);
 
+size_t mlp_heads_hidden_bytes(int64_t V);
+size_t mlp_heads_partial_bytes(int64_t V);
+void launch_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,
+                              const float* w1, const float* b1, const float* w2o, const float* b2o, const float* w2c,
+                              const float* b2c, const float* w2v, const float* b2v, void* hidden_save, float* out_o,
+                              float* out_c, float* out_v, hipStream_t st);
+void launch_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,
+                               const float* w1, const float* w2o, const float* w2c, const float* w2v,
+                               const void* hidden_save, const float* out_o, const float* out_c, const float* g_o,
+                               const float* g_c, const float* g_v, void* partial, float* d_feat, float* d_anchor,
+                               float* d_geo, float* d_w1, float* d_b1, float* d_w2o, float* d_b2o, float* d_w2c,
+                               float* d_b2c, float* d_w2v, float* d_b2v, hipStream_t st);
+
 size_t l1_ssim_scratch_bytes(int C, int H, int W, int with_grad);
 void launch_l1_ssim_forward(int C, int H, int W, const float* img1, const float* img2, void* scratch,
                             int with_grad, float* out2, hipStream_t st);

@@ -29,11 +29,12 @@ def _mlp_heads(pc, x):
     return tuple(h[2:](x_) for h, x_ in zip(heads, parts))
 
 
-def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False, expand=None):
+def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False, expand=None, fused_heads=True):
     """Anchors -> neural Gaussians (gaussian_renderer/__init__.py:18-116), same op order.
     The mask / compaction / post-processing block (:68-111) is the single HIP op of splatco_amd.expand
     (device tensors only, no CPU path).  expand: test hook -- a callable with expand_compact's signature
-    (tests/torch_restatements.py holds the torch op chain the kernel is checked against)."""
+    (tests/torch_restatements.py holds the torch op chain the kernel is checked against).  fused_heads=False keeps
+    the MLP heads as rocBLAS GEMMs (the checker of csrc/mlp_heads.hip)."""
     if visible_mask is None:
         visible_mask = torch.ones(pc.get_anchor.shape[0], dtype=torch.bool, device=pc.get_anchor.device)
     # `t[visible_mask]` four times (:23-29) = four mask->index conversions (each a host sync) and
@@ -46,12 +47,22 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     V, k = anchor.shape[0], pc.n_offsets
     geo_fea = pc.feat_planes.inference(
         anchor, torch.concat((feat, anchor, grid_offsets.reshape(V, -1), grid_scaling), dim=1), 0)
-    ob_view = anchor - viewpoint_camera.camera_center
-    ob_dist = ob_view.norm(dim=1, keepdim=True)
-    ob_view = ob_view / ob_dist
     if getattr(pc, "use_feat_bank", False) or getattr(pc, "appearance_dim", 0) > 0:
         raise NotImplementedError("feature bank / appearance embedding are off on the benchmarked path")
-    if not (pc.add_opacity_dist or pc.add_color_dist or pc.add_cov_dist):
+    from . import mlp_heads as _mh
+    plain = not (pc.add_opacity_dist or pc.add_color_dist or pc.add_cov_dist)
+    if plain and fused_heads and _mh.supported(pc, feat, geo_fea):
+        # the three heads as ONE fp32-MFMA kernel per direction (csrc/mlp_heads.hip): x = cat(feat, ob_view, geo_fea)
+        # (:58-60) is never built, ob_view (:34-38) is computed inside
+        neural_opacity, color, scale_rot = _mh.mlp_heads(pc, feat, anchor, viewpoint_camera.camera_center, geo_fea)
+        ob_view = None
+    else:
+        ob_view = anchor - viewpoint_camera.camera_center
+        ob_dist = ob_view.norm(dim=1, keepdim=True)
+        ob_view = ob_view / ob_dist
+    if ob_view is None:
+        pass
+    elif plain:
         # the three heads read the same [V, 99] input (:62-93 with the default flags): their first layers run
         # as ONE GEMM with stacked weights (one pass over the input instead of three, forward and backward)
         cat_local_view_wodist = torch.cat([feat, ob_view, geo_fea], dim=1)

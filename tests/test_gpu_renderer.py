@@ -352,3 +352,66 @@ def test_training_statis_kernel_golden_and_random():
         assert torch.equal(x, z)
     with pytest.raises(RuntimeError):
         training_statis(*[a.cpu() for a in a1], k, grad.cpu(), no.cpu(), upd.cpu(), sel.cpu(), vis.cpu())
+
+
+@pytest.mark.parametrize("V", [1, 37, 100_003])
+def test_fused_mlp_heads_match_the_torch_chain(V):
+    """csrc/mlp_heads.hip (fp32 MFMA, x / hidden layer never in HBM) == the module chain of
+    scene/gaussian_model.py:315-337 on x = cat(feat, ob_view, geo_fea) (gaussian_renderer/__init__.py:34-93):
+    outputs to 1e-5, every gradient (inputs, anchor through ob_view, all weights and biases) to rel-L2 1e-4 (fp32
+    summation order over V rows is the only difference); bit-reproducible."""
+    from splatco_amd.mlp_heads import mlp_heads, supported
+    from splatco_amd.scene_model import AnchorGaussianModel
+    dev = torch.device("cuda:0")
+    torch.manual_seed(V)
+    pc = AnchorGaussianModel(plane_size=16, num_channels=15).to(dev)
+    with torch.no_grad():
+        for p in list(pc.mlp_opacity.parameters()) + list(pc.mlp_color.parameters()) + list(pc.mlp_cov.parameters()):
+            p.add_(0.2 * torch.randn_like(p))
+    g = torch.Generator(device=dev).manual_seed(V + 1)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    feat, anchor, geo, cam = r(V, 32), r(V, 3) * 2, r(V, 64), torch.tensor([0.3, -0.2, -5.0], device=dev)
+    w = [r(V, 10), r(V, 30), r(V, 70)]
+    res = {}
+    for fused in (True, False, True):
+        f, a, ge = (t.clone().requires_grad_() for t in (feat, anchor, geo))
+        for p in pc.parameters():
+            p.grad = None
+        if fused:
+            assert supported(pc, f, ge)
+            outs = mlp_heads(pc, f, a, cam, ge)
+        else:
+            ob = a - cam
+            ob = ob / ob.norm(dim=1, keepdim=True)
+            x = torch.cat([f, ob, ge], dim=1)
+            outs = (pc.mlp_opacity(x), pc.mlp_color(x), pc.mlp_cov(x))
+        sum((o * wi).sum() for o, wi in zip(outs, w)).backward()
+        grads = {"feat": f.grad, "anchor": a.grad, "geo": ge.grad}
+        grads.update({n: p.grad.clone() for n, p in pc.named_parameters() if n.startswith("mlp_")})
+        res.setdefault(fused, []).append(([o.detach() for o in outs], grads))
+    (o1, g1), (o1b, g1b) = res[True]
+    (o0, g0), = res[False]
+    for a_, b_, name in zip(o1, o0, ("opacity", "color", "cov")):
+        assert a_.shape == b_.shape
+        assert torch.allclose(a_, b_, rtol=1e-5, atol=2e-6), (name, (a_ - b_).abs().max().item())
+    assert set(g1) == set(g0) and len(g1) == 3 + 12
+    for n in g0:
+        err = (g1[n] - g0[n]).norm().item() / max(g0[n].norm().item(), 1e-20)
+        assert err <= 1e-4, (n, err)
+        assert torch.equal(g1[n], g1b[n]), n                # bit-reproducible
+    assert all(torch.equal(x_, y_) for x_, y_ in zip(o1, o1b))
+
+
+def test_generate_neural_gaussians_fused_heads_golden():
+    """The whole anchor path with the fused heads against the reference's fixture (neural_gaussians.npz)."""
+    from splatco_amd.renderer import generate_neural_gaussians
+    dev = torch.device("cuda:0")
+    pc, d = _model(dev)
+    pc.train()
+    cam = types.SimpleNamespace(camera_center=torch.tensor(d["camera_center"], device=dev), uid=0)
+    vis = torch.tensor(d["visible_mask"], device=dev)
+    with torch.no_grad():
+        out = generate_neural_gaussians(cam, pc, vis, is_training=True, fused_heads=True)
+    assert np.array_equal(out[6].cpu().numpy(), d["L0_train.mask"])
+    for t, name in zip(out[:6], ["xyz", "color", "opacity", "scaling", "rot", "neural_opacity"]):
+        np.testing.assert_allclose(t.cpu().numpy(), d[f"L0_train.{name}"], rtol=1e-4, atol=1e-5, err_msg=name)
