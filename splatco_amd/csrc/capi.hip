@@ -103,12 +103,16 @@ static bool mailbox_wait(Mailbox& mb, unsigned long long seq, bool two, hipStrea
     if (!mb.host) return false;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
-        if (mb.host[1] == seq && (!two || mb.host[3] == seq)) return true;
+        // stamp first, with acquire ordering: the value words read afterwards are at least as new as the stamp
+        if (__atomic_load_n(&mb.host[1], __ATOMIC_ACQUIRE) == seq && (!two || __atomic_load_n(&mb.host[3], __ATOMIC_ACQUIRE) == seq))
+            return true;
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
         if ((spins & 1023u) == 1023u) {
-            if (hipStreamQuery(st) != hipErrorNotReady) return mb.host[1] == seq && (!two || mb.host[3] == seq);
+            if (hipStreamQuery(st) != hipErrorNotReady)
+                return __atomic_load_n(&mb.host[1], __ATOMIC_ACQUIRE) == seq &&
+                       (!two || __atomic_load_n(&mb.host[3], __ATOMIC_ACQUIRE) == seq);
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return false;
         }
     }

@@ -562,11 +562,15 @@ void launch_preprocess(int64_t P, int M, const float* means3D, const float* scal
                        const KSettings& ks, const GeomView& gv, int32_t* radii, hipStream_t st) {
     if (P <= 0) return;
     Grid g(ks.H, ks.W);
-    static bool big_lds = false;
-    if (!big_lds) {  // histograms beyond the default 64 KB dynamic-LDS limit (gfx950 has 160 KB per CU)
-        (void)hipFuncSetAttribute((const void*)preprocess_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  LDS_HIST_MAX_TILES * 4);
-        big_lds = true;
+    // histograms beyond the default 64 KB dynamic-LDS limit (gfx950 has 160 KB per CU): the attribute is per device
+    static bool big_lds[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !big_lds[dev]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)preprocess_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 LDS_HIST_MAX_TILES * 4);
+        if (e == hipSuccess && dev >= 0 && dev < 64) big_lds[dev] = true;
+        (void)hipGetLastError();      // a refused attribute shows up as a launch error below
     }
     if (g.tiles <= LDS_HIST_MAX_TILES)
         preprocess_kernel<true><<<nblk(P, BIN_GPW), BIN_THREADS, (size_t)g.tiles * 4, st>>>(

@@ -50,14 +50,17 @@ class _L1Ssim(torch.autograd.Function):
     def forward(ctx, x, y):
         from . import _C
         from .rasterizer import _stream
+        # whether the derivative maps are needed is a property of the INPUT: grad mode is off inside forward, so a
+        # converted copy (non-contiguous crop, other dtype) would report requires_grad = False
+        need = bool(ctx.needs_input_grad[0])
         x, y = x.contiguous().float(), y.contiguous().float()
         C, H, W = x.shape
-        need = x.requires_grad
         scratch = torch.empty(_C.lib.scr_l1_ssim_scratch_bytes(C, H, W, int(need)), dtype=torch.uint8, device=x.device)
         out = torch.empty(2, dtype=torch.float32, device=x.device)
         _C.check(_C.lib.scr_l1_ssim_forward(C, H, W, x.data_ptr(), y.data_ptr(), scratch.data_ptr(), int(need),
                                             out.data_ptr(), _stream()))
         ctx.save_for_backward(x, y, scratch)
+        ctx.have_maps = need
         return out[0], out[1]
 
     @staticmethod
@@ -65,6 +68,8 @@ class _L1Ssim(torch.autograd.Function):
         from . import _C
         from .rasterizer import _stream
         x, y, scratch = ctx.saved_tensors
+        if not ctx.have_maps:
+            raise RuntimeError("l1_ssim backward without the derivative maps of the forward pass")
         C, H, W = x.shape
         g_l1 = g_l1.contiguous().float().reshape(1)
         g_ssim = g_ssim.contiguous().float().reshape(1)

@@ -69,8 +69,9 @@ class _CSettings:
         return C.byref(self.c)
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None):
+    """The caller's current stream ON THE TENSORS' DEVICE (the process may have another device current)."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def _bytes(n, device):
@@ -95,6 +96,7 @@ class RasterState:
         shape, dt = shapes[which]
         out = torch.empty(shape, dtype=dt, device=dev)
         if out.numel():
+          with torch.cuda.device(dev):
             _C.check(_C.lib.scr_debug_get(which, self.P, self.I, self.cs.H, self.cs.W, _ptr(self.geom),
                                           _ptr(self.binning), _ptr(self.image), out.data_ptr(), _stream()))
         return out
@@ -116,16 +118,31 @@ def rasterize_forward(cs, means3D, opacities, scales, rotations, cov3D_precomp, 
     radii = torch.empty(P, dtype=torch.int32, device=dev)      # every entry is written by preprocess_kernel
     color = torch.empty(3, cs.H, cs.W, dtype=torch.float32, device=dev)
     plan = (C.c_int64 * 2)(0, 0)      # (tile instances, largest per-tile instance count)
-    _C.check(_C.lib.scr_forward_plan(P, M, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
-                                     _ptr(opacities), _ptr(shs), _ptr(colors_precomp), cs.ref(),
-                                     st.geom.data_ptr(), _ptr(radii), plan, _stream()))
-    st.I, st.max_tile = int(plan[0]), int(plan[1])
-    last_plan = (P, st.I, st.max_tile)
-    st.binning = _bytes(_C.lib.scr_binning_bytes(st.I, st.max_tile), dev)
-    _C.check(_C.lib.scr_forward_run(P, st.I, st.max_tile, cs.ref(), st.geom.data_ptr(), st.binning.data_ptr(),
-                                    st.image.data_ptr(), color.data_ptr(), _stream()))
+    with torch.cuda.device(dev):      # kernels launch on the CURRENT device: make it the tensors' device
+        _C.check(_C.lib.scr_forward_plan(P, M, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+                                         _ptr(opacities), _ptr(shs), _ptr(colors_precomp), cs.ref(),
+                                         st.geom.data_ptr(), _ptr(radii), plan, _stream()))
+        st.I, st.max_tile = int(plan[0]), int(plan[1])
+        last_plan = (P, st.I, st.max_tile)
+        st.binning = _bytes(_C.lib.scr_binning_bytes(st.I, st.max_tile), dev)
+        _C.check(_C.lib.scr_forward_run(P, st.I, st.max_tile, cs.ref(), st.geom.data_ptr(), st.binning.data_ptr(),
+                                        st.image.data_ptr(), color.data_ptr(), _stream()))
     st.radii = radii
     return color, radii, st
+
+
+def _debug_dump(path, raster_settings, **tensors):
+    """debug=True (pipe.debug, switched on by --debug_from, train.py:179-180): the C-ABI synchronises and checks
+    after every kernel; when a call fails the operator's inputs are written to `path` (snapshot_fw.dump /
+    snapshot_bw.dump in the working directory, the operator family's convention) before the error propagates."""
+    try:
+        blob = {"raster_settings": {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v)
+                                    for k, v in raster_settings._asdict().items()}}
+        blob.update({k: (None if v is None else v.detach().cpu()) for k, v in tensors.items()})
+        torch.save(blob, path)
+        return f" (inputs written to {path})"
+    except Exception as e:       # a faulted device may refuse the copies
+        return f" (could not write {path}: {e})"
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -147,9 +164,17 @@ class _RasterizeGaussians(torch.autograd.Function):
             ctx.shapes = (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
             ctx.mark_non_differentiable(radii)
             return color, radii
-        color, radii, st = rasterize_forward(cs, means3D, opacities, scales, rotations, cov3Ds_precomp, sh,
-                                             colors_precomp)
+        try:
+            color, radii, st = rasterize_forward(cs, means3D, opacities, scales, rotations, cov3Ds_precomp, sh,
+                                                 colors_precomp)
+        except RuntimeError as e:
+            if raster_settings.debug:
+                raise RuntimeError(str(e) + _debug_dump("snapshot_fw.dump", raster_settings, means3D=means3D, sh=sh,
+                                                        colors_precomp=colors_precomp, opacities=opacities, scales=scales,
+                                                        rotations=rotations, cov3Ds_precomp=cov3Ds_precomp)) from e
+            raise
         ctx.state = st
+        ctx.raster_settings = raster_settings
         ctx.save_for_backward(means3D, scales, rotations, cov3Ds_precomp, sh, colors_precomp, opacities)
         ctx.m2d_shape = tuple(means2D.shape)
         ctx.mark_non_differentiable(radii)
@@ -178,11 +203,20 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_sh = g_sh.view(P, st.M, 3)
         del arena, parts
         scratch = _bytes(_C.lib.scr_backward_scratch_bytes(st.I), dev)
-        _C.check(_C.lib.scr_backward(P, st.M, st.I, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D),
-                                     _ptr(sh), cs.ref(), st.radii.data_ptr(), st.geom.data_ptr(),
-                                     st.binning.data_ptr(), st.image.data_ptr(), g.data_ptr(), scratch.data_ptr(),
-                                     g_means3D.data_ptr(), g_means2D.data_ptr(), _ptr(g_col), _ptr(g_sh),
-                                     g_op.data_ptr(), _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), _stream()))
+        try:
+          with torch.cuda.device(dev):
+            _C.check(_C.lib.scr_backward(P, st.M, st.I, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D),
+                                         _ptr(sh), cs.ref(), st.radii.data_ptr(), st.geom.data_ptr(),
+                                         st.binning.data_ptr(), st.image.data_ptr(), g.data_ptr(), scratch.data_ptr(),
+                                         g_means3D.data_ptr(), g_means2D.data_ptr(), _ptr(g_col), _ptr(g_sh),
+                                         g_op.data_ptr(), _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), _stream()))
+        except RuntimeError as e:
+            if ctx.raster_settings.debug:
+                raise RuntimeError(str(e) + _debug_dump("snapshot_bw.dump", ctx.raster_settings, means3D=means3D, sh=sh,
+                                                        colors_precomp=colors, opacities=opacities, scales=scales,
+                                                        rotations=rotations, cov3Ds_precomp=cov3D, radii=st.radii,
+                                                        grad_out_color=g)) from e
+            raise
         g_op = g_op.reshape(opacities.shape)
         if ctx.m2d_shape != (P, 3):
             g_means2D = g_means2D[:, :ctx.m2d_shape[1]].reshape(ctx.m2d_shape) if len(ctx.m2d_shape) == 2 else None
@@ -210,7 +244,8 @@ class GaussianRasterizer(nn.Module):
             out = torch.zeros(P, dtype=torch.uint8, device=positions.device)
             view = _dev_f32(self.raster_settings.viewmatrix, "viewmatrix")
             if P:
-                _C.check(_C.lib.scr_mark_visible(P, positions.data_ptr(), view.data_ptr(), out.data_ptr(), _stream()))
+                with torch.cuda.device(positions.device):
+                    _C.check(_C.lib.scr_mark_visible(P, positions.data_ptr(), view.data_ptr(), out.data_ptr(), _stream()))
             return out.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
@@ -238,6 +273,7 @@ class GaussianRasterizer(nn.Module):
             P = means3D.shape[0]
             radii = torch.empty(P, dtype=torch.int32, device=means3D.device)  # filter_kernel writes every entry
             if P:
-                _C.check(_C.lib.scr_visible_filter(P, means3D.data_ptr(), _ptr(scales), _ptr(rotations),
-                                                   _ptr(cov3D_precomp), cs.ref(), radii.data_ptr(), _stream()))
+                with torch.cuda.device(means3D.device):
+                    _C.check(_C.lib.scr_visible_filter(P, means3D.data_ptr(), _ptr(scales), _ptr(rotations),
+                                                       _ptr(cov3D_precomp), cs.ref(), radii.data_ptr(), _stream()))
             return radii

@@ -108,9 +108,10 @@ def load_ply_sparse_gaussian(model, path, device=None):                         
     model._anchor_feat = nn.Parameter(t(family("f_anchor_feat")).requires_grad_(True))
     model._offset = nn.Parameter(t(offsets).transpose(1, 2).contiguous().requires_grad_(True))
     model._anchor = nn.Parameter(t(anchor).requires_grad_(True))
-    model._opacity = nn.Parameter(t(np.asarray(v["opacity"], dtype=np.float32)[:, None]), requires_grad=False)
+    # requires_grad True on all six, as the reference's loader does (:706-712)
+    model._opacity = nn.Parameter(t(np.asarray(v["opacity"], dtype=np.float32)[:, None]).requires_grad_(True))
     model._scaling = nn.Parameter(t(family("scale_")).requires_grad_(True))
-    model._rotation = nn.Parameter(t(family("rot")), requires_grad=False)
+    model._rotation = nn.Parameter(t(family("rot")).requires_grad_(True))
     return model
 
 
@@ -137,7 +138,11 @@ def save_scene(model, model_path, iteration):
     pc = os.path.join(model_path, "point_cloud", f"iteration_{iteration}")
     save_ply(model, os.path.join(pc, "point_cloud.ply"))
     save_mlp_checkpoints(model, pc)
-    torch.save((model.feat_planes.state_dict(), {}), os.path.join(model_path, f"chkpnt{iteration}.pth"))
+    # element 1 = the contractor's buffers (xyz_min / xyz_max, scene/gaussian_model.py:368-372; Scene loads them at
+    # scene/__init__.py:93).  The contraction itself is never applied on the render path,
+    # so the model only carries the two bounds along.
+    torch.save((model.feat_planes.state_dict(), dict(getattr(model, "contractor_state", {}))),
+               os.path.join(model_path, f"chkpnt{iteration}.pth"))
 
 
 def load_scene(model, model_path, iteration, device=None):                        # scene/__init__.py:80-94
@@ -146,4 +151,5 @@ def load_scene(model, model_path, iteration, device=None):                      
     load_mlp_checkpoints(model, pc)
     ck = torch.load(os.path.join(model_path, f"chkpnt{iteration}.pth"), map_location="cpu", weights_only=True)
     model.feat_planes.load_state_dict(ck[0], strict=False)
+    model.contractor_state = {k: v for k, v in dict(ck[1]).items()} if len(ck) > 1 else {}
     return model

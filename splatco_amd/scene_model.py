@@ -328,6 +328,7 @@ class AnchorGaussianModel(nn.Module):
         self._rotation = nn.Parameter(torch.empty(0, 4), requires_grad=False)   # requires_grad False in the reference
         self._opacity = nn.Parameter(torch.empty(0, 1), requires_grad=False)    # carried, never read by render()
         self.rotation_activation = F.normalize
+        self.contractor_state = {}        # xyz_min / xyz_max of the reference's Conctractor: carried through checkpoints only
 
     def set_anchors(self, anchor, offset, anchor_feat, scaling, rotation=None, opacity=None):
         N = anchor.shape[0]

@@ -95,7 +95,7 @@ def test_ply_layout_and_round_trip(tmp_path):
     scene_io.load_ply_sparse_gaussian(other, path)
     for n in ("_anchor", "_offset", "_anchor_feat", "_opacity", "_scaling", "_rotation"):
         assert torch.equal(getattr(other, n), getattr(pc, n)), n
-    assert other._anchor.requires_grad and not other._rotation.requires_grad
+    assert other._anchor.requires_grad and other._rotation.requires_grad and other._opacity.requires_grad   # as :706-712
 
 
 def test_ply_reader_accepts_ascii_and_permuted_properties(tmp_path):
@@ -124,3 +124,51 @@ def test_scene_save_load_round_trip(tmp_path):
     assert a.keys() == b.keys()
     for k_ in a:
         assert torch.equal(a[k_], b[k_]), k_
+
+
+def test_checkpoints_written_by_the_reference_load_and_match(tmp_path):
+    """tests/golden/ref_scene/ holds chkpnt7.pth (= torch.save(GaussianModel.capture()), train.py:313-316,
+    scene/gaussian_model.py:368-372) and checkpoints.pth (save_mlp_checkpoints 'unite', :1045-1066) written by the
+    REFERENCE's own code for the model of neural_gaussians.npz (tools/make_golden.py).  They must load through
+    splatco_amd.scene_io into our modules strictly, reproduce the fixture's weights, and what save_scene writes for
+    that model must have the same layout: same keys, shapes, dtypes and values, contractor bounds included."""
+    from splatco_amd import scene_io
+    from test_host_golden import _model_from_fixture
+    d = np.load(os.path.join(GOLD, "neural_gaussians.npz"))
+    ref_dir = os.path.join(GOLD, "ref_scene")
+    pc = _model_from_fixture(d)                                   # weights from the .npz arrays
+    other = _small_model(seed=9, N=4)
+    other.feat_planes = type(pc.feat_planes)(40, 15)              # plane_size of the fixture
+    scene_io.load_mlp_checkpoints(other, ref_dir)                 # <- reference-written file
+    for name in ("mlp_opacity", "mlp_cov", "mlp_color"):
+        a, b = getattr(pc, name).state_dict(), getattr(other, name).state_dict()
+        assert a.keys() == b.keys()
+        assert all(torch.equal(a[k_], b[k_]) for k_ in a), name
+    ck = torch.load(os.path.join(ref_dir, "chkpnt7.pth"), map_location="cpu", weights_only=True)
+    assert isinstance(ck, tuple) and len(ck) == 2
+    missing, unexpected = other.feat_planes.load_state_dict(ck[0], strict=False)
+    assert not unexpected and not missing, (missing, unexpected)    # our module tree IS the reference's key set
+    want = pc.feat_planes.state_dict()
+    for k_, v in other.feat_planes.state_dict().items():
+        if "num_batches_tracked" not in k_:
+            assert torch.equal(v, want[k_]), k_
+    assert sorted(ck[1]) == ["xyz_max", "xyz_min"]
+    # what we write for the same model == what the reference wrote
+    pc.contractor_state = dict(ck[1])
+    pc.set_anchors(torch.tensor(d["anchor"]), torch.tensor(d["offset"]), torch.tensor(d["anchor_feat"]), torch.tensor(d["scaling"]))
+    scene_io.save_scene(pc, str(tmp_path), 7)
+    mine = torch.load(tmp_path / "chkpnt7.pth", map_location="cpu", weights_only=True)
+    assert mine[0].keys() == ck[0].keys() and mine[1].keys() == ck[1].keys()
+    for k_ in ck[0]:
+        if "num_batches_tracked" not in k_:
+            assert mine[0][k_].dtype == ck[0][k_].dtype and torch.equal(mine[0][k_], ck[0][k_]), k_
+    assert all(torch.equal(mine[1][k_], ck[1][k_]) for k_ in ck[1])
+    mine_mlp = torch.load(tmp_path / "point_cloud" / "iteration_7" / "checkpoints.pth", weights_only=True)
+    ref_mlp = torch.load(os.path.join(ref_dir, "checkpoints.pth"), weights_only=True)
+    assert mine_mlp.keys() == ref_mlp.keys()
+    for k_ in ref_mlp:
+        assert mine_mlp[k_].keys() == ref_mlp[k_].keys() and all(torch.equal(mine_mlp[k_][j], ref_mlp[k_][j]) for j in ref_mlp[k_])
+    back = _small_model(seed=3, N=2)
+    back.feat_planes = type(pc.feat_planes)(40, 15)
+    scene_io.load_scene(back, str(tmp_path), 7)
+    assert sorted(back.contractor_state) == ["xyz_max", "xyz_min"] and torch.equal(back.contractor_state["xyz_min"], ck[1]["xyz_min"])

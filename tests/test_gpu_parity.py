@@ -11,6 +11,7 @@ Bars (SURVEY.md 8c / BASELINE.md 2):
     bit-reproducible run to run.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -233,6 +234,23 @@ def test_edge_cases(oracle):
         rast(means3D=z(1, 3), means2D=z(1, 3), opacities=z(1, 1), scales=z(1, 3), rotations=z(1, 4))
     with pytest.raises(Exception):
         rast(means3D=z(1, 3), means2D=z(1, 3), opacities=z(1, 1), colors_precomp=z(1, 3))
+
+
+def test_debug_mode_dumps_the_inputs_of_a_failed_call(tmp_path, monkeypatch):
+    """settings.debug (pipe.debug, --debug_from): a failing operator call leaves its inputs in snapshot_fw.dump before
+    the error propagates; without debug nothing is written."""
+    from splatco_amd.rasterizer import GaussianRasterizer
+    monkeypatch.chdir(tmp_path)
+    cam = synthetic_camera(64, 48)
+    d = _dev()
+    z = lambda *s: torch.rand(*s, device=d)
+    for debug in (False, True):
+        rast = GaussianRasterizer(_settings(cam, np.zeros(3, np.float32), sh_degree=7, debug=debug))   # degree 7: refused by the C-ABI
+        with pytest.raises(RuntimeError, match="sh_degree"):
+            rast(means3D=z(5, 3), means2D=z(5, 3), opacities=z(5, 1), shs=z(5, 16, 3), scales=z(5, 3), rotations=z(5, 4))
+        assert os.path.exists("snapshot_fw.dump") == debug
+    blob = torch.load("snapshot_fw.dump", weights_only=False)
+    assert blob["means3D"].shape == (5, 3) and blob["sh"].shape == (5, 16, 3) and blob["raster_settings"]["sh_degree"] == 7
 
 
 @pytest.mark.parametrize("P", [1500, 3000, 9000])

@@ -205,6 +205,15 @@ def make_neural_gaussians():
                 out[f"{tag}.{nme}"] = v.numpy() if v.dtype == torch.bool else f32(v)
     np.savez_compressed(os.path.join(OUT, "neural_gaussians.npz"), **out)
 
+    # ---- checkpoint files written by the reference's OWN code for this model: chkpnt<N>.pth = torch.save(capture())
+    # (train.py:313-316, scene/gaussian_model.py:368-372) and checkpoints.pth = save_mlp_checkpoints(mode 'unite')
+    # (scene/gaussian_model.py:1045-1066).  Binary data files (tensors), the layout test of splatco_amd.scene_io.
+    ref_dir = os.path.join(OUT, "ref_scene")
+    os.makedirs(ref_dir, exist_ok=True)
+    pc.setup_contractor([0.1, -0.2, 0.3], [4.0, 5.0, 6.0], False)
+    torch.save(pc.capture(), os.path.join(ref_dir, "chkpnt7.pth"))
+    pc.save_mlp_checkpoints(ref_dir, mode="unite")
+
     # ---- training_statis (scene/gaussian_model.py:761-782) on the same model object
     g = torch.Generator().manual_seed(5)
     Nn = 40
