@@ -236,6 +236,44 @@ __device__ __forceinline__ void row_fold9(float (&v)[9]) {
                  : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
                    "+v"(v[8]));
 }
+// The backward pass reduces SEPARABLE sums: a lane's pixel is (x, y) = (lane >> 3, lane & 7) inside the quadrant, so the
+// high lane bits carry x.  The levels that fold x away (permlane32, permlane16, the 8-lane DPP step) only need
+// S0 = Y, S1 = Y x, S2 = Y x^2 and the three colour terms: SIX values, not nine.  What depends on y is made afterwards,
+// from per-row partial sums, with two multiplications by the lane's y: y S0, y S1, y^2 S0.  Then the 4-lane step and
+// the two quad steps fold y away.  Input: v[0..5] = (S0, S1, S2, c0, c1, c2) after fold4 (rows = splats A, C, B, D).
+// Output by 4-lane bank of every row:  v[0] = (M0 | Mxx | Mx | c0),  v[4] = (c1 | My | c2 | Mxy),  myy = (Myy | - | - | -)
+// with M0 = sum Y, Mx = sum Y x, ... the moments about the quadrant's origin.  17 DPP adds + 2 multiplications where
+// row_fold9 takes 20 DPP adds after NINE (instead of six) permlane folds.
+__device__ __forceinline__ void row_fold6(float (&v)[6], float yl, float yl2, float& myy) {
+    float ya;
+    asm volatile("s_nop 1\n\t"
+                 // 8-lane step (x bit 0): (0,1) -> 0, (2,3) -> 2, (4,5) -> 4
+                 SCR_DPP("%0", "%0", "row_shl:8 row_mask:0xf bank_mask:0x3")
+                 SCR_DPP("%2", "%2", "row_shl:8 row_mask:0xf bank_mask:0x3")
+                 SCR_DPP("%4", "%4", "row_shl:8 row_mask:0xf bank_mask:0x3")
+                 SCR_DPP("%0", "%1", "row_shr:8 row_mask:0xf bank_mask:0xc")
+                 SCR_DPP("%2", "%3", "row_shr:8 row_mask:0xf bank_mask:0xc")
+                 SCR_DPP("%4", "%5", "row_shr:8 row_mask:0xf bank_mask:0xc")
+                 // v0 = (S0 | S1) per pixel row y: the y-dependent moments
+                 "v_mul_f32 %6, %0, %8\n\t"     // (y S0 | y S1)
+                 "v_mul_f32 %7, %0, %9\n\t"     // (y^2 S0 | -)
+                 // 4-lane step (y bit 2): (0,2) -> 0, (4,ya) -> 4, myy alone
+                 SCR_DPP("%0", "%0", "row_shl:4 row_mask:0xf bank_mask:0x5")
+                 SCR_DPP("%4", "%4", "row_shl:4 row_mask:0xf bank_mask:0x5")
+                 SCR_DPP("%7", "%7", "row_shl:4 row_mask:0xf bank_mask:0x5")
+                 SCR_DPP("%0", "%2", "row_shr:4 row_mask:0xf bank_mask:0xa")
+                 SCR_DPP("%4", "%6", "row_shr:4 row_mask:0xf bank_mask:0xa")
+                 // inside each 4-lane group (y bits 1, 0)
+                 SCR_DPP("%7", "%7", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%0", "%0", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%4", "%4", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%7", "%7", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%0", "%0", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%4", "%4", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "=&v"(ya), "=&v"(myy)
+                 : "v"(yl), "v"(yl2));
+}
 __device__ __forceinline__ float fold4(float a, float b, float c, float d) {
     auto ab = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     auto cd = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(d), false, false);
@@ -257,15 +295,16 @@ __device__ __forceinline__ float fold4(float a, float b, float c, float d) {
 //   * with Y = G * dL/dalpha, the position / conic gradients are opacity- and conic-weighted
 //     combinations of the five moments  sum Y dx, sum Y dy, sum Y dx^2, sum Y dx dy, sum Y dy^2;
 //     the weights are applied once per Gaussian in preprocess_backward_kernel.
-// A wave therefore reduces, per splat: the five moments, sum Y (opacity gradient), and the three
-// colour gradients  sum alpha T dL/dpixel_c.
+// A wave therefore reduces, per splat: the moments of Y (six: 1, x, y, x^2, xy, y^2 -- taken about the QUADRANT's
+// origin, so that they are separable in the lane's pixel coordinates, see row_fold6; the wave shifts them to the
+// splat's centre once per entry) and the three colour gradients  sum alpha T dL/dpixel_c.
 struct PixState {
     float T, dLp0, dLp1, dLp2;
     float behind, last_alpha, d_last;
 };
-__device__ __forceinline__ void splat_pixel_grad(PixState& s, float4 b, float cb, float dx, float dy, float G,
-                                                 float alpha, float& g_x, float& g_y, float& g_xx, float& g_xy,
-                                                 float& g_yy, float& g_o, float& g_c0, float& g_c1, float& g_c2) {
+__device__ __forceinline__ void splat_pixel_grad(PixState& s, float4 b, float cb, float xl, float G, float alpha,
+                                                 float& g_0, float& g_x, float& g_xx, float& g_c0, float& g_c1,
+                                                 float& g_c2) {
 #pragma clang fp contract(fast)
     // transmittance in front of this splat: T / (1 - alpha), correctly rounded as the division of the reference
     // arithmetic is -- v_rcp_f32, one Newton step, and one residual correction of the quotient (four fmas
@@ -284,10 +323,11 @@ __device__ __forceinline__ void splat_pixel_grad(PixState& s, float4 b, float cb
     const float Y = G * (s.T * (d - s.behind));  // G * dL/dalpha  (straight-through min(0.99, .))
     s.last_alpha = alpha;
     s.d_last = d;
-    const float yx = Y * dx, yy = Y * dy;
-    g_x = yx; g_y = yy;
-    g_xx = yx * dx; g_xy = yx * dy; g_yy = yy * dy;
-    g_o = Y;
+    // x-separable terms of the moments about the quadrant's origin (xl = this lane's pixel column, 0..7); the
+    // y-dependent ones are made from row sums inside the reduction (row_fold6)
+    g_0 = Y;
+    g_x = Y * xl;
+    g_xx = g_x * xl;
 }
 
 // ------------------------------------------------------------------ backward
@@ -322,10 +362,13 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
     if (n == 0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;  // wave == quadrant
-    const int px = (t % gx) * TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = (t / gx) * TILE + (wave >> 1) * 8 + (lane >> 3);
+    // x in the HIGH lane bits, y in the low ones: the reduction folds x away first (row_fold6)
+    const int qx0 = (t % gx) * TILE + (wave & 1) * 8, qy0 = (t / gx) * TILE + (wave >> 1) * 8;
+    const int px = qx0 + (lane >> 3), py = qy0 + (lane & 7);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
+    const float xl = (float)(lane >> 3), yl = (float)(lane & 7), yl2 = yl * yl;
+    const float qx0f = (float)qx0, qy0f = (float)qy0;
     const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
     const uint32_t last = inside ? n_contrib[pix] : 0u;
     PixState ps;
@@ -340,7 +383,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     ps.last_alpha = ps.d_last = 0.0f;
     float c099 = 0.99f;
     asm volatile("" : "+v"(c099));  // keep the clamp in a VGPR: VOP2 with a literal issues slower
-    const int comp = ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1);  // which sum this lane's 4-lane group ends up with
+    const int comp = (lane >> 2) & 3;  // 4-lane bank of the row: which sum this lane's group ends up with
     // per-wave largest contributor count: list positions >= it cannot matter to the wave
     uint32_t wm = last;
 #pragma unroll
@@ -413,7 +456,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         const int par = ACC_BUFS == 2 ? (ci & 1) : 0;
         if (ACC_BUFS == 1) __syncthreads();  // A: the previous round's combine has read acc
         for (int k = cnt - 1; k >= 0; k -= 4) {  // back to front, four splats per reduction
-            float g[4][9];
+            float g[4][6];
             uint32_t jj[4];
             unsigned long long any = 0ull;
             // all four records first (one LDS round trip per group instead of four)
@@ -441,28 +484,44 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 // back-to-front recurrences with alpha = 0, which leaves T and the colour-behind
                 // accumulator exactly as skipping it would (T / (1 - 0) = T; the accumulator folds
                 // 0 * d); only the G-weighted sums need an explicit zero.
-                splat_pixel_grad(ps, b, c.x, dx, dy, sel(hit, G, 0.0f), sel(hit, alpha, 0.0f), g[u][0], g[u][1], g[u][2],
-                                 g[u][3], g[u][4], g[u][5], g[u][6], g[u][7], g[u][8]);
+                splat_pixel_grad(ps, b, c.x, xl, sel(hit, G, 0.0f), sel(hit, alpha, 0.0f), g[u][0], g[u][1], g[u][2],
+                                 g[u][3], g[u][4], g[u][5]);
                 any |= hit;
                 jj[u] = valid ? j : 0xffffffffu;
             }
-            float r[9];
+            float r[6], myy;
             if (any) {
 #pragma unroll
-                for (int v = 0; v < 9; ++v) r[v] = fold4(g[0][v], g[1][v], g[2][v], g[3][v]);
-                row_fold9(r);
+                for (int v = 0; v < 6; ++v) r[v] = fold4(g[0][v], g[1][v], g[2][v], g[3][v]);
+                row_fold6(r, yl, yl2, myy);
             } else {
-                r[0] = r[4] = r[8] = 0.0f;
+                r[0] = r[4] = myy = 0.0f;
             }
-            // rows 0 / 1 / 2 / 3 hold splat u = 0 / 2 / 1 / 3 of the group; 4-lane group q of a row holds
-            // sums (0,2,1,3)[q] in r[0], (4,6,5,7)[q] in r[4], and group 3 holds sum 8 in r[8]
+            // rows 0 / 1 / 2 / 3 hold splat u = 0 / 2 / 1 / 3 of the group; 4-lane bank q of a row holds
+            // (M0, Mxx, Mx, c0)[q] in r[0], (c1, My, c2, Mxy)[q] in r[4], and bank 0 holds Myy in myy
             const int row = lane >> 4;
             const uint32_t jw = row == 0 ? jj[0] : row == 1 ? jj[2] : row == 2 ? jj[1] : jj[3];
             if ((lane & 3) == 0 && jw != 0xffffffffu) {  // every listed position is written
                 ((float*)&accA[par][wave][jw])[comp] = r[0];
                 ((float*)&accB[par][wave][jw])[comp] = r[4];
-                if (comp == 3) accC[par][wave][jw] = r[8];
+                if (comp == 0) accC[par][wave][jw] = myy;
             }
+        }
+        // ---- the wave's entries: moments about the quadrant's origin -> about the splat's centre, in the record layout
+        // the combine below and preprocess_backward_kernel read: (sum Y dx, sum Y dy, sum Y dx^2, sum Y dx dy |
+        // sum Y dy^2, sum Y, c0, c1 | c2) with d = mean - pixel = (mean - origin) - (x, y).  One lane per entry.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's result stores have landed (same wave: in order)
+        if (lane < cnt) {
+            const float4 ra = st[wave][0][lane + 3];
+            const uint32_t j = __float_as_uint(st[wave][2][lane + 3].y);
+            const float a = ra.x - qx0f, b = ra.y - qy0f;
+            const float4 A = accA[par][wave][j], B = accB[par][wave][j];
+            const float myy_ = accC[par][wave][j];
+            const float M0 = A.x, Mxx = A.y, Mx = A.z, My = B.y, Mxy = B.w;
+            const float t1 = a * M0 - Mx, t2 = b * M0 - My;      // sum Y dx, sum Y dy
+            accA[par][wave][j] = make_float4(t1, t2, a * (t1 - Mx) + Mxx, (a * t2 - b * Mx) + Mxy);
+            accB[par][wave][j] = make_float4(b * (t2 - My) + myy_, M0, A.w, B.x);
+            accC[par][wave][j] = B.z;
         }
         __syncthreads();  // B: every wave's sums for this round are in acc
         // ---- combine: wave p (< 3) writes float4 part p of the 48-byte record of position `lane`,

@@ -327,6 +327,7 @@ def test_full_size_cfg1_1M_1080p(oracle):
 
 
 STRESS_NAMES = ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"]
+EPS32 = 2.0 ** -24     # unit roundoff of binary32
 
 
 def _fp64_on_fp32_records(oracle, st, f):
@@ -355,8 +356,12 @@ def stress_case(oracle, rng, verbose=False):
           contains needle-like Gaussians (anisotropy up to 300:1 over hundreds of tiles) whose gradient sums cancel
           to a few per cent and whose covariance chain divides by a vanishing determinant: ANY fp32 evaluation -- the
           scalar fp32 oracle included -- is 1e-3 .. 1e-2 off on those rows, so no fp32 tolerance can hold there.  The
-          fraction of such rows is printed, and on them the device must still be no further than 10x the fp32
-          oracle's own distance from fp64 (rel-L2 over the set): a wrong term is O(1), rounding is not.
+          fraction of such rows is printed, and on them the device must still be no further from fp64 (L2 over the
+          set) than 10x the larger of (i) the fp32 oracle's own distance and (ii) the NOISE FLOOR of the fp32
+          projection chain: how far the fp32 oracle's own chain moves when its inputs (the per-Gaussian screen-space
+          sums, which no fp32 summation knows better) are jiggled by +-2 ulp -- for such a Gaussian two correct fp32
+          evaluations differ by O(1) (tools/exp/moment_check.py: identical moments to 1e-7, means3D.z anywhere in
+          -17 .. +45).  A wrong term is O(1) on EVERY row, rounding is not.
     Pixels whose n_contrib differs between any two of the three evaluations are excused on all sides (bounded,
     printed).  Returns a report line; raises AssertionError otherwise."""
     cam, g, sm = stress_scene(rng)
@@ -384,6 +389,12 @@ def stress_case(oracle, rng, verbose=False):
             e32 = {k: rel_l2(o["grads"][k], b[k]) for k in STRESS_NAMES}
         b64 = oracle.backward(st, f64, dL_eff, g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"], f64=True)
         vis = f["radii"] > 0
+        # noise floor of the fp32 chain: +-2 ulp relative jiggles (random signs) of the fp32 screen-space sums, three trials
+        gm2, gconic, gop, gcol = oracle.blend_backward(st, f, dL_eff)
+        prng = np.random.default_rng(12345)
+        jig = lambda a_: (a_.astype(np.float64) * (1.0 + 4.0 * EPS32 * prng.choice([-1.0, 1.0], a_.shape))).astype(np.float32)
+        trials = [oracle.preprocess_backward(st, f, jig(gm2), jig(gconic), gcol, g["means3D"], g["scales"], g["rotations"])
+                  for _ in range(3)]
         for k in STRESS_NAMES:
             if e32[k] <= GRAD_TOL and not verbose:
                 continue
@@ -393,12 +404,16 @@ def stress_case(oracle, rng, verbose=False):
             e_pinned = rel_l2(dev[pinned], o32[pinned])
             loose = ~pinned
             d_dev, d_o32 = np.linalg.norm(dev[loose] - ref[loose]), np.linalg.norm(o32[loose] - ref[loose])
+            d_noise = max(float(np.linalg.norm((tr[k].astype(np.float64) - o32)[loose])) for tr in trials) \
+                if trials[0].get(k) is not None else 0.0
             note += (f" {k}: {e32[k]:.1e} over all rows; {loose.sum()} of {vis.sum()} visible rows not pinned by fp32 "
                      f"(device {d_dev / max(np.linalg.norm(ref[loose]), 1e-300):.1e}, fp32 oracle "
-                     f"{d_o32 / max(np.linalg.norm(ref[loose]), 1e-300):.1e} from fp64 there), pinned rows {e_pinned:.1e};")
+                     f"{d_o32 / max(np.linalg.norm(ref[loose]), 1e-300):.1e}, 2-ulp noise floor "
+                     f"{d_noise / max(np.linalg.norm(ref[loose]), 1e-300):.1e} from fp64 there), pinned rows {e_pinned:.1e};")
             if e32[k] > GRAD_TOL:
                 assert e_pinned <= GRAD_TOL, (k, "rows pinned by fp32", e_pinned)
-                assert d_dev <= 10.0 * d_o32, (k, "ill-conditioned rows vs fp64: device", d_dev, "fp32 oracle", d_o32)
+                assert d_dev <= 10.0 * max(d_o32, d_noise), (k, "ill-conditioned rows vs fp64: device", d_dev, "fp32 oracle", d_o32,
+                                                             "noise floor", d_noise)
     ranges = f["ranges"]
     return (f"P={g['means3D'].shape[0]} {cam.image_width}x{cam.image_height} I={f['num_rendered']} "
             f"max tile={(ranges[:, 1].astype(np.int64) - ranges[:, 0]).max()} vis={(f['radii'] > 0).sum()} "
