@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 5
+#define SCR_ABI_VERSION 6
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -217,6 +217,16 @@ int scr_statis_compute(int64_t V, int32_t k, const float* neural_opacity, const 
 int scr_statis_apply(int64_t V, int32_t k, const int64_t* visible_index, const float* inc_opacity, const float* inc_grad,
                      float* opacity_accum, float* anchor_demon, float* offset_gradient_accum, float* offset_denom,
                      void* stream);
+
+/* ---- k nearest neighbours for GaussianModel.compute_curvature (scene/gaussian_model.py:1092-1110: sklearn on the host +
+ * a Python loop over the anchors there).  The caller buckets the N points into a uniform grid (grid_host[7] = x0, y0, z0,
+ * cell size h, nx, ny, nz -- HOST floats), sorts them by cell (sorted_pts[N,3], sorted_id[N] = original index,
+ * cell_start[nx*ny*nz + 1]); scr_knn writes out_idx[N,k]: the k nearest OTHER points of every point, nearest first,
+ * indexed by original point (k <= 16; exact).  scr_knn_curvature: lambda_min / trace of the covariance of those
+ * neighbours (mean-centred, / (k-1)), per point. */
+int scr_knn(int64_t N, int32_t k, const float* grid_host, const float* sorted_pts, const int64_t* sorted_id,
+            const int32_t* cell_start, int64_t* out_idx, void* stream);
+int scr_knn_curvature(int64_t N, int32_t k, const float* points, const int64_t* idx, float* curvature, void* stream);
 
 /* ---- measurement aid: a float4 grid-stride copy of `bytes` bytes (src -> dst, device pointers).  bench.py times it to
  * quote the HBM bandwidth a streaming kernel reaches on the box next to the 8 TB/s datasheet figure. */

@@ -494,6 +494,25 @@ int scr_statis_apply(int64_t V, int32_t k, const int64_t* visible_index, const f
     return 0;
 }
 
+int scr_knn(int64_t N, int32_t k, const float* grid_host, const float* sorted_pts, const int64_t* sorted_id,
+            const int32_t* cell_start, int64_t* out_idx, void* stream) {
+    if (N <= 0 || k <= 0 || k > 16) return fail("scr_knn: need N > 0 and 1 <= k <= 16");
+    if (N <= k) return fail("scr_knn: fewer than k + 1 points");
+    if (!grid_host || !sorted_pts || !sorted_id || !cell_start || !out_idx) return fail("NULL argument");
+    if (!(grid_host[3] > 0.0f) || grid_host[4] < 1 || grid_host[5] < 1 || grid_host[6] < 1) return fail("bad grid");
+    launch_knn(N, k, grid_host, sorted_pts, sorted_id, cell_start, out_idx, (hipStream_t)stream);
+    CHECK_LAUNCH("knn_kernel", 0, (hipStream_t)stream);
+    return 0;
+}
+
+int scr_knn_curvature(int64_t N, int32_t k, const float* points, const int64_t* idx, float* curvature, void* stream) {
+    if (N <= 0 || k < 2) return fail("bad N / k");
+    if (!points || !idx || !curvature) return fail("NULL argument");
+    launch_knn_curvature(N, k, points, idx, curvature, (hipStream_t)stream);
+    CHECK_LAUNCH("knn_curvature_kernel", 0, (hipStream_t)stream);
+    return 0;
+}
+
 int scr_copy_probe(const void* src, void* dst, size_t bytes, void* stream) {
     if (!src || !dst || bytes < 16) return fail("NULL argument");
     copy_probe_kernel<<<256 * 16, 256, 0, (hipStream_t)stream>>>((const float4*)src, (float4*)dst, bytes / 16);

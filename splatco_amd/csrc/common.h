@@ -295,6 +295,9 @@ void launch_statis_apply(int64_t V, int k, const int64_t* visible_index, const f
                          float* opacity_accum, float* anchor_demon, float* offset_gradient_accum, float* offset_denom,
                          hipStream_t st);
 
+void launch_knn(int64_t N, int k, const float* grid9, const float* sorted_pts, const int64_t* sorted_id,
+                const int32_t* cell_start, int64_t* out_idx, hipStream_t st);
+void launch_knn_curvature(int64_t N, int k, const float* pts, const int64_t* idx, float* curvature, hipStream_t st);
 size_t mlp_heads_hidden_bytes(int64_t V);
 size_t mlp_heads_partial_bytes(int64_t V);
 void launch_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,

@@ -81,3 +81,144 @@ void launch_statis_apply(int64_t V, int k, const int64_t* visible_index, const f
 }
 
 }  // namespace scr
+
+// ------------------------------------------------------------------ k nearest neighbours (compute_curvature)
+// GaussianModel.compute_curvature (scene/gaussian_model.py:1092-1110) asks sklearn for the k+1 nearest anchors of every
+// anchor on the HOST and loops over the anchors in Python.  Here: the anchors are bucketed into a uniform grid (cell
+// keys sorted by the caller with torch.sort, cell_start from the sorted keys), one thread per query walks the cells of
+// growing cubes around its own cell keeping its k best candidates in registers (insertion into a sorted list), and
+// stops as soon as the k-th best distance is inside the cube already searched.  Exact (same neighbour SET as a brute
+// force search; ties at equal distance aside).  knn_curvature_kernel then forms the neighbours' covariance and its
+// eigenvalues (closed form for a symmetric 3x3, in fp64) and returns lambda_min / sum(lambda).
+namespace scr {
+
+constexpr int KNN_MAX_K = 16;
+
+struct KnnGrid {
+    float x0, y0, z0, inv_h, h;
+    int nx, ny, nz;
+};
+
+__device__ __forceinline__ int knn_cell(float v, float lo, float inv_h, int n) {
+    const int c = (int)floorf((v - lo) * inv_h);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+// sorted_pts: points in cell order (float x,y,z per point), sorted_id: original index of every sorted point,
+// cell_start[ncells + 1].  out_idx[q * k + j] = original index of the j-th nearest OTHER point of query q (by
+// original index q), nearest first.
+template <int K>
+__global__ void __launch_bounds__(256)
+knn_kernel(int64_t N, int k, KnnGrid gr, const float* __restrict__ sorted_pts, const int64_t* __restrict__ sorted_id,
+           const int32_t* __restrict__ cell_start, int64_t* __restrict__ out_idx) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;      // position in cell order: neighbours in memory
+    if (s >= N) return;
+    const float qx = sorted_pts[3 * s], qy = sorted_pts[3 * s + 1], qz = sorted_pts[3 * s + 2];
+    const int cx = knn_cell(qx, gr.x0, gr.inv_h, gr.nx), cy = knn_cell(qy, gr.y0, gr.inv_h, gr.ny),
+              cz = knn_cell(qz, gr.z0, gr.inv_h, gr.nz);
+    float bd[K];          // the K best so far, ascending (K >= k; registers: every index below is a compile-time constant)
+    int64_t bi[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { bd[j] = 3.0e38f; bi[j] = -1; }
+    float kth = 3.0e38f;  // bd[k - 1]
+    const int rmax = max(gr.nx, max(gr.ny, gr.nz));
+    // distance from the query to the faces of its own cell: the searched cube of radius r reaches at least r*h + that
+    const float fx = (qx - gr.x0) * gr.inv_h - (float)cx, fy = (qy - gr.y0) * gr.inv_h - (float)cy,
+                fz = (qz - gr.z0) * gr.inv_h - (float)cz;
+    const float margin = gr.h * fminf(fminf(fminf(fx, 1.0f - fx), fminf(fy, 1.0f - fy)), fminf(fz, 1.0f - fz));
+    for (int r = 0; r <= rmax; ++r) {
+        for (int dz = -r; dz <= r; ++dz) {
+            const int z = cz + dz;
+            if (z < 0 || z >= gr.nz) continue;
+            for (int dy = -r; dy <= r; ++dy) {
+                const int y = cy + dy;
+                if (y < 0 || y >= gr.ny) continue;
+                const bool shell_yz = (dz == -r || dz == r || dy == -r || dy == r);
+                for (int dx = -r; dx <= r; dx += (shell_yz || r == 0 ? 1 : 2 * r)) {     // only the cube's surface
+                    const int x = cx + dx;
+                    if (x < 0 || x >= gr.nx) continue;
+                    const int cell = (z * gr.ny + y) * gr.nx + x;
+                    for (int p = cell_start[cell]; p < cell_start[cell + 1]; ++p) {
+                        if (p == s) continue;
+                        const float ex = sorted_pts[3 * (int64_t)p] - qx, ey = sorted_pts[3 * (int64_t)p + 1] - qy,
+                                    ez = sorted_pts[3 * (int64_t)p + 2] - qz;
+                        const float d = (ex * ex + ey * ey) + ez * ez;
+                        if (d < kth) {
+                            float cd = d;                    // insertion into the ascending list
+                            int64_t ci = sorted_id[p];
+#pragma unroll
+                            for (int j = 0; j < K; ++j) {
+                                const bool sw = cd < bd[j];
+                                const float td = bd[j];
+                                const int64_t ti = bi[j];
+                                bd[j] = sw ? cd : td; bi[j] = sw ? ci : ti;
+                                cd = sw ? td : cd; ci = sw ? ti : ci;
+                            }
+#pragma unroll
+                            for (int j = 0; j < K; ++j) if (j == k - 1) kth = bd[j];
+                        }
+                    }
+                }
+            }
+        }
+        const float reach = fmaxf(0.0f, (float)r * gr.h + margin);      // everything closer than this has been seen
+        if (kth <= reach * reach) break;
+    }
+    const int64_t q = sorted_id[s];
+#pragma unroll
+    for (int j = 0; j < K; ++j) if (j < k) out_idx[q * k + j] = bi[j];
+}
+
+// curvature[q] = lambda_min / (lambda_0 + lambda_1 + lambda_2) of cov = C^T C / (k - 1), C = neighbours - their mean
+__global__ void __launch_bounds__(256)
+knn_curvature_kernel(int64_t N, int k, const float* __restrict__ pts, const int64_t* __restrict__ idx,
+                     float* __restrict__ curvature) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= N) return;
+    double m[3] = {0, 0, 0};
+    for (int j = 0; j < k; ++j) {
+        const int64_t p = idx[q * k + j];
+        for (int c = 0; c < 3; ++c) m[c] += (double)pts[3 * p + c];
+    }
+    for (int c = 0; c < 3; ++c) m[c] /= k;
+    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+    for (int j = 0; j < k; ++j) {
+        const int64_t p = idx[q * k + j];
+        const double x = pts[3 * p] - m[0], y = pts[3 * p + 1] - m[1], z = pts[3 * p + 2] - m[2];
+        a00 += x * x; a01 += x * y; a02 += x * z; a11 += y * y; a12 += y * z; a22 += z * z;
+    }
+    const double s = 1.0 / (k - 1);
+    a00 *= s; a01 *= s; a02 *= s; a11 *= s; a12 *= s; a22 *= s;
+    // smallest eigenvalue of a symmetric 3x3 (trigonometric closed form), fp64
+    const double tr = a00 + a11 + a22, mq = tr / 3.0;
+    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+    const double b00 = a00 - mq, b11 = a11 - mq, b22 = a22 - mq;
+    const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
+    double lmin;
+    if (p2 <= 0.0) {
+        lmin = mq;
+    } else {
+        const double p = sqrt(p2 / 6.0);
+        const double det = (b00 * (b11 * b22 - a12 * a12) - a01 * (a01 * b22 - a12 * a02) + a02 * (a01 * a12 - b11 * a02)) / (p * p * p);
+        const double rr = fmin(1.0, fmax(-1.0, 0.5 * det));
+        const double phi = acos(rr) / 3.0;
+        lmin = mq + 2.0 * p * cos(phi + 2.0943951023931953);     // + 2 pi / 3: the smallest root
+    }
+    curvature[q] = (float)(lmin / tr);
+}
+
+void launch_knn(int64_t N, int k, const float* grid9, const float* sorted_pts, const int64_t* sorted_id,
+                const int32_t* cell_start, int64_t* out_idx, hipStream_t st) {
+    KnnGrid g;
+    g.x0 = grid9[0]; g.y0 = grid9[1]; g.z0 = grid9[2]; g.h = grid9[3]; g.inv_h = 1.0f / grid9[3];
+    g.nx = (int)grid9[4]; g.ny = (int)grid9[5]; g.nz = (int)grid9[6];
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    if (k <= 10) knn_kernel<10><<<grid, 256, 0, st>>>(N, k, g, sorted_pts, sorted_id, cell_start, out_idx);   // the reference's k
+    else knn_kernel<KNN_MAX_K><<<grid, 256, 0, st>>>(N, k, g, sorted_pts, sorted_id, cell_start, out_idx);
+}
+
+void launch_knn_curvature(int64_t N, int k, const float* pts, const int64_t* idx, float* curvature, hipStream_t st) {
+    knn_curvature_kernel<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(N, k, pts, idx, curvature);
+}
+
+}  // namespace scr

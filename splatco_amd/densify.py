@@ -25,27 +25,68 @@ def inverse_sigmoid(x):                      # utils/general_utils.py:17-18
     return torch.log(x / (1 - x))
 
 
+def _knn_grid(pts, per_cell=2.0):
+    """Uniform grid over the bounding box with about `per_cell` points per cell; returns (lo[3], h, n[3])."""
+    lo, hi = pts.amin(dim=0), pts.amax(dim=0)
+    ext = (hi - lo).double()
+    ext = torch.maximum(ext, ext.max().clamp_min(1e-30) * 1e-6)
+    N = pts.shape[0]
+    h = float((ext.prod() * per_cell / N) ** (1.0 / 3.0))
+    n = torch.ceil(ext / h).clamp_min(1)
+    over = float(n.prod()) / (4.0 * N + 64)              # flat / degenerate clouds: bound the cell count
+    if over > 1.0:
+        h *= over ** (1.0 / 3.0)
+        n = torch.ceil(ext / h).clamp_min(1)
+    return lo, h, [int(v) for v in n.tolist()]
+
+
 def _knn_indices(points, k):
     """indices [N, k] of the k nearest OTHER points, nearest first (column 0 of the k+1 query dropped,
-    as :1096-1100 does)."""
+    as :1096-1100 does).  Device tensors: grid-bucketed exact search in csrc/densify.hip (any N; the reference
+    goes to sklearn on the host); CPU tensors (the golden tests): brute force."""
     N = points.shape[0]
-    if N <= 65536:
-        out = torch.empty(N, k, dtype=torch.long, device=points.device)
-        step = max(1, (1 << 24) // max(N, 1))
-        for s in range(0, N, step):
-            d = torch.cdist(points[s:s + step], points)
-            out[s:s + step] = d.topk(k + 1, dim=1, largest=False).indices[:, 1:]
+    if points.is_cuda:
+        import ctypes as C
+        from . import _C
+        from .rasterizer import _stream
+        if k > 16:
+            raise ValueError("k <= 16")
+        pts = points.detach().float().contiguous()
+        lo, h, (nx, ny, nz) = _knn_grid(pts)
+        cell = ((pts - lo) / h).floor().long()
+        cell = torch.minimum(cell.clamp_min(0), torch.tensor([nx - 1, ny - 1, nz - 1], device=pts.device))
+        key = (cell[:, 2] * ny + cell[:, 1]) * nx + cell[:, 0]
+        skey, order = torch.sort(key)
+        ncell = nx * ny * nz
+        cell_start = torch.searchsorted(skey, torch.arange(ncell + 1, device=pts.device)).int()
+        spts = pts.index_select(0, order).contiguous()
+        out = torch.empty(N, k, dtype=torch.long, device=pts.device)
+        grid = (C.c_float * 7)(float(lo[0]), float(lo[1]), float(lo[2]), h, nx, ny, nz)
+        with torch.cuda.device(pts.device):
+            _C.check(_C.lib.scr_knn(N, k, grid, spts.data_ptr(), order.data_ptr(), cell_start.data_ptr(), out.data_ptr(),
+                                    _stream()))
         return out
-    from sklearn.neighbors import NearestNeighbors     # KD-tree on the host, as the reference does
-    p = points.detach().cpu().numpy()
-    idx = NearestNeighbors(n_neighbors=k + 1, algorithm="auto").fit(p).kneighbors(p, return_distance=False)
-    return torch.as_tensor(idx[:, 1:], device=points.device)
+    out = torch.empty(N, k, dtype=torch.long, device=points.device)
+    step = max(1, (1 << 24) // max(N, 1))
+    for s in range(0, N, step):
+        d = torch.cdist(points[s:s + step], points)
+        out[s:s + step] = d.topk(k + 1, dim=1, largest=False).indices[:, 1:]
+    return out
 
 
 def compute_curvature(points, k=10):
     """lambda_min / sum(lambda) of the covariance of each point's k nearest neighbours (:1092-1110)."""
     pts = points.detach()
-    nb = pts[_knn_indices(pts, k)]                                  # [N,k,3]
+    idx = _knn_indices(pts, k)
+    if pts.is_cuda:          # covariance + closed-form eigenvalues on the device (fp64), one thread per point
+        from . import _C
+        from .rasterizer import _stream
+        p32 = pts.float().contiguous()
+        out = torch.empty(p32.shape[0], dtype=torch.float32, device=p32.device)
+        with torch.cuda.device(p32.device):
+            _C.check(_C.lib.scr_knn_curvature(p32.shape[0], k, p32.data_ptr(), idx.data_ptr(), out.data_ptr(), _stream()))
+        return out
+    nb = pts[idx]                                                   # [N,k,3]
     c = nb - nb.mean(dim=1, keepdim=True)
     cov = c.transpose(1, 2) @ c / (k - 1)
     ev = torch.linalg.eigvalsh(cov)                                 # ascending
@@ -57,11 +98,12 @@ class AnchorDensifier:
     parameters + their Adam state in place of `adjust_anchor`."""
 
     def __init__(self, model, optimizer, voxel_size=0.001, update_depth=3, update_init_factor=16,
-                 update_hierachy_factor=4, seed=None):
+                 update_hierachy_factor=4, seed=None, rand=None):
         """seed: draw the random candidate picks of anchor_growing (:843-844, torch.rand_like on the global
         generator in the reference) from a private generator seeded with it -- every rank of the sharded --mv step
         passes the same seed, so that the replicas grow identical anchor sets."""
         self.model, self.optimizer = model, optimizer
+        self.rand = rand                  # test hook: rand(shape, device) -> uniform [0,1) floats (e.g. the CPU stream of a fixture)
         self.generator = None
         if seed is not None:
             self.generator = torch.Generator(device=model._anchor.device)
@@ -133,7 +175,9 @@ class AnchorDensifier:
         for i in range(self.update_depth):
             cur_threshold = threshold * ((self.update_hierachy_factor // 2) ** i)
             candidate_mask = (grads >= cur_threshold) & offset_mask
-            if self.generator is None:
+            if self.rand is not None:
+                rand = self.rand(candidate_mask.shape, candidate_mask.device)
+            elif self.generator is None:
                 rand = torch.rand_like(candidate_mask.float())
             else:
                 rand = torch.rand(candidate_mask.shape, device=candidate_mask.device, generator=self.generator)
