@@ -65,9 +65,17 @@ const char* const kProfNames[SCR_PROF_COUNT] = {
     "l1_ssim_backward_kernel", "triplane_forward_kernel", "mlp_heads_kernel", "mlp_heads_backward_kernel"};
 }  // namespace
 
-// float4 grid-stride copy: measures the HBM bandwidth a streaming kernel can reach on this device (bench.py)
-__global__ void __launch_bounds__(256) copy_probe_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+// streaming copy, 16 B per lane, four loads in flight per thread, non-temporal: the shape that reaches the highest HBM
+// bandwidth on MI355X among those of tools/exp/copy_probe.hip (6.3 TB/s read + write; a grid-stride loop with few
+// workgroups stays at 4.7).  bench.py quotes its rate as the achievable peak next to the 8 TB/s datasheet figure.
+typedef float copy_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) copy_probe_kernel(const copy_f4* __restrict__ src, copy_f4* __restrict__ dst, size_t n) {
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    copy_f4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (base + u * 256 < n) v[u] = __builtin_nontemporal_load(&src[base + u * 256]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (base + u * 256 < n) __builtin_nontemporal_store(v[u], &dst[base + u * 256]);
 }
 
 // pinned host memory the GPU writes and the host polls (scr_forward_plan); per host thread, lives for the process
@@ -515,7 +523,8 @@ int scr_knn_curvature(int64_t N, int32_t k, const float* points, const int64_t* 
 
 int scr_copy_probe(const void* src, void* dst, size_t bytes, void* stream) {
     if (!src || !dst || bytes < 16) return fail("NULL argument");
-    copy_probe_kernel<<<256 * 16, 256, 0, (hipStream_t)stream>>>((const float4*)src, (float4*)dst, bytes / 16);
+    const size_t n = bytes / 16;
+    copy_probe_kernel<<<(unsigned)((n + 1023) / 1024), 256, 0, (hipStream_t)stream>>>((const copy_f4*)src, (copy_f4*)dst, n);
     CHECK_LAUNCH("copy_probe_kernel", 0, (hipStream_t)stream);
     return 0;
 }
