@@ -12,7 +12,7 @@
 // Backward: the four waves of a tile share one workgroup.  Per (tile, Gaussian) gradient moments are
 // reduced on chip -- a folding reduction inside the wave (permlane swaps, then bank-masked DPP adds that
 // pack two values per register), one LDS slot per (wave, splat), a fixed-order add over the waves that
-// took part -- and written ONCE as a 48-byte
+// took part -- and written ONCE as a 36-byte
 // record at the instance's Gaussian-major index (so the per-Gaussian reduction reads its records
 // contiguously).  No floating-point atomics:
 // results are bit-reproducible.  The per-Gaussian sum over tiles happens in
@@ -330,6 +330,14 @@ __device__ __forceinline__ void splat_pixel_grad(PixState& s, float4 b, float cb
     g_xx = g_x * xl;
 }
 
+// 16-byte store to a dword-aligned address (the 36-byte gradient records): global memory on gfx950 only needs dword
+// alignment for multi-dword accesses, but the compiler splits a packed 16-byte store into four instructions
+typedef float f4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_dword_aligned(void* p, float4 v) {
+    const f4_t q = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(q) : "memory");
+}
+
 // ------------------------------------------------------------------ backward
 constexpr int BCH = 64;  // list entries per round: one per lane of each wave
 #ifndef SCR_BWD_ACC_BUFS
@@ -346,7 +354,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                       const uint8_t* __restrict__ qmask, const float4* __restrict__ rec,
                       const float* __restrict__ bg, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                      float4* __restrict__ grad_rec) {
+                      GradRec* __restrict__ grad_rec) {
     // wave-private compacted records of the round: [wave][field group][3 pad + position]; group 0/1 =
     // the first 32 bytes of the splat record, group 2 = (blue, position in round, -, -).  A group of four
     // reads slots k .. k+3 of each field group: one address register and immediate offsets.  The three
@@ -401,7 +409,12 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     if (wave < 3)
         for (int ci = nround - 1; ci > live_top; --ci) {
             uint32_t i = (uint32_t)ci * BCH + lane;
-            if (i < n) grad_rec[3 * (size_t)gm_index[lo + i] + wave] = make_float4(0, 0, 0, 0);
+            if (i < n) {
+                GradRec& gr = grad_rec[gm_index[lo + i]];
+                if (wave == 0) store16_dword_aligned(&gr.a, make_float4(0, 0, 0, 0));
+                else if (wave == 1) store16_dword_aligned(&gr.b, make_float4(0, 0, 0, 0));
+                else gr.c = 0.0f;
+            }
         }
 
     // ---- software pipeline over the live rounds, back to front:
@@ -537,7 +550,10 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             if (((m_this >> 1) & 1u) && i < wmax1) { const float4 x = part(1); r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
             if (((m_this >> 2) & 1u) && i < wmax2) { const float4 x = part(2); r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
             if (((m_this >> 3) & 1u) && i < wmax3) { const float4 x = part(3); r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
-            grad_rec[3 * (size_t)slot_this + wave] = r;
+            GradRec& gr = grad_rec[slot_this];
+            if (wave == 0) store16_dword_aligned(&gr.a, r);
+            else if (wave == 1) store16_dword_aligned(&gr.b, r);
+            else gr.c = r.x;
         }
     }
 }
@@ -552,7 +568,7 @@ void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView
 }
 
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                           const float* dL_dcolor, float4* grad_rec, hipStream_t st) {
+                           const float* dL_dcolor, GradRec* grad_rec, hipStream_t st) {
     Grid g(ks.H, ks.W);
     blend_backward_kernel<<<(unsigned)xcd_grid(g.tiles), 256, 0, st>>>(
         ks.W, ks.H, g.gx, g.tiles, gv.ranges, bv.point_list, bv.gm_index, bv.qmask, gv.rec, ks.bg, iv.final_T,

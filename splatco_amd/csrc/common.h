@@ -28,7 +28,7 @@ constexpr int BIN_GPW = BIN_THREADS * BIN_ROUNDS;  // Gaussians per preprocess /
 constexpr int LDS_HIST_MAX_TILES = SCR_LDS_HIST_MAX_TILES;  // per-tile LDS histogram (4 B / tile) in the CU's 160 KB of LDS (4K images: 32400 tiles)
 constexpr int ID_BITS = 28;             // sort key = depth:32 | id:28 | quadrant mask:4  ->  P < 2^28
 constexpr int REC_F = 12;               // floats per splat record (48 B, three float4)
-constexpr int GRAD_F = 12;              // floats per per-instance gradient record (9 used)
+constexpr int GRAD_F = 9;               // floats per per-instance gradient record (GradRec)
 
 inline __host__ __device__ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -100,6 +100,14 @@ inline __host__ BinView bin_view(void* base, int64_t I, int64_t max_tile_instanc
     v.bytes = off;
     return v;
 }
+
+// ---- backward scratch: one gradient record per (Gaussian, tile) instance at its Gaussian-major index: nine floats
+// (sum Y dx, sum Y dy, sum Y dx^2, sum Y dx dy | sum Y dy^2, sum Y, c0, c1 | c2), 36 bytes, back to back.  The two
+// four-float parts are moved with dword-aligned 16-byte accesses (gfx950 global memory needs dword alignment only);
+// separate arrays per part were measured and rejected: the lone 4-byte stores cost a whole 32-byte sector each.
+struct __attribute__((packed, aligned(4))) GradQuad { float x, y, z, w; };
+struct __attribute__((packed, aligned(4))) GradRec { GradQuad a, b; float c; };
+static_assert(sizeof(GradRec) == 36, "36-byte gradient records");
 
 // ---- image buffer ----
 struct ImgView {
@@ -268,11 +276,11 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
 void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
                           float* out_color, hipStream_t st);
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                           const float* dL_dcolor, float4* grad_rec, hipStream_t st);
+                           const float* dL_dcolor, GradRec* grad_rec, hipStream_t st);
 void launch_preprocess_backward(int64_t P, int M, const float* means3D, const float* scales,
                                 const float* rotations, const float* cov3D, const float* shs,
                                 const KSettings& ks, const int32_t* radii, const GeomView& gv,
-                                const BinView& bv, const float4* grad_rec, float* dL_dmeans3D,
+                                const BinView& bv, const GradRec* grad_rec, float* dL_dmeans3D,
                                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh, float* dL_dopacity,
                                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, hipStream_t st);
 

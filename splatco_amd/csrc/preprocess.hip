@@ -314,7 +314,7 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
                            const float* __restrict__ cov3D, const float* __restrict__ shs, KSettings ks,
                            const int32_t* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
                            const uint32_t* __restrict__ point_offsets, const uint8_t* __restrict__ clamped,
-                           const float4* __restrict__ rec, const float4* __restrict__ grad_rec,
+                           const float4* __restrict__ rec, const GradRec* __restrict__ grad_rec,
                            float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
                            float* __restrict__ dL_dcolors, float* __restrict__ dL_dsh,
                            float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
@@ -332,27 +332,26 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
         uint32_t n = tiles_touched[i];
         uint32_t off = point_offsets[i] - n;
         float sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0;  // moments of Y = G dL/dalpha over the footprint
-        // this Gaussian's records are contiguous, in tile order; four at a time so that twelve 16-byte loads
-        // are in flight per thread (the loop is otherwise one memory latency per record), summed in order
-        const float4* gr = grad_rec + 3 * (size_t)off;
+        // this Gaussian's records are contiguous, in tile order; four at a time so that
+        // twelve loads are in flight per thread (the loop is otherwise one memory latency per record), summed in order
+        const GradRec* gr = grad_rec + off;
         uint32_t k = 0;
         for (; k + 4 <= n; k += 4) {
-            float4 q[12];
+            GradRec q[4];
 #pragma unroll
-            for (int j = 0; j < 12; ++j) q[j] = gr[3 * (size_t)k + j];
+            for (int j = 0; j < 4; ++j) q[j] = gr[k + j];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float4 r0 = q[3 * j], r1 = q[3 * j + 1], r2 = q[3 * j + 2];
-                sx += r0.x; sy += r0.y; sxx += r0.z; sxy += r0.w;
-                syy += r1.x; gop += r1.y; gcol[0] += r1.z; gcol[1] += r1.w;
-                gcol[2] += r2.x;
+                sx += q[j].a.x; sy += q[j].a.y; sxx += q[j].a.z; sxy += q[j].a.w;
+                syy += q[j].b.x; gop += q[j].b.y; gcol[0] += q[j].b.z; gcol[1] += q[j].b.w;
+                gcol[2] += q[j].c;
             }
         }
         for (; k < n; ++k) {
-            const float4 r0 = gr[3 * (size_t)k], r1 = gr[3 * (size_t)k + 1], r2 = gr[3 * (size_t)k + 2];
-            sx += r0.x; sy += r0.y; sxx += r0.z; sxy += r0.w;
-            syy += r1.x; gop += r1.y; gcol[0] += r1.z; gcol[1] += r1.w;
-            gcol[2] += r2.x;
+            const GradRec q = gr[k];
+            sx += q.a.x; sy += q.a.y; sxx += q.a.z; sxy += q.a.w;
+            syy += q.b.x; gop += q.b.y; gcol[0] += q.b.z; gcol[1] += q.b.w;
+            gcol[2] += q.c;
         }
         // the per-splat constants the blend kernel left out: dL/dG = opacity * dL/dalpha,
         // dG/dmean = -G Q d with Q = (-2A, -B, -2C), dG/dQ = -G/2 d d^T (Qxy counted once: factor 1)
@@ -585,7 +584,7 @@ void launch_preprocess(int64_t P, int M, const float* means3D, const float* scal
 void launch_preprocess_backward(int64_t P, int M, const float* means3D, const float* scales,
                                 const float* rotations, const float* cov3D, const float* shs,
                                 const KSettings& ks, const int32_t* radii, const GeomView& gv,
-                                const BinView& bv, const float4* grad_rec, float* dL_dmeans3D,
+                                const BinView& bv, const GradRec* grad_rec, float* dL_dmeans3D,
                                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh, float* dL_dopacity,
                                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, hipStream_t st) {
     if (P <= 0) return;

@@ -38,7 +38,7 @@ _C.check(_C.lib.scr_backward(P, 0, I, m.data_ptr(), s.data_ptr(), r.data_ptr(), 
                              outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), None, outs[3].data_ptr(), outs[4].data_ptr(),
                              outs[5].data_ptr(), None, R._stream()))
 torch.cuda.synchronize()
-rec = scratch.cpu().numpy().view(np.float32)[:I * 12].reshape(I, 12).astype(np.float64)
+rec = scratch.cpu().numpy().view(np.float32)[:I * 9].reshape(I, 9).astype(np.float64)
 tt = f["tiles_touched"].astype(np.int64)
 off = np.concatenate([[0], np.cumsum(tt)])[:-1]
 vis = tt > 0
