@@ -59,14 +59,15 @@ def algorithmic_bytes(kernel, P, I, npix, extra=None):
         "blend_backward_kernel": 40 * I + 20 * npix + 44 * P,
         "preprocess_backward_kernel": P * (56 + 24 + 44 + 4) + P * 40,
         "filter_kernel": 44 * N,
-        "expand_kernel": 4 * n + 56 * n + 36 * V + 56 * P,          # count pass + candidates read + Gaussians written
+        # anchor path (per step; V visible anchors, n = V k candidates, P kept Gaussians)
+        "expand_kernel": 4 * n + 56 * n + 36 * V + 56 * P + 5 * n,   # count pass + candidates read + Gaussians written + index / mask
         "expand_backward_kernel": 56 * P + 60 * n + 36 * V + 4 * n,
-        "triplane_forward_kernel": 240 * V + 12 * V + 60 * V,       # per grid: corner gathers + coords + 15 outputs
-        "plane_sample_backward_kernels": 240 * V / 3 + 8 * V + 20 * V,   # per plane
+        "triplane_forward_kernel": 4 * (240 * V + 12 * V + 60 * V),  # four sampled grids (attention grid twice): corner gathers + coords + 15 outputs
+        "plane_sample_backward_kernels": 12 * (240 * V / 3 + 8 * V + 20 * V),   # twelve planes: corner scatter + coords + 5 gradient columns
         "l1_ssim_forward_kernel": 2 * 12 * npix + 3 * 12 * npix,
         "l1_ssim_backward_kernel": 2 * 12 * npix + 3 * 12 * npix + 12 * npix,
-        "mlp_heads_kernel": 4 * V * 99 + 4 * V * 110,
-        "mlp_heads_backward_kernel": 4 * V * (99 + 110 + 110 + 99),
+        "mlp_heads_kernel": 4 * V * (32 + 3 + 64) + 4 * V * 110 + 4 * V * 96,             # inputs + outputs + saved hidden layer
+        "mlp_heads_backward_kernel": 4 * V * (32 + 3 + 64 + 96 + 40 + 110) + 4 * V * (32 + 3 + 64),   # inputs, hidden, outputs(y), upstream; input gradients
     }
     return float(table.get(kernel, 0))
 
@@ -440,7 +441,8 @@ def run_anchor_config(args, rank, world, dev):
     extra = {"N": N, "V": V, "n": V * pc.n_offsets}
     from splatco_amd import rasterizer as R
     I = R.last_plan[1]                                       # (Gaussian, tile) instances of the last rasterised view
-    ab = algorithmic_bytes(dominant, P1, I, W * H, extra)
+    launches = {k: n / nwarm for k, (ms, n) in warm_prof.items() if n}
+    ab = algorithmic_bytes(dominant, P1, I, W * H, extra) / max(launches.get(dominant, 1.0), 1.0)     # per launch
     out = {
         "metric": METRIC if args.config != "cfg4" else "full train-step iter/s (BASELINE.json configs[4])",
         "value": (P_all / step_s / 1e6) if args.config != "cfg4" else 1.0 / step_s,
@@ -469,6 +471,12 @@ def run_anchor_config(args, rank, world, dev):
                                     "dominant among this library's kernel classes by time per step; the rocBLAS GEMMs of "
                                     "the anchor path are outside these classes"),
         "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(warm_step_ms.items(), key=lambda kv: -kv[1])},
+        # every kernel class of this library against ITS byte model (per step, all launches of the class)
+        "kernel_rooflines": {k: {"ms_per_step": round(ms, 4),
+                                 "algorithmic_MB_per_step": round(algorithmic_bytes(k, P1, I, W * H, extra) / 1e6, 1),
+                                 "GBps": round(algorithmic_bytes(k, P1, I, W * H, extra) / (ms * 1e-3) / 1e9, 1),
+                                 "frac_of_measured_peak": round(algorithmic_bytes(k, P1, I, W * H, extra) / (ms * 1e-3) / 1e9 / peak, 3)}
+                             for k, ms in sorted(warm_step_ms.items(), key=lambda kv: -kv[1]) if ms > 0},
         "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
     }
     if allreduce_info is not None:
