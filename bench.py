@@ -360,7 +360,7 @@ def run_anchor_config(args, rank, world, dev):
         groups = [{"params": [getattr(pc, "_" + n)], "lr": 1e-4, "name": n} for n in ("anchor", "offset", "anchor_feat", "scaling")]
         rest = [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad]
         groups.append({"params": rest, "lr": 1e-3, "name": "mlp_and_feat_planes"})
-        opt = torch.optim.Adam(groups, eps=1e-15)
+        opt = torch.optim.Adam(groups, eps=1e-15, fused=True)      # one pass over parameter / gradient / moments per tensor
         den = AnchorDensifier(pc, opt, seed=seed)
         arena = GradArena([p for grp in groups for p in grp["params"]], mode=args.exchange)
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 6
+#define SCR_ABI_VERSION 7
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -181,23 +181,24 @@ int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, con
 /* ---- the three MLP heads of generate_neural_gaussians (gaussian_renderer/__init__.py:58-93 with the default flags,
  * scene/gaussian_model.py:315-337) as one fp32-MFMA kernel per direction, for the reference's layer sizes
  * (feat 32, geo_fea 64, hidden 32 per head, n_offsets 10):
- *   x = cat(feat[V,32], (anchor - campos) / |anchor - campos|, geo_fea[V,64])       (never materialised)
+ *   x = cat(feat[V,32], (anchor - campos) / |anchor - campos|, geo_fea[V,64])       (never materialised; geo_fea is passed as
+ *   its two halves geo_a | geo_b [V,32], the outputs of FeaturePlanes' two GEMMs, scene/gaussian_model.py:160-168)
  *   out_opacity[V,10] = tanh(W2o relu(W1[0:32] x + b1[0:32]) + b2o);  out_color[V,30] = sigmoid(... [32:64] ...);
  *   out_cov[V,70] = W2v relu(W1[64:96] x + b1[64:96]) + b2v
  * w1[96,99] / b1[96] are the three first layers stacked (opacity, colour, cov).  hidden_save (opaque,
  * scr_mlp_heads_hidden_bytes) keeps the hidden layer for the backward pass.  The backward overwrites every output:
- * d_feat[V,32], d_anchor[V,3] (through ob_view), d_geo[V,64] and the parameter gradients; weight-gradient partial
+ * d_feat[V,32], d_anchor[V,3] (through ob_view), d_geo_a / d_geo_b [V,32] and the parameter gradients; weight-gradient partial
  * sums go through `partial` (scr_mlp_heads_partial_bytes) and are added in a fixed order (bit-reproducible). */
 size_t scr_mlp_heads_hidden_bytes(int64_t V);
 size_t scr_mlp_heads_partial_bytes(int64_t V);
-int scr_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,
+int scr_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
                           const float* w1, const float* b1, const float* w2o, const float* b2o, const float* w2c,
                           const float* b2c, const float* w2v, const float* b2v, void* hidden_save, float* out_opacity,
                           float* out_color, float* out_cov, void* stream);
-int scr_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,
+int scr_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
                            const float* w1, const float* w2o, const float* w2c, const float* w2v, const void* hidden_save,
                            const float* out_opacity, const float* out_color, const float* g_opacity, const float* g_color,
-                           const float* g_cov, void* partial, float* d_feat, float* d_anchor, float* d_geo, float* d_w1,
+                           const float* g_cov, void* partial, float* d_feat, float* d_anchor, float* d_geo_a, float* d_geo_b, float* d_w1,
                            float* d_b1, float* d_w2o, float* d_b2o, float* d_w2c, float* d_b2c, float* d_w2v, float* d_b2v,
                            void* stream);
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "scr_knn", "scr_knn_curvature", "scr_mlp_heads_hidden_bytes", "scr_mlp_heads_partial_bytes", "scr_mlp_heads_forward", "scr_mlp_heads_backward",
 ]
 PROF_COUNT = 16
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
 
@@ -92,8 +92,8 @@ def _load():
     lib.scr_statis_compute.restype = lib.scr_statis_apply.restype = C.c_int
     lib.scr_mlp_heads_hidden_bytes.argtypes = lib.scr_mlp_heads_partial_bytes.argtypes = [i64]
     lib.scr_mlp_heads_hidden_bytes.restype = lib.scr_mlp_heads_partial_bytes.restype = C.c_size_t
-    lib.scr_mlp_heads_forward.argtypes = [i64] + [vp] * 17
-    lib.scr_mlp_heads_backward.argtypes = [i64] + [vp] * 27
+    lib.scr_mlp_heads_forward.argtypes = [i64] + [vp] * 18
+    lib.scr_mlp_heads_backward.argtypes = [i64] + [vp] * 29
     lib.scr_mlp_heads_forward.restype = lib.scr_mlp_heads_backward.restype = C.c_int
     lib.scr_knn.argtypes = [i64, i32, C.POINTER(C.c_float), vp, vp, vp, vp, vp]
     lib.scr_knn_curvature.argtypes = [i64, i32, vp, vp, vp, vp]

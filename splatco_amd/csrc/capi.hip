@@ -436,38 +436,38 @@ int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, con
 size_t scr_mlp_heads_hidden_bytes(int64_t V) { return mlp_heads_hidden_bytes(V > 0 ? V : 1); }
 size_t scr_mlp_heads_partial_bytes(int64_t V) { return mlp_heads_partial_bytes(V > 0 ? V : 1); }
 
-int scr_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,
+int scr_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
                           const float* w1, const float* b1, const float* w2o, const float* b2o, const float* w2c,
                           const float* b2c, const float* w2v, const float* b2v, void* hidden_save, float* out_opacity,
                           float* out_color, float* out_cov, void* stream) {
     if (V < 0) return fail("V < 0");
     if (V == 0) return 0;
-    if (!feat || !anchor || !campos || !geo || !w1 || !b1 || !w2o || !b2o || !w2c || !b2c || !w2v || !b2v || !hidden_save ||
+    if (!feat || !anchor || !campos || !geo_a || !geo_b || !w1 || !b1 || !w2o || !b2o || !w2c || !b2c || !w2v || !b2v || !hidden_save ||
         !out_opacity || !out_color || !out_cov)
         return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
     { ProfScope ps_(SCR_PROF_MLP_HEADS, st);
-      launch_mlp_heads_forward(V, feat, anchor, campos, geo, w1, b1, w2o, b2o, w2c, b2c, w2v, b2v, hidden_save, out_opacity,
+      launch_mlp_heads_forward(V, feat, anchor, campos, geo_a, geo_b, w1, b1, w2o, b2o, w2c, b2c, w2v, b2v, hidden_save, out_opacity,
                                out_color, out_cov, st); }
     CHECK_LAUNCH("mlp_heads_forward_kernel", 0, st);
     return 0;
 }
 
-int scr_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,
+int scr_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
                            const float* w1, const float* w2o, const float* w2c, const float* w2v, const void* hidden_save,
                            const float* out_opacity, const float* out_color, const float* g_opacity, const float* g_color,
-                           const float* g_cov, void* partial, float* d_feat, float* d_anchor, float* d_geo, float* d_w1,
+                           const float* g_cov, void* partial, float* d_feat, float* d_anchor, float* d_geo_a, float* d_geo_b, float* d_w1,
                            float* d_b1, float* d_w2o, float* d_b2o, float* d_w2c, float* d_b2c, float* d_w2v, float* d_b2v,
                            void* stream) {
     if (V <= 0) return fail("V <= 0");
-    if (!feat || !anchor || !campos || !geo || !w1 || !w2o || !w2c || !w2v || !hidden_save || !out_opacity || !out_color ||
-        !g_opacity || !g_color || !g_cov || !partial || !d_feat || !d_anchor || !d_geo || !d_w1 || !d_b1 || !d_w2o || !d_b2o ||
+    if (!feat || !anchor || !campos || !geo_a || !geo_b || !w1 || !w2o || !w2c || !w2v || !hidden_save || !out_opacity || !out_color ||
+        !g_opacity || !g_color || !g_cov || !partial || !d_feat || !d_anchor || !d_geo_a || !d_geo_b || !d_w1 || !d_b1 || !d_w2o || !d_b2o ||
         !d_w2c || !d_b2c || !d_w2v || !d_b2v)
         return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
     { ProfScope ps_(SCR_PROF_MLP_HEADS_BACKWARD, st);
-      launch_mlp_heads_backward(V, feat, anchor, campos, geo, w1, w2o, w2c, w2v, hidden_save, out_opacity, out_color, g_opacity,
-                                g_color, g_cov, partial, d_feat, d_anchor, d_geo, d_w1, d_b1, d_w2o, d_b2o, d_w2c, d_b2c, d_w2v,
+      launch_mlp_heads_backward(V, feat, anchor, campos, geo_a, geo_b, w1, w2o, w2c, w2v, hidden_save, out_opacity, out_color, g_opacity,
+                                g_color, g_cov, partial, d_feat, d_anchor, d_geo_a, d_geo_b, d_w1, d_b1, d_w2o, d_b2o, d_w2c, d_b2c, d_w2v,
                                 d_b2v, st); }
     CHECK_LAUNCH("mlp_heads_backward_kernel", 0, st);
     return 0;

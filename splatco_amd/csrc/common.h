@@ -308,15 +308,15 @@ void launch_knn(int64_t N, int k, const float* grid9, const float* sorted_pts, c
 void launch_knn_curvature(int64_t N, int k, const float* pts, const int64_t* idx, float* curvature, hipStream_t st);
 size_t mlp_heads_hidden_bytes(int64_t V);
 size_t mlp_heads_partial_bytes(int64_t V);
-void launch_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,
+void launch_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
                               const float* w1, const float* b1, const float* w2o, const float* b2o, const float* w2c,
                               const float* b2c, const float* w2v, const float* b2v, void* hidden_save, float* out_o,
                               float* out_c, float* out_v, hipStream_t st);
-void launch_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,
+void launch_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
                                const float* w1, const float* w2o, const float* w2c, const float* w2v,
                                const void* hidden_save, const float* out_o, const float* out_c, const float* g_o,
                                const float* g_c, const float* g_v, void* partial, float* d_feat, float* d_anchor,
-                               float* d_geo, float* d_w1, float* d_b1, float* d_w2o, float* d_b2o, float* d_w2c,
+                               float* d_geo_a, float* d_geo_b, float* d_w1, float* d_b1, float* d_w2o, float* d_b2o, float* d_w2c,
                                float* d_b2c, float* d_w2v, float* d_b2v, hipStream_t st);
 
 size_t l1_ssim_scratch_bytes(int C, int H, int W, int with_grad);

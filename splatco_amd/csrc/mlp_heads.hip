@@ -3,6 +3,7 @@
 // (add_*_dist False, appearance_dim 0) and scene/gaussian_model.py:315-337:
 //
 //     x = cat(feat[V,32], ob_view[V,3], geo_fea[V,64])                 ob_view = (anchor - campos) / |anchor - campos|
+//     (geo_fea arrives as its two halves geo_a | geo_b [V,32] each: the outputs of FeaturePlanes' two GEMMs, never concatenated)
 //     neural_opacity = tanh   (W2o relu(W1o x + b1o) + b2o)   [V,10]
 //     color          = sigmoid(W2c relu(W1c x + b1c) + b2c)   [V,30]
 //     scale_rot      =         W2v relu(W1v x + b1v) + b2v    [V,70]
@@ -65,8 +66,8 @@ struct MhWeights {
 // ---------------------------------------------------------------- forward
 __global__ void __launch_bounds__(64 * MH_WAVES, 2)
 mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, const float* __restrict__ anchor,
-                         const float* __restrict__ campos, const float* __restrict__ geo, MhWeights w,
-                         f4* __restrict__ hidden_save, float* __restrict__ out_o, float* __restrict__ out_c,
+                         const float* __restrict__ campos, const float* __restrict__ geo_a,
+                         const float* __restrict__ geo_b, MhWeights w, f4* __restrict__ hidden_save, float* __restrict__ out_o, float* __restrict__ out_c,
                          float* __restrict__ out_v) {
     __shared__ f4 A1[MH_MT][MH_KB][64];    // layer-1 A operands: 4 K-steps per ds_read_b128
     __shared__ f4 A2[MH_OT][2][64];        // layer-2 A operands
@@ -111,7 +112,8 @@ mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, const float*
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) xb[blk] = *(const f4*)(feat + vc * MH_FEAT + 16 * blk + 4 * g);
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) xb[2 + blk] = *(const f4*)(geo + vc * MH_GEO + 16 * blk + 4 * g);
+        for (int blk = 0; blk < 4; ++blk)   // geo_fea = (geo_a | geo_b): the two halves come from two GEMMs, never concatenated
+            xb[2 + blk] = *(const f4*)((blk < 2 ? geo_a : geo_b) + vc * (MH_GEO / 2) + 16 * (blk & 1) + 4 * g);
         {
             const float ox = anchor[3 * vc] - cx, oy = anchor[3 * vc + 1] - cy, oz = anchor[3 * vc + 2] - cz;
             const float inv = 1.0f / sqrtf((ox * ox + oy * oy) + oz * oz);
@@ -188,12 +190,12 @@ constexpr int MH_STAGE_B = 96 * MH_AS > 16 * MH_XS ? 96 * MH_AS : 16 * MH_XS;   
 
 __global__ void __launch_bounds__(64 * MH_WAVES, 1)
 mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float* __restrict__ anchor,
-                          const float* __restrict__ campos, const float* __restrict__ geo, MhWeights w,
-                          const f4* __restrict__ hidden_save, const float* __restrict__ out_o,
+                          const float* __restrict__ campos, const float* __restrict__ geo_a,
+                          const float* __restrict__ geo_b, MhWeights w, const f4* __restrict__ hidden_save, const float* __restrict__ out_o,
                           const float* __restrict__ out_c, const float* __restrict__ g_o,
                           const float* __restrict__ g_c, const float* __restrict__ g_v,
-                          float* __restrict__ d_feat, float* __restrict__ d_anchor, float* __restrict__ d_geo,
-                          float* __restrict__ partial) {
+                          float* __restrict__ d_feat, float* __restrict__ d_anchor, float* __restrict__ d_geo_a,
+                          float* __restrict__ d_geo_b, float* __restrict__ partial) {
     __shared__ f4 A2T[MH_OT][2][64];           // dH = W2^T dZ : A[i = hidden][k = output]
     __shared__ f4 A1T[MH_KB][MH_MT][64];       // dX = W1^T dPre: A[i = input feature][k = hidden]
     __shared__ __attribute__((aligned(16))) float stA[MH_WAVES][MH_STAGE_A];
@@ -334,7 +336,8 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) xb[blk] = *(const f4*)(feat + vc * MH_FEAT + 16 * blk + 4 * g);
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) xb[2 + blk] = *(const f4*)(geo + vc * MH_GEO + 16 * blk + 4 * g);
+        for (int blk = 0; blk < 4; ++blk)
+            xb[2 + blk] = *(const f4*)((blk < 2 ? geo_a : geo_b) + vc * (MH_GEO / 2) + 16 * (blk & 1) + 4 * g);
         const float ox = anchor[3 * vc] - cx, oy = anchor[3 * vc + 1] - cy, oz = anchor[3 * vc + 2] - cz;
         const float inv = 1.0f / sqrtf((ox * ox + oy * oy) + oz * oz);
         xb[6] = g == 0 ? f4{ox * inv, oy * inv, oz * inv, 1.0f} : f4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -355,7 +358,7 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) *(f4*)(d_feat + v * MH_FEAT + 16 * ft + 4 * g) = dx[ft];
 #pragma unroll
-            for (int ft = 2; ft < 6; ++ft) *(f4*)(d_geo + v * MH_GEO + 16 * (ft - 2) + 4 * g) = dx[ft];
+            for (int ft = 2; ft < 6; ++ft) *(f4*)((ft < 4 ? d_geo_a : d_geo_b) + v * (MH_GEO / 2) + 16 * (ft & 1) + 4 * g) = dx[ft];
             if (g == 0) {   // ob = o / |o|:  d o = (d ob - ob <ob, d ob>) / |o|
                 const float ux = ox * inv, uy = oy * inv, uz = oz * inv;
                 const float dot = (ux * dx[6][0] + uy * dx[6][1]) + uz * dx[6][2];
@@ -450,25 +453,26 @@ static int mh_grid(int64_t V, int per_cu = 1) {
 size_t mlp_heads_hidden_bytes(int64_t V) { return align_up((size_t)((V + 15) / 16) * MH_MT * 64 * sizeof(f4)); }
 size_t mlp_heads_partial_bytes(int64_t V) { return align_up((size_t)mh_grid(V) * MH_WAVES * MH_PART * sizeof(float)); }
 
-void launch_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,
-                              const float* w1, const float* b1, const float* w2o, const float* b2o, const float* w2c,
+void launch_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a,
+                              const float* geo_b, const float* w1, const float* b1, const float* w2o, const float* b2o, const float* w2c,
                               const float* b2c, const float* w2v, const float* b2v, void* hidden_save, float* out_o,
                               float* out_c, float* out_v, hipStream_t st) {
     MhWeights w{w1, b1, {w2o, w2c, w2v}, {b2o, b2c, b2v}};
-    mlp_heads_forward_kernel<<<mh_grid(V, 2), 64 * MH_WAVES, 0, st>>>(V, feat, anchor, campos, geo, w, (f4*)hidden_save, out_o,
+    mlp_heads_forward_kernel<<<mh_grid(V, 2), 64 * MH_WAVES, 0, st>>>(V, feat, anchor, campos, geo_a, geo_b, w, (f4*)hidden_save, out_o,
                                                                    out_c, out_v);
 }
 
-void launch_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo,
-                               const float* w1, const float* w2o, const float* w2c, const float* w2v,
+void launch_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a,
+                               const float* geo_b, const float* w1, const float* w2o, const float* w2c, const float* w2v,
                                const void* hidden_save, const float* out_o, const float* out_c, const float* g_o,
                                const float* g_c, const float* g_v, void* partial, float* d_feat, float* d_anchor,
-                               float* d_geo, float* d_w1, float* d_b1, float* d_w2o, float* d_b2o, float* d_w2c,
+                               float* d_geo_a, float* d_geo_b, float* d_w1, float* d_b1, float* d_w2o, float* d_b2o, float* d_w2c,
                                float* d_b2c, float* d_w2v, float* d_b2v, hipStream_t st) {
     MhWeights w{w1, nullptr, {w2o, w2c, w2v}, {nullptr, nullptr, nullptr}};
     const int grid = mh_grid(V);
-    mlp_heads_backward_kernel<<<grid, 64 * MH_WAVES, 0, st>>>(V, feat, anchor, campos, geo, w, (const f4*)hidden_save, out_o,
-                                                              out_c, g_o, g_c, g_v, d_feat, d_anchor, d_geo, (float*)partial);
+    mlp_heads_backward_kernel<<<grid, 64 * MH_WAVES, 0, st>>>(V, feat, anchor, campos, geo_a, geo_b, w, (const f4*)hidden_save,
+                                                              out_o, out_c, g_o, g_c, g_v, d_feat, d_anchor, d_geo_a, d_geo_b,
+                                                              (float*)partial);
     mlp_heads_reduce_kernel<<<(MH_PART + 255) / 256, 256, 0, st>>>(grid * MH_WAVES, (const float*)partial, d_w1, d_b1, d_w2o,
                                                                   d_b2o, d_w2c, d_b2c, d_w2v, d_b2v);
 }

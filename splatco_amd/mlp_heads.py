@@ -12,7 +12,7 @@ from . import _C
 from .rasterizer import _stream
 
 
-def supported(pc, feat, geo_fea):
+def supported(pc, feat, geo_a, geo_b=None):
     """The kernel is written for the reference's sizes: feat 32, geo_fea 64, hidden 32, n_offsets 10, plain heads."""
     heads = (pc.get_opacity_mlp, pc.get_color_mlp, pc.get_cov_mlp)
     try:
@@ -23,14 +23,15 @@ def supported(pc, feat, geo_fea):
         ok = ok and [h[2].weight.shape[0] for h in heads] == [10, 30, 70]
     except (IndexError, AttributeError):
         return False
-    return bool(ok and feat.is_cuda and feat.shape[1] == 32 and geo_fea.shape[1] == 64 and feat.dtype == torch.float32)
+    geo_ok = (geo_a.shape[1] == 64) if geo_b is None else (geo_a.shape[1] == 32 and geo_b.shape[1] == 32)
+    return bool(ok and feat.is_cuda and feat.shape[1] == 32 and geo_ok and feat.dtype == torch.float32)
 
 
 class _MlpHeads(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, anchor, campos, geo, w1, b1, w2o, b2o, w2c, b2c, w2v, b2v):
+    def forward(ctx, feat, anchor, campos, geo_a, geo_b, w1, b1, w2o, b2o, w2c, b2c, w2v, b2v):
         c = lambda t: t.detach().contiguous().float()
-        feat, anchor, campos, geo = c(feat), c(anchor), c(campos), c(geo)
+        feat, anchor, campos, geo_a, geo_b = c(feat), c(anchor), c(campos), c(geo_a), c(geo_b)
         ws = [c(t) for t in (w1, b1, w2o, b2o, w2c, b2c, w2v, b2v)]
         V, dev = feat.shape[0], feat.device
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -38,20 +39,20 @@ class _MlpHeads(torch.autograd.Function):
         hidden = torch.empty(_C.lib.scr_mlp_heads_hidden_bytes(V), dtype=torch.uint8, device=dev)
         if V:
             with torch.cuda.device(dev):
-                _C.check(_C.lib.scr_mlp_heads_forward(V, feat.data_ptr(), anchor.data_ptr(), campos.data_ptr(), geo.data_ptr(),
-                                                      *[t.data_ptr() for t in ws], hidden.data_ptr(), out_o.data_ptr(),
+                _C.check(_C.lib.scr_mlp_heads_forward(V, feat.data_ptr(), anchor.data_ptr(), campos.data_ptr(), geo_a.data_ptr(),
+                                                      geo_b.data_ptr(), *[t.data_ptr() for t in ws], hidden.data_ptr(), out_o.data_ptr(),
                                                       out_c.data_ptr(), out_v.data_ptr(), _stream()))
-        ctx.save_for_backward(feat, anchor, campos, geo, ws[0], ws[2], ws[4], ws[6], hidden, out_o, out_c)
+        ctx.save_for_backward(feat, anchor, campos, geo_a, geo_b, ws[0], ws[2], ws[4], ws[6], hidden, out_o, out_c)
         return out_o, out_c, out_v
 
     @staticmethod
     def backward(ctx, g_o, g_c, g_v):
-        feat, anchor, campos, geo, w1, w2o, w2c, w2v, hidden, out_o, out_c = ctx.saved_tensors
+        feat, anchor, campos, geo_a, geo_b, w1, w2o, w2c, w2v, hidden, out_o, out_c = ctx.saved_tensors
         V, dev = feat.shape[0], feat.device
         z = lambda g, n: (torch.zeros(V, n, dtype=torch.float32, device=dev) if g is None else g.contiguous().float())
         g_o, g_c, g_v = z(g_o, 10), z(g_c, 30), z(g_v, 70)
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        d_feat, d_anchor, d_geo = new(V, 32), new(V, 3), new(V, 64)
+        d_feat, d_anchor, d_geo_a, d_geo_b = new(V, 32), new(V, 3), new(V, 32), new(V, 32)
         d_w1, d_b1 = new(96, 99), new(96)
         d_w2o, d_b2o, d_w2c, d_b2c, d_w2v, d_b2v = new(10, 32), new(10), new(30, 32), new(30), new(70, 32), new(70)
         if V == 0:
@@ -61,18 +62,21 @@ class _MlpHeads(torch.autograd.Function):
             partial = torch.empty(_C.lib.scr_mlp_heads_partial_bytes(V), dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
                 _C.check(_C.lib.scr_mlp_heads_backward(
-                    V, feat.data_ptr(), anchor.data_ptr(), campos.data_ptr(), geo.data_ptr(), w1.data_ptr(), w2o.data_ptr(),
+                    V, feat.data_ptr(), anchor.data_ptr(), campos.data_ptr(), geo_a.data_ptr(), geo_b.data_ptr(), w1.data_ptr(), w2o.data_ptr(),
                     w2c.data_ptr(), w2v.data_ptr(), hidden.data_ptr(), out_o.data_ptr(), out_c.data_ptr(), g_o.data_ptr(),
                     g_c.data_ptr(), g_v.data_ptr(), partial.data_ptr(), d_feat.data_ptr(), d_anchor.data_ptr(),
-                    d_geo.data_ptr(), d_w1.data_ptr(), d_b1.data_ptr(), d_w2o.data_ptr(), d_b2o.data_ptr(), d_w2c.data_ptr(),
+                    d_geo_a.data_ptr(), d_geo_b.data_ptr(), d_w1.data_ptr(), d_b1.data_ptr(), d_w2o.data_ptr(), d_b2o.data_ptr(), d_w2c.data_ptr(),
                     d_b2c.data_ptr(), d_w2v.data_ptr(), d_b2v.data_ptr(), _stream()))
-        return d_feat, d_anchor, None, d_geo, d_w1, d_b1, d_w2o, d_b2o, d_w2c, d_b2c, d_w2v, d_b2v
+        return d_feat, d_anchor, None, d_geo_a, d_geo_b, d_w1, d_b1, d_w2o, d_b2o, d_w2c, d_b2c, d_w2v, d_b2v
 
 
-def mlp_heads(pc, feat, anchor, camera_center, geo_fea):
-    """(neural_opacity [V,10], color [V,30], scale_rot [V,70]) of the visible anchors."""
+def mlp_heads(pc, feat, anchor, camera_center, geo_fea, geo_b=None):
+    """(neural_opacity [V,10], color [V,30], scale_rot [V,70]) of the visible anchors.  geo_fea [V,64], or its two halves
+    (geo_fea [V,32], geo_b [V,32]) as FeaturePlanes' two GEMMs leave them (no concatenation)."""
+    if geo_b is None:
+        geo_fea, geo_b = geo_fea[:, :32], geo_fea[:, 32:]
     ho, hc, hv = pc.get_opacity_mlp, pc.get_color_mlp, pc.get_cov_mlp
     w1 = torch.cat([ho[0].weight, hc[0].weight, hv[0].weight], dim=0)
     b1 = torch.cat([ho[0].bias, hc[0].bias, hv[0].bias], dim=0)
-    return _MlpHeads.apply(feat, anchor, camera_center, geo_fea, w1, b1, ho[2].weight, ho[2].bias, hc[2].weight, hc[2].bias,
+    return _MlpHeads.apply(feat, anchor, camera_center, geo_fea, geo_b, w1, b1, ho[2].weight, ho[2].bias, hc[2].weight, hc[2].bias,
                            hv[2].weight, hv[2].bias)

@@ -29,6 +29,11 @@ def _mlp_heads(pc, x):
     return tuple(h[2:](x_) for h, x_ in zip(heads, parts))
 
 
+def _parts_capable():
+    from .scene_model import GaussianLearner
+    return GaussianLearner
+
+
 def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False, expand=None, fused_heads=True):
     """Anchors -> neural Gaussians (gaussian_renderer/__init__.py:18-116), same op order.
     The mask / compaction / post-processing block (:68-111) is the single HIP op of splatco_amd.expand
@@ -45,18 +50,26 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     grid_offsets = pc._offset.index_select(0, idx)
     grid_scaling = pc.get_scaling.index_select(0, idx)
     V, k = anchor.shape[0], pc.n_offsets
-    geo_fea = pc.feat_planes.inference(
-        anchor, torch.concat((feat, anchor, grid_offsets.reshape(V, -1), grid_scaling), dim=1), 0)
     if getattr(pc, "use_feat_bank", False) or getattr(pc, "appearance_dim", 0) > 0:
         raise NotImplementedError("feature bank / appearance embedding are off on the benchmarked path")
     from . import mlp_heads as _mh
     plain = not (pc.add_opacity_dist or pc.add_color_dist or pc.add_cov_dist)
-    if plain and fused_heads and _mh.supported(pc, feat, geo_fea):
-        # the three heads as ONE fp32-MFMA kernel per direction (csrc/mlp_heads.hip): x = cat(feat, ob_view, geo_fea)
-        # (:58-60) is never built, ob_view (:34-38) is computed inside
+    g_fea = torch.concat((feat, anchor, grid_offsets.reshape(V, -1), grid_scaling), dim=1)
+    use_fused = plain and fused_heads and _mh.supported(pc, feat, feat, feat)
+    if use_fused and not isinstance(pc.feat_planes, _parts_capable()):
+        # someone else's feature planes (e.g. the reference's own GaussianModel): geo_fea arrives concatenated
+        geo_fea = pc.feat_planes.inference(anchor, g_fea, 0)
         neural_opacity, color, scale_rot = _mh.mlp_heads(pc, feat, anchor, viewpoint_camera.camera_center, geo_fea)
         ob_view = None
+    elif use_fused:
+        # the three heads as ONE fp32-MFMA kernel per direction (csrc/mlp_heads.hip): x = cat(feat, ob_view, geo_fea)
+        # (:58-60) is never built, ob_view (:34-38) is computed inside, and geo_fea is read as the two matrices
+        # FeaturePlanes' two GEMMs leave behind (its cat, scene/gaussian_model.py:166, is skipped as well)
+        geo_a, geo_b = pc.feat_planes.inference(anchor, g_fea, 0, parts=True)
+        neural_opacity, color, scale_rot = _mh.mlp_heads(pc, feat, anchor, viewpoint_camera.camera_center, geo_a, geo_b)
+        ob_view = None
     else:
+        geo_fea = pc.feat_planes.inference(anchor, g_fea, 0)
         ob_view = anchor - viewpoint_camera.camera_center
         ob_dist = ob_view.norm(dim=1, keepdim=True)
         ob_view = ob_view / ob_dist

@@ -271,14 +271,16 @@ class FeaturePlanes(nn.Module):               # scene/gaussian_model.py:97-169
             self.models.append(nn.Sequential(nn.BatchNorm1d(d), TallLinear(d, out_dim)))
             self.CTX_models.append(nn.Sequential(nn.BatchNorm1d(71), TallLinear(71, out_dim)))
 
-    def forward(self, x, g_fea, Q=0):
+    def forward(self, x, g_fea, Q=0, parts=False):
+        """parts=True: return the two 32-column halves (plane branch, attribute branch) instead of their
+        concatenation, when they exist as separate matrices (the fused MLP heads read them as they are)."""
         L = self.activate_level + 1
         if FUSE_NORM_LINEAR and all(m[0].training for m in list(self.models[:L]) + list(self.CTX_models[:L])):
             # sum_i cat(Linear(BN(feat_i)), Linear(BN(g_fea))) is linear in the normalised inputs: two GEMMs
             feats = torch.cat([self.k0s[i](x, Q) for i in range(L)], dim=1) if L > 1 else self.k0s[0](x, Q)
             a = _norm_linear(feats, [self.models[i][0] for i in range(L)], [self.models[i][1] for i in range(L)])
             b = _norm_linear(g_fea, [self.CTX_models[i][0] for i in range(L)], [self.CTX_models[i][1] for i in range(L)])
-            return torch.cat((a, b), dim=1)
+            return (a, b) if parts else torch.cat((a, b), dim=1)
         res = []
         for i in range(self.activate_level + 1):
             feat = self.k0s[i](x, Q)
@@ -296,9 +298,12 @@ class GaussianLearner(nn.Module):             # scene/gaussian_model.py:184-220
     def activate_plane_level(self):
         self._feat.activate_level += 1
 
-    def inference(self, xyz, g_fea, Q0):
+    def inference(self, xyz, g_fea, Q0, parts=False):
         # the reference ignores the Q0 argument and uses self.Q0 (:209-215); xyz is detached
-        return self._feat(xyz.detach(), g_fea, self.Q0)
+        out = self._feat(xyz.detach(), g_fea, self.Q0, parts=parts)
+        if parts and not isinstance(out, tuple):
+            out = (out[:, :32], out[:, 32:])
+        return out
 
 
 class AnchorGaussianModel(nn.Module):

@@ -371,6 +371,7 @@ def test_fused_mlp_heads_match_the_torch_chain(V):
     g = torch.Generator(device=dev).manual_seed(V + 1)
     r = lambda *s: torch.randn(*s, device=dev, generator=g)
     feat, anchor, geo, cam = r(V, 32), r(V, 3) * 2, r(V, 64), torch.tensor([0.3, -0.2, -5.0], device=dev)
+    two_parts = V != 37          # geo_fea as one [V,64] matrix or as its two [V,32] halves
     w = [r(V, 10), r(V, 30), r(V, 70)]
     res = {}
     for fused in (True, False, True):
@@ -379,7 +380,7 @@ def test_fused_mlp_heads_match_the_torch_chain(V):
             p.grad = None
         if fused:
             assert supported(pc, f, ge)
-            outs = mlp_heads(pc, f, a, cam, ge)
+            outs = mlp_heads(pc, f, a, cam, ge[:, :32].contiguous(), ge[:, 32:].contiguous()) if two_parts else mlp_heads(pc, f, a, cam, ge)
         else:
             ob = a - cam
             ob = ob / ob.norm(dim=1, keepdim=True)

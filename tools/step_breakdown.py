@@ -37,7 +37,7 @@ def main(cfg="cfg2", anchors=0, steps=3):
     else:
         groups = [{"params": [getattr(pc, "_" + n)], "lr": 1e-4, "name": n} for n in ("anchor", "offset", "anchor_feat", "scaling")]
         groups.append({"params": [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad], "lr": 1e-3, "name": "mlp_and_feat_planes"})
-        opt = torch.optim.Adam(groups, eps=1e-15)
+        opt = torch.optim.Adam(groups, eps=1e-15, fused=True)
         den = AnchorDensifier(pc, opt, seed=seed)
         arena = GradArena([p for grp in groups for p in grp["params"]])
 
