@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 7
+#define SCR_ABI_VERSION 8
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -177,6 +177,20 @@ int scr_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img1, cons
 int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2,
                          const void* scratch, const float* g_l1, const float* g_ssim, float* dimg1,
                          void* stream);
+
+/* ---- the head of generate_neural_gaussians (gaussian_renderer/__init__.py:23-31) for the reference's sizes (feat 32, 10 offsets):
+ * the four visible-anchor gathers, exp(_scaling) and the [V,71] concatenation in one pass.  visible_index[V] int64 = the
+ * visible anchors in order; outputs feat[V,32], anchor[V,3], offsets[V,30], grid_scaling[V,6] = exp(scaling) and
+ * g_fea[V,71] = cat of the four.  The backward takes inverse_index[N] int64 (row of every anchor, -1 = not visible) and
+ * the upstream gradients of the five outputs (any may be NULL) and overwrites EVERY element of the four parameter
+ * gradients [N,32] / [N,3] / [N,30] / [N,6] (zeros for invisible anchors; d exp applied): no atomics, no memset. */
+int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anchor_feat, const float* anchor,
+                      const float* offset, const float* scaling, float* feat_out, float* anchor_out, float* offsets_out,
+                      float* grid_scaling_out, float* g_fea_out, void* stream);
+int scr_anchor_gather_backward(int64_t N, const int64_t* inverse_index, const float* grid_scaling, const float* d_feat,
+                               const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
+                               const float* d_g_fea, float* g_anchor_feat, float* g_anchor, float* g_offset,
+                               float* g_scaling, void* stream);
 
 /* ---- the three MLP heads of generate_neural_gaussians (gaussian_renderer/__init__.py:58-93 with the default flags,
  * scene/gaussian_model.py:315-337) as one fp32-MFMA kernel per direction, for the reference's layer sizes

@@ -19,10 +19,10 @@ SYMBOLS = [
     "scr_expand_backward", "scr_plane_sample_scratch_bytes", "scr_plane_sample_backward", "scr_triplane_forward",
     "scr_l1_ssim_scratch_bytes", "scr_l1_ssim_forward", "scr_l1_ssim_backward",
     "scr_statis_compute", "scr_statis_apply", "scr_copy_probe",
-    "scr_knn", "scr_knn_curvature", "scr_mlp_heads_hidden_bytes", "scr_mlp_heads_partial_bytes", "scr_mlp_heads_forward", "scr_mlp_heads_backward",
+    "scr_knn", "scr_knn_curvature", "scr_anchor_gather", "scr_anchor_gather_backward", "scr_mlp_heads_hidden_bytes", "scr_mlp_heads_partial_bytes", "scr_mlp_heads_forward", "scr_mlp_heads_backward",
 ]
 PROF_COUNT = 16
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
 
@@ -95,6 +95,9 @@ def _load():
     lib.scr_mlp_heads_forward.argtypes = [i64] + [vp] * 18
     lib.scr_mlp_heads_backward.argtypes = [i64] + [vp] * 29
     lib.scr_mlp_heads_forward.restype = lib.scr_mlp_heads_backward.restype = C.c_int
+    lib.scr_anchor_gather.argtypes = [i64] + [vp] * 11
+    lib.scr_anchor_gather_backward.argtypes = [i64] + [vp] * 12
+    lib.scr_anchor_gather.restype = lib.scr_anchor_gather_backward.restype = C.c_int
     lib.scr_knn.argtypes = [i64, i32, C.POINTER(C.c_float), vp, vp, vp, vp, vp]
     lib.scr_knn_curvature.argtypes = [i64, i32, vp, vp, vp, vp]
     lib.scr_knn.restype = lib.scr_knn_curvature.restype = C.c_int

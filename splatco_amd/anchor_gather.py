@@ -1,0 +1,58 @@
+"""The head of generate_neural_gaussians as one autograd op (host side of csrc/anchor_gather.hip):
+gaussian_renderer/__init__.py:23-31 -- the four visible-anchor gathers, exp(_scaling) and the [V,71]
+concatenation that feeds FeaturePlanes' attribute branch.  Device tensors only."""
+import torch
+
+from . import _C
+from .rasterizer import _stream
+
+
+def supported(pc):
+    try:
+        return bool(pc._anchor_feat.is_cuda and pc._anchor_feat.shape[1] == 32 and pc._offset.shape[1:] == (10, 3)
+                    and pc._scaling.shape[1] == 6 and pc._anchor_feat.dtype == torch.float32)
+    except (AttributeError, IndexError):
+        return False
+
+
+class _AnchorGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, idx, anchor_feat, anchor, offset, scaling):
+        c = lambda t: t.detach().contiguous()
+        anchor_feat, anchor, offset, scaling = c(anchor_feat), c(anchor), c(offset), c(scaling)
+        idx = idx.contiguous().long()
+        V, N, dev = idx.numel(), anchor.shape[0], anchor.device
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        feat, anc, off, gs, g_fea = new(V, 32), new(V, 3), new(V, 10, 3), new(V, 6), new(V, 71)
+        if V:
+            with torch.cuda.device(dev):
+                _C.check(_C.lib.scr_anchor_gather(V, idx.data_ptr(), anchor_feat.data_ptr(), anchor.data_ptr(),
+                                                  offset.data_ptr(), scaling.data_ptr(), feat.data_ptr(), anc.data_ptr(),
+                                                  off.data_ptr(), gs.data_ptr(), g_fea.data_ptr(), _stream()))
+        ctx.save_for_backward(idx, gs)
+        ctx.N = N
+        return feat, anc, off, gs, g_fea
+
+    @staticmethod
+    def backward(ctx, d_feat, d_anc, d_off, d_gs, d_g_fea):
+        idx, gs = ctx.saved_tensors
+        N, V, dev = ctx.N, idx.numel(), idx.device
+        inv = torch.full((N,), -1, dtype=torch.long, device=dev)
+        inv[idx] = torch.arange(V, device=dev)
+        p = lambda t: None if t is None else t.contiguous().float()
+        d_feat, d_anc, d_off, d_gs, d_g_fea = p(d_feat), p(d_anc), p(d_off), p(d_gs), p(d_g_fea)
+        ptr = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        g_feat, g_anchor, g_offset, g_scaling = new(N, 32), new(N, 3), new(N, 10, 3), new(N, 6)
+        if N:
+            with torch.cuda.device(dev):
+                _C.check(_C.lib.scr_anchor_gather_backward(N, inv.data_ptr(), ptr(gs), ptr(d_feat), ptr(d_anc), ptr(d_off),
+                                                           ptr(d_gs), ptr(d_g_fea), g_feat.data_ptr(), g_anchor.data_ptr(),
+                                                           g_offset.data_ptr(), g_scaling.data_ptr(), _stream()))
+        return None, g_feat, g_anchor, g_offset, g_scaling
+
+
+def gather_anchors(pc, idx):
+    """(feat [V,32], anchor [V,3], grid_offsets [V,10,3], grid_scaling [V,6] = exp(_scaling), g_fea [V,71]) of the
+    visible anchors idx [V] (int64, ascending)."""
+    return _AnchorGather.apply(idx, pc._anchor_feat, pc._anchor, pc._offset, pc._scaling)

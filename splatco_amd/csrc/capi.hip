@@ -432,6 +432,35 @@ int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, con
     return 0;
 }
 
+// ---- visible-anchor gather (anchor_gather.hip)
+int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anchor_feat, const float* anchor,
+                      const float* offset, const float* scaling, float* feat_out, float* anchor_out, float* offsets_out,
+                      float* grid_scaling_out, float* g_fea_out, void* stream) {
+    if (V < 0) return fail("V < 0");
+    if (V == 0) return 0;
+    if (!visible_index || !anchor_feat || !anchor || !offset || !scaling || !feat_out || !anchor_out || !offsets_out ||
+        !grid_scaling_out || !g_fea_out)
+        return fail("NULL argument");
+    launch_anchor_gather(V, visible_index, anchor_feat, anchor, offset, scaling, feat_out, anchor_out, offsets_out,
+                         grid_scaling_out, g_fea_out, (hipStream_t)stream);
+    CHECK_LAUNCH("anchor_gather_kernel", 0, (hipStream_t)stream);
+    return 0;
+}
+
+int scr_anchor_gather_backward(int64_t N, const int64_t* inverse_index, const float* grid_scaling, const float* d_feat,
+                               const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
+                               const float* d_g_fea, float* g_anchor_feat, float* g_anchor, float* g_offset,
+                               float* g_scaling, void* stream) {
+    if (N < 0) return fail("N < 0");
+    if (N == 0) return 0;
+    if (!inverse_index || !g_anchor_feat || !g_anchor || !g_offset || !g_scaling) return fail("NULL argument");
+    if (d_grid_scaling || d_g_fea) { if (!grid_scaling) return fail("grid_scaling is needed for d exp"); }
+    launch_anchor_gather_backward(N, inverse_index, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea,
+                                  g_anchor_feat, g_anchor, g_offset, g_scaling, (hipStream_t)stream);
+    CHECK_LAUNCH("anchor_gather_backward_kernel", 0, (hipStream_t)stream);
+    return 0;
+}
+
 // ---- MLP heads (mlp_heads.hip)
 size_t scr_mlp_heads_hidden_bytes(int64_t V) { return mlp_heads_hidden_bytes(V > 0 ? V : 1); }
 size_t scr_mlp_heads_partial_bytes(int64_t V) { return mlp_heads_partial_bytes(V > 0 ? V : 1); }

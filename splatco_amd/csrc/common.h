@@ -303,6 +303,13 @@ void launch_statis_apply(int64_t V, int k, const int64_t* visible_index, const f
                          float* opacity_accum, float* anchor_demon, float* offset_gradient_accum, float* offset_denom,
                          hipStream_t st);
 
+void launch_anchor_gather(int64_t V, const int64_t* idx, const float* p_feat, const float* p_anchor, const float* p_offset,
+                          const float* p_scaling, float* feat, float* anchor, float* offsets, float* grid_scaling,
+                          float* g_fea, hipStream_t st);
+void launch_anchor_gather_backward(int64_t N, const int64_t* inv, const float* grid_scaling, const float* d_feat,
+                                   const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
+                                   const float* d_g_fea, float* g_feat, float* g_anchor, float* g_offset,
+                                   float* g_scaling, hipStream_t st);
 void launch_knn(int64_t N, int k, const float* grid9, const float* sorted_pts, const int64_t* sorted_id,
                 const int32_t* cell_start, int64_t* out_idx, hipStream_t st);
 void launch_knn_curvature(int64_t N, int k, const float* pts, const int64_t* idx, float* curvature, hipStream_t st);

@@ -29,6 +29,12 @@ def _mlp_heads(pc, x):
     return tuple(h[2:](x_) for h, x_ in zip(heads, parts))
 
 
+def _plain_exp_scaling():
+    """The get_scaling property the fused gather reproduces (1.0 * exp(_scaling), scene/gaussian_model.py:397-399)."""
+    from .scene_model import AnchorGaussianModel
+    return AnchorGaussianModel.get_scaling
+
+
 def _parts_capable():
     from .scene_model import GaussianLearner
     return GaussianLearner
@@ -45,16 +51,23 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     # `t[visible_mask]` four times (:23-29) = four mask->index conversions (each a host sync) and
     # four sort-based index_put backwards; one nonzero + index_select gives the same rows
     idx = visible_mask.nonzero(as_tuple=False).squeeze(1)
-    feat = pc._anchor_feat.index_select(0, idx)
-    anchor = pc.get_anchor.index_select(0, idx)
-    grid_offsets = pc._offset.index_select(0, idx)
-    grid_scaling = pc.get_scaling.index_select(0, idx)
+    from . import anchor_gather as _ag
+    g_fea = None
+    if fused_heads and _ag.supported(pc) and type(pc).get_scaling is _plain_exp_scaling():
+        # the four gathers, exp(_scaling) and the [V,71] concatenation of :23-31 as one pass (csrc/anchor_gather.hip)
+        feat, anchor, grid_offsets, grid_scaling, g_fea = _ag.gather_anchors(pc, idx)
+    else:
+        feat = pc._anchor_feat.index_select(0, idx)
+        anchor = pc.get_anchor.index_select(0, idx)
+        grid_offsets = pc._offset.index_select(0, idx)
+        grid_scaling = pc.get_scaling.index_select(0, idx)
     V, k = anchor.shape[0], pc.n_offsets
     if getattr(pc, "use_feat_bank", False) or getattr(pc, "appearance_dim", 0) > 0:
         raise NotImplementedError("feature bank / appearance embedding are off on the benchmarked path")
     from . import mlp_heads as _mh
     plain = not (pc.add_opacity_dist or pc.add_color_dist or pc.add_cov_dist)
-    g_fea = torch.concat((feat, anchor, grid_offsets.reshape(V, -1), grid_scaling), dim=1)
+    if g_fea is None:
+        g_fea = torch.concat((feat, anchor, grid_offsets.reshape(V, -1), grid_scaling), dim=1)
     use_fused = plain and fused_heads and _mh.supported(pc, feat, feat, feat)
     if use_fused and not isinstance(pc.feat_planes, _parts_capable()):
         # someone else's feature planes (e.g. the reference's own GaussianModel): geo_fea arrives concatenated
