@@ -15,12 +15,15 @@
  * Conventions
  *   - Plain C, no exceptions, no torch types.  Every pointer is a DEVICE pointer unless the
  *     name ends in `_host`.  All arrays are contiguous fp32 / int32 / uint32 as stated.
- *   - `stream` is a hipStream_t passed as void*.  Nothing synchronises the device; the only
- *     host wait is the stream-sync inside scr_forward_plan that returns num_rendered
- *     (and a sync + error check after every kernel when settings.debug != 0).
- *   - The library owns no memory and keeps no state between calls: the caller allocates every
- *     buffer (sizes from the scr_*_bytes queries) -- so several forward graphs (the mv views
- *     of train.py:171-240) can be alive at once.  One host thread per process/GPU.
+ *   - `stream` is a hipStream_t passed as void*.  Nothing synchronises the device; the only host waits
+ *     are the ones that return a data-dependent count (scr_forward_plan: num_rendered; scr_expand_plan):
+ *     the kernel posts the count to a pinned mailbox the calling thread polls, with a copy +
+ *     hipStreamSynchronize as fallback (and a sync + error check after every kernel when settings.debug != 0).
+ *   - The caller allocates every buffer (sizes from the scr_*_bytes queries), so several forward graphs
+ *     (the mv views of train.py:171-240) can be alive at once.  Process-lifetime state of the library:
+ *     one 64-byte pinned mailbox per calling host thread (created on first use), a per-device flag that
+ *     the >64 KB dynamic-LDS attribute has been set, and the opt-in profiling event pool (scr_profile_*).
+ *     One host thread per process/GPU.
  *   - Return value: 0 = ok, non-zero = error; scr_last_error() returns a thread-local message.
  */
 #ifndef SPLATCO_RASTER_H
@@ -93,7 +96,8 @@ int scr_forward_run(int64_t P, int64_t num_rendered, int64_t max_tile_instances,
  * dL_dmeans3D[P,3], dL_dmeans2D[P,3] (d/d NDC position, z = 0: the gradient SplatCo reads back
  * at scene/gaussian_model.py:779), dL_dcolors[P,3], dL_dsh[P,M,3], dL_dopacity[P], dL_dscales[P,3],
  * dL_drotations[P,4], dL_dcov3D[P,6].  Every output element is written (zeros for culled Gaussians).
- * Deterministic: bit-identical results run to run (no floating-point atomics). */
+ * Deterministic: bit-identical results run to run (no floating-point atomics).  scratch: scr_backward_scratch_bytes
+ * (one 36-byte gradient record per (Gaussian, tile) instance). */
 int scr_backward(int64_t P, int32_t M, int64_t num_rendered, const float* means3D, const float* scales,
                  const float* rotations, const float* cov3D_precomp, const float* shs,
                  const scr_settings* settings, const int32_t* radii, const void* geom_buf,
@@ -153,8 +157,10 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
  *
  * scr_plane_sample_backward: given grad_out (row stride ld, R used columns: pass the column-offset
  * pointer) and the columns (cx, cy) of coords that hold (gx, gy), overwrites grad_plane[R,A,B] with
- * the scatter-add of the four corner weights (points are bucketed by 32x32-cell tile and
- * accumulated in LDS; global float atomics only when a tile is flushed).  R <= 8; scratch from
+ * the scatter-add of the four corner weights (points are bucketed by 32x32-cell tile and summed per node in
+ * registers in a fixed order; the nodes on a tile's border are shared with the neighbouring tiles and are flushed
+ * with global float atomics -- plane gradients are therefore reproducible only up to the order of those few adds,
+ * unlike every other output of this library).  R <= 8; scratch from
  * scr_plane_sample_scratch_bytes.  The sample positions get no gradient (the reference detaches
  * them, scene/gaussian_model.py:210). */
 int scr_triplane_forward(int64_t V, const float* coords, int32_t cstride, const float* xy, const float* xz,

@@ -537,7 +537,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             accC[par][wave][j] = B.z;
         }
         __syncthreads();  // B: every wave's sums for this round are in acc
-        // ---- combine: wave p (< 3) writes float4 part p of the 48-byte record of position `lane`,
+        // ---- combine: wave p (< 3) writes part p of the 36-byte gradient record of position `lane`,
         // adding the waves that took part in a fixed order
         if (wave < 3 && base + lane < n) {
             const uint32_t i = base + lane;
