@@ -338,6 +338,13 @@ __device__ __forceinline__ void store16_dword_aligned(void* p, float4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(q) : "memory");
 }
 
+// Developer builds with -DSCR_TILE_TIMING (tools/tile_times.py): every backward workgroup leaves the wall-clock
+// ticks (100 MHz constant counter) at which it started and finished, to see the distribution of per-tile durations
+// and how much of the kernel is the tail of the last tiles.  Not in the product build.
+#ifdef SCR_TILE_TIMING
+__device__ unsigned long long scr_tile_ticks[2 * 65536];
+#endif
+
 // ------------------------------------------------------------------ backward
 constexpr int BCH = 64;  // list entries per round: one per lane of each wave
 #ifndef SCR_BWD_ACC_BUFS
@@ -367,6 +374,13 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     __shared__ uint32_t wave_max[4];
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
+#ifdef SCR_TILE_TIMING
+    struct Stamp {
+        int t;
+        __device__ Stamp(int t_) : t(t_) { if (threadIdx.x == 0 && t < 65536) scr_tile_ticks[2 * t] = wall_clock64(); }
+        __device__ ~Stamp() { __syncthreads(); if (threadIdx.x == 0 && t < 65536) scr_tile_ticks[2 * t + 1] = wall_clock64(); }
+    } stamp(t);
+#endif
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
     if (n == 0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;  // wave == quadrant
@@ -576,3 +590,9 @@ void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinVie
 }
 
 }  // namespace scr
+
+#ifdef SCR_TILE_TIMING
+extern "C" int scr_debug_tile_ticks(unsigned long long* out_host, int tiles) {
+    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(scr::scr_tile_ticks), (size_t)tiles * 16, 0, hipMemcpyDeviceToHost);
+}
+#endif

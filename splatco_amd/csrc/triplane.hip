@@ -19,7 +19,10 @@
 
 namespace scr {
 
-constexpr int TP_TILE = 32;            // cells per tile edge; a tile owns 33 x 33 nodes
+#ifndef SCR_TP_TILE
+#define SCR_TP_TILE 32
+#endif
+constexpr int TP_TILE = SCR_TP_TILE;   // cells per tile edge; a tile owns (TP_TILE + 1)^2 nodes
 constexpr int TP_NODES = TP_TILE + 1;
 constexpr int TP_MAX_R = 8;            // channels per plane supported by the LDS tile (R = num_channels / 3)
 constexpr int TP_THREADS = 1024;
