@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 8
+#define SCR_ABI_VERSION 9
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -155,21 +155,33 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
  * channel_last = 0: planes in the reference's layout [R,A,B]; 1: caller passes [A,B,R] copies (one or two
  * cache lines per sampled row instead of R; pays off when the planes exceed the L2).
  *
- * scr_plane_sample_backward: given grad_out (row stride ld, R used columns: pass the column-offset
- * pointer) and the columns (cx, cy) of coords that hold (gx, gy), overwrites grad_plane[R,A,B] with
- * the scatter-add of the four corner weights (points are bucketed by 32x32-cell tile and summed per node in
- * registers in a fixed order; the nodes on a tile's border are shared with the neighbouring tiles and are flushed
- * with global float atomics -- plane gradients are therefore reproducible only up to the order of those few adds,
- * unlike every other output of this library).  R <= 8; scratch from
- * scr_plane_sample_scratch_bytes.  The sample positions get no gradient (the reference detaches
- * them, scene/gaussian_model.py:210). */
+ * scr_plane_sample_backward: `planes` (1 or 2) planes [R,A,B] that are sampled at the same positions (the plain and
+ * the attended plane of the attention grid, scene/grids.py:174-181) receive the scatter-add of the four corner weights
+ * times their block of R gradient columns (grad_out0 / grad_out1: the column-offset pointers into the gradient matrix of
+ * row stride ld); (cx, cy) are the columns of coords that hold (gx, gy).  Both grad_plane arrays are overwritten.
+ * The points' coordinates and gradient pieces are first moved into per-tile runs of records (32x32-cell tiles), then
+ * summed per node in registers; the order of the points inside a cell follows LDS / global atomics and the nodes on a
+ * tile's border are flushed with global float atomics -- plane gradients are therefore reproducible only up to the
+ * order of those adds, unlike every other output of this library.  R <= 8; scratch from
+ * scr_plane_sample_scratch_bytes(V, A, B, R * planes).  The sample positions get no gradient (the reference detaches
+ * them, scene/gaussian_model.py:210).
+ *
+ * scr_triplane_backward: the same for the three projections of a grid in one pass over the points (the backward of
+ * scr_triplane_forward): grad_out is the gradient of the concatenated matrix (row stride ld); cols[3 * planes] (host
+ * array) holds the first column of xy, xz, yz and, with planes = 2, of the second triple sampled at the same
+ * positions; grad_planes[3 * planes] (host array of device pointers, same order) are overwritten.  Scratch from
+ * scr_triplane_backward_scratch_bytes(V, X, Y, Z, R * planes). */
 int scr_triplane_forward(int64_t V, const float* coords, int32_t cstride, const float* xy, const float* xz,
                          const float* yz, int32_t R, int32_t X, int32_t Y, int32_t Z, int32_t channel_last, float* out,
                          int32_t ld, int32_t col_xy, int32_t col_xz, int32_t col_yz, void* stream);
-size_t scr_plane_sample_scratch_bytes(int64_t V, int32_t A, int32_t B);
+size_t scr_plane_sample_scratch_bytes(int64_t V, int32_t A, int32_t B, int32_t channels);
+size_t scr_triplane_backward_scratch_bytes(int64_t V, int32_t X, int32_t Y, int32_t Z, int32_t channels);
+int scr_triplane_backward(int64_t V, const float* coords, int32_t cstride, int32_t R, int32_t X, int32_t Y, int32_t Z,
+                          int32_t planes, const float* grad_out, int32_t ld, const int32_t* cols, float* const* grad_planes,
+                          void* scratch, void* stream);
 int scr_plane_sample_backward(int64_t V, const float* coords, int32_t cstride, int32_t cx, int32_t cy, int32_t R,
-                              int32_t A, int32_t B, const float* grad_out, int32_t ld, float* grad_plane,
-                              void* scratch, void* stream);
+                              int32_t A, int32_t B, int32_t planes, const float* grad_out0, const float* grad_out1,
+                              int32_t ld, float* grad_plane0, float* grad_plane1, void* scratch, void* stream);
 
 /* ---- fused L1 + SSIM image loss (train.py:192-196, utils/loss_utils.py:17-63): img1 = rendered
  * image [C,H,W] (gets the gradient), img2 = ground truth.  Forward writes out2[0] = mean |img1-img2|

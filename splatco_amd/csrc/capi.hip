@@ -371,21 +371,51 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
 }
 
 // ---- tri-plane sampling backward (triplane.hip)
-size_t scr_plane_sample_scratch_bytes(int64_t V, int32_t A, int32_t B) { return triplane_scratch_bytes(V, A, B); }
+size_t scr_plane_sample_scratch_bytes(int64_t V, int32_t A, int32_t B, int32_t channels) {
+    return triplane_scratch_bytes(V, A, B, channels);
+}
 
 int scr_plane_sample_backward(int64_t V, const float* coords, int32_t cstride, int32_t cx, int32_t cy, int32_t R,
-                              int32_t A, int32_t B, const float* grad_out, int32_t ld, float* grad_plane,
-                              void* scratch, void* stream) {
+                              int32_t A, int32_t B, int32_t planes, const float* grad_out0, const float* grad_out1,
+                              int32_t ld, float* grad_plane0, float* grad_plane1, void* scratch, void* stream) {
     if (V < 0 || R <= 0 || A <= 1 || B <= 1) return fail("bad sizes");
+    if (planes != 1 && planes != 2) return fail("planes must be 1 or 2");
     if (cstride <= 0 || cx < 0 || cy < 0 || cx >= cstride || cy >= cstride || ld < R) return fail("bad strides");
-    if (!grad_plane || !scratch || (V > 0 && (!coords || !grad_out))) return fail("NULL argument");
+    if (!grad_plane0 || !scratch || (V > 0 && (!coords || !grad_out0))) return fail("NULL argument");
+    if (planes == 2 && (!grad_plane1 || (V > 0 && !grad_out1))) return fail("NULL argument (second plane)");
     hipStream_t st = (hipStream_t)stream;
     int rc;
     { ProfScope ps_(SCR_PROF_PLANE_BACKWARD, st);
-      rc = launch_plane_sample_backward(V, coords, cstride, cx, cy, R, A, B, grad_out, ld, grad_plane, scratch, st); }
+      rc = launch_plane_sample_backward(V, coords, cstride, cx, cy, R, A, B, planes, grad_out0, grad_out1, ld, grad_plane0,
+                                        grad_plane1, scratch, st); }
     if (rc == 1) return fail("R = %d channels per plane exceeds the supported 8", R);
     if (rc == 2) return fail("plane %dx%d has too many 32x32 tiles for the LDS histogram", A, B);
     CHECK_LAUNCH("plane_sample_backward", 0, st);
+    return 0;
+}
+
+size_t scr_triplane_backward_scratch_bytes(int64_t V, int32_t X, int32_t Y, int32_t Z, int32_t channels) {
+    return triplane_backward_scratch_bytes(V, X, Y, Z, channels);
+}
+
+int scr_triplane_backward(int64_t V, const float* coords, int32_t cstride, int32_t R, int32_t X, int32_t Y, int32_t Z,
+                          int32_t planes, const float* grad_out, int32_t ld, const int32_t* cols, float* const* grad_planes,
+                          void* scratch, void* stream) {
+    if (V < 0 || R <= 0 || X <= 1 || Y <= 1 || Z <= 1) return fail("bad sizes");
+    if (planes != 1 && planes != 2) return fail("planes must be 1 or 2");
+    if (cstride < 3 || ld < R * 3 * planes) return fail("bad strides");
+    if (!cols || !grad_planes || !scratch || (V > 0 && (!coords || !grad_out))) return fail("NULL argument");
+    for (int q = 0; q < 3 * planes; ++q) {
+        if (!grad_planes[q]) return fail("NULL plane gradient %d", q);
+        if (cols[q] < 0 || cols[q] + R > ld) return fail("column block %d outside the gradient rows", q);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    { ProfScope ps_(SCR_PROF_PLANE_BACKWARD, st);
+      rc = launch_triplane_backward(V, coords, cstride, R, X, Y, Z, planes, grad_out, ld, cols, grad_planes, scratch, st); }
+    if (rc == 1) return fail("R = %d channels per plane exceeds the supported 8", R);
+    if (rc == 2) return fail("a plane of %dx%dx%d has too many 32x32 tiles for the LDS histogram", X, Y, Z);
+    CHECK_LAUNCH("triplane_backward", 0, st);
     return 0;
 }
 

@@ -331,9 +331,14 @@ void launch_l1_ssim_forward(int C, int H, int W, const float* img1, const float*
                             int with_grad, float* out2, hipStream_t st);
 void launch_l1_ssim_backward(int C, int H, int W, const float* img1, const float* img2, const void* scratch,
                              const float* g_l1, const float* g_ssim, float* dimg1, hipStream_t st);
-size_t triplane_scratch_bytes(int64_t V, int A, int B);
-int launch_plane_sample_backward(int64_t V, const float* coords, int cs, int cx, int cy, int R, int A, int B,
-                                 const float* grad_out, int ld, float* grad_plane, void* scratch, hipStream_t st);
+size_t triplane_scratch_bytes(int64_t V, int A, int B, int channels);
+size_t triplane_backward_scratch_bytes(int64_t V, int X, int Y, int Z, int channels);
+int launch_triplane_backward(int64_t V, const float* coords, int cs, int R, int X, int Y, int Z, int planes,
+                             const float* grad_out, int ld, const int* cols, float* const* grad_planes, void* scratch,
+                             hipStream_t st);
+int launch_plane_sample_backward(int64_t V, const float* coords, int cs, int cx, int cy, int R, int A, int B, int planes,
+                                 const float* grad_out0, const float* grad_out1, int ld, float* grad_plane0,
+                                 float* grad_plane1, void* scratch, hipStream_t st);
 int launch_triplane_forward(int64_t V, const float* coords, int cs, const float* xy, const float* xz, const float* yz,
                              int R, int X, int Y, int Z, int channel_last, float* out, int ld, int col_xy, int col_xz,
                              int col_yz, hipStream_t st);

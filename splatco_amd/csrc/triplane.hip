@@ -10,11 +10,14 @@
 // 4.6 M anchors, and MI355X retires ~28 G device atomics/s whatever their scope, so those calls
 // are 41 % of the whole render() step at BASELINE.json configs[2].
 //
-// Here the points are first bucketed by 32x32-cell plane tile (the same LDS-aggregated
-// count / reserve / place scheme as the rasterizer's tile binning); one workgroup per tile then
-// sorts its points by cell in LDS and lets every thread sum, in registers, the contributions that reach
-// the tile nodes it owns (tp_node_gather_kernel): no float atomics inside a tile, global atomics only
-// for the 128 border nodes a tile shares with its neighbours (0.33 ms per plane at 4.6 M points).
+// Here the points are first bucketed by 32x32-cell plane tile (the same LDS-aggregated count / reserve / place
+// scheme as the rasterizer's tile binning), for the three projections of a grid in ONE pass over the points that
+// moves each point's coordinates and gradient piece into the tile's run of 32 / 48-byte records
+// (tp_scatter_kernel); one workgroup per tile then sorts chunks of its run by cell in LDS and every thread sums,
+// in registers, the four corner contributions of the cell it owns (tp_cell_gather_kernel): no float atomics
+// inside a tile, global atomics only for the 128 border nodes a tile shares with its neighbours.
+// Round 1 kept an index list per tile and gathered coordinates and gradients through it (0.43 ms per plane at
+// 4.6 M points, 5.2 ms per cfg2 step); records + one pass per grid + cell-centred sums: 3.2 ms per step.
 #include "common.h"
 
 namespace scr {
@@ -71,195 +74,342 @@ __device__ __forceinline__ uint32_t tp_block_scan(uint32_t v, uint32_t* lds_wave
     return base + inc - v;
 }
 
-// pass 1: per-tile point counts (LDS histogram per workgroup, one global atomic per touched tile)
+// ---- backward with respect to the planes.  One pass over the points serves up to three PROJECTIONS (the xy / xz / yz
+// planes of a grid): what it reads of a point -- the coordinate row and the grid's contiguous piece of the gradient row --
+// is read once, in point order.
+// record of a (point, projection): {grid x, grid y, RT gradient values}, padded to whole 16-byte pieces so that a record
+// is written with REC / 4 stores (lone dword stores to random tiles are bound by the L2 request rate)
+constexpr int tp_rec(int RT) { return (2 + RT + 3) / 4 * 4; }
+
+struct TpProj {
+    int cx, cy, A, B, tb, tiles;          // coordinate columns (grid x -> plane dim B, grid y -> dim A), plane size, tiles
+    int col0, col1;                       // first gradient column of the plane (and of the second plane sampled with it)
+    uint32_t *count, *start, *cursor;     // [tiles], [tiles + 1], [tiles]
+    float* rec;                           // [V][tp_rec(R * NP)]
+};
+struct TpProjSet {
+    TpProj p[3];
+    int n;
+};
+
+// pass 1: per-tile point counts (LDS histograms per workgroup, one global atomic per touched tile)
 __global__ void __launch_bounds__(TP_THREADS)
-tp_count_kernel(int64_t V, const float* __restrict__ coords, int cs, int cx, int cy, int A, int B, int tb, int tiles,
-                uint32_t* __restrict__ tile_count) {
+tp_count_kernel(int64_t V, const float* __restrict__ coords, int cs, TpProjSet ps) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
-    for (int t = threadIdx.x; t < tiles; t += TP_THREADS) hist[t] = 0;
+    const int total = ps.p[0].tiles + (ps.n > 1 ? ps.p[1].tiles + ps.p[2].tiles : 0);
+    for (int t = threadIdx.x; t < total; t += TP_THREADS) hist[t] = 0;
     __syncthreads();
     for (int r = 0; r < TP_ROUNDS; ++r) {
         const int64_t i = (int64_t)blockIdx.x * TP_PER_WG + r * TP_THREADS + threadIdx.x;
         if (i >= V) break;
-        const int t = tp_tile_of(coords[i * cs + cx], coords[i * cs + cy], A, B, tb);
-        if (t >= 0) atomicAdd(&hist[t], 1u);
+        int off = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (q >= ps.n) break;
+            const TpProj& pj = ps.p[q];
+            const int t = tp_tile_of(coords[i * cs + pj.cx], coords[i * cs + pj.cy], pj.A, pj.B, pj.tb);
+            if (t >= 0) atomicAdd(&hist[off + t], 1u);
+            off += pj.tiles;
+        }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < tiles; t += TP_THREADS) {
-        const uint32_t c = hist[t];
-        if (c) atomicAdd(&tile_count[t], c);
+    int off = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        if (q >= ps.n) break;
+        for (int t = threadIdx.x; t < ps.p[q].tiles; t += TP_THREADS) {
+            const uint32_t c = hist[off + t];
+            if (c) atomicAdd(&ps.p[q].count[t], c);
+        }
+        off += ps.p[q].tiles;
     }
 }
 
-// pass 2 (one workgroup): exclusive scan of the tile counts -> tile_start[tiles + 1]; cursor = 0
+// pass 2 (one workgroup per projection): exclusive scan of the tile counts -> start[tiles + 1]; cursor = 0
 __global__ void __launch_bounds__(1024)
-tp_scan_kernel(int tiles, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
-               uint32_t* __restrict__ cursor) {
+tp_scan_kernel(TpProjSet ps) {
     __shared__ uint32_t lds[1024 / WAVE];
+    const TpProj pj = blockIdx.x == 0 ? ps.p[0] : (blockIdx.x == 1 ? ps.p[1] : ps.p[2]);
     uint32_t carry = 0;
-    for (int base = 0; base < tiles; base += 1024) {
+    for (int base = 0; base < pj.tiles; base += 1024) {
         const int i = base + threadIdx.x;
-        const uint32_t v = i < tiles ? tile_count[i] : 0u;
+        const uint32_t v = i < pj.tiles ? pj.count[i] : 0u;
         uint32_t tot;
         const uint32_t ex = tp_block_scan(v, lds, tot);
-        if (i < tiles) {
-            tile_start[i] = carry + ex;
-            cursor[i] = 0;
+        if (i < pj.tiles) {
+            pj.start[i] = carry + ex;
+            pj.cursor[i] = 0;
         }
         carry += tot;
     }
-    if (threadIdx.x == 0) tile_start[tiles] = carry;
+    if (threadIdx.x == 0) pj.start[pj.tiles] = carry;
 }
 
-// pass 3: point indices grouped by tile
+// pass 3: one RECORD per (point, projection), grouped by tile: {grid x, grid y, the RT = R * NP gradient values}.
+// The point order is random with respect to the planes, so whatever pass 4 needs of a point is moved here into the
+// tile's contiguous run of records, and pass 4 reads nothing but its own run, fully coalesced.  With an index list
+// instead (round 1) pass 4 gathered a 16-byte coordinate row and a 20-byte gradient piece per point through two
+// 128-byte lines each: 0.33 ms per plane at 4.6 M points, the random-line rate of HBM.
+// NP (1 or 2) gradient blocks of R columns share a projection and its plane size: the attention grid samples the
+// plain and the attended plane at the same positions (scene/grids.py:174-181).
+// SPAN consecutive floats from p, which reaches 16-byte alignment after H of them (the same H for every row when the
+// row stride is a multiple of 16 bytes): head, 16-byte body, tail -- a quarter of the requests of dword loads, and
+// with rows scattered over as many cache lines as there are lanes the request count is what a load costs
+template <int SPAN, int H>
+__device__ __forceinline__ void tp_load_span(const float* __restrict__ p, float (&g)[SPAN]) {
+    constexpr int K0 = (H & 1) && SPAN >= 1 ? 1 : 0;
+    constexpr int K1 = K0 + (((H & 2) && SPAN - K0 >= 2) ? 2 : 0);
+    constexpr int KT = K1 + (SPAN - K1) / 4 * 4;
+    if (K0) g[0] = p[0];
+    if (K1 > K0) {
+        const float2 v = *(const float2*)(p + K0);
+        g[K0] = v.x;
+        g[K0 + 1] = v.y;
+    }
+    if (K1 == H) {
+#pragma unroll
+        for (int k = K1; k < KT; k += 4) {
+            const float4 v = *(const float4*)(p + k);
+            g[k] = v.x;
+            g[k + 1] = v.y;
+            g[k + 2] = v.z;
+            g[k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = K1; k < KT; ++k) g[k] = p[k];
+    }
+    if (SPAN - KT >= 2) {
+        const float2 v = *(const float2*)(p + KT);
+        g[KT] = v.x;
+        g[KT + 1] = v.y;
+    }
+    if ((SPAN - KT) & 1) g[SPAN - 1] = p[SPAN - 1];
+}
+
+// FAST: three projections whose gradient blocks lie side by side in projection order (projection q, plane s at column
+// span0 + (q * NP + s) * R: the layout of scene/grids.py:165,181) in rows of a 16-byte-multiple stride: the grid's
+// 3 * RT columns of a row are loaded once, with wide loads, and record q is the q-th third of them.
+template <int R, int NP, bool FAST>
 __global__ void __launch_bounds__(TP_THREADS)
-tp_scatter_kernel(int64_t V, const float* __restrict__ coords, int cs, int cx, int cy, int A, int B, int tb, int tiles,
-                  const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ cursor,
-                  uint32_t* __restrict__ perm) {
+tp_scatter_kernel(int64_t V, const float* __restrict__ coords, int cs, const float* __restrict__ grad, int ld, int span0,
+                  TpProjSet ps) {
+    constexpr int RT = R * NP, REC = tp_rec(RT);
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
-    for (int t = threadIdx.x; t < tiles; t += TP_THREADS) hist[t] = 0;
+    const int total = ps.p[0].tiles + (ps.n > 1 ? ps.p[1].tiles + ps.p[2].tiles : 0);
+    for (int t = threadIdx.x; t < total; t += TP_THREADS) hist[t] = 0;
     __syncthreads();
-    int tl[TP_ROUNDS];
+    int tl[TP_ROUNDS][3];
 #pragma unroll
     for (int r = 0; r < TP_ROUNDS; ++r) {
         const int64_t i = (int64_t)blockIdx.x * TP_PER_WG + r * TP_THREADS + threadIdx.x;
-        tl[r] = i < V ? tp_tile_of(coords[i * cs + cx], coords[i * cs + cy], A, B, tb) : -1;
-        if (tl[r] >= 0) atomicAdd(&hist[tl[r]], 1u);
+        int off = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            tl[r][q] = -1;
+            if (q < ps.n && i < V) {
+                const TpProj& pj = ps.p[q];
+                const int t = tp_tile_of(coords[i * cs + pj.cx], coords[i * cs + pj.cy], pj.A, pj.B, pj.tb);
+                if (t >= 0) {
+                    tl[r][q] = off + t;
+                    atomicAdd(&hist[off + t], 1u);
+                }
+                off += pj.tiles;
+            }
+        }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < tiles; t += TP_THREADS) {
-        const uint32_t c = hist[t];
-        if (c) hist[t] = tile_start[t] + atomicAdd(&cursor[t], c);
+    {
+        int off = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (q >= ps.n) break;
+            const TpProj& pj = ps.p[q];
+            for (int t = threadIdx.x; t < pj.tiles; t += TP_THREADS) {
+                const uint32_t c = hist[off + t];
+                if (c) hist[off + t] = pj.start[t] + atomicAdd(&pj.cursor[t], c);
+            }
+            off += pj.tiles;
+        }
     }
     __syncthreads();
+    const int head = (4 - (span0 & 3)) & 3;       // floats before the span reaches 16-byte alignment (FAST only)
 #pragma unroll
     for (int r = 0; r < TP_ROUNDS; ++r) {
-        if (tl[r] < 0) continue;
         const int64_t i = (int64_t)blockIdx.x * TP_PER_WG + r * TP_THREADS + threadIdx.x;
-        perm[atomicAdd(&hist[tl[r]], 1u)] = (uint32_t)i;
+        if (tl[r][0] < 0 && tl[r][1] < 0 && tl[r][2] < 0) continue;
+        const float* row = grad + (size_t)i * ld;
+        float span[FAST ? 3 * RT : 1];
+        if (FAST) {
+            float(&sp)[3 * RT] = reinterpret_cast<float(&)[3 * RT]>(span);
+            switch (head) {
+                case 0: tp_load_span<3 * RT, 0>(row + span0, sp); break;
+                case 1: tp_load_span<3 * RT, 1>(row + span0, sp); break;
+                case 2: tp_load_span<3 * RT, 2>(row + span0, sp); break;
+                default: tp_load_span<3 * RT, 3>(row + span0, sp); break;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (tl[r][q] < 0) continue;
+            const TpProj& pj = ps.p[q];
+            float v[REC];
+            v[0] = coords[i * cs + pj.cx];
+            v[1] = coords[i * cs + pj.cy];
+#pragma unroll
+            for (int k = 0; k < REC - 2; ++k) {
+                if (k >= RT) v[2 + k] = 0.0f;
+                else if (FAST) v[2 + k] = span[FAST ? q * RT + k : 0];
+                else v[2 + k] = row[(k < R ? pj.col0 : pj.col1 - R) + k];
+            }
+            float4* dst = (float4*)(pj.rec + (size_t)atomicAdd(&hist[tl[r][q]], 1u) * REC);
+#pragma unroll
+            for (int k = 0; k < REC / 4; ++k) dst[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        }
     }
 }
 
-// pass 4, node-centred.  The obvious kernel -- every point adds its 4 corners x R channels into an LDS copy of
-// the tile with ds_add_f32 -- is bound by the LDS float-atomic rate (about one lane every four cycles on
-// gfx950: 0.63 ms per plane at 4.6 M points, 0.37 ms with plain, wrong, read-modify-writes).  Here a
-// workgroup sorts a chunk of its tile's points by
-// CELL inside LDS (one integer LDS atomic per point hands out the slot), stages the points' bilinear
-// fractions and gradient rows in that order, and then every thread owns a few of the tile's 33 x 33 NODES and
-// sums, in registers, the contributions of the points in the node's four adjacent cells.  No float atomics
-// inside the tile; the sums of a tile's border nodes (shared with the neighbours) go out as global atomics,
-// interior nodes as plain stores.
-constexpr int TPN_CHUNK = 1024;                 // points staged per round
-constexpr int TPN_CELLS = TP_NODES * TP_NODES;  // local cells (la + 1, lb + 1), la, lb in [-1, 31]
-constexpr int TPN_NPT = (TP_NODES * TP_NODES + 255) / 256;  // nodes per thread
-template <int R>
-__global__ void __launch_bounds__(256)
-tp_node_gather_kernel(const float* __restrict__ coords, int cs, int cx, int cy, int A, int B, int tb,
-                      const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ perm,
-                      const float* __restrict__ grad_out /*[V][ld]*/, int ld, float* __restrict__ grad_plane /*[R][A][B]*/) {
-    __shared__ uint32_t cnt[TPN_CELLS + 1], start[TPN_CELLS + 1];
-    __shared__ uint32_t waves[4];
-    __shared__ float pfa[TPN_CHUNK], pfb[TPN_CHUNK];
-    __shared__ float pg[TPN_CHUNK][R];
+// pass 4, cell-centred.  The obvious kernel -- every point adds its 4 corners x R channels into an LDS copy of the
+// tile with ds_add_f32 -- is bound by the LDS float-atomic rate (about one lane every four cycles on gfx950: 0.63 ms per
+// plane at 4.6 M points).  Here a workgroup copies a chunk of its tile's records into LDS, sorts the chunk by CELL
+// (one integer LDS atomic per point hands out the rank inside the cell; an index list in cell order, the records
+// stay where they are), and every thread owns four of the tile's 32 x 32 cells: it walks the points of its cells
+// once and keeps the cell's four corner sums x RT channels in registers over all chunks.  At the end the corner sums
+// meet in an LDS image of the tile's 33 x 33 nodes, one corner per pass (within a pass every node receives from one
+// cell: plain read-modify-writes).  No float atomics inside the tile; the sums of a tile's border nodes (shared with
+// the neighbours) go out as global atomics, interior nodes as plain stores.  Points whose cell lies one step outside
+// the plane (grid coordinate just beyond -1: only their inner corners exist) are rare and go out as global atomics.
+constexpr int TPN_NODES = TP_NODES * TP_NODES;
+constexpr int TPN_CELLS = TP_TILE * TP_TILE;
+constexpr int TPN_THREADS = 1024;               // one cell per thread
+static_assert(TPN_CELLS == TPN_THREADS, "one cell per thread");
+template <int RT>
+constexpr int tpn_chunk() {   // points per round: a multiple of 256 whose records stay under 64 KB of LDS
+    int c = 65536 / (tp_rec(RT) * 4) / 256 * 256;
+    return c > 2048 ? 2048 : c;
+}
+template <int RT>
+constexpr size_t tpn_lds_bytes() {              // cnt, start, waves, order, records (or the node image at the end)
+    return (size_t)TPN_CELLS * 4 + (TPN_CELLS + 4) * 4 + 64 + (size_t)tpn_chunk<RT>() * 2 + (size_t)tpn_chunk<RT>() * tp_rec(RT) * 4;
+}
+
+template <int R, int NP>
+__global__ void __launch_bounds__(TPN_THREADS, (R * NP <= 5 ? 8 : 4))
+tp_cell_gather_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_start, const float* __restrict__ rec,
+                      float* __restrict__ grad_plane0 /*[R][A][B]*/, float* __restrict__ grad_plane1) {
+    constexpr int RT = R * NP, REC = tp_rec(RT);
+    constexpr int CHUNK = tpn_chunk<RT>();
+    constexpr int PPT = (CHUNK + TPN_THREADS - 1) / TPN_THREADS;
+    static_assert(CHUNK * REC >= TPN_NODES * RT, "the node image reuses the record buffer");
+    extern __shared__ __attribute__((aligned(16))) unsigned char tpn_lds[];
+    uint32_t* cnt = (uint32_t*)tpn_lds;                       // [TPN_CELLS]
+    uint32_t* start = cnt + TPN_CELLS;                        // [TPN_CELLS + 1] (+ 3 pad)
+    uint32_t* waves = start + TPN_CELLS + 4;                  // [16]
+    uint16_t* order = (uint16_t*)(waves + 16);                // [CHUNK]
+    float* raw = (float*)(order + CHUNK);                     // [CHUNK * REC], 16-byte aligned
     const int t = blockIdx.x;
     const uint32_t lo = tile_start[t], hi = tile_start[t + 1];
     if (lo == hi) return;
     const int ta = t / tb, tbb = t % tb;
-    float acc[TPN_NPT][R];
+    const int c = threadIdx.x;                                // this thread's cell: (c / 32, c % 32)
+    float acc[4][RT];
 #pragma unroll
-    for (int j = 0; j < TPN_NPT; ++j)
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[j][r] = 0.0f;
-    for (uint32_t c0 = lo; c0 < hi; c0 += TPN_CHUNK) {
-        for (int i = threadIdx.x; i <= TPN_CELLS; i += 256) cnt[i] = 0;
+        for (int r = 0; r < RT; ++r) acc[k][r] = 0.0f;
+    for (uint32_t c0 = lo; c0 < hi; c0 += CHUNK) {
+        const uint32_t n = min((uint32_t)CHUNK, hi - c0);
+        cnt[c] = 0;
+        {   // the chunk's records, as they lie in memory
+            const float4* src = (const float4*)(rec + (size_t)c0 * REC);
+            for (uint32_t w = threadIdx.x; w < n * (REC / 4); w += TPN_THREADS) ((float4*)raw)[w] = src[w];
+        }
         __syncthreads();
-        // ---- this thread's points: cell, rank inside the cell, fractions, gradient row (kept in registers)
-        int cell[TPN_CHUNK / 256];
-        uint32_t rank[TPN_CHUNK / 256];
-        float fa[TPN_CHUNK / 256], fb[TPN_CHUNK / 256], g[TPN_CHUNK / 256][R];
+        // ---- this thread's points: cell and rank inside the cell; the coordinates become the bilinear fractions
+        int cell[PPT];
+        uint32_t rank[PPT];
 #pragma unroll
-        for (int k = 0; k < TPN_CHUNK / 256; ++k) {
-            const uint32_t q = c0 + threadIdx.x + 256u * k;
+        for (int k = 0; k < PPT; ++k) {
+            const uint32_t q = threadIdx.x + (uint32_t)TPN_THREADS * k;
             cell[k] = -1;
-            if (q < hi) {
-                const uint32_t i = perm[q];
+            if (q < n) {
                 int a0, b0;
-                tp_cell(coords[(size_t)i * cs + cx], coords[(size_t)i * cs + cy], A, B, a0, b0, fa[k], fb[k]);
-                cell[k] = (a0 - ta * TP_TILE + 1) * TP_NODES + (b0 - tbb * TP_TILE + 1);  // la, lb in [-1, 31]
-                rank[k] = atomicAdd(&cnt[cell[k]], 1u);
+                float fa, fb;
+                tp_cell(raw[q * REC], raw[q * REC + 1], A, B, a0, b0, fa, fb);
+                const int la = a0 - ta * TP_TILE, lb = b0 - tbb * TP_TILE;      // in [-1, 31]
+                if (la >= 0 && lb >= 0) {
+                    raw[q * REC] = fa;
+                    raw[q * REC + 1] = fb;
+                    cell[k] = la * TP_TILE + lb;
+                    rank[k] = atomicAdd(&cnt[cell[k]], 1u);
+                } else {
 #pragma unroll
-                for (int r = 0; r < R; ++r) g[k][r] = grad_out[(size_t)i * ld + r];
-            }
-        }
-        __syncthreads();
-        // ---- exclusive scan of the cell counts (1089 cells, 5 per thread)
-        {
-            uint32_t v[TPN_NPT], s = 0;
+                    for (int corner = 0; corner < 4; ++corner) {
+                        const int da = corner >> 1, db = corner & 1;
+                        const int a = a0 + da, b = b0 + db;
+                        if (a < 0 || a >= A || b < 0 || b >= B) continue;
+                        const float w = (da ? fa : 1.0f - fa) * (db ? fb : 1.0f - fb);
 #pragma unroll
-            for (int j = 0; j < TPN_NPT; ++j) {
-                const int c = threadIdx.x * TPN_NPT + j;
-                v[j] = c < TPN_CELLS ? cnt[c] : 0u;
-                s += v[j];
-            }
-            uint32_t tot;
-            uint32_t ex = tp_block_scan(s, waves, tot);
-#pragma unroll
-            for (int j = 0; j < TPN_NPT; ++j) {
-                const int c = threadIdx.x * TPN_NPT + j;
-                if (c < TPN_CELLS) start[c] = ex;
-                ex += v[j];
-            }
-            if (threadIdx.x == 0) start[TPN_CELLS] = tot;
-        }
-        __syncthreads();
-        // ---- stage in cell order
-#pragma unroll
-        for (int k = 0; k < TPN_CHUNK / 256; ++k)
-            if (cell[k] >= 0) {
-                const uint32_t slot = start[cell[k]] + rank[k];
-                pfa[slot] = fa[k];
-                pfb[slot] = fb[k];
-#pragma unroll
-                for (int r = 0; r < R; ++r) pg[slot][r] = g[k][r];
-            }
-        __syncthreads();
-        // ---- nodes: node (na, nb) is corner (1,1) of cell (na-1, nb-1), (1,0) of (na-1, nb), (0,1) of (na, nb-1),
-        // (0,0) of (na, nb); weights as torch: (da ? fa : 1 - fa) * (db ? fb : 1 - fb)
-#pragma unroll
-        for (int j = 0; j < TPN_NPT; ++j) {
-            const int nd = threadIdx.x + 256 * j;
-            if (nd >= TPN_CELLS) break;
-            const int na = nd / TP_NODES, nb = nd % TP_NODES;
-#pragma unroll
-            for (int corner = 0; corner < 4; ++corner) {
-                const int da = corner >> 1, db = corner & 1;          // which corner of the cell this node is
-                const int ca = na - da, cb = nb - db;                 // local cell (la, lb) = (ca, cb) in [-1, 31]
-                if (ca > TP_TILE - 1 || cb > TP_TILE - 1) continue;   // cell of the next tile
-                const int c = (ca + 1) * TP_NODES + (cb + 1);
-                for (uint32_t sidx = start[c], e = start[c + 1]; sidx < e; ++sidx) {
-                    const float wa = da ? pfa[sidx] : 1.0f - pfa[sidx], wb = db ? pfb[sidx] : 1.0f - pfb[sidx];
-                    const float w = wa * wb;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) acc[j][r] += pg[sidx][r] * w;
+                        for (int r = 0; r < RT; ++r) {
+                            float* dst = (r < R ? grad_plane0 + ((size_t)r * A + a) * B : grad_plane1 + ((size_t)(r - R) * A + a) * B) + b;
+                            unsafeAtomicAdd(dst, raw[q * REC + 2 + r] * w);
+                        }
+                    }
                 }
             }
         }
         __syncthreads();
+        // ---- exclusive scan of the cell counts
+        {
+            const uint32_t v = cnt[c];
+            uint32_t tot;
+            const uint32_t ex = tp_block_scan(v, waves, tot);
+            start[c] = ex;
+            if (threadIdx.x == 0) start[TPN_CELLS] = tot;
+        }
+        __syncthreads();
+        // ---- index list in cell order
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            if (cell[k] >= 0) order[start[cell[k]] + rank[k]] = (uint16_t)(threadIdx.x + TPN_THREADS * k);
+        __syncthreads();
+        // ---- the cell's points: weights as torch, (da ? fa : 1 - fa) * (db ? fb : 1 - fb) for corner (da, db)
+        for (uint32_t sidx = start[c], e = start[c + 1]; sidx < e; ++sidx) {
+            const float* pr = raw + (uint32_t)order[sidx] * REC;
+            const float fa = pr[0], fb = pr[1];
+            const float w[4] = {(1.0f - fa) * (1.0f - fb), (1.0f - fa) * fb, fa * (1.0f - fb), fa * fb};
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const float g = pr[2 + r];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k][r] += g * w[k];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- corner sums -> nodes (LDS image of the 33 x 33 nodes, RT channels)
+    for (int i = threadIdx.x; i < TPN_NODES * RT; i += TPN_THREADS) raw[i] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int da = k >> 1, db = k & 1;
+        const int nd = (c / TP_TILE + da) * TP_NODES + (c % TP_TILE + db);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) raw[nd * RT + r] += acc[k][r];
+        __syncthreads();
     }
     // ---- out: nodes outside the plane receive nothing (zeros padding)
-#pragma unroll
-    for (int j = 0; j < TPN_NPT; ++j) {
-        const int nd = threadIdx.x + 256 * j;
-        if (nd >= TPN_CELLS) break;
+    for (int nd = threadIdx.x; nd < TPN_NODES; nd += TPN_THREADS) {
         const int na = nd / TP_NODES, nb = nd % TP_NODES;
         const int a = ta * TP_TILE + na, b = tbb * TP_TILE + nb;
         if (a >= A || b >= B) continue;
         const bool shared = na == 0 || na == TP_TILE || nb == 0 || nb == TP_TILE;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float* dst = grad_plane + ((size_t)r * A + a) * B + b;
-            if (!shared) *dst = acc[j][r];
-            else if (acc[j][r] != 0.0f) unsafeAtomicAdd(dst, acc[j][r]);
+        for (int r = 0; r < RT; ++r) {
+            float* dst = (r < R ? grad_plane0 + ((size_t)r * A + a) * B : grad_plane1 + ((size_t)(r - R) * A + a) * B) + b;
+            const float v = raw[nd * RT + r];
+            if (!shared) *dst = v;
+            else if (v != 0.0f) unsafeAtomicAdd(dst, v);
         }
     }
 }
@@ -373,37 +523,136 @@ int launch_triplane_forward(int64_t V, const float* coords, int cs, const float*
     return 0;
 }
 
-size_t triplane_scratch_bytes(int64_t V, int A, int B) {
-    const size_t tiles = (size_t)((A + TP_TILE - 1) / TP_TILE) * ((B + TP_TILE - 1) / TP_TILE);
-    return align_up((3 * tiles + 2) * 4) + align_up((size_t)(V > 0 ? V : 1) * 4);
+static inline size_t tp_tiles(int A, int B) { return (size_t)((A + TP_TILE - 1) / TP_TILE) * ((B + TP_TILE - 1) / TP_TILE); }
+static inline size_t tp_proj_bytes(int64_t V, int A, int B, int channels) {
+    return align_up((3 * tp_tiles(A, B) + 2) * 4) + align_up((size_t)(V > 0 ? V : 1) * tp_rec(channels) * 4);
 }
 
-int launch_plane_sample_backward(int64_t V, const float* coords, int cs, int cx, int cy, int R, int A, int B,
-                                 const float* grad_out, int ld, float* grad_plane, void* scratch, hipStream_t st) {
-    if (R > TP_MAX_R) return 1;
-    const int ta = (A + TP_TILE - 1) / TP_TILE, tb = (B + TP_TILE - 1) / TP_TILE, tiles = ta * tb;
-    if ((size_t)tiles * 4 > 64 * 1024) return 2;  // LDS histogram of the tile counts
-    uint32_t* tile_count = (uint32_t*)scratch;
-    uint32_t* tile_start = tile_count + tiles;
-    uint32_t* cursor = tile_start + tiles + 1;
-    uint32_t* perm = (uint32_t*)((char*)scratch + align_up((3 * (size_t)tiles + 2) * 4));
-    (void)hipMemsetAsync(tile_count, 0, (size_t)tiles * 4, st);
-    (void)hipMemsetAsync(grad_plane, 0, (size_t)R * A * B * 4, st);
-    if (V <= 0) return 0;
+size_t triplane_scratch_bytes(int64_t V, int A, int B, int channels) { return tp_proj_bytes(V, A, B, channels); }
+
+size_t triplane_backward_scratch_bytes(int64_t V, int X, int Y, int Z, int channels) {
+    return tp_proj_bytes(V, X, Y, channels) + tp_proj_bytes(V, X, Z, channels) + tp_proj_bytes(V, Y, Z, channels);
+}
+
+static char* tp_carve(TpProj& pj, int64_t V, int channels, char* scratch) {
+    pj.tb = (pj.B + TP_TILE - 1) / TP_TILE;
+    pj.tiles = (int)tp_tiles(pj.A, pj.B);
+    pj.count = (uint32_t*)scratch;
+    pj.start = pj.count + pj.tiles;
+    pj.cursor = pj.start + pj.tiles + 1;
+    pj.rec = (float*)(scratch + align_up((3 * (size_t)pj.tiles + 2) * 4));
+    return scratch + tp_proj_bytes(V, pj.A, pj.B, channels);
+}
+
+constexpr int TP_HIST_MAX_TILES = 16384;   // 64 KB of LDS histogram per workgroup, over the projections of a pass
+
+template <int R, int NP>
+static void tp_backward_launch(int64_t V, const float* coords, int cs, const float* grad, int ld, const TpProjSet& ps,
+                               float* const* gp0, float* const* gp1, hipStream_t st) {
+    int total = 0;
+    for (int q = 0; q < ps.n; ++q) total += ps.p[q].tiles;
     const unsigned nwg = (unsigned)((V + TP_PER_WG - 1) / TP_PER_WG);
-    tp_count_kernel<<<nwg, TP_THREADS, (size_t)tiles * 4, st>>>(V, coords, cs, cx, cy, A, B, tb, tiles, tile_count);
-    tp_scan_kernel<<<1, 1024, 0, st>>>(tiles, tile_count, tile_start, cursor);
-    tp_scatter_kernel<<<nwg, TP_THREADS, (size_t)tiles * 4, st>>>(V, coords, cs, cx, cy, A, B, tb, tiles, tile_start, cursor, perm);
-#define SCR_TP_BWD(RR)                                                                                         \
-    case RR:                                                                                                   \
-        tp_node_gather_kernel<RR><<<tiles, 256, 0, st>>>(coords, cs, cx, cy, A, B, tb, tile_start, perm, grad_out, ld, \
-                                                         grad_plane);                                          \
-        break;
-    switch (R) {
-        SCR_TP_BWD(1) SCR_TP_BWD(2) SCR_TP_BWD(3) SCR_TP_BWD(4) SCR_TP_BWD(5) SCR_TP_BWD(6) SCR_TP_BWD(7) SCR_TP_BWD(8)
+    tp_count_kernel<<<nwg, TP_THREADS, (size_t)total * 4, st>>>(V, coords, cs, ps);
+    tp_scan_kernel<<<ps.n, 1024, 0, st>>>(ps);
+    // the grid's gradient blocks side by side in projection order, rows and base 16-byte compatible: wide row loads
+    bool fast = ps.n == 3 && ld % 4 == 0 && ((uintptr_t)grad & 15) == 0;
+    for (int q = 0; q < ps.n && fast; ++q)
+        fast = ps.p[q].col0 == ps.p[0].col0 + q * R * NP && (NP == 1 || ps.p[q].col1 == ps.p[q].col0 + R);
+    if (fast)
+        tp_scatter_kernel<R, NP, true><<<nwg, TP_THREADS, (size_t)total * 4, st>>>(V, coords, cs, grad, ld, ps.p[0].col0, ps);
+    else
+        tp_scatter_kernel<R, NP, false><<<nwg, TP_THREADS, (size_t)total * 4, st>>>(V, coords, cs, grad, ld, 0, ps);
+    // more than the default 64 KB of dynamic LDS (gfx950 has 160 KB per CU): the attribute is per device
+    static bool big_lds[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !big_lds[dev]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)tp_cell_gather_kernel<R, NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)tpn_lds_bytes<R * NP>());
+        if (e == hipSuccess && dev >= 0 && dev < 64) big_lds[dev] = true;
+        (void)hipGetLastError();      // a refused attribute shows up as a launch error
     }
+    for (int q = 0; q < ps.n; ++q)
+        tp_cell_gather_kernel<R, NP><<<ps.p[q].tiles, TPN_THREADS, tpn_lds_bytes<R * NP>(), st>>>(
+            ps.p[q].A, ps.p[q].B, ps.p[q].tb, ps.p[q].start, ps.p[q].rec, gp0[q], gp1[q]);
+}
+
+// nproj projections (1, or the 3 of a grid) x `planes` (1 or 2) planes each; cols0/cols1: first gradient column of the
+// first / second plane of every projection; pairs[q] = (cx, cy) of projection q; sizes[q] = (A, B)
+static int tp_backward(int64_t V, const float* coords, int cs, int R, int planes, int nproj, const int (*pairs)[2],
+                       const int (*sizes)[2], const float* grad, int ld, const int* cols0, const int* cols1,
+                       float* const* gp0, float* const* gp1, void* scratch, hipStream_t st) {
+    if (R > TP_MAX_R || R < 1 || planes < 1 || planes > 2) return 1;
+    if (planes == 2 && R > 5) {          // 4 cells x 4 corners x 2R sums per thread would not fit the registers
+        // one plane after the other; both passes use the same scratch (stream order serialises them)
+        const int rc = tp_backward(V, coords, cs, R, 1, nproj, pairs, sizes, grad, ld, cols0, cols0, gp0, gp0, scratch, st);
+        return rc ? rc : tp_backward(V, coords, cs, R, 1, nproj, pairs, sizes, grad, ld, cols1, cols1, gp1, gp1, scratch, st);
+    }
+    TpProjSet ps;
+    ps.n = nproj;
+    char* sc = (char*)scratch;
+    int total = 0;
+    for (int q = 0; q < nproj; ++q) {
+        TpProj& pj = ps.p[q];
+        pj.cx = pairs[q][0];
+        pj.cy = pairs[q][1];
+        pj.A = sizes[q][0];
+        pj.B = sizes[q][1];
+        pj.col0 = cols0[q];
+        pj.col1 = cols1[q];
+        sc = tp_carve(pj, V, R * planes, sc);
+        if (pj.tiles > TP_HIST_MAX_TILES) return 2;
+        total += pj.tiles;
+        (void)hipMemsetAsync(pj.count, 0, (size_t)pj.tiles * 4, st);
+        (void)hipMemsetAsync(gp0[q], 0, (size_t)R * pj.A * pj.B * 4, st);
+        if (planes == 2) (void)hipMemsetAsync(gp1[q], 0, (size_t)R * pj.A * pj.B * 4, st);
+    }
+    for (int q = nproj; q < 3; ++q) ps.p[q] = ps.p[0];
+    if (V <= 0) return 0;
+    if (total > TP_HIST_MAX_TILES) {     // the three histograms do not fit one workgroup's LDS: one projection per pass
+        for (int q = 0; q < nproj; ++q) {
+            TpProjSet one;
+            one.n = 1;
+            one.p[0] = one.p[1] = one.p[2] = ps.p[q];
+#define SCR_TP_ONE(RR)                                                                                   \
+    case RR:                                                                                             \
+        if (planes == 2) tp_backward_launch<(RR <= 5 ? RR : 1), 2>(V, coords, cs, grad, ld, one, gp0 + q, gp1 + q, st); \
+        else tp_backward_launch<RR, 1>(V, coords, cs, grad, ld, one, gp0 + q, gp1 + q, st);              \
+        break;
+            switch (R) { SCR_TP_ONE(1) SCR_TP_ONE(2) SCR_TP_ONE(3) SCR_TP_ONE(4) SCR_TP_ONE(5) SCR_TP_ONE(6) SCR_TP_ONE(7) SCR_TP_ONE(8) }
+#undef SCR_TP_ONE
+        }
+        return 0;
+    }
+#define SCR_TP_BWD(RR)                                                                                   \
+    case RR:                                                                                             \
+        if (planes == 2) tp_backward_launch<(RR <= 5 ? RR : 1), 2>(V, coords, cs, grad, ld, ps, gp0, gp1, st); \
+        else tp_backward_launch<RR, 1>(V, coords, cs, grad, ld, ps, gp0, gp1, st);                       \
+        break;
+    switch (R) { SCR_TP_BWD(1) SCR_TP_BWD(2) SCR_TP_BWD(3) SCR_TP_BWD(4) SCR_TP_BWD(5) SCR_TP_BWD(6) SCR_TP_BWD(7) SCR_TP_BWD(8) }
 #undef SCR_TP_BWD
     return 0;
+}
+
+int launch_plane_sample_backward(int64_t V, const float* coords, int cs, int cx, int cy, int R, int A, int B, int planes,
+                                 const float* grad_out0, const float* grad_out1, int ld, float* grad_plane0,
+                                 float* grad_plane1, void* scratch, hipStream_t st) {
+    const int pairs[1][2] = {{cx, cy}}, sizes[1][2] = {{A, B}};
+    // the second block as a column offset from the first (the two blocks lie in the same gradient matrix)
+    const int cols0[1] = {0}, cols1[1] = {planes == 2 ? (int)(grad_out1 - grad_out0) : 0};
+    float* gp0[1] = {grad_plane0};
+    float* gp1[1] = {planes == 2 ? grad_plane1 : grad_plane0};
+    return tp_backward(V, coords, cs, R, planes, 1, pairs, sizes, grad_out0, ld, cols0, cols1, gp0, gp1, scratch, st);
+}
+
+// the three projections of a grid (coordinate pairs of scene/grids.py:148-150) in one pass over the points
+int launch_triplane_backward(int64_t V, const float* coords, int cs, int R, int X, int Y, int Z, int planes,
+                             const float* grad_out, int ld, const int* cols /*[3 * planes]*/, float* const* grad_planes,
+                             void* scratch, hipStream_t st) {
+    const int pairs[3][2] = {{1, 0}, {2, 0}, {2, 1}}, sizes[3][2] = {{X, Y}, {X, Z}, {Y, Z}};
+    const int* cols1 = planes == 2 ? cols + 3 : cols;
+    float* const* gp1 = planes == 2 ? grad_planes + 3 : grad_planes;
+    return tp_backward(V, coords, cs, R, planes, 3, pairs, sizes, grad_out, ld, cols, cols1, grad_planes, gp1, scratch, st);
 }
 
 }  // namespace scr

@@ -218,29 +218,35 @@ class PlaneGrid(nn.Module):                   # scene/grids.py:102-201
     def get_dim(self):
         return self.channels * 2 if self.TAflag else self.channels
 
+    def fused_ok(self, xyz):
+        return self.xy_plane.is_cuda and self.channels // 3 <= 8 and not xyz.requires_grad    # csrc/triplane.hip
+
+    def sample_spec(self, xyz, col0=0):
+        """(ind [V,3], planes, first output column of every plane) for triplane.multi_triplane_sample: what
+        compute_planes_feat samples and where the reference's torch.cat puts it (scene/grids.py:165,181)."""
+        R = self.channels // 3
+        ind3 = (xyz.reshape(-1, 3) - self.xyz_min) / (self.xyz_max - self.xyz_min) * 2 - 1
+        if not self.TAflag:
+            return ind3, (self.xy_plane, self.xz_plane, self.yz_plane), tuple(col0 + R * j for j in range(3))
+        tri = self.TA(torch.cat((self.xy_plane, self.xz_plane, self.yz_plane), dim=1))   # every call (:166-168)
+        xyA, xzA, yzA = torch.chunk(tri, 3, dim=1)
+        # column order of :181: xy, xyA, xz, xzA, yz, yzA
+        return ind3, (self.xy_plane, self.xz_plane, self.yz_plane, xyA, xzA, yzA), \
+            tuple(col0 + c for c in (0, 2 * R, 4 * R, R, 3 * R, 5 * R))
+
     def forward(self, xyz, Q=0):
         shape = xyz.shape[:-1]
+        if self.fused_ok(xyz):
+            from .triplane import multi_triplane_sample
+            feat = multi_triplane_sample([self.sample_spec(xyz)])
+            # training-time uniform noise (:159-164) reaches plain grids only: for the attention grid the reference
+            # builds the noised concatenation and then overwrites it at :174-181 with the un-noised samples
+            if Q != 0 and not self.TAflag:
+                feat = feat + torch.empty_like(feat).uniform_(-0.5, 0.5) * Q
+            return feat.reshape(*shape, self.get_dim())
         xyz = xyz.reshape(1, 1, -1, 3)
         ind = (xyz - self.xyz_min) / (self.xyz_max - self.xyz_min) * 2 - 1
         ind = torch.cat([ind, torch.zeros_like(ind[..., [0]])], dim=-1)
-        R = self.channels // 3
-        fused = self.xy_plane.is_cuda and R <= 8 and not ind.requires_grad    # csrc/triplane.hip
-        if fused:
-            from .triplane import triplane_sample
-            ind3 = ind[0, 0, :, :3]
-            if not self.TAflag:
-                feat = triplane_sample(ind3, (self.xy_plane, self.xz_plane, self.yz_plane))
-                if Q != 0:                                          # training-time uniform noise (:159-164)
-                    feat = feat + torch.empty_like(feat).uniform_(-0.5, 0.5) * Q
-                return feat.reshape(*shape, self.channels)
-            tri = self.TA(torch.cat((self.xy_plane, self.xz_plane, self.yz_plane), dim=1))   # every call (:166-168)
-            xyA, xzA, yzA = torch.chunk(tri, 3, dim=1)
-            # column order of :181: xy, xyA, xz, xzA, yz, yzA
-            feat = triplane_sample(ind3, (self.xy_plane, self.xz_plane, self.yz_plane, xyA, xzA, yzA),
-                                   cols=(0, 2 * R, 4 * R, R, 3 * R, 5 * R))
-            # no noise reaches the attention grid's output whatever Q is: the reference builds the noised
-            # concatenation at :159-164 and then overwrites it at :174-181 with the un-noised samples
-            return feat.reshape(*shape, self.channels * 2)
         xy, xz, yz = _sample(self.xy_plane, ind, [1, 0]), _sample(self.xz_plane, ind, [2, 0]), _sample(self.yz_plane, ind, [2, 1])
         if not self.TAflag:
             if Q != 0:                                          # training-time uniform noise (:159-164), plain grids only
@@ -277,7 +283,23 @@ class FeaturePlanes(nn.Module):               # scene/gaussian_model.py:97-169
         L = self.activate_level + 1
         if FUSE_NORM_LINEAR and all(m[0].training for m in list(self.models[:L]) + list(self.CTX_models[:L])):
             # sum_i cat(Linear(BN(feat_i)), Linear(BN(g_fea))) is linear in the normalised inputs: two GEMMs
-            feats = torch.cat([self.k0s[i](x, Q) for i in range(L)], dim=1) if L > 1 else self.k0s[0](x, Q)
+            if x.dim() == 2 and all(self.k0s[i].fused_ok(x) for i in range(L)):
+                # every active grid samples straight into its columns of one matrix (no torch.cat of the grids' outputs)
+                from .triplane import multi_triplane_sample
+                specs, col = [], 0
+                for i in range(L):
+                    specs.append(self.k0s[i].sample_spec(x, col))
+                    col += self.k0s[i].get_dim()
+                feats = multi_triplane_sample(specs)
+                if Q != 0:                       # uniform noise on the plain grids' blocks only (scene/grids.py:159-181)
+                    col = 0
+                    for i in range(L):
+                        d = self.k0s[i].get_dim()
+                        if not self.k0s[i].TAflag:
+                            feats[:, col:col + d] += torch.empty(feats.shape[0], d, device=feats.device).uniform_(-0.5, 0.5) * Q
+                        col += d
+            else:
+                feats = torch.cat([self.k0s[i](x, Q) for i in range(L)], dim=1) if L > 1 else self.k0s[0](x, Q)
             a = _norm_linear(feats, [self.models[i][0] for i in range(L)], [self.models[i][1] for i in range(L)])
             b = _norm_linear(g_fea, [self.CTX_models[i][0] for i in range(L)], [self.CTX_models[i][1] for i in range(L)])
             return (a, b) if parts else torch.cat((a, b), dim=1)

@@ -19,48 +19,90 @@ _PAIRS = ((1, 0), (2, 0), (2, 1))
 CHANNEL_LAST_MIN_POINTS = 262144
 
 
+def _forward_into(out, ind, cols, planes):
+    """Samples the plane triples of one grid at ind [V,3] into the columns cols[j].. of out [V, ld]."""
+    V, R = ind.shape[0], planes[0].shape[1]
+    # random gathers are bound by the number of cache lines requested: for many points the planes are
+    # first copied to channel-last [A,B,R] (a streaming pass), which cuts the lines per sampled row from R to 1-2
+    cl = 1 if V >= CHANNEL_LAST_MIN_POINTS else 0
+    for t in range(0, len(planes), 3):
+        xy, xz, yz = planes[t:t + 3]
+        X, Y, Z = xy.shape[2], xy.shape[3], xz.shape[3]
+        assert xz.shape[2] == X and yz.shape[2] == Y and yz.shape[3] == Z, "plane shapes do not form a tri-plane"
+        xy, xz, yz = ((p.permute(0, 2, 3, 1) if cl else p).contiguous() for p in (xy, xz, yz))
+        _C.check(_C.lib.scr_triplane_forward(V, ind.data_ptr(), ind.stride(0), xy.data_ptr(), xz.data_ptr(), yz.data_ptr(),
+                                             R, X, Y, Z, cl, out.data_ptr(), out.stride(0), cols[t], cols[t + 1], cols[t + 2],
+                                             _stream()))
+
+
+def _backward_from(g, ind, cols, shapes):
+    """Gradients of the planes of one grid (3 or 6 planes; planes j and j + 3 -- plain / attended,
+    scene/grids.py:174-181 -- are sampled at the same positions): the three projections x (1 or 2) planes go
+    through ONE pass over the points.  g [V, ld] (unit column stride) is read in place."""
+    import ctypes as C
+    V, n = ind.shape[0], len(shapes)
+    R, X, Y, Z = shapes[0][1], shapes[0][2], shapes[0][3], shapes[1][3]
+    gp = [torch.empty(s, dtype=torch.float32, device=g.device) for s in shapes]
+    scratch = torch.empty(_C.lib.scr_triplane_backward_scratch_bytes(V, X, Y, Z, R * (n // 3)), dtype=torch.uint8,
+                          device=g.device)
+    c_cols = (C.c_int32 * n)(*cols)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in gp])
+    _C.check(_C.lib.scr_triplane_backward(V, ind.data_ptr(), ind.stride(0), R, X, Y, Z, n // 3, g.data_ptr(), g.stride(0),
+                                          c_cols, ptrs, scratch.data_ptr(), _stream()))
+    return gp
+
+
 class _TriPlaneSample(torch.autograd.Function):
+    """Several grids at once: meta = ((n_planes, cols), ...) per grid, tensors = ind_0, planes of grid 0..., ind_1, ...
+    The samples of all grids land in ONE matrix (the reference concatenates the grids' outputs,
+    scene/gaussian_model.py:160-166) whose gradient is read in place by every grid's backward."""
+
     @staticmethod
-    def forward(ctx, ind, cols, *planes):
-        # ind [V,3] normalised coordinates; planes = k triples (xy [1,R,X,Y], xz [1,R,X,Z], yz [1,R,Y,Z]);
-        # cols[j] = first output column of plane j
-        V, R = ind.shape[0], planes[0].shape[1]
-        ld = R * len(planes)
-        out = torch.empty(V, ld, dtype=torch.float32, device=ind.device)
-        # random gathers are bound by the number of cache lines requested: for many points the planes are
-        # first copied to channel-last [A,B,R] (a streaming pass), which cuts the lines per sampled row from R to 1-2
-        cl = 1 if V >= CHANNEL_LAST_MIN_POINTS else 0
-        for t in range(0, len(planes), 3):
-            xy, xz, yz = planes[t:t + 3]
-            X, Y, Z = xy.shape[2], xy.shape[3], xz.shape[3]
-            assert xz.shape[2] == X and yz.shape[2] == Y and yz.shape[3] == Z, "plane shapes do not form a tri-plane"
-            xy, xz, yz = ((p.permute(0, 2, 3, 1) if cl else p).contiguous() for p in (xy, xz, yz))
-            _C.check(_C.lib.scr_triplane_forward(V, ind.data_ptr(), ind.stride(0), xy.data_ptr(), xz.data_ptr(), yz.data_ptr(),
-                                                 R, X, Y, Z, cl, out.data_ptr(), ld, cols[t], cols[t + 1], cols[t + 2],
-                                                 _stream()))
-        ctx.save_for_backward(ind)
-        ctx.cols, ctx.shapes = cols, [tuple(p.shape) for p in planes]
+    def forward(ctx, meta, width, *tensors):
+        k, inds, shapes = 0, [], []
+        out = None
+        for n, cols in meta:
+            ind, planes = tensors[k], tensors[k + 1:k + 1 + n]
+            if out is None:
+                out = torch.empty(ind.shape[0], width, dtype=torch.float32, device=ind.device)
+            _forward_into(out, ind, cols, planes)
+            inds.append(ind)
+            shapes.append([tuple(p.shape) for p in planes])
+            k += 1 + n
+        ctx.save_for_backward(*inds)
+        ctx.meta, ctx.shapes = meta, shapes
         return out
 
     @staticmethod
     def backward(ctx, g):
-        (ind,) = ctx.saved_tensors
-        V = ind.shape[0]
-        g = g.contiguous().float()
-        grads = []
-        for j, shape in enumerate(ctx.shapes):
-            if not ctx.needs_input_grad[2 + j]:
-                grads.append(None)
-                continue
-            _, R, A, B = shape
-            cx, cy = _PAIRS[j % 3]
-            gp = torch.empty(shape, dtype=torch.float32, device=g.device)
-            scratch = torch.empty(_C.lib.scr_plane_sample_scratch_bytes(V, A, B), dtype=torch.uint8, device=g.device)
-            _C.check(_C.lib.scr_plane_sample_backward(V, ind.data_ptr(), ind.stride(0), cx, cy, R, A, B,
-                                                      g.data_ptr() + 4 * ctx.cols[j], g.stride(0), gp.data_ptr(),
-                                                      scratch.data_ptr(), _stream()))
-            grads.append(gp)
+        if g.dtype != torch.float32 or g.stride(1) != 1:     # a column block of a wider matrix is read in place
+            g = g.contiguous().float()
+        grads, k = [], 0
+        for (n, cols), ind, shapes in zip(ctx.meta, ctx.saved_tensors, ctx.shapes):
+            need = ctx.needs_input_grad[2 + k + 1:2 + k + 1 + n]
+            gp = _backward_from(g, ind, cols, shapes) if any(need) else [None] * n
+            grads.append(None)
+            grads.extend(t if nd else None for t, nd in zip(gp, need))
+            k += 1 + n
         return (None, None, *grads)
+
+
+def _prep_ind(ind):
+    ind = ind.detach().float()
+    return ind if ind.stride(1) == 1 else ind.contiguous()
+
+
+def multi_triplane_sample(grids):
+    """grids: [(ind [V,3], planes (3 or 6 tensors), cols (first output column of every plane))...]; returns the
+    [V, width] matrix with every grid's samples in its columns (width = the largest column end)."""
+    meta, flat, width = [], [], 0
+    for ind, planes, cols in grids:
+        R = planes[0].shape[1]
+        meta.append((len(planes), tuple(int(c) for c in cols)))
+        flat.append(_prep_ind(ind))
+        flat.extend(planes)
+        width = max(width, max(cols) + R)
+    return _TriPlaneSample.apply(tuple(meta), width, *flat)
 
 
 def triplane_sample(ind, planes, cols=None):
@@ -69,10 +111,7 @@ def triplane_sample(ind, planes, cols=None):
     R = planes[0].shape[1]
     if cols is None:
         cols = tuple(R * j for j in range(len(planes)))
-    ind = ind.detach().float()
-    if ind.stride(1) != 1:
-        ind = ind.contiguous()
-    return _TriPlaneSample.apply(ind, tuple(cols), *planes)
+    return multi_triplane_sample([(ind, tuple(planes), tuple(cols))])
 
 
 def plane_sample(plane, grid):
@@ -97,7 +136,8 @@ class _PlaneSample(torch.autograd.Function):
         V = grid.shape[0]
         g = g.contiguous().float()
         grad_plane = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
-        scratch = torch.empty(_C.lib.scr_plane_sample_scratch_bytes(V, A, B), dtype=torch.uint8, device=g.device)
-        _C.check(_C.lib.scr_plane_sample_backward(V, grid.data_ptr(), 2, 0, 1, R, A, B, g.data_ptr(), g.stride(0),
-                                                  grad_plane.data_ptr(), scratch.data_ptr(), _stream()))
+        scratch = torch.empty(_C.lib.scr_plane_sample_scratch_bytes(V, A, B, R), dtype=torch.uint8, device=g.device)
+        _C.check(_C.lib.scr_plane_sample_backward(V, grid.data_ptr(), 2, 0, 1, R, A, B, 1, g.data_ptr(), g.data_ptr(),
+                                                  g.stride(0), grad_plane.data_ptr(), grad_plane.data_ptr(),
+                                                  scratch.data_ptr(), _stream()))
         return grad_plane, None

@@ -21,6 +21,23 @@ def main(cfg="cfg2", anchors=0, steps=3):
     N, _, seed = ANCHOR_CONFIGS[cfg]
     N = anchors or N
     pc = synthetic_anchor_model(N, seed, dev)
+    import os
+    if os.environ.get("SPLATCO_EXP_MORTON"):
+        a = pc._anchor.data
+        q = ((a + 2) / 4 * 1024).long().clamp(0, 1023)
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            v = (v | (v << 2)) & 0x09249249
+            return v
+        code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        if os.environ["SPLATCO_EXP_MORTON"] == "lex":
+            q = ((a + 2) / 4 * (1 << 20)).long().clamp(0, (1 << 20) - 1)
+            code = (q[:, 0] << 40) | (q[:, 1] << 20) | q[:, 2]
+        perm = torch.argsort(code)
+        for nme in ("_anchor", "_offset", "_anchor_feat", "_scaling", "_rotation", "_opacity"):
+            getattr(pc, nme).data = getattr(pc, nme).data[perm].contiguous()
     pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
     bg = torch.ones(3, device=dev)
     views = [v.to(dev) for v in synthetic_views(1)]
