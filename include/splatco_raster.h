@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 9
+#define SCR_ABI_VERSION 10
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -199,16 +199,33 @@ int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, con
 /* ---- the head of generate_neural_gaussians (gaussian_renderer/__init__.py:23-31) for the reference's sizes (feat 32, 10 offsets):
  * the four visible-anchor gathers, exp(_scaling) and the [V,71] concatenation in one pass.  visible_index[V] int64 = the
  * visible anchors in order; outputs feat[V,32], anchor[V,3], offsets[V,30], grid_scaling[V,6] = exp(scaling) and
- * g_fea[V,71] = cat of the four.  The backward takes inverse_index[N] int64 (row of every anchor, -1 = not visible) and
+ * g_fea[V,71] = cat of the four, with row stride g_fea_ld = 71 (packed) or 72 (16-byte aligned rows, the pad column
+ * written as 0 / ignored on the way back: what the fused BatchNorm-Linear wants).  The backward takes inverse_index[N] int64 (row of every anchor, -1 = not visible) and
  * the upstream gradients of the five outputs (any may be NULL) and overwrites EVERY element of the four parameter
  * gradients [N,32] / [N,3] / [N,30] / [N,6] (zeros for invisible anchors; d exp applied): no atomics, no memset. */
 int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anchor_feat, const float* anchor,
                       const float* offset, const float* scaling, float* feat_out, float* anchor_out, float* offsets_out,
-                      float* grid_scaling_out, float* g_fea_out, void* stream);
+                      float* grid_scaling_out, float* g_fea_out, int32_t g_fea_ld, void* stream);
 int scr_anchor_gather_backward(int64_t N, const int64_t* inverse_index, const float* grid_scaling, const float* d_feat,
                                const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
-                               const float* d_g_fea, float* g_anchor_feat, float* g_anchor, float* g_offset,
-                               float* g_scaling, void* stream);
+                               const float* d_g_fea, int32_t g_fea_ld, float* g_anchor_feat, float* g_anchor,
+                               float* g_offset, float* g_scaling, void* stream);
+
+/* ---- BatchNorm1d in training mode folded into the Linear(d, 32) that follows it: the two nn.Sequential(BatchNorm1d,
+ * Linear) stacks of FeaturePlanes (scene/gaussian_model.py:118-124,160-166) for all active levels at once.  The caller
+ * folds the BatchNorm affine parameters and the levels into G [32,d] and c [32] (scene_model._norm_linear):
+ *     y = xhat G^T + c,  xhat = (x - mean) * inv,  inv = 1 / sqrt(var + eps),  mean / var (biased) over the V rows.
+ * forward writes y [V,32] and mean, var, inv [d] (the caller updates the running statistics from mean / var).
+ * backward, given dy [V,32] (row stride lddy, 16-byte aligned), writes dG [32,d], dc [32] and, unless dx is NULL,
+ * dx [V,d] (row stride lddx) including both BatchNorm reduction terms.  d <= 80; x rows may have any stride (16-byte
+ * aligned rows take the wide-load path).  Sums over the rows are formed per workgroup and combined in a fixed order:
+ * bit-reproducible.  Scratch from scr_norm_linear_scratch_bytes(V), the same block for forward and backward. */
+size_t scr_norm_linear_scratch_bytes(int64_t V);
+int scr_norm_linear_forward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* G, const float* c, float eps,
+                            float* y, float* mean, float* var, float* inv, void* scratch, void* stream);
+int scr_norm_linear_backward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* G,
+                             const float* mean, const float* inv, float* dx, int32_t lddx, float* dG, float* dc,
+                             void* scratch, void* stream);
 
 /* ---- the three MLP heads of generate_neural_gaussians (gaussian_renderer/__init__.py:58-93 with the default flags,
  * scene/gaussian_model.py:315-337) as one fp32-MFMA kernel per direction, for the reference's layer sizes
@@ -277,7 +294,7 @@ enum {
     SCR_PROF_TILE_SORT = 4, SCR_PROF_BLEND_FORWARD = 5, SCR_PROF_BLEND_BACKWARD = 6,
     SCR_PROF_PREPROCESS_BACKWARD = 7, SCR_PROF_EXPAND = 8, SCR_PROF_EXPAND_BACKWARD = 9, SCR_PROF_PLANE_BACKWARD = 10,
     SCR_PROF_L1_SSIM = 11, SCR_PROF_L1_SSIM_BACKWARD = 12, SCR_PROF_TRIPLANE_FORWARD = 13, SCR_PROF_MLP_HEADS = 14,
-    SCR_PROF_MLP_HEADS_BACKWARD = 15, SCR_PROF_COUNT = 16
+    SCR_PROF_MLP_HEADS_BACKWARD = 15, SCR_PROF_NORM_LINEAR = 16, SCR_PROF_NORM_LINEAR_BACKWARD = 17, SCR_PROF_COUNT = 18
 };
 int scr_profile_enable(int mask);
 int scr_profile_read(double* total_ms, int64_t* launches);

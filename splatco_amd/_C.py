@@ -20,9 +20,10 @@ SYMBOLS = [
     "scr_l1_ssim_scratch_bytes", "scr_l1_ssim_forward", "scr_l1_ssim_backward",
     "scr_statis_compute", "scr_statis_apply", "scr_copy_probe",
     "scr_knn", "scr_knn_curvature", "scr_anchor_gather", "scr_anchor_gather_backward", "scr_mlp_heads_hidden_bytes", "scr_mlp_heads_partial_bytes", "scr_mlp_heads_forward", "scr_mlp_heads_backward",
+    "scr_norm_linear_scratch_bytes", "scr_norm_linear_forward", "scr_norm_linear_backward",
 ]
-PROF_COUNT = 16
-ABI_VERSION = 9
+PROF_COUNT = 18
+ABI_VERSION = 10
 
 DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
 
@@ -85,6 +86,12 @@ def _load():
     lib.scr_triplane_backward_scratch_bytes.restype = C.c_size_t
     lib.scr_triplane_backward.argtypes = [i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp]
     lib.scr_triplane_backward.restype = C.c_int
+    lib.scr_norm_linear_scratch_bytes.argtypes = [C.c_int64]
+    lib.scr_norm_linear_scratch_bytes.restype = C.c_size_t
+    lib.scr_norm_linear_forward.argtypes = [i64, i32, vp, i32, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp]
+    lib.scr_norm_linear_forward.restype = C.c_int
+    lib.scr_norm_linear_backward.argtypes = [i64, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    lib.scr_norm_linear_backward.restype = C.c_int
     lib.scr_plane_sample_backward.restype = C.c_int
     lib.scr_l1_ssim_scratch_bytes.argtypes = [i32, i32, i32, i32]
     lib.scr_l1_ssim_scratch_bytes.restype = C.c_size_t
@@ -99,8 +106,8 @@ def _load():
     lib.scr_mlp_heads_forward.argtypes = [i64] + [vp] * 18
     lib.scr_mlp_heads_backward.argtypes = [i64] + [vp] * 29
     lib.scr_mlp_heads_forward.restype = lib.scr_mlp_heads_backward.restype = C.c_int
-    lib.scr_anchor_gather.argtypes = [i64] + [vp] * 11
-    lib.scr_anchor_gather_backward.argtypes = [i64] + [vp] * 12
+    lib.scr_anchor_gather.argtypes = [i64] + [vp] * 10 + [i32, vp]
+    lib.scr_anchor_gather_backward.argtypes = [i64] + [vp] * 7 + [i32] + [vp] * 5
     lib.scr_anchor_gather.restype = lib.scr_anchor_gather_backward.restype = C.c_int
     lib.scr_knn.argtypes = [i64, i32, C.POINTER(C.c_float), vp, vp, vp, vp, vp]
     lib.scr_knn_curvature.argtypes = [i64, i32, vp, vp, vp, vp]

@@ -23,12 +23,13 @@ class _AnchorGather(torch.autograd.Function):
         idx = idx.contiguous().long()
         V, N, dev = idx.numel(), anchor.shape[0], anchor.device
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        feat, anc, off, gs, g_fea = new(V, 32), new(V, 3), new(V, 10, 3), new(V, 6), new(V, 71)
+        # g_fea rows padded to 72 floats: 16-byte aligned rows for the fused BatchNorm-Linear (csrc/normlinear.hip)
+        feat, anc, off, gs, g_fea = new(V, 32), new(V, 3), new(V, 10, 3), new(V, 6), new(V, 72)[:, :71]
         if V:
             with torch.cuda.device(dev):
                 _C.check(_C.lib.scr_anchor_gather(V, idx.data_ptr(), anchor_feat.data_ptr(), anchor.data_ptr(),
                                                   offset.data_ptr(), scaling.data_ptr(), feat.data_ptr(), anc.data_ptr(),
-                                                  off.data_ptr(), gs.data_ptr(), g_fea.data_ptr(), _stream()))
+                                                  off.data_ptr(), gs.data_ptr(), g_fea.data_ptr(), 72, _stream()))
         ctx.save_for_backward(idx, gs)
         ctx.N = N
         return feat, anc, off, gs, g_fea
@@ -40,14 +41,19 @@ class _AnchorGather(torch.autograd.Function):
         inv = torch.full((N,), -1, dtype=torch.long, device=dev)
         inv[idx] = torch.arange(V, device=dev)
         p = lambda t: None if t is None else t.contiguous().float()
-        d_feat, d_anc, d_off, d_gs, d_g_fea = p(d_feat), p(d_anc), p(d_off), p(d_gs), p(d_g_fea)
+        ldg = 71
+        if d_g_fea is not None and d_g_fea.dtype == torch.float32 and d_g_fea.stride() == (72, 1):
+            ldg = 72                                # rows as the fused BatchNorm-Linear backward leaves them: read in place
+        else:
+            d_g_fea = p(d_g_fea)
+        d_feat, d_anc, d_off, d_gs = p(d_feat), p(d_anc), p(d_off), p(d_gs)
         ptr = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         g_feat, g_anchor, g_offset, g_scaling = new(N, 32), new(N, 3), new(N, 10, 3), new(N, 6)
         if N:
             with torch.cuda.device(dev):
                 _C.check(_C.lib.scr_anchor_gather_backward(N, inv.data_ptr(), ptr(gs), ptr(d_feat), ptr(d_anc), ptr(d_off),
-                                                           ptr(d_gs), ptr(d_g_fea), g_feat.data_ptr(), g_anchor.data_ptr(),
+                                                           ptr(d_gs), ptr(d_g_fea), ldg, g_feat.data_ptr(), g_anchor.data_ptr(),
                                                            g_offset.data_ptr(), g_scaling.data_ptr(), _stream()))
         return None, g_feat, g_anchor, g_offset, g_scaling
 

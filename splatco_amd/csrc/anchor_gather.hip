@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(AG_THREADS)
 anchor_gather_kernel(int64_t V, const int64_t* __restrict__ idx, const float* __restrict__ p_feat,
                      const float* __restrict__ p_anchor, const float* __restrict__ p_offset,
                      const float* __restrict__ p_scaling, float* __restrict__ feat, float* __restrict__ anchor,
-                     float* __restrict__ offsets, float* __restrict__ grid_scaling, float* __restrict__ g_fea) {
+                     float* __restrict__ offsets, float* __restrict__ grid_scaling, float* __restrict__ g_fea, int ldg) {
     __shared__ __attribute__((aligned(16))) float tile[AG_ROWS * AG_LD];
     __shared__ int64_t rowsrc[AG_ROWS];
     const int64_t v0 = (int64_t)blockIdx.x * AG_ROWS;
@@ -75,10 +75,11 @@ anchor_gather_kernel(int64_t V, const int64_t* __restrict__ idx, const float* __
         const float2 x = *(const float2*)(p_scaling + rowsrc[r] * 6 + 2 * q);
         tile[r * AG_LD + 65 + 2 * q] = expf(x.x);        // get_scaling = exp(_scaling)
         tile[r * AG_LD + 66 + 2 * q] = expf(x.y);
+        if (q == 0) tile[r * AG_LD + AG_COLS] = 0.0f;    // the pad column of 16-byte aligned g_fea rows (ldg = 72)
     }
     __syncthreads();
     // ---- the workgroup's chunks of the five outputs are contiguous
-    ag_store_chunk(g_fea + v0 * AG_COLS, tile, rows * AG_COLS, AG_COLS, 0);
+    ag_store_chunk(g_fea + v0 * ldg, tile, rows * ldg, ldg, 0);      // ldg = 71 (packed) or 72 = AG_LD (a straight copy)
     ag_store_chunk(feat + v0 * AG_FEAT, tile, rows * AG_FEAT, AG_FEAT, 0);
     ag_store_chunk(anchor + v0 * 3, tile, rows * 3, 3, 32);
     ag_store_chunk(offsets + v0 * AG_OFF, tile, rows * AG_OFF, AG_OFF, 35);
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(AG_THREADS)
 anchor_gather_backward_kernel(int64_t N, const int64_t* __restrict__ inv, const float* __restrict__ grid_scaling,
                               const float* __restrict__ d_feat, const float* __restrict__ d_anchor,
                               const float* __restrict__ d_offsets, const float* __restrict__ d_grid_scaling,
-                              const float* __restrict__ d_g_fea, float* __restrict__ g_feat,
+                              const float* __restrict__ d_g_fea, int ldg, float* __restrict__ g_feat,
                               float* __restrict__ g_anchor, float* __restrict__ g_offset,
                               float* __restrict__ g_scaling) {
     __shared__ __attribute__((aligned(16))) float tile[AG_ROWS * AG_LD];   // rows = the VISIBLE anchors of the block, in order
@@ -133,7 +134,7 @@ anchor_gather_backward_kernel(int64_t N, const int64_t* __restrict__ inv, const 
     const int nv = nvis;
     if (nv) {
         const int64_t fv = first_v;
-        ag_add_chunk(d_g_fea ? d_g_fea + fv * AG_COLS : nullptr, tile, nv * AG_COLS, AG_COLS, 0);
+        ag_add_chunk(d_g_fea ? d_g_fea + fv * ldg : nullptr, tile, nv * ldg, ldg, 0);   // (the pad column lands in tile column 71: unused)
         __syncthreads();   // the parts below add into the same cells
         ag_add_chunk(d_feat ? d_feat + fv * AG_FEAT : nullptr, tile, nv * AG_FEAT, AG_FEAT, 0);
         ag_add_chunk(d_anchor ? d_anchor + fv * 3 : nullptr, tile, nv * 3, 3, 32);
@@ -161,19 +162,19 @@ anchor_gather_backward_kernel(int64_t N, const int64_t* __restrict__ inv, const 
 
 void launch_anchor_gather(int64_t V, const int64_t* idx, const float* p_feat, const float* p_anchor, const float* p_offset,
                           const float* p_scaling, float* feat, float* anchor, float* offsets, float* grid_scaling,
-                          float* g_fea, hipStream_t st) {
+                          float* g_fea, int ldg, hipStream_t st) {
     if (V <= 0) return;
     anchor_gather_kernel<<<(unsigned)((V + AG_ROWS - 1) / AG_ROWS), AG_THREADS, 0, st>>>(
-        V, idx, p_feat, p_anchor, p_offset, p_scaling, feat, anchor, offsets, grid_scaling, g_fea);
+        V, idx, p_feat, p_anchor, p_offset, p_scaling, feat, anchor, offsets, grid_scaling, g_fea, ldg);
 }
 
 void launch_anchor_gather_backward(int64_t N, const int64_t* inv, const float* grid_scaling, const float* d_feat,
                                    const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
-                                   const float* d_g_fea, float* g_feat, float* g_anchor, float* g_offset,
+                                   const float* d_g_fea, int ldg, float* g_feat, float* g_anchor, float* g_offset,
                                    float* g_scaling, hipStream_t st) {
     if (N <= 0) return;
     anchor_gather_backward_kernel<<<(unsigned)((N + AG_ROWS - 1) / AG_ROWS), AG_THREADS, 0, st>>>(
-        N, inv, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea, g_feat, g_anchor, g_offset, g_scaling);
+        N, inv, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea, ldg, g_feat, g_anchor, g_offset, g_scaling);
 }
 
 }  // namespace scr

@@ -62,7 +62,8 @@ const char* const kProfNames[SCR_PROF_COUNT] = {
     "filter_kernel", "preprocess_kernel", "plan_scan_kernel", "scatter_kernel", "tile_sort_kernel",
     "blend_forward_kernel", "blend_backward_kernel", "preprocess_backward_kernel", "expand_kernel",
     "expand_backward_kernel", "plane_sample_backward_kernels", "l1_ssim_forward_kernel",
-    "l1_ssim_backward_kernel", "triplane_forward_kernel", "mlp_heads_kernel", "mlp_heads_backward_kernel"};
+    "l1_ssim_backward_kernel", "triplane_forward_kernel", "mlp_heads_kernel", "mlp_heads_backward_kernel",
+    "norm_linear_kernels", "norm_linear_backward_kernels"};
 }  // namespace
 
 // streaming copy, 16 B per lane, four loads in flight per thread, non-temporal: the shape that reaches the highest HBM
@@ -465,29 +466,62 @@ int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, con
 // ---- visible-anchor gather (anchor_gather.hip)
 int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anchor_feat, const float* anchor,
                       const float* offset, const float* scaling, float* feat_out, float* anchor_out, float* offsets_out,
-                      float* grid_scaling_out, float* g_fea_out, void* stream) {
+                      float* grid_scaling_out, float* g_fea_out, int32_t g_fea_ld, void* stream) {
     if (V < 0) return fail("V < 0");
+    if (g_fea_ld != 71 && g_fea_ld != 72) return fail("g_fea row stride must be 71 (packed) or 72 (16-byte aligned rows)");
     if (V == 0) return 0;
     if (!visible_index || !anchor_feat || !anchor || !offset || !scaling || !feat_out || !anchor_out || !offsets_out ||
         !grid_scaling_out || !g_fea_out)
         return fail("NULL argument");
     launch_anchor_gather(V, visible_index, anchor_feat, anchor, offset, scaling, feat_out, anchor_out, offsets_out,
-                         grid_scaling_out, g_fea_out, (hipStream_t)stream);
+                         grid_scaling_out, g_fea_out, g_fea_ld, (hipStream_t)stream);
     CHECK_LAUNCH("anchor_gather_kernel", 0, (hipStream_t)stream);
     return 0;
 }
 
 int scr_anchor_gather_backward(int64_t N, const int64_t* inverse_index, const float* grid_scaling, const float* d_feat,
                                const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
-                               const float* d_g_fea, float* g_anchor_feat, float* g_anchor, float* g_offset,
-                               float* g_scaling, void* stream) {
+                               const float* d_g_fea, int32_t g_fea_ld, float* g_anchor_feat, float* g_anchor,
+                               float* g_offset, float* g_scaling, void* stream) {
     if (N < 0) return fail("N < 0");
+    if (g_fea_ld != 71 && g_fea_ld != 72) return fail("g_fea row stride must be 71 (packed) or 72 (16-byte aligned rows)");
     if (N == 0) return 0;
     if (!inverse_index || !g_anchor_feat || !g_anchor || !g_offset || !g_scaling) return fail("NULL argument");
     if (d_grid_scaling || d_g_fea) { if (!grid_scaling) return fail("grid_scaling is needed for d exp"); }
-    launch_anchor_gather_backward(N, inverse_index, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea,
+    launch_anchor_gather_backward(N, inverse_index, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea, g_fea_ld,
                                   g_anchor_feat, g_anchor, g_offset, g_scaling, (hipStream_t)stream);
     CHECK_LAUNCH("anchor_gather_backward_kernel", 0, (hipStream_t)stream);
+    return 0;
+}
+
+// ---- BatchNorm1d (batch statistics) folded into Linear(d, 32) (normlinear.hip)
+size_t scr_norm_linear_scratch_bytes(int64_t V) { return norm_linear_scratch_bytes(V > 0 ? V : 1); }
+
+int scr_norm_linear_forward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* G, const float* c, float eps,
+                            float* y, float* mean, float* var, float* inv, void* scratch, void* stream) {
+    if (V < 1 || d < 1 || ldx < d) return fail("bad sizes");
+    if (!x || !G || !c || !y || !mean || !var || !inv || !scratch) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    { ProfScope ps_(SCR_PROF_NORM_LINEAR, st);
+      rc = launch_norm_linear_forward(V, d, x, ldx, G, c, eps, y, mean, var, inv, scratch, st); }
+    if (rc == 1) return fail("d = %d input columns exceed the supported 80", d);
+    CHECK_LAUNCH("norm_linear_forward", 0, st);
+    return 0;
+}
+
+int scr_norm_linear_backward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* G,
+                             const float* mean, const float* inv, float* dx, int32_t lddx, float* dG, float* dc,
+                             void* scratch, void* stream) {
+    if (V < 1 || d < 1 || ldx < d || lddy < 32 || (dx && lddx < d)) return fail("bad sizes");
+    if (!x || !dy || !G || !mean || !inv || !dG || !dc || !scratch) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    { ProfScope ps_(SCR_PROF_NORM_LINEAR_BACKWARD, st);
+      rc = launch_norm_linear_backward(V, d, x, ldx, dy, lddy, G, mean, inv, dx, lddx, dG, dc, scratch, st); }
+    if (rc == 1) return fail("d = %d input columns exceed the supported 80", d);
+    if (rc == 2) return fail("dy must be 16-byte aligned with a row stride that is a multiple of 4 floats");
+    CHECK_LAUNCH("norm_linear_backward", 0, st);
     return 0;
 }
 

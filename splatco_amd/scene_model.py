@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+NORM_LINEAR_HIP = True       # _NormLinearFn on the GPU: csrc/normlinear.hip (False: the torch ops, kept as the checker's other leg)
 FUSE_NORM_LINEAR = True      # FeaturePlanes: fold the train-mode BatchNorms into their Linears (see _NormLinearFn)
 
 
@@ -103,7 +104,29 @@ class _NormLinearFn(torch.autograd.Function):
     Also returns (mean, biased var) for the running-statistics update."""
 
     @staticmethod
+    def fused_ok(x, G):
+        # csrc/normlinear.hip: 32 output features, at most 80 input columns, fp32 rows with unit column stride
+        return (NORM_LINEAR_HIP and x.is_cuda and x.dtype == torch.float32 and G.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 1
+                and G.shape[0] == 32 and x.shape[1] <= 80 and x.stride(1) == 1)
+
+    @staticmethod
     def forward(ctx, x, G, c, eps):
+        ctx.fused = _NormLinearFn.fused_ok(x, G)
+        if ctx.fused:
+            from . import _C
+            from .rasterizer import _stream
+            V, d = x.shape
+            Gc, cc = G.detach().contiguous(), c.detach().contiguous().float()
+            y = torch.empty(V, 32, dtype=torch.float32, device=x.device)
+            mean, var, inv = (torch.empty(d, dtype=torch.float32, device=x.device) for _ in range(3))
+            scratch = torch.empty(_C.lib.scr_norm_linear_scratch_bytes(V), dtype=torch.uint8, device=x.device)
+            with torch.cuda.device(x.device):
+                _C.check(_C.lib.scr_norm_linear_forward(V, d, x.data_ptr(), x.stride(0), Gc.data_ptr(), cc.data_ptr(), float(eps),
+                                                        y.data_ptr(), mean.data_ptr(), var.data_ptr(), inv.data_ptr(),
+                                                        scratch.data_ptr(), _stream()))
+            ctx.save_for_backward(x, Gc, mean, inv)
+            ctx.mark_non_differentiable(mean, var)
+            return y, mean, var
         var, mean = _col_var_mean(x)
         inv = torch.rsqrt(var + eps)
         Gs = G * inv                                   # scale columns
@@ -116,6 +139,23 @@ class _NormLinearFn(torch.autograd.Function):
     def backward(ctx, dy, _dm, _dv):
         x, G, mean, inv = ctx.saved_tensors
         V = x.shape[0]
+        if ctx.fused:
+            from . import _C
+            from .rasterizer import _stream
+            d = x.shape[1]
+            if dy.dtype != torch.float32 or dy.stride(1) != 1 or dy.stride(0) % 4 or dy.data_ptr() % 16:
+                dy = dy.contiguous().float()
+            need_dx = ctx.needs_input_grad[0]
+            ldx = (d + 3) // 4 * 4                   # 16-byte aligned rows (the pad columns are never written or read)
+            dx = torch.empty(V, ldx, dtype=torch.float32, device=x.device)[:, :d] if need_dx else None
+            dG = torch.empty(32, d, dtype=torch.float32, device=x.device)
+            dc = torch.empty(32, dtype=torch.float32, device=x.device)
+            scratch = torch.empty(_C.lib.scr_norm_linear_scratch_bytes(V), dtype=torch.uint8, device=x.device)
+            with torch.cuda.device(x.device):
+                _C.check(_C.lib.scr_norm_linear_backward(V, d, x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), G.data_ptr(),
+                                                         mean.data_ptr(), inv.data_ptr(), dx.data_ptr() if need_dx else None,
+                                                         ldx, dG.data_ptr(), dc.data_ptr(), scratch.data_ptr(), _stream()))
+            return dx, dG, dc, None
         if dy.stride(1) != 1:      # a column block of a wider gradient (row stride > width) is fine for every op below
             dy = dy.contiguous()
         sdy = dy.sum(0)

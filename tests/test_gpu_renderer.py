@@ -527,3 +527,50 @@ def test_fused_anchor_gather_matches_the_torch_ops():
     for a, b in zip(g1, g0):
         assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-6, atol=1e-7)
         assert torch.all(a[~vis] == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,d,ld", [(2, 60, 60), (15, 71, 71), (1000, 60, 64), (4099, 71, 71), (100003, 60, 60), (100003, 71, 71),
+                                    (65536, 30, 30), (20000, 80, 80), (20000, 16, 99), (33333, 7, 7)])
+def test_fused_norm_linear_matches_batchnorm_linear_chain(V, d, ld):
+    """csrc/normlinear.hip (column statistics, folded GEMM, the three backward passes) against BatchNorm1d (training
+    mode) -> Linear evaluated by torch autograd in float64, and against the torch ops the CPU path uses.  Columns
+    with a large mean / small spread (the log-scalings of the anchors: -5 +- 0.3) stress the variance.  Tolerance:
+    fp32 summation order (1e-5 of the tensor's scale; the reduction terms of dx sum V products)."""
+    from splatco_amd import scene_model as sm
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(V * 131 + d)
+    base = torch.randn(V, ld, device=dev, generator=g)
+    base[:, : d // 2] = base[:, : d // 2] * 0.3 - 5.0
+    x = base[:, :d].detach().requires_grad_()                          # a column block when ld > d
+    G = (torch.randn(32, d, device=dev, generator=g) * 0.2).requires_grad_()
+    c = torch.randn(32, device=dev, generator=g).requires_grad_()
+    w = torch.randn(V, 32, device=dev, generator=g)
+    eps = 1e-5
+
+    def run(hip):
+        sm.NORM_LINEAR_HIP = hip
+        try:
+            for t in (x, G, c):
+                t.grad = None
+            y, mean, var = sm._NormLinearFn.apply(x, G, c, eps)
+            (y * w).sum().backward()
+            return [t.detach().double().cpu() for t in (y, mean, var, x.grad, G.grad, c.grad)]
+        finally:
+            sm.NORM_LINEAR_HIP = True
+
+    got, tor = run(True), run(False)
+    x64, G64, c64 = (t.detach().double().cpu().requires_grad_() for t in (x, G, c))
+    m64, v64 = x64.mean(0), x64.var(0, unbiased=False)
+    y64 = ((x64 - m64) / torch.sqrt(v64 + eps)) @ G64.t() + c64
+    (y64 * w.double().cpu()).sum().backward()
+    ref = [y64.detach(), m64.detach(), v64.detach(), x64.grad, G64.grad, c64.grad]
+    for name, a, b, t in zip(("y", "mean", "var", "dx", "dG", "dc"), got, ref, tor):
+        scale = max(float(b.abs().max()), 1e-6)
+        err, err_t = float((a - b).abs().max()) / scale, float((t - b).abs().max()) / scale
+        # (two rows: the variance is the difference of two numbers and the folded form cancels 1 / sqrt(var) against it;
+        #  there the bar is the error of the torch ops on the same formulation)
+        assert err < max(2e-5, 1.5 * err_t), f"{name}: fused {err:.2e} (torch ops {err_t:.2e}) of scale {scale:.3g}"
+    # bit-reproducible
+    again = run(True)
+    assert all(torch.equal(a, b) for a, b in zip(got, again))
