@@ -346,6 +346,8 @@ def run_anchor_config(args, rank, world, dev):
     N = args.anchors or N
     W, H = 1920, 1080
     pc = synthetic_anchor_model(N, seed, dev)
+    if args.anchor_order == "morton":       # the layout AnchorDensifier.sort_anchors keeps (before the optimizer exists)
+        pc.sort_anchors()
     pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
     bg = torch.ones(3, device=dev)
     train = args.config in ("cfg3", "cfg4")
@@ -456,7 +458,9 @@ def run_anchor_config(args, rank, world, dev):
             "cfg3": f"cfg3: {N} anchors (seed {seed}), mv = {mv} views 1080p, 1 per GPU: full sharded training step",
             "cfg4": f"cfg4: {N} anchors (seed {seed}), mv = {mv} views 1080p, 1 per GPU: full training step "
                     f"(prefilter, render, loss, backward, gradient exchange, densification statistics, Adam)"}[args.config],
-                   "anchors": N, "visible_anchors_last_view": V, "gaussians_last_view": P1, "tile_instances_last_view": I,
+                   "anchors": N, "anchor_order": {"random": "random (as drawn: the worst case for every gather)",
+                                                  "morton": "Morton (AnchorDensifier.sort_anchors)"}[args.anchor_order],
+                   "visible_anchors_last_view": V, "gaussians_last_view": P1, "tile_instances_last_view": I,
                    "image": f"{W}x{H}",
                    "rendered_last_view": int((stats["rendered"] > 0).sum().item()),
                    "parallelism": f"{mv} view(s), 1 per GPU" + (", RCCL gradient exchange in place" if world > 1 else "")},
@@ -491,6 +495,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3", "cfg4"], default="cfg1")
     ap.add_argument("--anchors", type=int, default=0, help="override the anchor count of cfg2..4 (developer runs)")
+    ap.add_argument("--anchor-order", choices=["random", "morton"], default="random",
+                    help="memory order of the anchors of cfg2..4: as drawn (random in space) or Morton-sorted")
     ap.add_argument("--exchange", choices=["all_reduce", "rs_ag"], default="all_reduce",
                     help="shape of the gradient exchange of cfg3/cfg4 (GradArena)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -167,6 +167,23 @@ class AnchorDensifier:
                 with torch.no_grad():
                     p[:, 3:].clamp_(max=0.05)
 
+    @torch.no_grad()
+    def sort_anchors(self, perm=None):
+        """Puts the anchors -- parameters, Adam moments and the four densification accumulators -- in Morton order
+        (scene_model.morton_order): new row i = old row perm[i].  Not in the reference (the anchor
+        order carries no meaning there); call it after adjust_anchor to keep 64 consecutive anchors spatial neighbours."""
+        if perm is None:
+            from .scene_model import morton_order
+            perm = morton_order(self.model._anchor)
+        k = self.n_offsets
+        for group in self._groups():
+            self._replace(group, group["params"][0].detach()[perm].contiguous(), lambda s: s[perm].contiguous())
+        self.opacity_accum = self.opacity_accum[perm]
+        self.anchor_demon = self.anchor_demon[perm]
+        self.offset_gradient_accum = self.offset_gradient_accum.view(-1, k)[perm].reshape(-1, 1)
+        self.offset_denom = self.offset_denom.view(-1, k)[perm].reshape(-1, 1)
+        return perm
+
     # ---- :826-925
     @torch.no_grad()
     def anchor_growing(self, grads, threshold, offset_mask):

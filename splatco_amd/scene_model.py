@@ -368,6 +368,22 @@ class GaussianLearner(nn.Module):             # scene/gaussian_model.py:184-220
         return out
 
 
+@torch.no_grad()
+def morton_order(anchor, bits=10):
+    """Permutation (int64 [N]) that sorts points [N,3] by the 3-D Morton code of their position in their bounding
+    box (`bits` per axis, at most 21)."""
+    a = anchor.detach()
+    if a.shape[0] == 0:
+        return torch.empty(0, dtype=torch.long, device=a.device)
+    lo, hi = a.amin(0), a.amax(0)
+    q = ((a - lo) / (hi - lo).clamp_min(1e-12) * (1 << bits)).long().clamp_(0, (1 << bits) - 1)
+    code = torch.zeros(a.shape[0], dtype=torch.long, device=a.device)
+    for b in range(bits):
+        for ax in range(3):
+            code |= ((q[:, ax] >> b) & 1) << (3 * b + ax)
+    return torch.argsort(code, stable=True)
+
+
 class AnchorGaussianModel(nn.Module):
     """The attributes of the reference's GaussianModel that render() / prefilter_voxel() touch
     (scene/gaussian_model.py:253-337,396-432), with the same names."""
@@ -420,6 +436,25 @@ class AnchorGaussianModel(nn.Module):
     def train(self, mode=True):
         self.mlp_opacity.train(mode); self.mlp_cov.train(mode); self.mlp_color.train(mode)
         return self
+
+    # ---- memory layout: anchors in spatial (Morton) order.  Nothing in the reference depends on the order of the
+    # anchors (it only breaks exact depth ties); on MI355X it decides whether the tri-plane samples, the gradient
+    # scatter and the rasterizer's tile scatter of 64 consecutive anchors touch neighbouring cache lines or 64 random
+    # ones.  create_from_pcd leaves them in np.unique (lexicographic) order, anchor_growing appends (scene/gaussian_model.py:
+    # 449,913-925); a training loop can restore the locality after every adjust_anchor with AnchorDensifier.sort_anchors.
+    def morton_order(self, bits=10):
+        return morton_order(self._anchor, bits)
+
+    @torch.no_grad()
+    def sort_anchors(self, perm=None):
+        """Reorders the per-anchor tensors in place (no optimizer attached: use AnchorDensifier.sort_anchors when
+        there is one).  Returns the permutation applied (new row i = old row perm[i])."""
+        perm = self.morton_order() if perm is None else perm
+        for name in ("_anchor", "_offset", "_anchor_feat", "_scaling", "_rotation", "_opacity"):
+            p = getattr(self, name)
+            if p.shape[0] == perm.shape[0]:
+                p.data = p.data[perm].contiguous()
+        return perm
 
     @property
     def get_anchor(self):

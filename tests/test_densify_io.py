@@ -57,6 +57,32 @@ def test_adjust_anchor_matches_reference(case):
     assert m._anchor.shape[0] > d[pre + "in.anchor"].shape[0] // 2
 
 
+def test_sort_anchors_permutes_parameters_moments_and_accumulators():
+    """AnchorDensifier.sort_anchors (Morton order; not in the reference): every per-anchor tensor -- parameters, Adam
+    moments, the four accumulators -- moves with the same permutation, and adjust_anchor afterwards gives the reference's
+    anchors in the permuted order (same set of rows)."""
+    from splatco_amd.scene_model import morton_order
+    d = np.load(os.path.join(GOLD, "densify.npz"))
+    m, opt, den, pre = _case(d, 0)
+    k = den.n_offsets
+    before = {n: getattr(m, "_" + n).detach().clone() for n in NAMES}
+    mom = {n: opt.state[getattr(m, "_" + n)]["exp_avg"].clone() for n in NAMES if getattr(m, "_" + n) in opt.state}
+    acc = {n: getattr(den, n).clone() for n in ("offset_gradient_accum", "offset_denom", "opacity_accum", "anchor_demon")}
+    perm = den.sort_anchors()
+    assert torch.equal(perm, morton_order(before["anchor"])) and sorted(perm.tolist()) == list(range(len(perm)))
+    code = lambda a: morton_order(a)        # sorted input -> identity permutation (stable sort)
+    assert torch.equal(code(m._anchor), torch.arange(len(perm)))
+    for n in NAMES:
+        p = getattr(m, "_" + n)
+        assert torch.equal(p.detach(), before[n][perm]), n
+        assert p is [g for g in opt.param_groups if g["name"] == n][0]["params"][0]
+        if n in mom:
+            assert torch.equal(opt.state[p]["exp_avg"], mom[n][perm]), n
+    assert torch.equal(den.opacity_accum, acc["opacity_accum"][perm]) and torch.equal(den.anchor_demon, acc["anchor_demon"][perm])
+    assert torch.equal(den.offset_denom.view(-1, k), acc["offset_denom"].view(-1, k)[perm])
+    assert torch.equal(den.offset_gradient_accum.view(-1, k), acc["offset_gradient_accum"].view(-1, k)[perm])
+
+
 def test_compute_curvature_matches_reference():
     from splatco_amd.densify import compute_curvature
     d = np.load(os.path.join(GOLD, "densify.npz"))

@@ -574,3 +574,35 @@ def test_fused_norm_linear_matches_batchnorm_linear_chain(V, d, ld):
     # bit-reproducible
     again = run(True)
     assert all(torch.equal(a, b) for a, b in zip(got, again))
+
+
+@pytest.mark.gpu
+def test_sorted_anchors_render_the_same_image():
+    """AnchorGaussianModel.sort_anchors (Morton order) is a pure relabelling: the rendered image and the loss are the
+    same (the anchor order only breaks exact depth ties and changes the order of fp32 sums in weight gradients), the
+    per-anchor gradients are the permuted ones."""
+    import types
+    from splatco_amd.renderer import prefilter_voxel, render
+    from splatco_amd.synthetic import synthetic_anchor_model, synthetic_views
+    dev = torch.device("cuda:0")
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
+    bg = torch.ones(3, device=dev)
+    view = synthetic_views(1, 640, 360)[0].to(dev)
+
+    def run(sort):
+        pc = synthetic_anchor_model(60000, 7, dev, plane_size=256)
+        perm = pc.sort_anchors() if sort else torch.arange(60000, device=dev)
+        vis = prefilter_voxel(view, pc, pipe, bg)
+        out = render(view, pc, pipe, bg, visible_mask=vis, retain_grad=True)
+        out["render"].square().mean().backward()
+        return out["render"].detach(), perm, {n: getattr(pc, n).grad for n in ("_anchor", "_offset", "_anchor_feat", "_scaling")}, \
+            pc.feat_planes._feat.k0s[1].xy_plane.grad, int(vis.sum())
+
+    img0, _, g0, gp0, n0 = run(False)
+    img1, perm, g1, gp1, n1 = run(True)
+    assert n0 == n1 and n0 > 10000
+    assert float((img0 - img1).abs().max()) < 2e-5
+    for n in g0:
+        scale = float(g0[n].abs().max())
+        assert float((g0[n][perm] - g1[n]).abs().max()) < 2e-4 * scale + 1e-12, n
+    assert float((gp0 - gp1).abs().max()) < 2e-4 * float(gp0.abs().max())

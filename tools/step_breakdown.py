@@ -1,7 +1,7 @@
 """Steady-state kernel breakdown of one BASELINE.json configuration (torch profiler over N steps after the warm-up,
 so MIOpen's solver search and the allocator's growth stay out of the numbers -- `rocprofv3 --stats` of the whole
 process mixes those in).  Writes the per-step table committed under profiles/.
-usage: python tools/step_breakdown.py cfg2|cfg3|cfg4 [anchors] [steps] > profiles/<round>_<cfg>_step_breakdown.txt"""
+usage: python tools/step_breakdown.py cfg2|cfg3|cfg4 [anchors] [steps] [random|morton] > profiles/<round>_<cfg>_step_breakdown.txt"""
 import sys
 import types
 
@@ -16,28 +16,13 @@ from splatco_amd.synthetic import ANCHOR_CONFIGS, synthetic_anchor_model, synthe
 from splatco_amd.train_step import collaborative_step
 
 
-def main(cfg="cfg2", anchors=0, steps=3):
+def main(cfg="cfg2", anchors=0, steps=3, order="random"):
     dev = torch.device("cuda:0")
     N, _, seed = ANCHOR_CONFIGS[cfg]
     N = anchors or N
     pc = synthetic_anchor_model(N, seed, dev)
-    import os
-    if os.environ.get("SPLATCO_EXP_MORTON"):
-        a = pc._anchor.data
-        q = ((a + 2) / 4 * 1024).long().clamp(0, 1023)
-        def spread(v):
-            v = (v | (v << 16)) & 0x030000FF
-            v = (v | (v << 8)) & 0x0300F00F
-            v = (v | (v << 4)) & 0x030C30C3
-            v = (v | (v << 2)) & 0x09249249
-            return v
-        code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
-        if os.environ["SPLATCO_EXP_MORTON"] == "lex":
-            q = ((a + 2) / 4 * (1 << 20)).long().clamp(0, (1 << 20) - 1)
-            code = (q[:, 0] << 40) | (q[:, 1] << 20) | q[:, 2]
-        perm = torch.argsort(code)
-        for nme in ("_anchor", "_offset", "_anchor_feat", "_scaling", "_rotation", "_opacity"):
-            getattr(pc, nme).data = getattr(pc, nme).data[perm].contiguous()
+    if order == "morton":
+        pc.sort_anchors()
     pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
     bg = torch.ones(3, device=dev)
     views = [v.to(dev) for v in synthetic_views(1)]
@@ -77,7 +62,7 @@ def main(cfg="cfg2", anchors=0, steps=3):
     rows = [(e.key, e.self_device_time_total / steps / 1e3, e.count / steps) for e in prof.key_averages() if e.self_device_time_total > 0]
     rows.sort(key=lambda r: -r[1])
     total = sum(r[1] for r in rows)
-    print(f"# {cfg}: {N} anchors, 1 view 1920x1080, steady state ({steps} steps after 3 warm-up steps), MI355X")
+    print(f"# {cfg}: {N} anchors ({order} order), 1 view 1920x1080, steady state ({steps} steps after 3 warm-up steps), MI355X")
     print(f"# step wall time (un-profiled) {wall:.2f} ms; sum of kernel times under the profiler {total:.2f} ms")
     print(f"# {'kernel':88s} {'ms/step':>9s} {'calls/step':>10s} {'pct':>6s}")
     for k, ms, n in rows[:60]:
@@ -86,4 +71,4 @@ def main(cfg="cfg2", anchors=0, steps=3):
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    main(a[0] if a else "cfg2", int(a[1]) if len(a) > 1 else 0, int(a[2]) if len(a) > 2 else 3)
+    main(a[0] if a else "cfg2", int(a[1]) if len(a) > 1 else 0, int(a[2]) if len(a) > 2 else 3, a[3] if len(a) > 3 else "random")
