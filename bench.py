@@ -68,6 +68,10 @@ def algorithmic_bytes(kernel, P, I, npix, extra=None):
         "l1_ssim_backward_kernel": 2 * 12 * npix + 3 * 12 * npix + 12 * npix,
         "mlp_heads_kernel": 4 * V * (32 + 3 + 64) + 4 * V * 110 + 4 * V * 96,             # inputs + outputs + saved hidden layer
         "mlp_heads_backward_kernel": 4 * V * (32 + 3 + 64 + 96 + 40 + 110) + 4 * V * (32 + 3 + 64),   # inputs, hidden, outputs(y), upstream; input gradients
+        # BatchNorm-Linear pair of FeaturePlanes (d = 60 and 71 columns): statistics pass + GEMM pass forward;
+        # dy^T x pass + dx pass backward (x re-read by every pass: the algorithm needs the statistics first)
+        "norm_linear_kernels": 4 * V * (2 * (60 + 71) + 2 * 32),
+        "norm_linear_backward_kernels": 4 * V * (2 * (60 + 71) + 2 * 2 * 32 + (60 + 71)),
     }
     return float(table.get(kernel, 0))
 
@@ -282,6 +286,9 @@ def run_cfg1(args, rank, world, dev):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        if os.environ.get("SPLATCO_BENCH_TRACE"):        # developer aid: per-step times (adds a sync per step)
+            torch.cuda.synchronize()
+            print(f"[trace] step done at {(time.perf_counter() - t0) * 1e3:.1f} ms", file=sys.stderr)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -391,6 +398,25 @@ def run_anchor_config(args, rank, world, dev):
         step()
     torch.cuda.synchronize()
     warm_prof = _C.profile_read() if args.warmup else {}
+    # The anchors move with every Adam step, so the number of visible anchors / kept Gaussians -- and with it the size of
+    # every intermediate -- changes from step to step, and torch's caching allocator keeps requesting fresh device memory
+    # (hundreds of ms per step on a fresh box) until its pool covers the pattern: at 20 M anchors the pool grows for
+    # about nine steps (56 -> 149 GiB reserved, 26 GiB live).  Steady state = the pool has stopped growing: settle
+    # (untimed, every rank the same count) before the K timed steps.
+    settle = 0
+    if train and args.warmup:
+        _C.profile_enable(False)
+        last = torch.cuda.memory_reserved()
+        while settle < 16:
+            step()
+            torch.cuda.synchronize()
+            settle += 1
+            grew = torch.tensor([float(torch.cuda.memory_reserved() > last)], device=dev)
+            last = torch.cuda.memory_reserved()
+            if world > 1:
+                dist.all_reduce(grew, op=dist.ReduceOp.MAX)
+            if not grew.item():
+                break
     nwarm = min(args.warmup, 2) or 1
     dominant, warm_kern = pick_dominant(warm_prof)
     warm_step_ms = {k: ms / nwarm for k, (ms, n) in warm_prof.items() if n}
@@ -402,6 +428,9 @@ def run_anchor_config(args, rank, world, dev):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        if os.environ.get("SPLATCO_BENCH_TRACE"):        # developer aid: per-step times (adds a sync per step)
+            torch.cuda.synchronize()
+            print(f"[trace] step done at {(time.perf_counter() - t0) * 1e3:.1f} ms", file=sys.stderr)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -451,6 +480,7 @@ def run_anchor_config(args, rank, world, dev):
         "unit": "Msplats/s" if args.config != "cfg4" else "iter/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "allocator_settle_steps": settle, "reserved_gib": round(torch.cuda.memory_reserved() / 2**30, 1),
         "config": {"workload": {
             "cfg2": f"cfg2: {N} anchors uniform in [-2,2]^3 (seed {seed}), k=10, tri-planes 700/700/1400 active "
                     f"(plane_size 2800, 15 channels, activate_level 2), 1 view 1920x1080: prefilter_voxel + render() "
