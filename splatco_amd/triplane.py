@@ -65,7 +65,8 @@ class _TriPlaneSample(torch.autograd.Function):
             ind, planes = tensors[k], tensors[k + 1:k + 1 + n]
             if out is None:
                 out = torch.empty(ind.shape[0], width, dtype=torch.float32, device=ind.device)
-            _forward_into(out, ind, cols, planes)
+            with torch.cuda.device(ind.device):
+                _forward_into(out, ind, cols, planes)
             inds.append(ind)
             shapes.append([tuple(p.shape) for p in planes])
             k += 1 + n
@@ -80,7 +81,8 @@ class _TriPlaneSample(torch.autograd.Function):
         grads, k = [], 0
         for (n, cols), ind, shapes in zip(ctx.meta, ctx.saved_tensors, ctx.shapes):
             need = ctx.needs_input_grad[2 + k + 1:2 + k + 1 + n]
-            gp = _backward_from(g, ind, cols, shapes) if any(need) else [None] * n
+            with torch.cuda.device(ind.device):
+                gp = _backward_from(g, ind, cols, shapes) if any(need) else [None] * n
             grads.append(None)
             grads.extend(t if nd else None for t, nd in zip(gp, need))
             k += 1 + n
