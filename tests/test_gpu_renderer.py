@@ -606,3 +606,38 @@ def test_sorted_anchors_render_the_same_image():
         scale = float(g0[n].abs().max())
         assert float((g0[n][perm] - g1[n]).abs().max()) < 2e-4 * scale + 1e-12, n
     assert float((gp0 - gp1).abs().max()) < 2e-4 * float(gp0.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [1, 3, 4, 5, 7, 8])
+def test_multi_grid_sampling_into_one_matrix_all_alignments(R):
+    """multi_triplane_sample with the FeaturePlanes layout -- attention grid (six planes, columns interleaved), two plain
+    grids of different sizes, all into one [V, 12 R] matrix -- against F.grid_sample per plane.  The widths 12 R put the
+    grids' column blocks at every 16-byte phase (R = 5: 0 / 2 / 1 floats past a boundary), which drives the
+    alignment-peeled row loads of the one-pass gradient scatter (R <= 5) and the split path for two planes with R > 5."""
+    import torch.nn.functional as F
+    from splatco_amd.triplane import multi_triplane_sample
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(R)
+    V = 70_001
+    ind = torch.rand(V, 3, device=dev, generator=g) * 2.3 - 1.15
+    ind[:300] = torch.randint(0, 2, (300, 3), device=dev, generator=g).float() * 2 - 1
+    mk = lambda n, X, Y, Z: [(torch.randn(1, R, a, b, device=dev, generator=g) * 0.5).requires_grad_()
+                             for _ in range(n // 3) for a, b in ((X, Y), (X, Z), (Y, Z))]
+    grids = [(mk(6, 40, 40, 40), tuple(c * R for c in (0, 2, 4, 1, 3, 5))),
+             (mk(3, 40, 48, 56), tuple(6 * R + c * R for c in range(3))),
+             (mk(3, 90, 70, 80), tuple(9 * R + c * R for c in range(3)))]
+    out = multi_triplane_sample([(ind, tuple(pl), cols) for pl, cols in grids])
+    assert out.shape == (V, 12 * R) and out.stride(0) % 4 == 0
+    w = torch.randn(V, 12 * R, device=dev, generator=g)
+    (out * w).sum().backward()
+    got = [[p.grad.clone() for p in pl] for pl, _ in grids]
+    pairs = ((1, 0), (2, 0), (2, 1))
+    for (pl, cols), gg in zip(grids, got):
+        for j, p in enumerate(pl):
+            p.grad = None
+            samp = F.grid_sample(p, ind[:, list(pairs[j % 3])].view(1, 1, V, 2), mode="bilinear", align_corners=True).flatten(0, 2).T
+            assert torch.allclose(out[:, cols[j]:cols[j] + R], samp, rtol=1e-5, atol=1e-6), (R, j)
+            (samp * w[:, cols[j]:cols[j] + R]).sum().backward()
+            err, scale = float((gg[j] - p.grad).abs().max()), float(p.grad.abs().max())
+            assert err <= 5e-5 * scale + 1e-7, (R, j, err, scale)
