@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(uint32_t nblk, uint32_t
             uint32_t m = 0;
             for (int w = 0; w < 1024 / WAVE; ++w) m = max(m, lds[w]);
             total[1] = m;
+            total[2] = 0;      // no tile order yet (tile_order_kernel sets it)
             if (mailbox) {
                 mailbox[2] = m;
                 __threadfence_system();

@@ -239,7 +239,7 @@ int scr_forward_run(int64_t P, int64_t I, int64_t max_tile, const scr_settings* 
         { ProfScope ps_(SCR_PROF_TILE_SORT, st); launch_tile_sort(ks, gv, bv, max_tile, st); }
         CHECK_LAUNCH("tile_sort_kernel", settings->debug, st);
     }
-    { ProfScope ps_(SCR_PROF_BLEND_FORWARD, st); launch_blend_forward(ks, gv, bv, iv, out_color, st); }
+    { ProfScope ps_(SCR_PROF_BLEND_FORWARD, st); launch_blend_forward(ks, gv, bv, iv, out_color, 2 * max_tile * (int64_t)Grid(ks.H, ks.W).tiles > 3 * I, st); }
     CHECK_LAUNCH("blend_forward_kernel", settings->debug, st);
     return 0;
 }

@@ -47,10 +47,10 @@ struct GeomView {
     uint2* gm_base;           // [P] (b, rw): Gaussian-major index of the instance in tile (tx, ty) = b + ty*rw + tx
                               //     (b = first index - y0*rw - x0 mod 2^32, rw = rect width; written by the scatter kernel)
     uint32_t* block_sums;     // [ceil(P/BIN_GPW)] -> exclusive prefix after scan
-    uint32_t* tile_count;     // [tiles]
+    uint32_t* tile_count;     // [tiles] instances per tile (preprocess -> plan scan); afterwards the blend launches' tile order
     uint32_t* ranges;         // [tiles][2] (start, end)
     uint32_t* cursor;         // [tiles]
-    unsigned long long* total;  // [2] number of instances, largest per-tile instance count
+    unsigned long long* total;  // [3] number of instances, largest per-tile instance count, 1 = tile_count holds the blend tile order
     size_t bytes;
 };
 
@@ -70,7 +70,7 @@ inline __host__ GeomView geom_view(void* base, int64_t P, int H, int W) {
     v.tile_count = (uint32_t*)take((size_t)g.tiles * 4);
     v.ranges = (uint32_t*)take((size_t)g.tiles * 8);
     v.cursor = (uint32_t*)take((size_t)g.tiles * 4);
-    v.total = (unsigned long long*)take(16);
+    v.total = (unsigned long long*)take(32);
     v.bytes = off;
     return v;
 }
@@ -274,7 +274,7 @@ void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const Bi
 void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, int64_t max_tile_instances,
                       hipStream_t st);
 void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                          float* out_color, hipStream_t st);
+                          float* out_color, bool longest_first, hipStream_t st);
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
                            const float* dL_dcolor, GradRec* grad_rec, hipStream_t st);
 void launch_preprocess_backward(int64_t P, int M, const float* means3D, const float* scales,
