@@ -45,38 +45,43 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long ballot) {  //
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
 }
 
-// XCD-aware block -> (tile, quadrant): the four quadrant waves of a tile, and neighbouring
-// tiles, run on the same XCD so the record gathers they share hit one L2.
-__device__ __forceinline__ bool block_to_tile_quad(int block, int tiles, int& tile, int& quad) {
-    int chunk = (tiles + NUM_XCD - 1) / NUM_XCD;
-    int xcd = block % NUM_XCD, slot = block / NUM_XCD;
-    tile = xcd * chunk + (slot >> 2);
-    quad = slot & 3;
-    return (slot >> 2) < chunk && tile < tiles;
-}
-
-// ------------------------------------------------------------------ longest tiles first
-// A blend launch is a few rounds of tiles over the chip's workgroup slots, and its last, partial round lasts as long as
-// the longest tile in it.  Blocks are handed out in order, so each XCD band walks ITS tiles longest list first and the
-// tail of the launch is made of the shortest tiles.  Neutral on the uniform cfg1 scene (tile durations within +-10 %:
-// 1.168 vs 1.165 ms per step), -5 % / -11 % on the blend backward / forward of the cfg2 view, whose central tiles hold
-// twice the mean (3.50 -> 3.33 ms, 1.25 -> 1.11 ms including this kernel).  One workgroup per band: counting sort of the band's tiles by list length (1024 bins),
-// descending; ties and the order inside a bin follow LDS atomics -- it only schedules, results do not depend on it.
+// ------------------------------------------------------------------ longest tiles first, XCDs balanced
+// A blend launch is a few rounds of tiles over the chip's workgroup slots; blocks are handed out in order, round-robin
+// over the 8 XCDs.  Two things go wrong on a scene that is not uniform: the last, partial round lasts as long as the
+// longest tile in it, and with the contiguous bands of xcd_tile the XCDs of the image centre hold most of the work
+// while the others wait for their turn.  When the largest tile holds more than 1.5 x the mean the launcher runs this
+// kernel first: every XCD gets the tiles of 4x4-tile blocks dealt round-robin (xcd_of_tile) and walks them longest list
+// first.  One workgroup per XCD: counting sort of its tiles by list length (1024 bins), descending; ties and the order
+// inside a bin follow LDS atomics -- it only schedules, results do not depend on it.  The lists lie back to back in
+// `order` (the consumed tile_count array), their first entries in first[0..8]; *ordered = 1 tells the blend kernels.
+// Uniform cfg1 scene: not run (its 6 us would not be repaid: 1.168 vs 1.165 ms per step with it).
 __global__ void __launch_bounds__(1024)
-tile_order_kernel(int tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order, unsigned long long* __restrict__ ordered) {
+tile_order_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order,
+                  unsigned long long* __restrict__ ordered, unsigned long long* __restrict__ first) {
     __shared__ uint32_t hist[1024], start[1024], wsum[16];
-    __shared__ uint32_t s_max;
-    const int chunk = (tiles + NUM_XCD - 1) / NUM_XCD;
-    const int t0 = blockIdx.x * chunk, t1 = min(t0 + chunk, tiles);
+    __shared__ uint32_t s_max, cnt[NUM_XCD];
+    const int me = blockIdx.x;
     hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_max = 1;
+    if (threadIdx.x < NUM_XCD) cnt[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t mx = 0;
-    for (int t = t0 + threadIdx.x; t < t1; t += 1024) mx = max(mx, ranges[2 * t + 1] - ranges[2 * t]);
+    uint32_t mx = 0, mine[NUM_XCD] = {};
+    for (int t = threadIdx.x; t < tiles; t += 1024) {
+        const int x = xcd_of_tile(t, gx);
+#pragma unroll
+        for (int q = 0; q < NUM_XCD; ++q) mine[q] += x == q;
+        if (x == me) mx = max(mx, ranges[2 * t + 1] - ranges[2 * t]);
+    }
+#pragma unroll
+    for (int q = 0; q < NUM_XCD; ++q)
+        if (mine[q]) atomicAdd(&cnt[q], mine[q]);
     if (mx) atomicMax(&s_max, mx);
     __syncthreads();
+    uint32_t off = 0;
+    for (int q = 0; q < me; ++q) off += cnt[q];
     const float scale = 1023.0f / (float)s_max;
-    for (int t = t0 + threadIdx.x; t < t1; t += 1024) {
+    for (int t = threadIdx.x; t < tiles; t += 1024) {
+        if (xcd_of_tile(t, gx) != me) continue;
         const uint32_t n = ranges[2 * t + 1] - ranges[2 * t];
         atomicAdd(&hist[1023 - min(1023u, (uint32_t)((float)n * scale))], 1u);      // bin 0 = the longest lists
     }
@@ -96,18 +101,36 @@ tile_order_kernel(int tiles, const uint32_t* __restrict__ ranges, uint32_t* __re
         start[threadIdx.x] = base + inc - v;
     }
     __syncthreads();
-    for (int t = t0 + threadIdx.x; t < t1; t += 1024) {
+    for (int t = threadIdx.x; t < tiles; t += 1024) {
+        if (xcd_of_tile(t, gx) != me) continue;
         const uint32_t n = ranges[2 * t + 1] - ranges[2 * t];
-        order[t0 + atomicAdd(&start[1023 - min(1023u, (uint32_t)((float)n * scale))], 1u)] = (uint32_t)t;
+        order[off + atomicAdd(&start[1023 - min(1023u, (uint32_t)((float)n * scale))], 1u)] = (uint32_t)t;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *ordered = 1;
+    if (threadIdx.x == 0) {
+        first[me] = off;
+        if (me == NUM_XCD - 1) first[NUM_XCD] = off + cnt[me];
+        if (me == 0) *ordered = 1;
+    }
+}
+
+// block -> tile of a blend launch: the XCD's list when the tiles were ordered, its contiguous band otherwise
+__device__ __forceinline__ int blend_tile(int slot, int tiles, const uint32_t* __restrict__ order,
+                                          const unsigned long long* __restrict__ total) {
+    const int xcd = slot % NUM_XCD, j = slot / NUM_XCD;
+    if (total[2]) {
+        const uint32_t f = (uint32_t)total[4 + xcd], e = (uint32_t)total[5 + xcd];
+        return f + j < e ? (int)order[f + j] : -1;
+    }
+    const int chunk = (tiles + NUM_XCD - 1) / NUM_XCD;
+    const int t = xcd * chunk + j;
+    return j < chunk && t < tiles ? t : -1;
 }
 
 // ------------------------------------------------------------------ forward
 constexpr int FCHUNK = 64;  // list entries examined per round (one per lane)
 
 __global__ void __launch_bounds__(64)
-blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const unsigned long long* __restrict__ ordered,
+blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const unsigned long long* __restrict__ total,
                      const uint32_t* __restrict__ ranges,
                      const uint32_t* __restrict__ point_list, const uint8_t* __restrict__ qmask,
                      const float4* __restrict__ rec, const float* __restrict__ bg,
@@ -117,9 +140,10 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
     // ds_read_b128 lands (field of splat 2q, field of splat 2q+1) in adjacent registers and the
     // per-pixel arithmetic runs as packed fp32 (v_pk_fma_f32 & co: two splats per instruction)
     __shared__ float4 sp[5][FCHUNK / 2];  // (mx,mx',my,my') (A,A',B,B') (C,C',o,o') (r,r',g,g') (b,b',j,j')
-    int t, quad;
-    if (!block_to_tile_quad(blockIdx.x, tiles, t, quad)) return;
-    if (*ordered) t = (int)order[t];
+    // the four quadrant waves of a tile are consecutive slots of one XCD
+    const int quad = (blockIdx.x / NUM_XCD) & 3;
+    const int t = blend_tile((int)(blockIdx.x % NUM_XCD + (blockIdx.x / (4 * NUM_XCD)) * NUM_XCD), tiles, order, total);
+    if (t < 0) return;
     const int lane = threadIdx.x;
     const int px = (t % gx) * TILE + (quad & 1) * 8 + (lane & 7);
     const int py = (t / gx) * TILE + (quad >> 1) * 8 + (lane >> 3);
@@ -406,7 +430,7 @@ constexpr int BCH = 64;  // list entries per round: one per lane of each wave
 constexpr int ACC_BUFS = SCR_BWD_ACC_BUFS;  // 2: per-round sums double-buffered (one barrier per round)
 
 __global__ void __launch_bounds__(256, SCR_BWD_MIN_WAVES)
-blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const unsigned long long* __restrict__ ordered,
+blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const unsigned long long* __restrict__ total,
                       const uint32_t* __restrict__ ranges,
                       const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ gm_index,
                       const uint8_t* __restrict__ qmask, const float4* __restrict__ rec,
@@ -423,9 +447,8 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     __shared__ float4 accA[ACC_BUFS][4][BCH], accB[ACC_BUFS][4][BCH];
     __shared__ float accC[ACC_BUFS][4][BCH];
     __shared__ uint32_t wave_max[4];
-    int t = xcd_tile(blockIdx.x, tiles);
+    const int t = blend_tile((int)blockIdx.x, tiles, order, total);
     if (t < 0) return;
-    if (*ordered) t = (int)order[t];
 #ifdef SCR_TILE_TIMING
     struct Stamp {
         int t;
@@ -625,23 +648,32 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
 }
 
 // ------------------------------------------------------------------ launchers
+// blocks per XCD that cover either mapping: the contiguous bands or the round-robin 4x4-tile blocks
+static int blend_slots_per_xcd(const Grid& g) {
+    int cnt[NUM_XCD] = {};
+    for (int t = 0; t < g.tiles; ++t) ++cnt[xcd_of_tile(t, g.gx)];
+    int m = (g.tiles + NUM_XCD - 1) / NUM_XCD;
+    for (int q = 0; q < NUM_XCD; ++q) m = cnt[q] > m ? cnt[q] : m;
+    return m;
+}
+
 void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
                           float* out_color, bool longest_first, hipStream_t st) {
     Grid g(ks.H, ks.W);
-    // gv.tile_count has been consumed by the plan scan: with longest_first it holds from here on the tiles of every XCD
-    // band, longest list first, and total[2] says so to this launch and to the backward one.  The caller asks for it
-    // when the largest tile holds more than 1.5 x the mean (the order kernel costs 6 us that a uniform scene cannot repay)
-    if (longest_first) tile_order_kernel<<<NUM_XCD, 1024, 0, st>>>(g.tiles, gv.ranges, gv.tile_count, gv.total + 2);
-    blend_forward_kernel<<<(unsigned)xcd_grid(g.tiles) * 4, 64, 0, st>>>(
-        ks.W, ks.H, g.gx, g.tiles, gv.tile_count, gv.total + 2, gv.ranges, bv.point_list, bv.qmask, gv.rec, ks.bg, out_color, iv.final_T,
+    // gv.tile_count has been consumed by the plan scan: with longest_first it holds from here on every XCD's tiles,
+    // longest list first, and total[2] says so to this launch and to the backward one
+    if (longest_first)
+        tile_order_kernel<<<NUM_XCD, 1024, 0, st>>>(g.tiles, g.gx, gv.ranges, gv.tile_count, gv.total + 2, gv.total + 4);
+    blend_forward_kernel<<<(unsigned)blend_slots_per_xcd(g) * NUM_XCD * 4, 64, 0, st>>>(
+        ks.W, ks.H, g.gx, g.tiles, gv.tile_count, gv.total, gv.ranges, bv.point_list, bv.qmask, gv.rec, ks.bg, out_color, iv.final_T,
         iv.n_contrib);
 }
 
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
                            const float* dL_dcolor, GradRec* grad_rec, hipStream_t st) {
     Grid g(ks.H, ks.W);
-    blend_backward_kernel<<<(unsigned)xcd_grid(g.tiles), 256, 0, st>>>(
-        ks.W, ks.H, g.gx, g.tiles, gv.tile_count, gv.total + 2, gv.ranges, bv.point_list, bv.gm_index, bv.qmask, gv.rec, ks.bg, iv.final_T,
+    blend_backward_kernel<<<(unsigned)blend_slots_per_xcd(g) * NUM_XCD, 256, 0, st>>>(
+        ks.W, ks.H, g.gx, g.tiles, gv.tile_count, gv.total, gv.ranges, bv.point_list, bv.gm_index, bv.qmask, gv.rec, ks.bg, iv.final_T,
         iv.n_contrib, dL_dcolor, grad_rec);
 }
 

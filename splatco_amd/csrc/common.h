@@ -50,7 +50,8 @@ struct GeomView {
     uint32_t* tile_count;     // [tiles] instances per tile (preprocess -> plan scan); afterwards the blend launches' tile order
     uint32_t* ranges;         // [tiles][2] (start, end)
     uint32_t* cursor;         // [tiles]
-    unsigned long long* total;  // [3] number of instances, largest per-tile instance count, 1 = tile_count holds the blend tile order
+    unsigned long long* total;  // [16] number of instances, largest per-tile instance count, [2] 1 = tile_count holds the blend tile
+                                //      order, [4..12] first entry of every XCD's list in it
     size_t bytes;
 };
 
@@ -70,7 +71,7 @@ inline __host__ GeomView geom_view(void* base, int64_t P, int H, int W) {
     v.tile_count = (uint32_t*)take((size_t)g.tiles * 4);
     v.ranges = (uint32_t*)take((size_t)g.tiles * 8);
     v.cursor = (uint32_t*)take((size_t)g.tiles * 4);
-    v.total = (unsigned long long*)take(32);
+    v.total = (unsigned long long*)take(128);
     v.bytes = off;
     return v;
 }
@@ -187,6 +188,13 @@ __device__ inline int xcd_tile(int block, int tiles) {
     return t < tiles ? t : -1;
 }
 inline __host__ int xcd_grid(int tiles) { return ((tiles + NUM_XCD - 1) / NUM_XCD) * NUM_XCD; }
+// XCD of a tile when the scene is not uniform (tile_order_kernel): 4x4-tile blocks dealt round-robin, so that every XCD
+// gets the same mix of dense and sparse image regions (the contiguous bands of xcd_tile leave the XCDs of the image
+// centre with most of the work, and blocks are dealt to the XCDs in turn: the launch runs at the pace of the slowest)
+__host__ __device__ inline int xcd_of_tile(int t, int gx) {
+    const int tx = t % gx, ty = t / gx;
+    return ((tx >> 2) + (ty >> 2) * ((gx + 3) >> 2)) % NUM_XCD;
+}
 
 // Conservative sub-tile culling.  A 16x16 tile is blended by four waves, one per 8x8-pixel
 // quadrant (bit q = (y half << 1) | x half).  Bit q is CLEARED only when no pixel of the quadrant
