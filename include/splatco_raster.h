@@ -162,7 +162,7 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
  * The points' coordinates and gradient pieces are first moved into per-tile runs of records (32x32-cell tiles), then
  * summed per node in registers; the order of the points inside a cell follows LDS / global atomics and the nodes on a
  * tile's border are flushed with global float atomics -- plane gradients are therefore reproducible only up to the
- * order of those adds, unlike every other output of this library.  R <= 8; scratch from
+ * order of those adds, unlike every other output of this library.  R <= 16 (with planes = 2: two passes above R = 5); scratch from
  * scr_plane_sample_scratch_bytes(V, A, B, R * planes).  The sample positions get no gradient (the reference detaches
  * them, scene/gaussian_model.py:210).
  *

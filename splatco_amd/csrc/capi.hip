@@ -389,7 +389,7 @@ int scr_plane_sample_backward(int64_t V, const float* coords, int32_t cstride, i
     { ProfScope ps_(SCR_PROF_PLANE_BACKWARD, st);
       rc = launch_plane_sample_backward(V, coords, cstride, cx, cy, R, A, B, planes, grad_out0, grad_out1, ld, grad_plane0,
                                         grad_plane1, scratch, st); }
-    if (rc == 1) return fail("R = %d channels per plane exceeds the supported 8", R);
+    if (rc == 1) return fail("R = %d channels per plane exceeds the supported 16", R);
     if (rc == 2) return fail("plane %dx%d has too many 32x32 tiles for the LDS histogram", A, B);
     CHECK_LAUNCH("plane_sample_backward", 0, st);
     return 0;
@@ -414,7 +414,7 @@ int scr_triplane_backward(int64_t V, const float* coords, int32_t cstride, int32
     int rc;
     { ProfScope ps_(SCR_PROF_PLANE_BACKWARD, st);
       rc = launch_triplane_backward(V, coords, cstride, R, X, Y, Z, planes, grad_out, ld, cols, grad_planes, scratch, st); }
-    if (rc == 1) return fail("R = %d channels per plane exceeds the supported 8", R);
+    if (rc == 1) return fail("R = %d channels per plane exceeds the supported 16", R);
     if (rc == 2) return fail("a plane of %dx%dx%d has too many 32x32 tiles for the LDS histogram", X, Y, Z);
     CHECK_LAUNCH("triplane_backward", 0, st);
     return 0;
@@ -431,7 +431,7 @@ int scr_triplane_forward(int64_t V, const float* coords, int32_t cstride, const 
     int rc;
     { ProfScope ps_(SCR_PROF_TRIPLANE_FORWARD, st);
       rc = launch_triplane_forward(V, coords, cstride, xy, xz, yz, R, X, Y, Z, channel_last, out, ld, col_xy, col_xz, col_yz, st); }
-    if (rc == 1) return fail("R = %d channels per plane exceeds the supported 8", R);
+    if (rc == 1) return fail("R = %d channels per plane exceeds the supported 16", R);
     CHECK_LAUNCH("triplane_forward_kernel", 0, st);
     return 0;
 }

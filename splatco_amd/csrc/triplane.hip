@@ -27,7 +27,7 @@ namespace scr {
 #endif
 constexpr int TP_TILE = SCR_TP_TILE;   // cells per tile edge; a tile owns (TP_TILE + 1)^2 nodes
 constexpr int TP_NODES = TP_TILE + 1;
-constexpr int TP_MAX_R = 8;            // channels per plane supported by the LDS tile (R = num_channels / 3)
+constexpr int TP_MAX_R = 16;           // channels per plane (R = num_channels / 3; a plain plane stacked on its attended twin: 2 R)
 constexpr int TP_THREADS = 1024;
 constexpr int TP_ROUNDS = 4;
 constexpr int TP_PER_WG = TP_THREADS * TP_ROUNDS;
@@ -160,13 +160,13 @@ __device__ __forceinline__ void tp_load_span(const float* __restrict__ p, float 
     constexpr int K0 = (H & 1) && SPAN >= 1 ? 1 : 0;
     constexpr int K1 = K0 + (((H & 2) && SPAN - K0 >= 2) ? 2 : 0);
     constexpr int KT = K1 + (SPAN - K1) / 4 * 4;
-    if (K0) g[0] = p[0];
-    if (K1 > K0) {
+    if constexpr (K0 != 0) g[0] = p[0];
+    if constexpr (K1 > K0) {
         const float2 v = *(const float2*)(p + K0);
         g[K0] = v.x;
         g[K0 + 1] = v.y;
     }
-    if (K1 == H) {
+    if constexpr (K1 == H) {
 #pragma unroll
         for (int k = K1; k < KT; k += 4) {
             const float4 v = *(const float4*)(p + k);
@@ -179,12 +179,12 @@ __device__ __forceinline__ void tp_load_span(const float* __restrict__ p, float 
 #pragma unroll
         for (int k = K1; k < KT; ++k) g[k] = p[k];
     }
-    if (SPAN - KT >= 2) {
+    if constexpr (SPAN - KT >= 2) {
         const float2 v = *(const float2*)(p + KT);
         g[KT] = v.x;
         g[KT + 1] = v.y;
     }
-    if ((SPAN - KT) & 1) g[SPAN - 1] = p[SPAN - 1];
+    if constexpr (((SPAN - KT) & 1) != 0) g[SPAN - 1] = p[SPAN - 1];
 }
 
 // FAST: three projections whose gradient blocks lie side by side in projection order (projection q, plane s at column
@@ -289,8 +289,13 @@ constexpr int tpn_chunk() {   // points per round: a multiple of 256 whose recor
     return c > 2048 ? 2048 : c;
 }
 template <int RT>
-constexpr size_t tpn_lds_bytes() {              // cnt, start, waves, order, records (or the node image at the end)
-    return (size_t)TPN_CELLS * 4 + (TPN_CELLS + 4) * 4 + 64 + (size_t)tpn_chunk<RT>() * 2 + (size_t)tpn_chunk<RT>() * tp_rec(RT) * 4;
+constexpr size_t tpn_raw_floats() {             // the chunk's records; the node image at the end reuses the space
+    return (size_t)tpn_chunk<RT>() * tp_rec(RT) > (size_t)(TP_NODES * TP_NODES) * RT ? (size_t)tpn_chunk<RT>() * tp_rec(RT)
+                                                                                      : (size_t)(TP_NODES * TP_NODES) * RT;
+}
+template <int RT>
+constexpr size_t tpn_lds_bytes() {              // cnt, start, waves, order, records / node image
+    return (size_t)TPN_CELLS * 4 + (TPN_CELLS + 4) * 4 + 64 + (size_t)tpn_chunk<RT>() * 2 + tpn_raw_floats<RT>() * 4;
 }
 
 template <int R, int NP>
@@ -300,7 +305,6 @@ tp_cell_gather_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_st
     constexpr int RT = R * NP, REC = tp_rec(RT);
     constexpr int CHUNK = tpn_chunk<RT>();
     constexpr int PPT = (CHUNK + TPN_THREADS - 1) / TPN_THREADS;
-    static_assert(CHUNK * REC >= TPN_NODES * RT, "the node image reuses the record buffer");
     extern __shared__ __attribute__((aligned(16))) unsigned char tpn_lds[];
     uint32_t* cnt = (uint32_t*)tpn_lds;                       // [TPN_CELLS]
     uint32_t* start = cnt + TPN_CELLS;                        // [TPN_CELLS + 1] (+ 3 pad)
@@ -517,7 +521,7 @@ int launch_triplane_forward(int64_t V, const float* coords, int cs, const float*
                                                                    col_xz, col_yz);                              \
         break;
     switch (R) {
-        SCR_TP_FWD(1) SCR_TP_FWD(2) SCR_TP_FWD(3) SCR_TP_FWD(4) SCR_TP_FWD(5) SCR_TP_FWD(6) SCR_TP_FWD(7) SCR_TP_FWD(8)
+        SCR_TP_FWD(1) SCR_TP_FWD(2) SCR_TP_FWD(3) SCR_TP_FWD(4) SCR_TP_FWD(5) SCR_TP_FWD(6) SCR_TP_FWD(7) SCR_TP_FWD(8) SCR_TP_FWD(9) SCR_TP_FWD(10) SCR_TP_FWD(11) SCR_TP_FWD(12) SCR_TP_FWD(13) SCR_TP_FWD(14) SCR_TP_FWD(15) SCR_TP_FWD(16)
     }
 #undef SCR_TP_FWD
     return 0;
@@ -619,7 +623,7 @@ static int tp_backward(int64_t V, const float* coords, int cs, int R, int planes
         if (planes == 2) tp_backward_launch<(RR <= 5 ? RR : 1), 2>(V, coords, cs, grad, ld, one, gp0 + q, gp1 + q, st); \
         else tp_backward_launch<RR, 1>(V, coords, cs, grad, ld, one, gp0 + q, gp1 + q, st);              \
         break;
-            switch (R) { SCR_TP_ONE(1) SCR_TP_ONE(2) SCR_TP_ONE(3) SCR_TP_ONE(4) SCR_TP_ONE(5) SCR_TP_ONE(6) SCR_TP_ONE(7) SCR_TP_ONE(8) }
+            switch (R) { SCR_TP_ONE(1) SCR_TP_ONE(2) SCR_TP_ONE(3) SCR_TP_ONE(4) SCR_TP_ONE(5) SCR_TP_ONE(6) SCR_TP_ONE(7) SCR_TP_ONE(8) SCR_TP_ONE(9) SCR_TP_ONE(10) SCR_TP_ONE(11) SCR_TP_ONE(12) SCR_TP_ONE(13) SCR_TP_ONE(14) SCR_TP_ONE(15) SCR_TP_ONE(16) }
 #undef SCR_TP_ONE
         }
         return 0;
@@ -629,7 +633,7 @@ static int tp_backward(int64_t V, const float* coords, int cs, int R, int planes
         if (planes == 2) tp_backward_launch<(RR <= 5 ? RR : 1), 2>(V, coords, cs, grad, ld, ps, gp0, gp1, st); \
         else tp_backward_launch<RR, 1>(V, coords, cs, grad, ld, ps, gp0, gp1, st);                       \
         break;
-    switch (R) { SCR_TP_BWD(1) SCR_TP_BWD(2) SCR_TP_BWD(3) SCR_TP_BWD(4) SCR_TP_BWD(5) SCR_TP_BWD(6) SCR_TP_BWD(7) SCR_TP_BWD(8) }
+    switch (R) { SCR_TP_BWD(1) SCR_TP_BWD(2) SCR_TP_BWD(3) SCR_TP_BWD(4) SCR_TP_BWD(5) SCR_TP_BWD(6) SCR_TP_BWD(7) SCR_TP_BWD(8) SCR_TP_BWD(9) SCR_TP_BWD(10) SCR_TP_BWD(11) SCR_TP_BWD(12) SCR_TP_BWD(13) SCR_TP_BWD(14) SCR_TP_BWD(15) SCR_TP_BWD(16) }
 #undef SCR_TP_BWD
     return 0;
 }

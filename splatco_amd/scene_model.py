@@ -259,7 +259,7 @@ class PlaneGrid(nn.Module):                   # scene/grids.py:102-201
         return self.channels * 2 if self.TAflag else self.channels
 
     def fused_ok(self, xyz):
-        return self.xy_plane.is_cuda and self.channels // 3 <= 8 and not xyz.requires_grad    # csrc/triplane.hip
+        return self.xy_plane.is_cuda and self.channels // 3 <= 8 and not xyz.requires_grad    # csrc/triplane.hip (2 R <= 16)
 
     def sample_spec(self, xyz, col0=0):
         """(ind [V,3], planes, first output column of every plane) for triplane.multi_triplane_sample: what
@@ -270,9 +270,11 @@ class PlaneGrid(nn.Module):                   # scene/grids.py:102-201
             return ind3, (self.xy_plane, self.xz_plane, self.yz_plane), tuple(col0 + R * j for j in range(3))
         tri = self.TA(torch.cat((self.xy_plane, self.xz_plane, self.yz_plane), dim=1))   # every call (:166-168)
         xyA, xzA, yzA = torch.chunk(tri, 3, dim=1)
-        # column order of :181: xy, xyA, xz, xzA, yz, yzA
-        return ind3, (self.xy_plane, self.xz_plane, self.yz_plane, xyA, xzA, yzA), \
-            tuple(col0 + c for c in (0, 2 * R, 4 * R, R, 3 * R, 5 * R))
+        # column order of :181: xy, xyA, xz, xzA, yz, yzA -- a plane and its attended twin are sampled at the same
+        # positions and land side by side, so each pair is stacked into ONE plane of 2 R channels: half the random
+        # cache lines per sample (the channel-last rows of the pair are adjacent), one launch instead of two
+        return ind3, (torch.cat((self.xy_plane, xyA), dim=1), torch.cat((self.xz_plane, xzA), dim=1),
+                      torch.cat((self.yz_plane, yzA), dim=1)), tuple(col0 + 2 * R * j for j in range(3))
 
     def forward(self, xyz, Q=0):
         shape = xyz.shape[:-1]

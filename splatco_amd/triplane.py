@@ -108,7 +108,7 @@ def multi_triplane_sample(grids):
 
 
 def triplane_sample(ind, planes, cols=None):
-    """ind [V,3] in [-1,1] (detached); planes: 3 or 6 tensors (xy, xz, yz[, xyA, xzA, yzA]), R <= 8 channels each.
+    """ind [V,3] in [-1,1] (detached); planes: 3 or 6 tensors (xy, xz, yz[, xyA, xzA, yzA]), R <= 16 channels each.
     Returns [V, len(planes)*R]; plane j occupies columns cols[j] .. cols[j]+R (default: in the order given)."""
     R = planes[0].shape[1]
     if cols is None:
