@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 METRIC = "rasterizer fwd+bwd Msplats/s @1080p; PSNR-match vs ref"
 P_CFG1, W_CFG1, H_CFG1 = 1_000_000, 1920, 1080
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32 / 32x32x2_f32, f32 in / f32 accumulate (MI355X_MICROARCH.md; 155 measured)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md (datasheet; a float4 copy reaches ~6.3 TB/s)
 XGMI_LINK_GBS = 153.0
 
@@ -74,6 +75,14 @@ def algorithmic_bytes(kernel, P, I, npix, extra=None):
         "norm_linear_backward_kernels": 4 * V * (2 * (60 + 71) + 2 * 2 * 32 + (60 + 71)),
     }
     return float(table.get(kernel, 0))
+
+
+def algorithmic_flops(kernel, V):
+    """fp32-MFMA work of the kernels that are bound by it: MFMA instructions per 16-anchor tile x 2048 flop
+    (v_mfma_f32_16x16x4_f32), counted from the kernel's loops (csrc/mlp_heads.hip): forward 25 k-steps x 6 hidden tiles
+    + 24 k-steps x 7 output tiles = 318; backward dH 168 + dX 168 + dW2 168 + dW1 168 = 672."""
+    per_tile = {"mlp_heads_kernel": 318, "mlp_heads_backward_kernel": 672}.get(kernel)
+    return None if per_tile is None else per_tile * 2048.0 * ((V + 15) // 16)
 
 
 # ------------------------------------------------------------------ launch
@@ -213,7 +222,7 @@ def pick_dominant(warm_prof):
     return (max(per_step, key=per_step.get) if per_step else "blend_backward_kernel"), kern
 
 
-def roofline_object(dom, avg_ms, ab, peak_measured, note):
+def roofline_object(dom, avg_ms, ab, peak_measured, note, flops=None):
     achieved = ab / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC-derived bytes per launch, if measured
@@ -223,6 +232,13 @@ def roofline_object(dom, avg_ms, ab, peak_measured, note):
            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": ab,
            "avg_launch_ms": avg_ms, "peak_measured": peak_measured,
            "frac_of_measured": (achieved / peak_measured) if peak_measured else None, "note": note}
+    if flops:      # a kernel whose floor is the matrix pipe, not HBM: the roofline that bounds it (the HBM view stays beside it)
+        tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms else 0.0
+        out.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / MFMA_F32_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops,
+                    "hbm_view": {"achieved_GBps": achieved, "frac": achieved / HBM_PEAK_GBS,
+                                 "frac_of_measured": (achieved / peak_measured) if peak_measured else None}})
+        out.pop("frac_of_measured", None)
     vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
     if os.path.exists(vpath):
         n_inst = json.load(open(vpath)).get(dom)
@@ -502,14 +518,17 @@ def run_anchor_config(args, rank, world, dev):
             "anchor_path_Manchors_per_s": N / (step_s * 1e3 - ras_f - ras_b) / 1e3 if not train else None,
         },
         "roofline": roofline_object(dominant, kern.get(dominant, 0.0), ab, peak,
-                                    "dominant among this library's kernel classes by time per step; the rocBLAS GEMMs of "
-                                    "the anchor path are outside these classes"),
+                                    "dominant among this library's kernel classes by time per step",
+                                    flops=algorithmic_flops(dominant, V)),
         "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(warm_step_ms.items(), key=lambda kv: -kv[1])},
         # every kernel class of this library against ITS byte model (per step, all launches of the class)
         "kernel_rooflines": {k: {"ms_per_step": round(ms, 4),
                                  "algorithmic_MB_per_step": round(algorithmic_bytes(k, P1, I, W * H, extra) / 1e6, 1),
                                  "GBps": round(algorithmic_bytes(k, P1, I, W * H, extra) / (ms * 1e-3) / 1e9, 1),
-                                 "frac_of_measured_peak": round(algorithmic_bytes(k, P1, I, W * H, extra) / (ms * 1e-3) / 1e9 / peak, 3)}
+                                 "frac_of_measured_peak": round(algorithmic_bytes(k, P1, I, W * H, extra) / (ms * 1e-3) / 1e9 / peak, 3),
+                                 **({"mfma_TFLOPs": round(algorithmic_flops(k, V) / (ms * 1e-3) / 1e12, 1),
+                                     "frac_of_f32_mfma_peak": round(algorithmic_flops(k, V) / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 3)}
+                                    if algorithmic_flops(k, V) else {})}
                              for k, ms in sorted(warm_step_ms.items(), key=lambda kv: -kv[1]) if ms > 0},
         "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
     }

@@ -239,7 +239,11 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
     // dZ = upstream gradient x activation derivative, in B-operand layout (lane (n, g): outputs 16 q + 4 g + t), and the
     // saved hidden layer of one tile.  Software pipeline: the loads of tile i+1 are issued in the middle of tile i,
     // into the registers of dz / h that have just died (one wave per SIMD: nobody else would hide the latency).
-    f4 dz[MH_OT], h[MH_MT];
+    // load_tile only ISSUES the loads (raw upstream gradients ru, raw outputs ry of the two heads with an activation,
+    // hidden layer h); the activation derivatives are applied at the top of the next iteration (finish_tile).  Doing the
+    // arithmetic inside load_tile made the compiler wait for every load pair right there -- ten exposed memory
+    // latencies per tile with one wave per SIMD, as much time as all the MFMAs of the tile.
+    f4 dz[MH_OT], h[MH_MT], ru[MH_OT], ry[3];
     auto load_tile = [&](int64_t tile) {
         const int64_t v = tile * 16 + n;
         const bool valid = v < V;
@@ -249,31 +253,41 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
 #pragma unroll
             for (int t = 0; t < 4; t += 2) {     // rows are 8-byte aligned and the output counts even: float2 loads
                 const int col = 16 * (q - ot0) + 4 * g + t;
-                float2 d = make_float2(0.0f, 0.0f);
+                float2 u = make_float2(0.0f, 0.0f), y = make_float2(0.0f, 0.0f);
                 if (valid) {
                     if (head == 0) {
-                        if (col < MH_NO) {
-                            const float2 y = *(const float2*)(out_o + v * MH_NO + col), u = *(const float2*)(g_o + v * MH_NO + col);
-                            d = make_float2(u.x * (1.0f - y.x * y.x), u.y * (1.0f - y.y * y.y));
-                        }
+                        if (col < MH_NO) { y = *(const float2*)(out_o + v * MH_NO + col); u = *(const float2*)(g_o + v * MH_NO + col); }
                     } else if (head == 1) {
-                        if (col < MH_NC) {
-                            const float2 y = *(const float2*)(out_c + v * MH_NC + col), u = *(const float2*)(g_c + v * MH_NC + col);
-                            d = make_float2(u.x * (y.x * (1.0f - y.x)), u.y * (y.y * (1.0f - y.y)));
-                        }
+                        if (col < MH_NC) { y = *(const float2*)(out_c + v * MH_NC + col); u = *(const float2*)(g_c + v * MH_NC + col); }
                     } else if (col < MH_NV) {
-                        d = *(const float2*)(g_v + v * MH_NV + col);
+                        u = *(const float2*)(g_v + v * MH_NV + col);
                     }
                 }
-                dz[q][t] = d.x;
-                dz[q][t + 1] = d.y;
+                ru[q][t] = u.x;
+                ru[q][t + 1] = u.y;
+                if (q < 3) {
+                    ry[q][t] = y.x;
+                    ry[q][t + 1] = y.y;
+                }
             }
         }
 #pragma unroll
-        for (int mt = 0; mt < MH_MT; ++mt) {
-            h[mt] = hidden_save[(tile * MH_MT + mt) * 64 + lane];
-            if (!valid) h[mt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int mt = 0; mt < MH_MT; ++mt) {     // predicated load, not load + select: a select would wait for the load here
+            f4 hv = f4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (valid) hv = hidden_save[(tile * MH_MT + mt) * 64 + lane];
+            h[mt] = hv;
         }
+    };
+    // dZ = upstream gradient x activation derivative (tanh: 1 - y^2, sigmoid: y (1 - y), none for the covariance head)
+    auto finish_tile = [&]() {
+#pragma unroll
+        for (int q = 0; q < MH_OT; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (q == 0) dz[q][t] = ru[q][t] * (1.0f - ry[q][t] * ry[q][t]);
+                else if (q < 3) dz[q][t] = ru[q][t] * (ry[q][t] * (1.0f - ry[q][t]));
+                else dz[q][t] = ru[q][t];
+            }
     };
     const int64_t tile0 = (int64_t)blockIdx.x * MH_WAVES + wave, tstep = (int64_t)gridDim.x * MH_WAVES;
     if (tile0 < tiles) load_tile(tile0);
@@ -281,6 +295,7 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
         const int64_t v = tile * 16 + n;
         const bool valid = v < V;
         const int64_t vc = valid ? v : V - 1;
+        finish_tile();
         // ---- stage dZ^T [output][anchor] and H^T [hidden][anchor] for the dW2 contraction over the anchors
 #pragma unroll
         for (int q = 0; q < MH_OT; ++q)
@@ -338,9 +353,7 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk)
             xb[2 + blk] = *(const f4*)((blk < 2 ? geo_a : geo_b) + vc * (MH_GEO / 2) + 16 * (blk & 1) + 4 * g);
-        const float ox = anchor[3 * vc] - cx, oy = anchor[3 * vc + 1] - cy, oz = anchor[3 * vc + 2] - cz;
-        const float inv = 1.0f / sqrtf((ox * ox + oy * oy) + oz * oz);
-        xb[6] = g == 0 ? f4{ox * inv, oy * inv, oz * inv, 1.0f} : f4{0.0f, 0.0f, 0.0f, 0.0f};
+        const float ax = anchor[3 * vc], ay = anchor[3 * vc + 1], az = anchor[3 * vc + 2];   // used after the dX MFMAs
         f4 dx[MH_KB];
 #pragma unroll
         for (int ft = 0; ft < MH_KB; ++ft) dx[ft] = f4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -354,6 +367,13 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
 #pragma unroll
                 for (int ft = 0; ft < MH_KB; ++ft) dx[ft] = mfma4(a[ft][r], dpre[mt][r], dx[ft]);
         }
+        // Nothing that needs one of the loads above may be scheduled before the 168 MFMAs above: vmcnt retires in order,
+        // so the first use waits for ALL of them (the compiler had hoisted this 1 / |o| arithmetic over the MFMAs: one
+        // exposed memory round trip per tile).
+        __builtin_amdgcn_sched_barrier(0);
+        const float ox = ax - cx, oy = ay - cy, oz = az - cz;
+        const float inv = 1.0f / sqrtf((ox * ox + oy * oy) + oz * oz);
+        xb[6] = g == 0 ? f4{ox * inv, oy * inv, oz * inv, 1.0f} : f4{0.0f, 0.0f, 0.0f, 0.0f};
         if (valid) {
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) *(f4*)(d_feat + v * MH_FEAT + 16 * ft + 4 * g) = dx[ft];
