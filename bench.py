@@ -79,9 +79,9 @@ def algorithmic_bytes(kernel, P, I, npix, extra=None):
 
 def algorithmic_flops(kernel, V):
     """fp32-MFMA work of the kernels that are bound by it: MFMA instructions per 16-anchor tile x 2048 flop
-    (v_mfma_f32_16x16x4_f32), counted from the kernel's loops (csrc/mlp_heads.hip): forward 25 k-steps x 6 hidden tiles
-    + 24 k-steps x 7 output tiles = 318; backward dH 168 + dX 168 + dW2 168 + dW1 168 = 672."""
-    per_tile = {"mlp_heads_kernel": 318, "mlp_heads_backward_kernel": 672}.get(kernel)
+    (v_mfma_f32_16x16x4_f32), counted in the kernels' ISA (profiles/r02_isa_mix.txt): forward 28 k-steps x 6 hidden tiles
+    + 8 k-steps x 8 output tiles = 232; backward dH 64 + dW2 64 + dX 168 + dW1 168 = 464."""
+    per_tile = {"mlp_heads_kernel": 232, "mlp_heads_backward_kernel": 464}.get(kernel)
     return None if per_tile is None else per_tile * 2048.0 * ((V + 15) // 16)
 
 

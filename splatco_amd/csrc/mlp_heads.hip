@@ -291,6 +291,9 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
     };
     const int64_t tile0 = (int64_t)blockIdx.x * MH_WAVES + wave, tstep = (int64_t)gridDim.x * MH_WAVES;
     if (tile0 < tiles) load_tile(tile0);
+    // The phases of a tile are fenced with sched_barrier(0): left alone, the scheduler (one wave per SIMD, 500 registers)
+    // moves pieces of one phase into another and ends up 12 % slower than the fenced order (found with a phase-stamped
+    // build, tools/exp/mh_phase_probe.py: the stamps' fences alone made the kernel faster).
     for (int64_t tile = tile0; tile < tiles; tile += tstep) {
         const int64_t v = tile * 16 + n;
         const bool valid = v < V;
@@ -305,6 +308,7 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
         for (int mt = 0; mt < MH_MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sb[(16 * mt + 4 * g + r) * MH_AS + n] = h[mt][r];
+        __builtin_amdgcn_sched_barrier(0);
         // ---- dH^T = W2^T dZ^T per head; dPre = dH where the hidden unit was active
         f4 dpre[MH_MT];
 #pragma unroll
@@ -323,6 +327,7 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
         for (int mt = 0; mt < MH_MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) dpre[mt][r] = h[mt][r] > 0.0f ? dpre[mt][r] : 0.0f;
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's staging writes have landed (wave-private buffers)
         // ---- dW2[out][hidden] += dZ^T H ; db2[out] += sum over the anchors
 #pragma unroll
@@ -345,6 +350,7 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
             for (int c = 0; c < 16; c += 4) { const f4 x = *(const f4*)&row[c]; sum += (x[0] + x[1]) + (x[2] + x[3]); }
             db2[half] += sum;
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (tile + tstep < tiles) load_tile(tile + tstep);      // dz and h are dead from here on: next tile's loads
         // ---- dX^T = W1^T dPre^T -> d feat, d geo_fea, d ob_view
         f4 xb[MH_KB];
@@ -354,6 +360,7 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
         for (int blk = 0; blk < 4; ++blk)
             xb[2 + blk] = *(const f4*)((blk < 2 ? geo_a : geo_b) + vc * (MH_GEO / 2) + 16 * (blk & 1) + 4 * g);
         const float ax = anchor[3 * vc], ay = anchor[3 * vc + 1], az = anchor[3 * vc + 2];   // used after the dX MFMAs
+        __builtin_amdgcn_sched_barrier(0);
         f4 dx[MH_KB];
 #pragma unroll
         for (int ft = 0; ft < MH_KB; ++ft) dx[ft] = f4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -387,6 +394,7 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
                 d_anchor[3 * v + 2] = (dx[6][2] - uz * dot) * inv;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- dW1[hidden][k] += dPre^T X : restage (the dW2 reads above are done: same wave, program order)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -410,6 +418,7 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
                 for (int ft = 0; ft < MH_KB; ++ft) aW1[mt][ft] = mfma4(a[s], bx[ft][s], aW1[mt][ft]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads finished before the next tile's staging writes
+        __builtin_amdgcn_sched_barrier(0);
     }
     // ---- this wave's partial sums: accumulator (lane (j, gi), register r) = row 4 gi + r, column j of its 16x16 tile
     float* p = partial + ((size_t)blockIdx.x * MH_WAVES + wave) * MH_PART;
