@@ -325,8 +325,20 @@ tp_cell_gather_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_st
         const uint32_t n = min((uint32_t)CHUNK, hi - c0);
         cnt[c] = 0;
         {   // the chunk's records, as they lie in memory
+            // straight into LDS (global_load_lds_dwordx4: lane l of a wave lands at the wave's base + 16 l): all pieces
+            // of the chunk are in flight at once and no registers are involved -- a load -> ds_write loop served the
+            // pieces one memory round trip after the other (55 % of the kernel), and staging them in registers does not
+            // fit the 64 registers of two 1024-thread workgroups per CU
             const float4* src = (const float4*)(rec + (size_t)c0 * REC);
-            for (uint32_t w = threadIdx.x; w < n * (REC / 4); w += TPN_THREADS) ((float4*)raw)[w] = src[w];
+            constexpr int PIECES = (CHUNK * (REC / 4) + TPN_THREADS - 1) / TPN_THREADS;
+#pragma unroll
+            for (int k = 0; k < PIECES; ++k) {
+                const uint32_t w = threadIdx.x + (uint32_t)TPN_THREADS * k;
+                if (w < n * (REC / 4))
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + w),
+                                                     (__attribute__((address_space(3))) void*)((float4*)raw + (threadIdx.x & ~63u) + TPN_THREADS * k),
+                                                     16, 0, 0);
+            }
         }
         __syncthreads();
         // ---- this thread's points: cell and rank inside the cell; the coordinates become the bilinear fractions
