@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 10
+#define SCR_ABI_VERSION 11
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -200,13 +200,13 @@ int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, con
  * the four visible-anchor gathers, exp(_scaling) and the [V,71] concatenation in one pass.  visible_index[V] int64 = the
  * visible anchors in order; outputs feat[V,32], anchor[V,3], offsets[V,30], grid_scaling[V,6] = exp(scaling) and
  * g_fea[V,71] = cat of the four, with row stride g_fea_ld = 71 (packed) or 72 (16-byte aligned rows, the pad column
- * written as 0 / ignored on the way back: what the fused BatchNorm-Linear wants).  The backward takes inverse_index[N] int64 (row of every anchor, -1 = not visible) and
+ * written as 0 / ignored on the way back: what the fused BatchNorm-Linear wants).  The backward takes V (rows of the upstream gradients), inverse_index[N] int64 (row of every anchor, -1 = not visible) and
  * the upstream gradients of the five outputs (any may be NULL) and overwrites EVERY element of the four parameter
  * gradients [N,32] / [N,3] / [N,30] / [N,6] (zeros for invisible anchors; d exp applied): no atomics, no memset. */
 int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anchor_feat, const float* anchor,
                       const float* offset, const float* scaling, float* feat_out, float* anchor_out, float* offsets_out,
                       float* grid_scaling_out, float* g_fea_out, int32_t g_fea_ld, void* stream);
-int scr_anchor_gather_backward(int64_t N, const int64_t* inverse_index, const float* grid_scaling, const float* d_feat,
+int scr_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inverse_index, const float* grid_scaling, const float* d_feat,
                                const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                const float* d_g_fea, int32_t g_fea_ld, float* g_anchor_feat, float* g_anchor,
                                float* g_offset, float* g_scaling, void* stream);

@@ -52,7 +52,7 @@ class _AnchorGather(torch.autograd.Function):
         g_feat, g_anchor, g_offset, g_scaling = new(N, 32), new(N, 3), new(N, 10, 3), new(N, 6)
         if N:
             with torch.cuda.device(dev):
-                _C.check(_C.lib.scr_anchor_gather_backward(N, inv.data_ptr(), ptr(gs), ptr(d_feat), ptr(d_anc), ptr(d_off),
+                _C.check(_C.lib.scr_anchor_gather_backward(N, V, inv.data_ptr(), ptr(gs), ptr(d_feat), ptr(d_anc), ptr(d_off),
                                                            ptr(d_gs), ptr(d_g_fea), ldg, g_feat.data_ptr(), g_anchor.data_ptr(),
                                                            g_offset.data_ptr(), g_scaling.data_ptr(), _stream()))
         return None, g_feat, g_anchor, g_offset, g_scaling

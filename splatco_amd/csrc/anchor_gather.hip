@@ -58,24 +58,48 @@ anchor_gather_kernel(int64_t V, const int64_t* __restrict__ idx, const float* __
     const int rows = (int)min((int64_t)AG_ROWS, V - v0);
     if (threadIdx.x < AG_ROWS) rowsrc[threadIdx.x] = threadIdx.x < rows ? idx[v0 + threadIdx.x] : 0;
     __syncthreads();
-    // ---- gather: feat rows are 128 B (float4), offset rows 120 B and scaling rows 24 B (float2), anchor rows 12 B
-    for (int e = threadIdx.x; e < rows * 8; e += AG_THREADS) {
-        const int r = e >> 3, q = e & 7;
-        *(float4*)&tile[r * AG_LD + 4 * q] = *(const float4*)(p_feat + rowsrc[r] * AG_FEAT + 4 * q);
-    }
-    for (int e = threadIdx.x; e < rows * 15; e += AG_THREADS) {
-        const int r = e / 15, q = e - 15 * r;
-        const float2 x = *(const float2*)(p_offset + rowsrc[r] * AG_OFF + 2 * q);
-        tile[r * AG_LD + 35 + 2 * q] = x.x;
-        tile[r * AG_LD + 36 + 2 * q] = x.y;
-    }
-    for (int e = threadIdx.x; e < rows * 3; e += AG_THREADS) {
-        const int r = e / 3, q = e - 3 * r;
-        tile[r * AG_LD + 32 + q] = p_anchor[rowsrc[r] * 3 + q];
-        const float2 x = *(const float2*)(p_scaling + rowsrc[r] * 6 + 2 * q);
-        tile[r * AG_LD + 65 + 2 * q] = expf(x.x);        // get_scaling = exp(_scaling)
-        tile[r * AG_LD + 66 + 2 * q] = expf(x.y);
-        if (q == 0) tile[r * AG_LD + AG_COLS] = 0.0f;    // the pad column of 16-byte aligned g_fea rows (ldg = 72)
+    // ---- gather: feat rows are 128 B (float4), offset rows 120 B and scaling rows 24 B (float2), anchor rows 12 B.
+    // All eight loads of a thread are issued before the first LDS write, from clamped (always valid) rows and without a
+    // branch around them: as loops of `load -> LDS write` the compiler closed every iteration with s_waitcnt vmcnt(0),
+    // seven memory round trips one after the other per workgroup.
+    {
+        const int last = rows - 1;
+        float4 vf[2];
+        float2 vo[4], vs;
+        float va;
+        int rf[2], qf[2], ro[4], qo[4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = threadIdx.x + AG_THREADS * k;          // rows * 8 float4 pieces of the feature rows
+            rf[k] = e >> 3;
+            qf[k] = e & 7;
+            vf[k] = *(const float4*)(p_feat + rowsrc[min(rf[k], last)] * AG_FEAT + 4 * qf[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = threadIdx.x + AG_THREADS * k;          // rows * 15 float2 pieces of the offset rows
+            ro[k] = e / 15;
+            qo[k] = e - 15 * ro[k];
+            vo[k] = *(const float2*)(p_offset + rowsrc[min(ro[k], last)] * AG_OFF + 2 * qo[k]);
+        }
+        const int ra = threadIdx.x / 3, qa = threadIdx.x - 3 * ra;     // rows * 3: one anchor coordinate + two scalings
+        va = p_anchor[rowsrc[min(ra, last)] * 3 + qa];
+        vs = *(const float2*)(p_scaling + rowsrc[min(ra, last)] * 6 + 2 * qa);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (rf[k] < rows) *(float4*)&tile[rf[k] * AG_LD + 4 * qf[k]] = vf[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (ro[k] < rows) {
+                tile[ro[k] * AG_LD + 35 + 2 * qo[k]] = vo[k].x;
+                tile[ro[k] * AG_LD + 36 + 2 * qo[k]] = vo[k].y;
+            }
+        if (ra < rows) {
+            tile[ra * AG_LD + 32 + qa] = va;
+            tile[ra * AG_LD + 65 + 2 * qa] = expf(vs.x);        // get_scaling = exp(_scaling)
+            tile[ra * AG_LD + 66 + 2 * qa] = expf(vs.y);
+            if (qa == 0) tile[ra * AG_LD + AG_COLS] = 0.0f;     // the pad column of 16-byte aligned g_fea rows (ldg = 72)
+        }
     }
     __syncthreads();
     // ---- the workgroup's chunks of the five outputs are contiguous
@@ -86,27 +110,76 @@ anchor_gather_kernel(int64_t V, const int64_t* __restrict__ idx, const float* __
     ag_store_chunk(grid_scaling + v0 * 6, tile, rows * 6, 6, 65);
 }
 
-// loads `count` floats of a contiguous chunk starting at src (any 4-byte alignment: the chunk starts at the first
-// visible row of the workgroup) and ADDS them into the tile at (e / width, col0 + e % width)
-__device__ __forceinline__ void ag_add_chunk(const float* __restrict__ src, float* tile, int count, int width, int col0) {
-    if (!src) return;
-    auto add = [&](int e, float x) {
-        const int r = e / width, c = e - r * width;
-        tile[r * AG_LD + col0 + c] += x;
-    };
-    // scalars up to the first 16-byte boundary, float4s, scalars for the rest
-    const int head = min(count, (int)(((16u - (uint32_t)((uintptr_t)src & 15u)) & 15u) >> 2));
-    const int n4 = (count - head) >> 2;
-    if ((int)threadIdx.x < head) add(threadIdx.x, src[threadIdx.x]);
-    for (int q = threadIdx.x; q < n4; q += AG_THREADS) {
-        const float4 x = *(const float4*)(src + head + 4 * q);
-        add(head + 4 * q, x.x); add(head + 4 * q + 1, x.y); add(head + 4 * q + 2, x.z); add(head + 4 * q + 3, x.w);
+// A contiguous chunk of `count` upstream floats starting at src (any 4-byte alignment: it starts at the first visible row
+// of the workgroup), as 16-byte pieces from the aligned address below src: piece q holds chunk elements 4 q - h .. 4 q - h + 3
+// (h = floats between that address and src).  ISSUE and USE are separate: all pieces of all five chunks of a workgroup
+// are in flight before the first one is added into the LDS tile -- as `load -> LDS add` loops the compiler closed every
+// iteration with s_waitcnt vmcnt(0), ten memory round trips one after the other per workgroup.
+template <int NIT>
+struct AgPieces {
+    float4 v[NIT];
+    int h, count;
+};
+// TAIL: the aligned pieces may reach past the end of the tensor (its last rows only): element-wise, guarded
+template <int NIT, bool TAIL>
+__device__ __forceinline__ void ag_issue(const float* __restrict__ src, int count, const float* __restrict__ end, AgPieces<NIT>& p) {
+    p.count = src ? count : 0;
+    p.h = src ? (int)(((uintptr_t)src & 15u) >> 2) : 0;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) p.v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (!src) return;                                    // kernel argument: uniform
+    const float* base = src - p.h;
+    const int n4 = (p.h + count + 3) >> 2;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const float* a = base + 4 * min((int)threadIdx.x + AG_THREADS * k, n4 - 1);      // clamped: no branch around the load
+        if (!TAIL) p.v[k] = *(const float4*)a;
+        else {
+            if (a < end) p.v[k].x = a[0];
+            if (a + 1 < end) p.v[k].y = a[1];
+            if (a + 2 < end) p.v[k].z = a[2];
+            if (a + 3 < end) p.v[k].w = a[3];
+        }
     }
-    for (int e = head + 4 * n4 + threadIdx.x; e < count; e += AG_THREADS) add(e, src[e]);
+}
+// adds (STORE: writes) the chunk into the tile at (e / width, col0 + e % width)
+template <int NIT, bool STORE>
+__device__ __forceinline__ void ag_use(const AgPieces<NIT>& p, float* tile, int width, int col0) {
+    if (!p.count) return;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int e0 = 4 * ((int)threadIdx.x + AG_THREADS * k) - p.h;
+        const float x[4] = {p.v[k].x, p.v[k].y, p.v[k].z, p.v[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = e0 + j;
+            if (e >= 0 && e < p.count) {
+                const int r = e / width, c = e - r * width;
+                if (STORE) tile[r * AG_LD + col0 + c] = x[j];
+                else tile[r * AG_LD + col0 + c] += x[j];
+            }
+        }
+    }
+}
+
+struct AgUpstream {
+    AgPieces<5> gf;          // d g_fea: up to 64 rows x 72 floats = 1152 pieces + 1
+    AgPieces<3> feat, off;   // 512 + 1, 480 + 1
+    AgPieces<1> anc, gs;     // 48 + 1, 96 + 1
+};
+template <bool TAIL>
+__device__ __forceinline__ void ag_issue_all(AgUpstream& u, int64_t fv, int nv, int64_t V, int ldg, const float* __restrict__ d_g_fea,
+                                             const float* __restrict__ d_feat, const float* __restrict__ d_anchor,
+                                             const float* __restrict__ d_offsets, const float* __restrict__ d_grid_scaling) {
+    ag_issue<5, TAIL>(d_g_fea ? d_g_fea + fv * ldg : nullptr, nv * ldg, d_g_fea + V * ldg, u.gf);
+    ag_issue<3, TAIL>(d_feat ? d_feat + fv * AG_FEAT : nullptr, nv * AG_FEAT, d_feat + V * AG_FEAT, u.feat);
+    ag_issue<3, TAIL>(d_offsets ? d_offsets + fv * AG_OFF : nullptr, nv * AG_OFF, d_offsets + V * AG_OFF, u.off);
+    ag_issue<1, TAIL>(d_anchor ? d_anchor + fv * 3 : nullptr, nv * 3, d_anchor + V * 3, u.anc);
+    ag_issue<1, TAIL>(d_grid_scaling ? d_grid_scaling + fv * 6 : nullptr, nv * 6, d_grid_scaling + V * 6, u.gs);
 }
 
 __global__ void __launch_bounds__(AG_THREADS)
-anchor_gather_backward_kernel(int64_t N, const int64_t* __restrict__ inv, const float* __restrict__ grid_scaling,
+anchor_gather_backward_kernel(int64_t N, int64_t V, const int64_t* __restrict__ inv, const float* __restrict__ grid_scaling,
                               const float* __restrict__ d_feat, const float* __restrict__ d_anchor,
                               const float* __restrict__ d_offsets, const float* __restrict__ d_grid_scaling,
                               const float* __restrict__ d_g_fea, int ldg, float* __restrict__ g_feat,
@@ -134,16 +207,26 @@ anchor_gather_backward_kernel(int64_t N, const int64_t* __restrict__ inv, const 
     const int nv = nvis;
     if (nv) {
         const int64_t fv = first_v;
-        ag_add_chunk(d_g_fea ? d_g_fea + fv * ldg : nullptr, tile, nv * ldg, ldg, 0);   // (the pad column lands in tile column 71: unused)
+        AgUpstream u;
+        // the aligned 16-byte pieces of a chunk may start up to 12 bytes before it (inside the tensor: a chunk that starts
+        // the tensor is aligned) and end up to 12 bytes after it: only the workgroup holding the last visible rows can
+        // leave the tensor that way, and it takes the guarded element-wise path
+        if (fv + nv + 1 < V) ag_issue_all<false>(u, fv, nv, V, ldg, d_g_fea, d_feat, d_anchor, d_offsets, d_grid_scaling);
+        else ag_issue_all<true>(u, fv, nv, V, ldg, d_g_fea, d_feat, d_anchor, d_offsets, d_grid_scaling);
+        const float gsc = (int)threadIdx.x < nv * 6 ? grid_scaling[fv * 6 + threadIdx.x] : 0.0f;      // exp(s) of the rows, for d exp
+        const float gsc2 = (int)threadIdx.x + AG_THREADS < nv * 6 ? grid_scaling[fv * 6 + threadIdx.x + AG_THREADS] : 0.0f;
+        ag_use<5, false>(u.gf, tile, ldg, 0);            // (the pad column lands in tile column 71: unused)
         __syncthreads();   // the parts below add into the same cells
-        ag_add_chunk(d_feat ? d_feat + fv * AG_FEAT : nullptr, tile, nv * AG_FEAT, AG_FEAT, 0);
-        ag_add_chunk(d_anchor ? d_anchor + fv * 3 : nullptr, tile, nv * 3, 3, 32);
-        ag_add_chunk(d_offsets ? d_offsets + fv * AG_OFF : nullptr, tile, nv * AG_OFF, AG_OFF, 35);
-        ag_add_chunk(d_grid_scaling ? d_grid_scaling + fv * 6 : nullptr, tile, nv * 6, 6, 65);
+        ag_use<3, false>(u.feat, tile, AG_FEAT, 0);
+        ag_use<1, false>(u.anc, tile, 3, 32);
+        ag_use<3, false>(u.off, tile, AG_OFF, 35);
+        ag_use<1, false>(u.gs, tile, 6, 65);
         __syncthreads();
-        for (int e = threadIdx.x; e < nv * 6; e += AG_THREADS) {            // d exp(s) = exp(s) ds
-            const int r = e / 6, c = e - 6 * r;
-            tile[r * AG_LD + 65 + c] *= grid_scaling[(fv + r) * 6 + c];
+        {   // d exp(s) = exp(s) ds
+            const int e = threadIdx.x;
+            if (e < nv * 6) tile[(e / 6) * AG_LD + 65 + e % 6] *= gsc;
+            const int e2 = e + AG_THREADS;
+            if (e2 < nv * 6) tile[(e2 / 6) * AG_LD + 65 + e2 % 6] *= gsc2;
         }
         __syncthreads();
     }
@@ -168,13 +251,13 @@ void launch_anchor_gather(int64_t V, const int64_t* idx, const float* p_feat, co
         V, idx, p_feat, p_anchor, p_offset, p_scaling, feat, anchor, offsets, grid_scaling, g_fea, ldg);
 }
 
-void launch_anchor_gather_backward(int64_t N, const int64_t* inv, const float* grid_scaling, const float* d_feat,
+void launch_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inv, const float* grid_scaling, const float* d_feat,
                                    const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                    const float* d_g_fea, int ldg, float* g_feat, float* g_anchor, float* g_offset,
                                    float* g_scaling, hipStream_t st) {
     if (N <= 0) return;
     anchor_gather_backward_kernel<<<(unsigned)((N + AG_ROWS - 1) / AG_ROWS), AG_THREADS, 0, st>>>(
-        N, inv, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea, ldg, g_feat, g_anchor, g_offset, g_scaling);
+        N, V, inv, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea, ldg, g_feat, g_anchor, g_offset, g_scaling);
 }
 
 }  // namespace scr

@@ -314,7 +314,7 @@ void launch_statis_apply(int64_t V, int k, const int64_t* visible_index, const f
 void launch_anchor_gather(int64_t V, const int64_t* idx, const float* p_feat, const float* p_anchor, const float* p_offset,
                           const float* p_scaling, float* feat, float* anchor, float* offsets, float* grid_scaling,
                           float* g_fea, int ldg, hipStream_t st);
-void launch_anchor_gather_backward(int64_t N, const int64_t* inv, const float* grid_scaling, const float* d_feat,
+void launch_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inv, const float* grid_scaling, const float* d_feat,
                                    const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                    const float* d_g_fea, int ldg, float* g_feat, float* g_anchor, float* g_offset,
                                    float* g_scaling, hipStream_t st);
