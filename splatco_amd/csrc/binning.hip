@@ -440,14 +440,30 @@ __device__ __forceinline__ uint32_t merge_passes_needed(uint32_t n) {  // ceil(l
     return p;
 }
 
-// number of A-keys among the first s keys of merge(A[0..la), B[0..lb))
+// number of A-keys among the first s keys of merge(A[0..la), B[0..lb)): the smallest i in [lo, hi] for which
+// A[i] < B[s - i - 1] is false.  A WAVE searches: every step probes 64 evenly spaced positions at once and the ballot of
+// the (monotone) predicate narrows the range 65-fold -- three dependent memory round trips for a run pair of 2^17 keys
+// where a scalar bisection takes seventeen.
 __device__ __forceinline__ uint32_t merge_path_cut(const unsigned long long* __restrict__ A, uint32_t la,
                                                    const unsigned long long* __restrict__ B, uint32_t lb, uint32_t s) {
+    const uint32_t lane = threadIdx.x & 63;
     uint32_t lo = s > lb ? s - lb : 0u, hi = min(s, la);
     while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (A[mid] < B[s - mid - 1]) lo = mid + 1;
-        else hi = mid;
+        const uint32_t span = hi - lo;                                  // candidates lo .. hi-1 for "first false", else hi
+        // probe p_l = lo + floor(span * (l + 1) / 65), l = 0..63 (strictly inside [lo, hi) when span >= 65; for small
+        // spans the probes are lo + l, clamped)
+        const uint32_t p = span >= 65u ? lo + (uint32_t)(((unsigned long long)span * (lane + 1)) / 65u) : min(lo + lane, hi - 1);
+        const bool below = A[p] < B[s - p - 1];                         // true: the cut lies right of p
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(below);
+        const int c = __builtin_popcountll(bal);                        // monotone: the true lanes are the first c
+        // new range: right of the last true probe, up to the first false probe
+        const uint32_t plast = __shfl(p, c > 0 ? c - 1 : 0, 64), pfirst = __shfl(p, c < 64 ? c : 63, 64);
+        const uint32_t nlo = c > 0 ? plast + 1 : lo, nhi = c < 64 ? pfirst : hi;
+        if (span < 65u) {                                               // every candidate was probed
+            return c < (int)min(span, 64u) ? lo + (uint32_t)c : hi;
+        }
+        lo = nlo;
+        hi = nhi;
     }
     return lo;
 }
@@ -472,14 +488,29 @@ tile_merge_path_kernel(int tiles, int gx, uint32_t pass, const uint32_t* __restr
     const uint32_t s0 = e0 - pairbase, s1 = min(s0 + (uint32_t)WG_SORT_MAX, lenA + lenB);
     const unsigned long long* A = src + lo + pairbase;
     const unsigned long long* B = A + L;
-    if ((threadIdx.x & 63) == 0 && threadIdx.x < 128) {  // lane 0 of waves 0 and 1: the two cuts, concurrently
+    if (threadIdx.x < 128) {  // waves 0 and 1: the two cuts, concurrently
         const int w = threadIdx.x >> 6;
-        cut[w] = merge_path_cut(A, lenA, B, lenB, w ? s1 : s0);
+        const uint32_t cw = merge_path_cut(A, lenA, B, lenB, w ? s1 : s0);
+        if ((threadIdx.x & 63) == 0) cut[w] = cw;
     }
     __syncthreads();
     const uint32_t i0 = cut[0], na = cut[1] - i0, j0 = s0 - i0, nb = (s1 - s0) - na;
-    for (uint32_t e = threadIdx.x; e < na; e += 256) buf[e] = A[i0 + e];
-    for (uint32_t e = threadIdx.x; e < nb; e += 256) buf[na + e] = B[j0 + e];
+    {   // the segment's keys (na from run A, then nb from run B): all 16 loads of a thread in flight before the first LDS
+        // write, from clamped addresses and without a branch around them -- as `load -> LDS write` loops every iteration
+        // waited for its own load (sixteen memory round trips per workgroup: the pass ran at 28 % of the copy rate)
+        const uint32_t tot = na + nb;
+        unsigned long long v[WG_SORT_MAX / 256];
+#pragma unroll
+        for (int k = 0; k < WG_SORT_MAX / 256; ++k) {
+            const uint32_t e = min(threadIdx.x + 256u * k, tot - 1);          // tot >= 1: the segment exists
+            v[k] = e < na ? A[i0 + e] : B[j0 + (e - na)];
+        }
+#pragma unroll
+        for (int k = 0; k < WG_SORT_MAX / 256; ++k) {
+            const uint32_t e = threadIdx.x + 256u * k;
+            if (e < tot) buf[e] = v[k];
+        }
+    }
     __syncthreads();
     unsigned long long x[WG_SORT_MAX / 256];
     uint32_t pos[WG_SORT_MAX / 256];
