@@ -445,10 +445,29 @@ __global__ void __launch_bounds__(256)
 mlp_heads_reduce_kernel(int nparts, const float* __restrict__ partial, float* __restrict__ d_w1, float* __restrict__ d_b1,
                         float* __restrict__ d_w2o, float* __restrict__ d_b2o, float* __restrict__ d_w2c,
                         float* __restrict__ d_b2c, float* __restrict__ d_w2v, float* __restrict__ d_b2v) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= MH_PART) return;
+    // 32 outputs per workgroup x 8 groups of partials (group g takes partials g, g + 8, ...; eight loads in flight), the
+    // groups' sums added in group order: still one fixed order, but 0.03 instead of 0.24 ms for the 1024 partials of a
+    // full grid (one thread walking all of them was pure load latency)
+    __shared__ float red[8][32];
+    const int e = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+    float acc = 0.0f;
+    if (e < MH_PART) {
+        int p = grp;
+        for (; p + 56 < nparts; p += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(p + 8 * u) * MH_PART + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; p < nparts; p += 8) acc += partial[(size_t)p * MH_PART + e];
+    }
+    red[grp][threadIdx.x & 31] = acc;
+    __syncthreads();
+    if (threadIdx.x >= 32 || e >= MH_PART) return;
     float s = 0.0f;
-    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * MH_PART + e];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += red[q][threadIdx.x];
     const int n1 = MH_MT * 16 * MH_KB * 16, n2 = MH_OT * 16 * MH_HID;
     if (e < n1) {
         const int row = e / (MH_KB * 16), k = e % (MH_KB * 16);
@@ -502,7 +521,7 @@ void launch_mlp_heads_backward(int64_t V, const float* feat, const float* anchor
     mlp_heads_backward_kernel<<<grid, 64 * MH_WAVES, 0, st>>>(V, feat, anchor, campos, geo_a, geo_b, w, (const f4*)hidden_save,
                                                               out_o, out_c, g_o, g_c, g_v, d_feat, d_anchor, d_geo_a, d_geo_b,
                                                               (float*)partial);
-    mlp_heads_reduce_kernel<<<(MH_PART + 255) / 256, 256, 0, st>>>(grid * MH_WAVES, (const float*)partial, d_w1, d_b1, d_w2o,
+    mlp_heads_reduce_kernel<<<(MH_PART + 31) / 32, 256, 0, st>>>(grid * MH_WAVES, (const float*)partial, d_w1, d_b1, d_w2o,
                                                                   d_b2o, d_w2c, d_b2c, d_w2v, d_b2v);
 }
 
