@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 11
+#define SCR_ABI_VERSION 12
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -153,7 +153,9 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
  * of scene/grids.py:148-150 ((y,x), (z,x), (z,y)) and written to out[v*ld + col_xy/col_xz/col_yz + r], i.e.
  * straight into the concatenated feature matrix the reference builds with torch.cat (:165,:181).
  * channel_last = 0: planes in the reference's layout [R,A,B]; 1: caller passes [A,B,R] copies (one or two
- * cache lines per sampled row instead of R; pays off when the planes exceed the L2).
+ * cache lines per sampled row instead of R; pays off when the planes exceed the L2); 2: caller passes the row-pair
+ * layout [A-1,B,2,R] that scr_plane_row_pairs builds from [R,A,B] (the four corners of a sample are 4 R consecutive
+ * floats: 1.6 instead of 2.6 random cache lines per sample at R = 5; twice the plane's size).
  *
  * scr_plane_sample_backward: `planes` (1 or 2) planes [R,A,B] that are sampled at the same positions (the plain and
  * the attended plane of the attention grid, scene/grids.py:174-181) receive the scatter-add of the four corner weights
@@ -171,6 +173,7 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
  * array) holds the first column of xy, xz, yz and, with planes = 2, of the second triple sampled at the same
  * positions; grad_planes[3 * planes] (host array of device pointers, same order) are overwritten.  Scratch from
  * scr_triplane_backward_scratch_bytes(V, X, Y, Z, R * planes). */
+int scr_plane_row_pairs(int32_t R, int32_t A, int32_t B, const float* plane, float* pairs, void* stream);
 int scr_triplane_forward(int64_t V, const float* coords, int32_t cstride, const float* xy, const float* xz,
                          const float* yz, int32_t R, int32_t X, int32_t Y, int32_t Z, int32_t channel_last, float* out,
                          int32_t ld, int32_t col_xy, int32_t col_xz, int32_t col_yz, void* stream);

@@ -420,6 +420,14 @@ int scr_triplane_backward(int64_t V, const float* coords, int32_t cstride, int32
     return 0;
 }
 
+int scr_plane_row_pairs(int32_t R, int32_t A, int32_t B, const float* plane, float* pairs, void* stream) {
+    if (A < 2 || B < 2) return fail("bad sizes");
+    if (!plane || !pairs) return fail("NULL argument");
+    if (launch_plane_row_pairs(R, A, B, plane, pairs, (hipStream_t)stream)) return fail("R = %d channels per plane exceeds the supported 16", R);
+    CHECK_LAUNCH("plane_row_pairs_kernel", 0, (hipStream_t)stream);
+    return 0;
+}
+
 int scr_triplane_forward(int64_t V, const float* coords, int32_t cstride, const float* xy, const float* xz,
                          const float* yz, int32_t R, int32_t X, int32_t Y, int32_t Z, int32_t channel_last, float* out,
                          int32_t ld, int32_t col_xy, int32_t col_xz, int32_t col_yz, void* stream) {

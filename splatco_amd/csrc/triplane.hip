@@ -2,6 +2,8 @@
 //
 // Forward: one thread per anchor samples all three planes and writes its 3*R features as one
 // contiguous row segment of the caller's [V, ld] matrix (no per-plane outputs, no concatenation).
+// For many points the planes are first rewritten as row pairs (plane_row_pairs_kernel, tp_sample_plane_rp): the
+// forward is bound by the number of random cache lines it requests, and a sample's four corners are then contiguous.
 //
 // PlaneGrid samples three learnable planes [1,R,A,B] at V anchor positions with
 // F.grid_sample(bilinear, align_corners=True, zeros padding) (scene/grids.py:146-182).  The
@@ -496,7 +498,34 @@ __device__ __forceinline__ void tp_sample_plane_cl(const float* __restrict__ pla
     for (int r = 0; r < R; ++r) out[r] = ((v0[r] * w00 + v0[R + r] * w01) + v1[r] * w10) + v1[R + r] * w11;
 }
 
-template <int R, bool CL>
+// row-pair planes [A-1][B][2][R]: entry (a, b) holds the texels (a, b) and (a + 1, b), so the four corners of a sample are
+// 4 R consecutive floats -- one gather of 80 bytes (R = 5) instead of two of 40 bytes 14 KB apart: 1.6 instead of 2.6
+// cache lines per sample.  The caller builds the layout (twice the plane's size) next to the channel-last copy.
+template <int R>
+__device__ __forceinline__ void tp_sample_plane_rp(const float* __restrict__ plane, int A, int B, float gx, float gy,
+                                                   float* __restrict__ out) {
+    int a0, b0;
+    float fa, fb;
+    tp_cell(gx, gy, A, B, a0, b0, fa, fb);
+    const bool va0 = a0 >= 0 && a0 < A, va1 = a0 + 1 >= 0 && a0 + 1 < A;
+    const bool vb0 = b0 >= 0 && b0 < B, vb1 = b0 + 1 >= 0 && b0 + 1 < B;
+    const int pb = min(max(b0, 0), B - 2), pa = min(max(a0, 0), A - 2);
+    const float wx0 = vb0 ? 1.0f - fb : 0.0f, wx1 = vb1 ? fb : 0.0f;
+    const float we0 = b0 == pb ? wx0 : (b0 + 1 == pb ? wx1 : 0.0f);
+    const float we1 = b0 == pb + 1 ? wx0 : (b0 + 1 == pb + 1 ? wx1 : 0.0f);
+    const float wy0 = va0 ? 1.0f - fa : 0.0f, wy1 = va1 ? fa : 0.0f;
+    const float wr0 = a0 == pa ? wy0 : (a0 + 1 == pa ? wy1 : 0.0f);
+    const float wr1 = a0 == pa + 1 ? wy0 : (a0 + 1 == pa + 1 ? wy1 : 0.0f);
+    const float w00 = wr0 * we0, w01 = wr0 * we1, w10 = wr1 * we0, w11 = wr1 * we1;
+    const float* p = plane + ((size_t)pa * B + pb) * (2 * R);
+    float v[4 * R];
+#pragma unroll
+    for (int k = 0; k < 4 * R; ++k) v[k] = p[k];          // (row pa, col pb) (row pa+1, col pb) (row pa, col pb+1) (row pa+1, col pb+1)
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[r] = ((v[r] * w00 + v[2 * R + r] * w01) + v[R + r] * w10) + v[3 * R + r] * w11;
+}
+
+template <int R, int CL>
 __global__ void __launch_bounds__(256)
 triplane_forward_kernel(int64_t V, const float* __restrict__ coords, int cs, const float* __restrict__ xy,
                         const float* __restrict__ xz, const float* __restrict__ yz, int X, int Y, int Z,
@@ -506,7 +535,11 @@ triplane_forward_kernel(int64_t V, const float* __restrict__ coords, int cs, con
     const float x = coords[i * cs], y = coords[i * cs + 1], z = coords[i * cs + 2];
     float* o = out + i * ld;
     // coordinate pairs of scene/grids.py:148-150: grid x indexes the LAST plane dimension
-    if (CL) {
+    if (CL == 2) {
+        tp_sample_plane_rp<R>(xy, X, Y, y, x, o + col_xy);
+        tp_sample_plane_rp<R>(xz, X, Z, z, x, o + col_xz);
+        tp_sample_plane_rp<R>(yz, Y, Z, z, y, o + col_yz);
+    } else if (CL) {
         tp_sample_plane_cl<R>(xy, X, Y, y, x, o + col_xy);
         tp_sample_plane_cl<R>(xz, X, Z, z, x, o + col_xz);
         tp_sample_plane_cl<R>(yz, Y, Z, z, y, o + col_yz);
@@ -517,6 +550,39 @@ triplane_forward_kernel(int64_t V, const float* __restrict__ coords, int cs, con
     }
 }
 
+// plane [R][A][B] (the reference's layout) -> row pairs [A-1][B][2][R] for tp_sample_plane_rp: one streaming pass
+template <int R>
+__global__ void __launch_bounds__(256)
+plane_row_pairs_kernel(int A, int B, const float* __restrict__ plane, float* __restrict__ pairs) {
+    const int b = blockIdx.x * 256 + threadIdx.x, a = blockIdx.y;
+    if (b >= B) return;
+    float v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = plane[((size_t)r * A + a) * B + b];
+    if (a < A - 1) {
+        float* d = pairs + (((size_t)a * B + b) * 2) * R;
+#pragma unroll
+        for (int r = 0; r < R; ++r) d[r] = v[r];
+    }
+    if (a > 0) {
+        float* d = pairs + (((size_t)(a - 1) * B + b) * 2 + 1) * R;
+#pragma unroll
+        for (int r = 0; r < R; ++r) d[r] = v[r];
+    }
+}
+
+int launch_plane_row_pairs(int R, int A, int B, const float* plane, float* pairs, hipStream_t st) {
+    if (R < 1 || R > TP_MAX_R) return 1;
+    const dim3 grid((unsigned)((B + 255) / 256), (unsigned)A);
+#define SCR_TP_RP(RR) case RR: plane_row_pairs_kernel<RR><<<grid, 256, 0, st>>>(A, B, plane, pairs); break;
+    switch (R) {
+        SCR_TP_RP(1) SCR_TP_RP(2) SCR_TP_RP(3) SCR_TP_RP(4) SCR_TP_RP(5) SCR_TP_RP(6) SCR_TP_RP(7) SCR_TP_RP(8)
+        SCR_TP_RP(9) SCR_TP_RP(10) SCR_TP_RP(11) SCR_TP_RP(12) SCR_TP_RP(13) SCR_TP_RP(14) SCR_TP_RP(15) SCR_TP_RP(16)
+    }
+#undef SCR_TP_RP
+    return 0;
+}
+
 int launch_triplane_forward(int64_t V, const float* coords, int cs, const float* xy, const float* xz, const float* yz,
                             int R, int X, int Y, int Z, int channel_last, float* out, int ld, int col_xy, int col_xz,
                             int col_yz, hipStream_t st) {
@@ -525,12 +591,15 @@ int launch_triplane_forward(int64_t V, const float* coords, int cs, const float*
     const unsigned nb = (unsigned)((V + 255) / 256);
 #define SCR_TP_FWD(RR)                                                                                          \
     case RR:                                                                                                    \
-        if (channel_last)                                                                                       \
-            triplane_forward_kernel<RR, true><<<nb, 256, 0, st>>>(V, coords, cs, xy, xz, yz, X, Y, Z, out, ld, col_xy,   \
-                                                                  col_xz, col_yz);                               \
+        if (channel_last == 2)                                                                                  \
+            triplane_forward_kernel<RR, 2><<<nb, 256, 0, st>>>(V, coords, cs, xy, xz, yz, X, Y, Z, out, ld, col_xy,      \
+                                                               col_xz, col_yz);                                  \
+        else if (channel_last)                                                                                  \
+            triplane_forward_kernel<RR, 1><<<nb, 256, 0, st>>>(V, coords, cs, xy, xz, yz, X, Y, Z, out, ld, col_xy,      \
+                                                               col_xz, col_yz);                                  \
         else                                                                                                    \
-            triplane_forward_kernel<RR, false><<<nb, 256, 0, st>>>(V, coords, cs, xy, xz, yz, X, Y, Z, out, ld, col_xy,  \
-                                                                   col_xz, col_yz);                              \
+            triplane_forward_kernel<RR, 0><<<nb, 256, 0, st>>>(V, coords, cs, xy, xz, yz, X, Y, Z, out, ld, col_xy,      \
+                                                               col_xz, col_yz);                                  \
         break;
     switch (R) {
         SCR_TP_FWD(1) SCR_TP_FWD(2) SCR_TP_FWD(3) SCR_TP_FWD(4) SCR_TP_FWD(5) SCR_TP_FWD(6) SCR_TP_FWD(7) SCR_TP_FWD(8) SCR_TP_FWD(9) SCR_TP_FWD(10) SCR_TP_FWD(11) SCR_TP_FWD(12) SCR_TP_FWD(13) SCR_TP_FWD(14) SCR_TP_FWD(15) SCR_TP_FWD(16)
