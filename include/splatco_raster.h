@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 12
+#define SCR_ABI_VERSION 13
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -205,14 +205,16 @@ int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, con
  * g_fea[V,71] = cat of the four, with row stride g_fea_ld = 71 (packed) or 72 (16-byte aligned rows, the pad column
  * written as 0 / ignored on the way back: what the fused BatchNorm-Linear wants).  The backward takes V (rows of the upstream gradients), inverse_index[N] int64 (row of every anchor, -1 = not visible) and
  * the upstream gradients of the five outputs (any may be NULL) and overwrites EVERY element of the four parameter
- * gradients [N,32] / [N,3] / [N,30] / [N,6] (zeros for invisible anchors; d exp applied): no atomics, no memset. */
+ * gradients [N,32] / [N,3] / [N,30] / [N,6] (zeros for invisible anchors; d exp applied): no atomics, no memset.
+ * accumulate != 0: ADDS to what the four arrays hold instead (a further view of the same step writing into the same
+ * gradient buffers: the caller hands the parameters' .grad memory itself, multiview.GradArena.sink). */
 int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anchor_feat, const float* anchor,
                       const float* offset, const float* scaling, float* feat_out, float* anchor_out, float* offsets_out,
                       float* grid_scaling_out, float* g_fea_out, int32_t g_fea_ld, void* stream);
 int scr_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inverse_index, const float* grid_scaling, const float* d_feat,
                                const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                const float* d_g_fea, int32_t g_fea_ld, float* g_anchor_feat, float* g_anchor,
-                               float* g_offset, float* g_scaling, void* stream);
+                               float* g_offset, float* g_scaling, int32_t accumulate, void* stream);
 
 /* ---- BatchNorm1d in training mode folded into the Linear(d, 32) that follows it: the two nn.Sequential(BatchNorm1d,
  * Linear) stacks of FeaturePlanes (scene/gaussian_model.py:118-124,160-166) for all active levels at once.  The caller

@@ -23,7 +23,7 @@ SYMBOLS = [
     "scr_norm_linear_scratch_bytes", "scr_norm_linear_forward", "scr_norm_linear_backward",
 ]
 PROF_COUNT = 18
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
 
@@ -109,7 +109,7 @@ def _load():
     lib.scr_mlp_heads_backward.argtypes = [i64] + [vp] * 29
     lib.scr_mlp_heads_forward.restype = lib.scr_mlp_heads_backward.restype = C.c_int
     lib.scr_anchor_gather.argtypes = [i64] + [vp] * 10 + [i32, vp]
-    lib.scr_anchor_gather_backward.argtypes = [i64, i64] + [vp] * 7 + [i32] + [vp] * 5
+    lib.scr_anchor_gather_backward.argtypes = [i64, i64] + [vp] * 7 + [i32] + [vp] * 4 + [i32, vp]
     lib.scr_anchor_gather.restype = lib.scr_anchor_gather_backward.restype = C.c_int
     lib.scr_knn.argtypes = [i64, i32, C.POINTER(C.c_float), vp, vp, vp, vp, vp]
     lib.scr_knn_curvature.argtypes = [i64, i32, vp, vp, vp, vp]

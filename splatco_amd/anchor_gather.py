@@ -15,9 +15,22 @@ def supported(pc):
         return False
 
 
+class GradSink:
+    """Where the backward of the gather writes the gradients of (_anchor_feat, _anchor, _offset, _scaling) directly: the
+    parameters' own .grad memory (views of multiview.GradArena's buffer).  Every gradient of those four parameters comes
+    through this one op, and its kernel overwrites EVERY element (zeros for invisible anchors), so the first view of a
+    step needs neither a zero-filled buffer nor autograd's `grad += new` pass over 71 floats per anchor (5.7 GB read
+    twice and written once at 20 M anchors); further views of the same step add in the kernel.  `fresh` is set by the
+    owner at the start of a step and cleared by the first write."""
+
+    def __init__(self, feat, anchor, offset, scaling):
+        self.tensors = (feat, anchor, offset, scaling)
+        self.fresh = True
+
+
 class _AnchorGather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, idx, anchor_feat, anchor, offset, scaling):
+    def forward(ctx, idx, sink, anchor_feat, anchor, offset, scaling):
         c = lambda t: t.detach().contiguous()
         anchor_feat, anchor, offset, scaling = c(anchor_feat), c(anchor), c(offset), c(scaling)
         idx = idx.contiguous().long()
@@ -31,7 +44,7 @@ class _AnchorGather(torch.autograd.Function):
                                                   offset.data_ptr(), scaling.data_ptr(), feat.data_ptr(), anc.data_ptr(),
                                                   off.data_ptr(), gs.data_ptr(), g_fea.data_ptr(), 72, _stream()))
         ctx.save_for_backward(idx, gs)
-        ctx.N = N
+        ctx.N, ctx.sink = N, sink
         return feat, anc, off, gs, g_fea
 
     @staticmethod
@@ -48,17 +61,33 @@ class _AnchorGather(torch.autograd.Function):
             d_g_fea = p(d_g_fea)
         d_feat, d_anc, d_off, d_gs = p(d_feat), p(d_anc), p(d_off), p(d_gs)
         ptr = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
-        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        g_feat, g_anchor, g_offset, g_scaling = new(N, 32), new(N, 3), new(N, 10, 3), new(N, 6)
+        sink = ctx.sink
+        if sink is not None:
+            g_feat, g_anchor, g_offset, g_scaling = sink.tensors
+            accumulate = 0 if sink.fresh else 1
+            sink.fresh = False
+        else:
+            new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            g_feat, g_anchor, g_offset, g_scaling = new(N, 32), new(N, 3), new(N, 10, 3), new(N, 6)
+            accumulate = 0
         if N:
             with torch.cuda.device(dev):
                 _C.check(_C.lib.scr_anchor_gather_backward(N, V, inv.data_ptr(), ptr(gs), ptr(d_feat), ptr(d_anc), ptr(d_off),
                                                            ptr(d_gs), ptr(d_g_fea), ldg, g_feat.data_ptr(), g_anchor.data_ptr(),
-                                                           g_offset.data_ptr(), g_scaling.data_ptr(), _stream()))
-        return None, g_feat, g_anchor, g_offset, g_scaling
+                                                           g_offset.data_ptr(), g_scaling.data_ptr(), accumulate, _stream()))
+        if sink is not None:
+            return None, None, None, None, None, None        # written where the optimiser reads them
+        return None, None, g_feat, g_anchor, g_offset, g_scaling
 
 
 def gather_anchors(pc, idx):
     """(feat [V,32], anchor [V,3], grid_offsets [V,10,3], grid_scaling [V,6] = exp(_scaling), g_fea [V,71]) of the
-    visible anchors idx [V] (int64, ascending)."""
-    return _AnchorGather.apply(idx, pc._anchor_feat, pc._anchor, pc._offset, pc._scaling)
+    visible anchors idx [V] (int64, ascending).  With pc._grad_sink set (train_step.collaborative_step with a GradArena)
+    the gradients of the four parameters go straight into their .grad memory."""
+    sink = getattr(pc, "_grad_sink", None)
+    if sink is not None:
+        ok = all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.shape == q.shape
+                 for t, q in zip(sink.tensors, (pc._anchor_feat, pc._anchor, pc._offset, pc._scaling)))
+        if not ok or not torch.is_grad_enabled():
+            sink = None
+    return _AnchorGather.apply(idx, sink, pc._anchor_feat, pc._anchor, pc._offset, pc._scaling)

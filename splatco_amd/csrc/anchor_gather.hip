@@ -30,7 +30,9 @@ constexpr int AG_THREADS = 256;
 // streams `count` floats (a contiguous, 16-byte aligned chunk that starts at dst) out of the tile; element e of the
 // chunk is tile[(e / width) * AG_LD + col0 + e % width].  Whole float4s, the tail (count not a multiple of 4, last
 // workgroup only) as scalars.
-__device__ __forceinline__ void ag_store_chunk(float* __restrict__ dst, const float* tile, int count, int width, int col0) {
+// `add`: the chunk is added to what dst holds (gradients of a further view into the same buffer).
+__device__ __forceinline__ void ag_store_chunk(float* __restrict__ dst, const float* tile, int count, int width, int col0,
+                                               bool add = false) {
     const int n4 = count >> 2;
     for (int q = threadIdx.x; q < n4; q += AG_THREADS) {
         float v[4];
@@ -39,11 +41,16 @@ __device__ __forceinline__ void ag_store_chunk(float* __restrict__ dst, const fl
             const int e = 4 * q + j, r = e / width, c = e - r * width;
             v[j] = tile[r * AG_LD + col0 + c];
         }
-        *(float4*)(dst + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (add) {
+            const float4 old = *(const float4*)(dst + 4 * q);
+            o = make_float4(old.x + o.x, old.y + o.y, old.z + o.z, old.w + o.w);
+        }
+        *(float4*)(dst + 4 * q) = o;
     }
     for (int e = 4 * n4 + threadIdx.x; e < count; e += AG_THREADS) {
         const int r = e / width, c = e - r * width;
-        dst[e] = tile[r * AG_LD + col0 + c];
+        dst[e] = (add ? dst[e] : 0.0f) + tile[r * AG_LD + col0 + c];
     }
 }
 
@@ -184,7 +191,7 @@ anchor_gather_backward_kernel(int64_t N, int64_t V, const int64_t* __restrict__ 
                               const float* __restrict__ d_offsets, const float* __restrict__ d_grid_scaling,
                               const float* __restrict__ d_g_fea, int ldg, float* __restrict__ g_feat,
                               float* __restrict__ g_anchor, float* __restrict__ g_offset,
-                              float* __restrict__ g_scaling) {
+                              float* __restrict__ g_scaling, int accumulate) {
     __shared__ __attribute__((aligned(16))) float tile[AG_ROWS * AG_LD];   // rows = the VISIBLE anchors of the block, in order
     __shared__ __attribute__((aligned(16))) float outt[AG_ROWS * AG_LD];   // rows = the block's 64 anchors
     __shared__ int rowv[AG_ROWS];                                          // row of `tile` of every anchor, -1 = invisible
@@ -237,10 +244,11 @@ anchor_gather_backward_kernel(int64_t N, int64_t V, const int64_t* __restrict__ 
         outt[e] = (rv >= 0 && c < AG_COLS) ? tile[rv * AG_LD + c] : 0.0f;
     }
     __syncthreads();
-    ag_store_chunk(g_feat + n0 * AG_FEAT, outt, rows * AG_FEAT, AG_FEAT, 0);
-    ag_store_chunk(g_anchor + n0 * 3, outt, rows * 3, 3, 32);
-    ag_store_chunk(g_offset + n0 * AG_OFF, outt, rows * AG_OFF, AG_OFF, 35);
-    ag_store_chunk(g_scaling + n0 * 6, outt, rows * 6, 6, 65);
+    const bool add = accumulate != 0;
+    ag_store_chunk(g_feat + n0 * AG_FEAT, outt, rows * AG_FEAT, AG_FEAT, 0, add);
+    ag_store_chunk(g_anchor + n0 * 3, outt, rows * 3, 3, 32, add);
+    ag_store_chunk(g_offset + n0 * AG_OFF, outt, rows * AG_OFF, AG_OFF, 35, add);
+    ag_store_chunk(g_scaling + n0 * 6, outt, rows * 6, 6, 65, add);
 }
 
 void launch_anchor_gather(int64_t V, const int64_t* idx, const float* p_feat, const float* p_anchor, const float* p_offset,
@@ -254,10 +262,10 @@ void launch_anchor_gather(int64_t V, const int64_t* idx, const float* p_feat, co
 void launch_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inv, const float* grid_scaling, const float* d_feat,
                                    const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                    const float* d_g_fea, int ldg, float* g_feat, float* g_anchor, float* g_offset,
-                                   float* g_scaling, hipStream_t st) {
+                                   float* g_scaling, int accumulate, hipStream_t st) {
     if (N <= 0) return;
     anchor_gather_backward_kernel<<<(unsigned)((N + AG_ROWS - 1) / AG_ROWS), AG_THREADS, 0, st>>>(
-        N, V, inv, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea, ldg, g_feat, g_anchor, g_offset, g_scaling);
+        N, V, inv, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea, ldg, g_feat, g_anchor, g_offset, g_scaling, accumulate);
 }
 
 }  // namespace scr

@@ -490,14 +490,14 @@ int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anch
 int scr_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inverse_index, const float* grid_scaling, const float* d_feat,
                                const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                const float* d_g_fea, int32_t g_fea_ld, float* g_anchor_feat, float* g_anchor,
-                               float* g_offset, float* g_scaling, void* stream) {
+                               float* g_offset, float* g_scaling, int32_t accumulate, void* stream) {
     if (N < 0 || V < 0 || V > N) return fail("bad sizes");
     if (g_fea_ld != 71 && g_fea_ld != 72) return fail("g_fea row stride must be 71 (packed) or 72 (16-byte aligned rows)");
     if (N == 0) return 0;
     if (!inverse_index || !g_anchor_feat || !g_anchor || !g_offset || !g_scaling) return fail("NULL argument");
     if (d_grid_scaling || d_g_fea) { if (!grid_scaling) return fail("grid_scaling is needed for d exp"); }
     launch_anchor_gather_backward(N, V, inverse_index, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea, g_fea_ld,
-                                  g_anchor_feat, g_anchor, g_offset, g_scaling, (hipStream_t)stream);
+                                  g_anchor_feat, g_anchor, g_offset, g_scaling, accumulate, (hipStream_t)stream);
     CHECK_LAUNCH("anchor_gather_backward_kernel", 0, (hipStream_t)stream);
     return 0;
 }

@@ -317,7 +317,7 @@ void launch_anchor_gather(int64_t V, const int64_t* idx, const float* p_feat, co
 void launch_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inv, const float* grid_scaling, const float* d_feat,
                                    const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                    const float* d_g_fea, int ldg, float* g_feat, float* g_anchor, float* g_offset,
-                                   float* g_scaling, hipStream_t st);
+                                   float* g_scaling, int accumulate, hipStream_t st);
 void launch_knn(int64_t N, int k, const float* grid9, const float* sorted_pts, const int64_t* sorted_id,
                 const int32_t* cell_start, int64_t* out_idx, hipStream_t st);
 void launch_knn_curvature(int64_t N, int k, const float* pts, const int64_t* idx, float* curvature, hipStream_t st);

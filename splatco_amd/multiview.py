@@ -164,11 +164,43 @@ class GradArena:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
+    def sink(self, pc):
+        """Lets the fused anchor gather write the gradients of pc's four per-anchor parameters straight into their
+        arena views (anchor_gather.GradSink): zero() then skips those 71 floats per anchor and autograd's accumulation
+        pass over them disappears.  Returns the sink (also kept as self._sink), or None when the gather is not the fused
+        one or a parameter is missing from the arena."""
+        from . import anchor_gather as _ag
+        self._sink, self._sink_ids = None, ()
+        ps = [getattr(pc, n, None) for n in ("_anchor_feat", "_anchor", "_offset", "_scaling")]
+        ids = {id(p): i for i, p in enumerate(self.params)}
+        if not _ag.supported(pc) or any(p is None or id(p) not in ids for p in ps):
+            return None
+        self._sink = _ag.GradSink(*[self.views[ids[id(p)]] for p in ps])
+        self._sink_ids = tuple(ids[id(p)] for p in ps)
+        return self._sink
+
     def zero(self):
-        """Start of a step: clear the arena and make sure every .grad still aliases it."""
-        self.flat.zero_()
+        """Start of a step: clear the arena and make sure every .grad still aliases it.  Parameters written through
+        the sink are overwritten by the first view's backward: they are not cleared here."""
+        sink = getattr(self, "_sink", None)
+        if sink is None:
+            self.flat.zero_()
+        else:
+            for i, v in enumerate(self.views):
+                if i not in self._sink_ids:
+                    v.zero_()
+            sink.fresh = True
         self._fired = [False] * len(self.params)
         self.bind()
+
+    def _settle_sink(self):
+        # no view of this step wrote through the sink (a rank without views): its parameters still hold the previous
+        # step's gradients
+        sink = getattr(self, "_sink", None)
+        if sink is not None and sink.fresh:
+            for i in self._sink_ids:
+                self.views[i].zero_()
+            sink.fresh = False
 
     def _issue(self, i):
         for a, b in self.pieces[i]:
@@ -193,6 +225,7 @@ class GradArena:
     def reduce(self):
         """SUM over ranks of everything in the arena; returns when the reduced gradients are usable on the current
         stream.  Parameters whose hook did not fire (no gradient on this rank: zeros) are exchanged now."""
+        self._settle_sink()
         if self.world > 1:
             for i in range(len(self.params)):
                 if not (self.overlap and self._fired[i]):

@@ -60,27 +60,37 @@ def collaborative_step(pc, views, gt_images, pipe, bg_color, optimizer=None, buc
     packed into `bucket`.  Returns (local loss sum, last render dict, bucket or arena buffer)."""
     params = arena.params if arena is not None else [p for p in pc.parameters() if p.requires_grad]
     if arena is not None:
+        # the per-anchor gradients (99 % of the arena) are written in place by the gather's backward kernel; the sink is
+        # attached to the model for the duration of this step only (a render() outside it must reach autograd as usual)
+        if getattr(arena, "_sink_model", None) is not pc:
+            arena.sink(pc)
+            arena._sink_model = pc
+        pc._grad_sink = getattr(arena, "_sink", None)
         arena.zero()
     else:
+        pc._grad_sink = None
         for p in params:
             p.grad = None
     rank, world = world_info()
     device = params[0].device
     total, out, vis, rendered = None, None, None, []
-    for k, (cam, gt) in enumerate(zip(shard_views(views), shard_views(gt_images))):
-        vis = prefilter_voxel(cam, pc, pipe, bg_color)
-        out = render(cam, pc, pipe, bg_color, visible_mask=vis, retain_grad=True)
-        gt = gt.to(out["render"].device, non_blocking=True)
-        loss = view_loss(out["render"], gt, out["scaling"])
-        total = loss if total is None else total + loss
+    try:
+        for k, (cam, gt) in enumerate(zip(shard_views(views), shard_views(gt_images))):
+            vis = prefilter_voxel(cam, pc, pipe, bg_color)
+            out = render(cam, pc, pipe, bg_color, visible_mask=vis, retain_grad=True)
+            gt = gt.to(out["render"].device, non_blocking=True)
+            loss = view_loss(out["render"], gt, out["scaling"])
+            total = loss if total is None else total + loss
+            if consistency_weight:
+                rendered.append((rank + k * world, out["render"], gt))
         if consistency_weight:
-            rendered.append((rank + k * world, out["render"], gt))
-    if consistency_weight:
-        term, _ = consistency_loss(rendered, consistency_weight, device=device)
-        if term is not None:
-            total = term if total is None else total + term
-    if total is not None:
-        total.backward()
+            term, _ = consistency_loss(rendered, consistency_weight, device=device)
+            if term is not None:
+                total = term if total is None else total + term
+        if total is not None:
+            total.backward()
+    finally:
+        pc._grad_sink = None
     if arena is not None:
         bucket = arena.reduce()
     else:

@@ -641,3 +641,52 @@ def test_multi_grid_sampling_into_one_matrix_all_alignments(R):
             (samp * w[:, cols[j]:cols[j] + R]).sum().backward()
             err, scale = float((gg[j] - p.grad).abs().max()), float(p.grad.abs().max())
             assert err <= 5e-5 * scale + 1e-7, (R, j, err, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_views", [1, 2])
+def test_arena_sink_gradients_equal_autograd_accumulation(n_views):
+    """collaborative_step with a GradArena: the gather's backward kernel writes the per-anchor gradients straight into the
+    arena (overwriting for the first view, adding for the second) -- same values as the step without an arena, where
+    autograd accumulates them; a render() after the step goes through autograd again; the arena is not cleared for the
+    parameters the kernel overwrites, so a stale step must not leak (two steps, second compared)."""
+    import types
+    from splatco_amd.multiview import GradArena
+    from splatco_amd.renderer import prefilter_voxel, render
+    from splatco_amd.synthetic import synthetic_anchor_model, synthetic_views
+    from splatco_amd.train_step import collaborative_step
+    dev = torch.device("cuda:0")
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
+    bg = torch.ones(3, device=dev)
+    views = [v.to(dev) for v in synthetic_views(n_views, 640, 360)]
+    g = torch.Generator(device=dev).manual_seed(5)
+    gts = [torch.rand(3, 360, 640, device=dev, generator=g) for _ in views]
+    names = ("_anchor_feat", "_anchor", "_offset", "_scaling")
+
+    def run(use_arena):
+        torch.manual_seed(11)
+        pc = synthetic_anchor_model(50000, 9, dev, plane_size=256)
+        params = [p for p in pc.parameters() if p.requires_grad]
+        arena = GradArena(params) if use_arena else None
+        for _ in range(2):                       # the second step sees what the first left in the buffers
+            collaborative_step(pc, views, gts, pipe, bg, arena=arena)
+        assert getattr(pc, "_grad_sink", None) is None
+        grads = {n: getattr(pc, n).grad.detach().clone() for n in names}
+        plane = pc.feat_planes._feat.k0s[1].xy_plane.grad.detach().clone()
+        if use_arena:
+            assert arena._sink is not None and all(getattr(pc, n).grad.data_ptr() == v.data_ptr()
+                                                   for n, v in zip(names, arena._sink.tensors))
+            # outside the step the same model goes through autograd as usual
+            for p in params:
+                p.grad = None
+            vis = prefilter_voxel(views[0], pc, pipe, bg)
+            render(views[0], pc, pipe, bg, visible_mask=vis)["render"].mean().backward()
+            assert pc._anchor.grad is not None and pc._anchor.grad.data_ptr() != arena._sink.tensors[1].data_ptr()
+        return grads, plane
+
+    g0, p0 = run(False)
+    g1, p1 = run(True)
+    for n in names:
+        scale = float(g0[n].abs().max())
+        assert scale > 0 and float((g0[n] - g1[n]).abs().max()) <= 1e-6 * scale, n
+    assert float((p0 - p1).abs().max()) <= 1e-5 * float(p0.abs().max())
