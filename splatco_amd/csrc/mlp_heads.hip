@@ -63,6 +63,16 @@ struct MhWeights {
     const float* b2[3];
 };
 
+// Output activations through v_exp_f32 + v_rcp_f32 (1 ulp each): a wave spends a third of the forward kernel in them and
+// in the output stores (phase-stamped build), and libm's tanhf alone is ~50 instructions.  |error| <= 2e-7 absolute;
+// exp overflow / underflow give exactly +-1 / 0 / 1.
+__device__ __forceinline__ void mh_store16(float* p, float a, float b, float c, float d) {     // dword-aligned address
+    const f4 q = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(q) : "memory");
+}
+__device__ __forceinline__ float mh_sigmoid(float z) { return __frcp_rn(1.0f + __expf(-z)); }
+__device__ __forceinline__ float mh_tanh(float z) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * z)); }
+
 // ---------------------------------------------------------------- forward
 __global__ void __launch_bounds__(64 * MH_WAVES, 2)
 mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, const float* __restrict__ anchor,
@@ -168,15 +178,19 @@ mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, const float*
             for (int ot = 0; ot < MH_OT; ++ot) {
                 const int head = ot == 0 ? 0 : (ot < 3 ? 1 : 2), ot0 = ot == 0 ? 0 : (ot < 3 ? 1 : 3);
                 const int col0 = 16 * (ot - ot0) + 4 * g;     // first of this lane's four output columns
+                // the lane's four columns in one 16-byte store (rows are only 8-byte aligned: gfx950 needs dword alignment
+                // for multi-dword accesses, the compiler does not know), two columns where the head ends mid-way: as
+                // 8-byte stores a store instruction left 64 fragments 16 bytes apart and the kernel queued behind them
+                float z[4];
 #pragma unroll
-                for (int r = 0; r < 4; r += 2) {              // rows are 8-byte aligned, the output counts even: float2 stores
-                    const float z0 = o[ot][r] + B2[16 * ot + 4 * g + r], z1 = o[ot][r + 1] + B2[16 * ot + 4 * g + r + 1];
-                    const int col = col0 + r;
-                    if (head == 0) { if (col < MH_NO) *(float2*)(out_o + v * MH_NO + col) = make_float2(tanhf(z0), tanhf(z1)); }
-                    else if (head == 1) {
-                        if (col < MH_NC) *(float2*)(out_c + v * MH_NC + col) = make_float2(1.0f / (1.0f + __expf(-z0)), 1.0f / (1.0f + __expf(-z1)));
-                    } else { if (col < MH_NV) *(float2*)(out_v + v * MH_NV + col) = make_float2(z0, z1); }
+                for (int r = 0; r < 4; ++r) {
+                    const float zr = o[ot][r] + B2[16 * ot + 4 * g + r];
+                    z[r] = head == 0 ? mh_tanh(zr) : (head == 1 ? mh_sigmoid(zr) : zr);
                 }
+                const int nout = head == 0 ? MH_NO : (head == 1 ? MH_NC : MH_NV);
+                float* dst = (head == 0 ? out_o : (head == 1 ? out_c : out_v)) + v * nout + col0;
+                if (col0 + 3 < nout) mh_store16(dst, z[0], z[1], z[2], z[3]);
+                else if (col0 + 1 < nout) *(float2*)dst = make_float2(z[0], z[1]);
             }
         }
     }
