@@ -533,6 +533,14 @@ int scr_norm_linear_backward(int64_t V, int32_t d, const float* x, int32_t ldx, 
     return 0;
 }
 
+#ifdef SCR_PHASE_TIMING
+extern "C++" { namespace scr { int mh_debug_ticks(int fwd, unsigned long long* out); int tp_debug_ticks(unsigned long long* out); } }
+// developer builds only (see common.h): per-phase wall-clock ticks of an instrumented kernel, read and cleared
+int scr_debug_phase_ticks(int32_t which, unsigned long long* out16) {
+    return which == 2 ? scr::tp_debug_ticks(out16) : scr::mh_debug_ticks(which == 1, out16);
+}
+#endif
+
 // ---- MLP heads (mlp_heads.hip)
 size_t scr_mlp_heads_hidden_bytes(int64_t V) { return mlp_heads_hidden_bytes(V > 0 ? V : 1); }
 size_t scr_mlp_heads_partial_bytes(int64_t V) { return mlp_heads_partial_bytes(V > 0 ? V : 1); }

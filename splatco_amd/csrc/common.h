@@ -269,6 +269,33 @@ __device__ inline uint32_t quadrant_mask(float4 r0, float4 r1, int tile_x0, int 
     return mask;
 }
 
+// ---- developer builds with -DSCR_PHASE_TIMING: a kernel stamps the wall clock (100 MHz) at its phase boundaries and
+// the leader thread of every workgroup / wave adds the per-phase ticks into a device array that
+// scr_debug_phase_ticks(which, out[16]) reads and clears (which: 0 = mlp_heads backward, 1 = mlp_heads forward,
+// 2 = plane-gradient cell gather).  tools/exp/phase_probe.py prints the shares.  The stamps are fenced with sched_barrier(0); the product build contains none of this.
+#ifdef SCR_PHASE_TIMING
+#define SCR_PHASES(n) unsigned long long ph_last_ = wall_clock64(), ph_[n] = {}
+#define SCR_PHASE(k)                                        \
+    do {                                                    \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        const unsigned long long ph_now_ = wall_clock64();  \
+        ph_[k] += ph_now_ - ph_last_;                       \
+        ph_last_ = ph_now_;                                 \
+        __builtin_amdgcn_sched_barrier(0);                  \
+    } while (0)
+#define SCR_PHASES_FLUSH(arr, n, leader)                                   \
+    do {                                                                   \
+        if (leader) {                                                      \
+            for (int k_ = 0; k_ < (n); ++k_) atomicAdd(&(arr)[k_], ph_[k_]); \
+            atomicAdd(&(arr)[15], 1ull);                                   \
+        }                                                                  \
+    } while (0)
+#else
+#define SCR_PHASES(n)
+#define SCR_PHASE(k)
+#define SCR_PHASES_FLUSH(arr, n, leader)
+#endif
+
 // launchers (defined in the .hip files)
 void launch_filter(int64_t P, const float* means3D, const float* scales, const float* rotations,
                    const float* cov3D, const KSettings& ks, int32_t* radii, hipStream_t st);

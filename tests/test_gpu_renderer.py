@@ -601,11 +601,21 @@ def test_sorted_anchors_render_the_same_image():
     img0, _, g0, gp0, n0 = run(False)
     img1, perm, g1, gp1, n1 = run(True)
     assert n0 == n1 and n0 > 10000
-    assert float((img0 - img1).abs().max()) < 2e-5
+    # the features differ by fp32 summation order (BatchNorm statistics over differently ordered rows: 1e-7), so a splat
+    # whose alpha sits at the 1/255 cut, or a pixel at the T < 1e-4 stop, can fall on the other side in a few pixels: those
+    # differ by at most one splat's contribution (alpha 1/255), every other pixel by rounding only
+    diff = (img0 - img1).abs()
+    assert int((diff > 2e-5).sum()) <= 24 and float(diff.max()) < 1.5 / 255, (int((diff > 2e-5).sum()), float(diff.max()))
+    # gradients: the same up to rounding, except for the handful of Gaussians that meet a pixel where such a cut fell the
+    # other way (they change by that splat's share): at most 0.01 % of the elements beyond 2e-4 of the scale, none beyond 5 %
+    def close(a, b, name):
+        scale = float(a.abs().max())
+        d = (a - b).abs()
+        bad = int((d > 2e-4 * scale + 1e-12).sum())
+        assert bad <= max(4, a.numel() // 10000) and float(d.max()) < 0.05 * scale, (name, bad, float(d.max()), scale)
     for n in g0:
-        scale = float(g0[n].abs().max())
-        assert float((g0[n][perm] - g1[n]).abs().max()) < 2e-4 * scale + 1e-12, n
-    assert float((gp0 - gp1).abs().max()) < 2e-4 * float(gp0.abs().max())
+        close(g0[n][perm], g1[n], n)
+    close(gp0, gp1, "plane")
 
 
 @pytest.mark.gpu
