@@ -389,32 +389,41 @@ tile_sort_wg_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, unsi
             buf[wg_slot((int)w0 + lane * 16 + e)] = ((unsigned long long)khi[e] << 32) | klo[e];
     }
     __syncthreads();
-    // ---- rank merges in LDS: runs of L -> 2L (padding keys compare equal: their ranks would collide, so a
-    // padding key keeps its position -- all padding sits at the end of the last runs and stays there)
-    // One buffer: a thread reads its 16 keys, finds their places while everybody still sees the old runs,
-    // and the moves happen after a barrier.
+    // ---- merges in LDS: runs of L -> 2L.  One buffer: every thread forms its 16 outputs in registers while everybody
+    // still sees the old runs, and the writes happen after a barrier.
     for (uint32_t L = WAVE_SORT_MAX; L < (uint32_t)WG_SORT_MAX && L < cnt; L <<= 1) {
-        unsigned long long x[WG_SORT_MAX / 256];
-        uint32_t pos[WG_SORT_MAX / 256];
+        // every thread merges ITS 16 consecutive outputs of its run pair: one bisection along its diagonal, then 16
+        // compare-and-advance steps (padding keys are +inf and come out last), instead of one bisection per key
+        constexpr int PER = WG_SORT_MAX / 256;
+        unsigned long long outk[PER];
+        const uint32_t o0 = threadIdx.x * PER, pairbase = o0 / (2u * L) * (2u * L), d0 = o0 - pairbase;
+        {
+            auto keyA = [&](uint32_t i) { return buf[wg_slot((int)(pairbase + i))]; };
+            auto keyB = [&](uint32_t j) { return buf[wg_slot((int)(pairbase + L + j))]; };
+            uint32_t a = d0 > L ? d0 - L : 0u, b = min(d0, L);
+            while (a < b) {
+                const uint32_t mid = (a + b) >> 1;
+                if (keyA(mid) < keyB(d0 - mid - 1)) a = mid + 1;
+                else b = mid;
+            }
+            uint32_t ia = a, ib = d0 - a;
+            unsigned long long x = ia < L ? keyA(ia) : ~0ull, y = ib < L ? keyB(ib) : ~0ull;
 #pragma unroll
-        for (int k = 0; k < WG_SORT_MAX / 256; ++k) {
-            const uint32_t e = threadIdx.x + 256u * k;
-            x[k] = buf[wg_slot((int)e)];
-            pos[k] = e;
-            if (x[k] != ~0ull) {
-                const uint32_t run = e / L, base = (run ^ 1u) * L, inrun = e - run * L;
-                uint32_t a = 0, b = L;  // lower_bound in the partner run (padding there is +inf: never below x)
-                while (a < b) {
-                    const uint32_t mid = (a + b) >> 1;
-                    if (buf[wg_slot((int)(base + mid))] < x[k]) a = mid + 1;
-                    else b = mid;
+            for (int k = 0; k < PER; ++k) {
+                const bool takeA = x <= y;                // real keys are unique; ties only between +inf paddings
+                outk[k] = takeA ? x : y;
+                if (takeA) {
+                    ++ia;
+                    x = ia < L ? keyA(ia) : ~0ull;
+                } else {
+                    ++ib;
+                    y = ib < L ? keyB(ib) : ~0ull;
                 }
-                pos[k] = (run & ~1u) * L + inrun + a;
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < WG_SORT_MAX / 256; ++k) buf[wg_slot((int)pos[k])] = x[k];
+        for (int k = 0; k < PER; ++k) buf[wg_slot((int)(o0 + k))] = outk[k];
         __syncthreads();
     }
     const unsigned long long* src = buf;
@@ -473,7 +482,9 @@ tile_merge_path_kernel(int tiles, int gx, uint32_t pass, const uint32_t* __restr
                        const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst,
                        const uint2* __restrict__ gm_base, uint32_t* __restrict__ point_list,
                        uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
-    __shared__ unsigned long long buf[WG_SORT_MAX];
+    // run A at slots [0, na), run B at [na, na + nb), every index p stored at p + (p >> 4) (17 slots per 16 keys): the
+    // threads walk the runs 16 keys apart, which would put them all on the same LDS banks
+    __shared__ unsigned long long buf[WG_SORT_MAX + WG_SORT_MAX / 16];
     __shared__ uint32_t cut[2];
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
@@ -495,10 +506,10 @@ tile_merge_path_kernel(int tiles, int gx, uint32_t pass, const uint32_t* __restr
     }
     __syncthreads();
     const uint32_t i0 = cut[0], na = cut[1] - i0, j0 = s0 - i0, nb = (s1 - s0) - na;
+    const uint32_t tot = na + nb;
     {   // the segment's keys (na from run A, then nb from run B): all 16 loads of a thread in flight before the first LDS
         // write, from clamped addresses and without a branch around them -- as `load -> LDS write` loops every iteration
         // waited for its own load (sixteen memory round trips per workgroup: the pass ran at 28 % of the copy rate)
-        const uint32_t tot = na + nb;
         unsigned long long v[WG_SORT_MAX / 256];
 #pragma unroll
         for (int k = 0; k < WG_SORT_MAX / 256; ++k) {
@@ -508,40 +519,50 @@ tile_merge_path_kernel(int tiles, int gx, uint32_t pass, const uint32_t* __restr
 #pragma unroll
         for (int k = 0; k < WG_SORT_MAX / 256; ++k) {
             const uint32_t e = threadIdx.x + 256u * k;
-            if (e < tot) buf[e] = v[k];
+            if (e < tot) buf[wg_slot((int)e)] = v[k];
         }
     }
     __syncthreads();
-    unsigned long long x[WG_SORT_MAX / 256];
-    uint32_t pos[WG_SORT_MAX / 256];
+    // ---- every thread merges ITS 16 consecutive outputs: one bisection along its diagonal (how many keys of run A lie
+    // among the first 16 t outputs), then 16 compare-and-advance steps -- instead of one bisection per key
+    constexpr int PER = WG_SORT_MAX / 256;
+    unsigned long long outk[PER];
+    const uint32_t d0 = min((uint32_t)threadIdx.x * PER, tot);
+    {
+        auto keyA = [&](uint32_t i) { return buf[wg_slot((int)i)]; };
+        auto keyB = [&](uint32_t j) { return buf[wg_slot((int)(na + j))]; };
+        uint32_t a = d0 > nb ? d0 - nb : 0u, b = min(d0, na);
+        while (a < b) {
+            const uint32_t mid = (a + b) >> 1;
+            if (keyA(mid) < keyB(d0 - mid - 1)) a = mid + 1;
+            else b = mid;
+        }
+        uint32_t ia = a, ib = d0 - a;
+        unsigned long long x = ia < na ? keyA(ia) : ~0ull, y = ib < nb ? keyB(ib) : ~0ull;
 #pragma unroll
-    for (int k = 0; k < WG_SORT_MAX / 256; ++k) {
-        const uint32_t e = threadIdx.x + 256u * k;
-        pos[k] = 0xffffffffu;
-        if (e < na + nb) {
-            x[k] = buf[e];
-            const bool left = e < na;
-            const unsigned long long* other = left ? buf + na : buf;
-            uint32_t a = 0, b = left ? nb : na;  // lower_bound in the other run
-            while (a < b) {
-                const uint32_t mid = (a + b) >> 1;
-                if (other[mid] < x[k]) a = mid + 1;
-                else b = mid;
+        for (int k = 0; k < PER; ++k) {
+            const bool takeA = x < y;                     // keys are unique; +inf only when a run is exhausted
+            outk[k] = takeA ? x : y;
+            if (takeA) {
+                ++ia;
+                x = ia < na ? keyA(ia) : ~0ull;
+            } else {
+                ++ib;
+                y = ib < nb ? keyB(ib) : ~0ull;
             }
-            pos[k] = (left ? e : e - na) + a;
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < WG_SORT_MAX / 256; ++k)
-        if (pos[k] != 0xffffffffu) buf[pos[k]] = x[k];
+    for (int k = 0; k < PER; ++k)
+        if (d0 + k < tot) buf[wg_slot((int)(d0 + k))] = outk[k];
     __syncthreads();
     if (pass + 1 == merge_passes_needed(n)) {  // the tile's last pass writes the final lists directly
         const FinalLists fl{gm_base, point_list, gm_index, qmask, t % gx, t / gx};
-        for (uint32_t e = threadIdx.x; e < na + nb; e += 256) fl.write(lo + pairbase + s0 + e, (uint32_t)buf[e]);
+        for (uint32_t e = threadIdx.x; e < tot; e += 256) fl.write(lo + pairbase + s0 + e, (uint32_t)buf[wg_slot((int)e)]);
     } else {
         unsigned long long* out = dst + lo + pairbase + s0;
-        for (uint32_t e = threadIdx.x; e < na + nb; e += 256) out[e] = buf[e];
+        for (uint32_t e = threadIdx.x; e < tot; e += 256) out[e] = buf[wg_slot((int)e)];
     }
 }
 
