@@ -183,7 +183,7 @@ scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec, uin
 // network.  Padding elements are +inf keys and sort to the end.
 //   tiles with <= 1024 instances : one wave sorts the tile and writes the final lists;
 //   up to 4096                   : a four-wave workgroup -- each wave sorts 1024 keys this way, the runs are
-//                                  rank-merged in LDS (tile_sort_wg_kernel);
+//                                  merged in LDS, 16 outputs per thread (tile_sort_wg_kernel);
 //   larger tiles                 : every 4096-chunk is sorted like that (in place), then log2(chunks)
 //                                  merge-path passes double the sorted run length, ping-ponging between
 //                                  two buffers; a tile's last pass writes its final lists.
@@ -359,8 +359,8 @@ tile_sort_wave_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, un
 }
 
 // Tiles with more than 1024 instances: a four-wave workgroup sorts a chunk of up to 4096 keys on chip --
-// every wave sorts 1024 keys in registers, the four sorted runs meet in LDS and two rank-merge passes
-// (each key binary-searches its rank in the partner run; keys are unique) make one run of them.  A tile
+// every wave sorts 1024 keys in registers, the four sorted runs meet in LDS and two merge passes (a thread forms 16
+// consecutive outputs: one bisection along its diagonal, 16 compare-and-advance steps) make one run of them.  A tile
 // of up to 4096 instances is finished here (final lists written); a larger tile gets its 4096-chunks
 // sorted in place and goes on to the global merge passes.
 constexpr int WG_SORT_MAX = 4096;
@@ -441,7 +441,7 @@ tile_sort_wg_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, unsi
 // Merge path: every workgroup produces one 4096-key segment of the merged output.  Two lanes find where
 // the segment's first and last diagonal cut the two runs (one binary search each over global memory --
 // per workgroup, not per key), the at most 4096 input keys between the cuts are staged in LDS as two
-// short runs, rank-merged there (each key binary-searches its rank in the other run; keys are unique)
+// short runs, merged there (a thread forms 16 consecutive outputs: one bisection, 16 compare-and-advance steps)
 // and streamed out coalesced.
 __device__ __forceinline__ uint32_t merge_passes_needed(uint32_t n) {  // ceil(log2(ceil(n/4096)))
     uint32_t chunks = (n + WG_SORT_MAX - 1) / WG_SORT_MAX, p = 0;
