@@ -7,7 +7,7 @@
 //               key (depth_bits << 32 | gaussian id << 4 | quadrant mask).  Slot order inside a
 //               segment is arbitrary.
 //   2. sort:    one wave per tile sorts up to 1024 keys in registers (bitonic network), a four-wave
-//               workgroup up to 4096 through LDS; bigger tiles add merge-path passes.  Sorting by (depth, id)
+//               workgroup up to 8192 through LDS; bigger tiles add merge-path passes.  Sorting by (depth, id)
 //               reproduces the stable (tile, depth) order of the reference semantics, so
 //               point_list / ranges are bit-identical to the oracle's.  The final write also derives
 //               each instance's Gaussian-major index (where the backward pass puts its gradient
@@ -182,9 +182,9 @@ scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec, uin
 // or v_permlane16_swap / v_permlane32_swap (16, 32).  No LDS, no barriers, no s_waitcnt inside the
 // network.  Padding elements are +inf keys and sort to the end.
 //   tiles with <= 1024 instances : one wave sorts the tile and writes the final lists;
-//   up to 4096                   : a four-wave workgroup -- each wave sorts 1024 keys this way, the runs are
+//   up to 8192                   : an eight-wave workgroup -- each wave sorts 1024 keys this way, the runs are
 //                                  merged in LDS, 16 outputs per thread (tile_sort_wg_kernel);
-//   larger tiles                 : every 4096-chunk is sorted like that (in place), then log2(chunks)
+//   larger tiles                 : every 8192-chunk is sorted like that (in place), then log2(chunks)
 //                                  merge-path passes double the sorted run length, ping-ponging between
 //                                  two buffers; a tile's last pass writes its final lists.
 template <int D>
@@ -358,18 +358,19 @@ tile_sort_wave_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, un
     wave_sort_any<true>(n, keys + lo, lo, fl, tr);
 }
 
-// Tiles with more than 1024 instances: a four-wave workgroup sorts a chunk of up to 4096 keys on chip --
-// every wave sorts 1024 keys in registers, the four sorted runs meet in LDS and two merge passes (a thread forms 16
+// Tiles with more than 1024 instances: an eight-wave workgroup sorts a chunk of up to 8192 keys on chip --
+// every wave sorts 1024 keys in registers, the eight sorted runs meet in LDS and three merge passes (a thread forms 16
 // consecutive outputs: one bisection along its diagonal, 16 compare-and-advance steps) make one run of them.  A tile
-// of up to 4096 instances is finished here (final lists written); a larger tile gets its 4096-chunks
+// of up to 8192 instances is finished here (final lists written); a larger tile gets its 8192-chunks
 // sorted in place and goes on to the global merge passes.
-constexpr int WG_SORT_MAX = 4096;
+constexpr int WG_SORT_MAX = 8192;   // keys a workgroup sorts on chip: 8 waves x 1024
+constexpr int WG_SORT_THREADS = WG_SORT_MAX / 16;   // 16 keys per lane
 __device__ __forceinline__ int wg_slot(int p) { return p + (p >> 4); }  // 16 keys of a lane start 17 slots apart
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(WG_SORT_THREADS)
 tile_sort_wg_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, unsigned long long* __restrict__ keys,
                     const uint2* __restrict__ gm_base, uint32_t* __restrict__ point_list,
                     uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
-    __shared__ unsigned long long buf[WG_SORT_MAX + WG_SORT_MAX / 16];  // 34 KB: four workgroups per CU
+    extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];  // [WG_SORT_MAX * 17 / 16]: 68 KB, two workgroups per CU
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
@@ -394,7 +395,7 @@ tile_sort_wg_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, unsi
     for (uint32_t L = WAVE_SORT_MAX; L < (uint32_t)WG_SORT_MAX && L < cnt; L <<= 1) {
         // every thread merges ITS 16 consecutive outputs of its run pair: one bisection along its diagonal, then 16
         // compare-and-advance steps (padding keys are +inf and come out last), instead of one bisection per key
-        constexpr int PER = WG_SORT_MAX / 256;
+        constexpr int PER = WG_SORT_MAX / WG_SORT_THREADS;
         unsigned long long outk[PER];
         const uint32_t o0 = threadIdx.x * PER, pairbase = o0 / (2u * L) * (2u * L), d0 = o0 - pairbase;
         {
@@ -430,20 +431,21 @@ tile_sort_wg_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, unsi
     // ---- out: final lists (the whole tile was this chunk) or the sorted chunk back in place
     if (n <= (uint32_t)WG_SORT_MAX) {
         const FinalLists fl{gm_base, point_list, gm_index, qmask, t % gx, t / gx};
-        for (uint32_t e = threadIdx.x; e < cnt; e += 256) fl.write(lo + e, (uint32_t)src[wg_slot((int)e)]);
+        for (uint32_t e = threadIdx.x; e < cnt; e += WG_SORT_THREADS) fl.write(lo + e, (uint32_t)src[wg_slot((int)e)]);
     } else {
-        for (uint32_t e = threadIdx.x; e < cnt; e += 256) chunk[e] = src[wg_slot((int)e)];
+        for (uint32_t e = threadIdx.x; e < cnt; e += WG_SORT_THREADS) chunk[e] = src[wg_slot((int)e)];
     }
 }
 
-// Merge pass over sorted runs of length L = 4096 << pass -> runs of length 2L, for tiles above 4096
+constexpr int MP_SEG = 4096;        // keys of the merged output one merge-path workgroup produces
+// Merge pass over sorted runs of length L = WG_SORT_MAX << pass -> runs of length 2L, for tiles above WG_SORT_MAX
 // instances (data of pass p lives in buffer (p & 1); tiles that are already fully merged are skipped).
 // Merge path: every workgroup produces one 4096-key segment of the merged output.  Two lanes find where
 // the segment's first and last diagonal cut the two runs (one binary search each over global memory --
 // per workgroup, not per key), the at most 4096 input keys between the cuts are staged in LDS as two
 // short runs, merged there (a thread forms 16 consecutive outputs: one bisection, 16 compare-and-advance steps)
 // and streamed out coalesced.
-__device__ __forceinline__ uint32_t merge_passes_needed(uint32_t n) {  // ceil(log2(ceil(n/4096)))
+__device__ __forceinline__ uint32_t merge_passes_needed(uint32_t n) {  // ceil(log2(ceil(n / WG_SORT_MAX)))
     uint32_t chunks = (n + WG_SORT_MAX - 1) / WG_SORT_MAX, p = 0;
     while ((1u << p) < chunks) ++p;
     return p;
@@ -484,19 +486,19 @@ tile_merge_path_kernel(int tiles, int gx, uint32_t pass, const uint32_t* __restr
                        uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
     // run A at slots [0, na), run B at [na, na + nb), every index p stored at p + (p >> 4) (17 slots per 16 keys): the
     // threads walk the runs 16 keys apart, which would put them all on the same LDS banks
-    __shared__ unsigned long long buf[WG_SORT_MAX + WG_SORT_MAX / 16];
+    __shared__ unsigned long long buf[MP_SEG + MP_SEG / 16];
     __shared__ uint32_t cut[2];
     int t = xcd_tile(blockIdx.x, tiles);
     if (t < 0) return;
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
     if (n <= (uint32_t)WG_SORT_MAX || pass >= merge_passes_needed(n)) return;
     const uint32_t L = (uint32_t)WG_SORT_MAX << pass;
-    const uint32_t e0 = blockIdx.y * (uint32_t)WG_SORT_MAX;
+    const uint32_t e0 = blockIdx.y * (uint32_t)MP_SEG;
     if (e0 >= n) return;
     const uint32_t pairbase = e0 / (2u * L) * (2u * L);
     const uint32_t lenA = min(L, n - pairbase);
     const uint32_t lenB = n - pairbase > L ? min(L, n - pairbase - L) : 0u;
-    const uint32_t s0 = e0 - pairbase, s1 = min(s0 + (uint32_t)WG_SORT_MAX, lenA + lenB);
+    const uint32_t s0 = e0 - pairbase, s1 = min(s0 + (uint32_t)MP_SEG, lenA + lenB);
     const unsigned long long* A = src + lo + pairbase;
     const unsigned long long* B = A + L;
     if (threadIdx.x < 128) {  // waves 0 and 1: the two cuts, concurrently
@@ -510,14 +512,14 @@ tile_merge_path_kernel(int tiles, int gx, uint32_t pass, const uint32_t* __restr
     {   // the segment's keys (na from run A, then nb from run B): all 16 loads of a thread in flight before the first LDS
         // write, from clamped addresses and without a branch around them -- as `load -> LDS write` loops every iteration
         // waited for its own load (sixteen memory round trips per workgroup: the pass ran at 28 % of the copy rate)
-        unsigned long long v[WG_SORT_MAX / 256];
+        unsigned long long v[MP_SEG / 256];
 #pragma unroll
-        for (int k = 0; k < WG_SORT_MAX / 256; ++k) {
+        for (int k = 0; k < MP_SEG / 256; ++k) {
             const uint32_t e = min(threadIdx.x + 256u * k, tot - 1);          // tot >= 1: the segment exists
             v[k] = e < na ? A[i0 + e] : B[j0 + (e - na)];
         }
 #pragma unroll
-        for (int k = 0; k < WG_SORT_MAX / 256; ++k) {
+        for (int k = 0; k < MP_SEG / 256; ++k) {
             const uint32_t e = threadIdx.x + 256u * k;
             if (e < tot) buf[wg_slot((int)e)] = v[k];
         }
@@ -525,7 +527,7 @@ tile_merge_path_kernel(int tiles, int gx, uint32_t pass, const uint32_t* __restr
     __syncthreads();
     // ---- every thread merges ITS 16 consecutive outputs: one bisection along its diagonal (how many keys of run A lie
     // among the first 16 t outputs), then 16 compare-and-advance steps -- instead of one bisection per key
-    constexpr int PER = WG_SORT_MAX / 256;
+    constexpr int PER = MP_SEG / 256;
     unsigned long long outk[PER];
     const uint32_t d0 = min((uint32_t)threadIdx.x * PER, tot);
     {
@@ -608,16 +610,26 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
                                              bv.qmask);
     if (max_tile_instances <= WAVE_SORT_MAX) return;
     const unsigned chunks = (unsigned)((max_tile_instances + WG_SORT_MAX - 1) / WG_SORT_MAX);
-    tile_sort_wg_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.gm_base, bv.point_list,
-                                                         bv.gm_index, bv.qmask);
+    const size_t lds = (size_t)(WG_SORT_MAX + WG_SORT_MAX / 16) * 8;
+    static bool big_lds[64] = {};      // more than the default 64 KB of dynamic LDS: the attribute is per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !big_lds[dev]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)tile_sort_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess && dev >= 0 && dev < 64) big_lds[dev] = true;
+        (void)hipGetLastError();
+    }
+    tile_sort_wg_kernel<<<dim3(gt, chunks), WG_SORT_THREADS, lds, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.gm_base, bv.point_list,
+                                                                        bv.gm_index, bv.qmask);
     if (chunks <= 1) return;
     unsigned passes = 0;
     while ((1u << passes) < chunks) ++passes;
+    const unsigned segs = (unsigned)((max_tile_instances + MP_SEG - 1) / MP_SEG);
     for (unsigned p = 0; p < passes; ++p) {
         const unsigned long long* src = (p & 1u) ? bv.keys2 : bv.keys;  // data of pass p lives in buffer (p & 1)
         unsigned long long* dst = (p & 1u) ? bv.keys : bv.keys2;
-        tile_merge_path_kernel<<<dim3(gt, chunks), 256, 0, st>>>(g.tiles, g.gx, p, gv.ranges, src, dst, gv.gm_base,
-                                                                 bv.point_list, bv.gm_index, bv.qmask);
+        tile_merge_path_kernel<<<dim3(gt, segs), 256, 0, st>>>(g.tiles, g.gx, p, gv.ranges, src, dst, gv.gm_base,
+                                                               bv.point_list, bv.gm_index, bv.qmask);
     }
 }
 

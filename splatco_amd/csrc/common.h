@@ -96,7 +96,7 @@ inline __host__ BinView bin_view(void* base, int64_t I, int64_t max_tile_instanc
     v.point_list = (uint32_t*)take(n * 4);
     v.gm_index = (uint32_t*)take(n * 4);
     v.qmask = (uint8_t*)take(n);
-    const bool merge = max_tile_instances > 4096;  // WG_SORT_MAX: tiles above it take global merge passes
+    const bool merge = max_tile_instances > 8192;  // WG_SORT_MAX (binning.hip): tiles above it take global merge passes
     v.keys2 = merge ? (unsigned long long*)take(n * 8) : nullptr;
     v.bytes = off;
     return v;
