@@ -85,9 +85,12 @@ def gather_anchors(pc, idx):
     visible anchors idx [V] (int64, ascending).  With pc._grad_sink set (train_step.collaborative_step with a GradArena)
     the gradients of the four parameters go straight into their .grad memory."""
     sink = getattr(pc, "_grad_sink", None)
+    if sink is not None and not torch.is_grad_enabled():
+        sink = None                                 # no backward will come
     if sink is not None:
         ok = all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.shape == q.shape
                  for t, q in zip(sink.tensors, (pc._anchor_feat, pc._anchor, pc._offset, pc._scaling)))
-        if not ok or not torch.is_grad_enabled():
-            sink = None
+        if not ok:      # falling back to autograd here would ADD into gradient memory the arena did not clear
+            raise RuntimeError("the gradient sink does not match the model's per-anchor parameters "
+                               "(rebuild the GradArena after adjust_anchor / sort_anchors)")
     return _AnchorGather.apply(idx, sink, pc._anchor_feat, pc._anchor, pc._offset, pc._scaling)
