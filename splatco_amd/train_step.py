@@ -66,6 +66,11 @@ def collaborative_step(pc, views, gt_images, pipe, bg_color, optimizer=None, buc
             arena.sink(pc)
             arena._sink_model = pc
         pc._grad_sink = getattr(arena, "_sink", None)
+        if pc._grad_sink is not None and any(getattr(pc, n) is not arena.params[i] for n, i in
+                                             zip(("_anchor_feat", "_anchor", "_offset", "_scaling"), arena._sink_ids)):
+            pc._grad_sink = None
+            raise RuntimeError("the GradArena was built from parameters the model no longer holds "
+                               "(adjust_anchor / sort_anchors replace them): build a new arena")
         arena.zero()
     else:
         pc._grad_sink = None
