@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 13
+#define SCR_ABI_VERSION 14
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -173,6 +173,18 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
  * array) holds the first column of xy, xz, yz and, with planes = 2, of the second triple sampled at the same
  * positions; grad_planes[3 * planes] (host array of device pointers, same order) are overwritten.  Scratch from
  * scr_triplane_backward_scratch_bytes(V, X, Y, Z, R * planes). */
+/* scr_triplane_backward_multi: the backward of up to three grids that were sampled at the SAME coordinates into one
+ * matrix (FeaturePlanes: the attention grid with every plane stacked on its attended twin, R = 2 r, then one or two plain
+ * grids, R = r) in one pass over the points: R/X/Y/Z/col[ngrids] (host arrays) give the channels per plane, the plane
+ * sizes and the first gradient column of every grid (grid g owns columns col[g] .. col[g] + 3 R[g], xy | xz | yz, the
+ * grids back to back); grad_planes[3 * ngrids] (host array of device pointers, grid-major) are overwritten.  Returns 3
+ * WITHOUT touching anything that matters when the layout is not one the fused pass is built for -- the caller then calls
+ * scr_triplane_backward per grid.  Scratch from scr_triplane_backward_multi_scratch_bytes. */
+size_t scr_triplane_backward_multi_scratch_bytes(int64_t V, int32_t ngrids, const int32_t* R, const int32_t* X, const int32_t* Y,
+                                                 const int32_t* Z);
+int scr_triplane_backward_multi(int64_t V, const float* coords, int32_t cstride, int32_t ngrids, const int32_t* R,
+                                const int32_t* X, const int32_t* Y, const int32_t* Z, const int32_t* col, const float* grad_out,
+                                int32_t ld, float* const* grad_planes, void* scratch, void* stream);
 int scr_plane_row_pairs(int32_t R, int32_t A, int32_t B, const float* plane, float* pairs, void* stream);
 int scr_triplane_forward(int64_t V, const float* coords, int32_t cstride, const float* xy, const float* xz,
                          const float* yz, int32_t R, int32_t X, int32_t Y, int32_t Z, int32_t channel_last, float* out,

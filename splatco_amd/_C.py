@@ -16,14 +16,14 @@ SYMBOLS = [
     "scr_backward_scratch_bytes", "scr_visible_filter", "scr_mark_visible", "scr_forward_plan",
     "scr_forward_run", "scr_backward", "scr_debug_get", "scr_profile_enable", "scr_profile_read",
     "scr_profile_kernel_name", "scr_expand_scratch_bytes", "scr_expand_plan", "scr_expand_run",
-    "scr_expand_backward", "scr_plane_sample_scratch_bytes", "scr_plane_sample_backward", "scr_plane_row_pairs", "scr_triplane_forward", "scr_triplane_backward_scratch_bytes", "scr_triplane_backward",
+    "scr_expand_backward", "scr_plane_sample_scratch_bytes", "scr_plane_sample_backward", "scr_triplane_backward_multi_scratch_bytes", "scr_triplane_backward_multi", "scr_plane_row_pairs", "scr_triplane_forward", "scr_triplane_backward_scratch_bytes", "scr_triplane_backward",
     "scr_l1_ssim_scratch_bytes", "scr_l1_ssim_forward", "scr_l1_ssim_backward",
     "scr_statis_compute", "scr_statis_apply", "scr_copy_probe",
     "scr_knn", "scr_knn_curvature", "scr_anchor_gather", "scr_anchor_gather_backward", "scr_mlp_heads_hidden_bytes", "scr_mlp_heads_partial_bytes", "scr_mlp_heads_forward", "scr_mlp_heads_backward",
     "scr_norm_linear_scratch_bytes", "scr_norm_linear_forward", "scr_norm_linear_backward",
 ]
 PROF_COUNT = 18
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
 
@@ -83,6 +83,10 @@ def _load():
     lib.scr_triplane_forward.argtypes = [i64, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]
     lib.scr_triplane_forward.restype = C.c_int
     lib.scr_plane_row_pairs.argtypes = [i32, i32, i32, vp, vp, vp]
+    lib.scr_triplane_backward_multi_scratch_bytes.argtypes = [i64, i32, vp, vp, vp, vp]
+    lib.scr_triplane_backward_multi_scratch_bytes.restype = C.c_size_t
+    lib.scr_triplane_backward_multi.argtypes = [i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]
+    lib.scr_triplane_backward_multi.restype = C.c_int
     lib.scr_plane_row_pairs.restype = C.c_int
     lib.scr_triplane_backward_scratch_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.scr_triplane_backward_scratch_bytes.restype = C.c_size_t

@@ -420,6 +420,31 @@ int scr_triplane_backward(int64_t V, const float* coords, int32_t cstride, int32
     return 0;
 }
 
+size_t scr_triplane_backward_multi_scratch_bytes(int64_t V, int32_t ngrids, const int32_t* R, const int32_t* X, const int32_t* Y,
+                                                 const int32_t* Z) {
+    if (!R || !X || !Y || !Z || ngrids < 1 || ngrids > 3) return 0;
+    return triplane_multi_scratch_bytes(V, ngrids, R, X, Y, Z);
+}
+
+int scr_triplane_backward_multi(int64_t V, const float* coords, int32_t cstride, int32_t ngrids, const int32_t* R,
+                                const int32_t* X, const int32_t* Y, const int32_t* Z, const int32_t* col, const float* grad_out,
+                                int32_t ld, float* const* grad_planes, void* scratch, void* stream) {
+    if (V < 0 || ngrids < 1 || ngrids > 3) return fail("bad sizes");
+    if (!R || !X || !Y || !Z || !col || !grad_planes || !scratch || (V > 0 && (!coords || !grad_out))) return fail("NULL argument");
+    for (int g = 0; g < ngrids; ++g) {
+        if (R[g] < 1 || X[g] < 2 || Y[g] < 2 || Z[g] < 2 || col[g] < 0 || col[g] + 3 * R[g] > ld) return fail("bad grid %d", g);
+        for (int q = 0; q < 3; ++q)
+            if (!grad_planes[3 * g + q]) return fail("NULL plane gradient %d", 3 * g + q);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    { ProfScope ps_(SCR_PROF_PLANE_BACKWARD, st);
+      rc = launch_triplane_backward_multi(V, coords, cstride, ngrids, R, X, Y, Z, col, grad_out, ld, grad_planes, scratch, st); }
+    if (rc == 3) return 3;      // not a layout of the fused pass: not an error, the caller goes grid by grid
+    CHECK_LAUNCH("triplane_backward_multi", 0, st);
+    return 0;
+}
+
 int scr_plane_row_pairs(int32_t R, int32_t A, int32_t B, const float* plane, float* pairs, void* stream) {
     if (A < 2 || B < 2) return fail("bad sizes");
     if (!plane || !pairs) return fail("NULL argument");

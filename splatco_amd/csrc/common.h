@@ -372,6 +372,10 @@ void launch_l1_ssim_forward(int C, int H, int W, const float* img1, const float*
                             int with_grad, float* out2, hipStream_t st);
 void launch_l1_ssim_backward(int C, int H, int W, const float* img1, const float* img2, const void* scratch,
                              const float* g_l1, const float* g_ssim, float* dimg1, hipStream_t st);
+size_t triplane_multi_scratch_bytes(int64_t V, int ngrids, const int* R, const int* X, const int* Y, const int* Z);
+int launch_triplane_backward_multi(int64_t V, const float* coords, int cs, int ngrids, const int* R, const int* X, const int* Y,
+                                   const int* Z, const int* col, const float* grad, int ld, float* const* grad_planes,
+                                   void* scratch, hipStream_t st);
 int launch_plane_row_pairs(int R, int A, int B, const float* plane, float* pairs, hipStream_t st);
 size_t triplane_scratch_bytes(int64_t V, int A, int B, int channels);
 size_t triplane_backward_scratch_bytes(int64_t V, int X, int Y, int Z, int channels);

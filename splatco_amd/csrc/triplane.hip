@@ -21,6 +21,7 @@
 // Round 1 kept an index list per tile and gathered coordinates and gradients through it (0.43 ms per plane at
 // 4.6 M points, 5.2 ms per cfg2 step); records + one pass per grid + cell-centred sums: 3.2 ms per step.
 #include "common.h"
+#include <type_traits>
 
 namespace scr {
 
@@ -268,6 +269,133 @@ tp_scatter_kernel(int64_t V, const float* __restrict__ coords, int cs, const flo
 #pragma unroll
             for (int k = 0; k < REC / 4; ++k) dst[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
         }
+    }
+}
+
+// ---- all grids of a step in ONE pass over the points (up to three grids = nine projections that sample the same
+// coordinates; FeaturePlanes: the attention grid with its planes stacked, R = 2 r, and one or two plain grids, R = r).
+// The [V, ld] gradient matrix and the coordinates are read once instead of once per grid, with whole 16-byte loads.
+struct TpProjSet9 {
+    TpProj p[9];
+    int n;          // 3 * number of grids
+};
+
+__device__ __forceinline__ float tp_pick(float x, float y, float z, int c) { return c == 0 ? x : (c == 1 ? y : z); }
+
+__global__ void __launch_bounds__(TP_THREADS)
+tp_count9_kernel(int64_t V, const float* __restrict__ coords, int cs, TpProjSet9 ps) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    int total = 0;
+    for (int q = 0; q < ps.n; ++q) total += ps.p[q].tiles;
+    for (int t = threadIdx.x; t < total; t += TP_THREADS) hist[t] = 0;
+    __syncthreads();
+    for (int r = 0; r < TP_ROUNDS; ++r) {
+        const int64_t i = (int64_t)blockIdx.x * TP_PER_WG + r * TP_THREADS + threadIdx.x;
+        if (i >= V) break;
+        const float x = coords[i * cs], y = coords[i * cs + 1], z = coords[i * cs + 2];
+        int off = 0;
+        for (int q = 0; q < ps.n; ++q) {
+            const int t = tp_tile_of(tp_pick(x, y, z, ps.p[q].cx), tp_pick(x, y, z, ps.p[q].cy), ps.p[q].A, ps.p[q].B, ps.p[q].tb);
+            if (t >= 0) atomicAdd(&hist[off + t], 1u);
+            off += ps.p[q].tiles;
+        }
+    }
+    __syncthreads();
+    int off = 0;
+    for (int q = 0; q < ps.n; ++q) {
+        for (int t = threadIdx.x; t < ps.p[q].tiles; t += TP_THREADS) {
+            const uint32_t c = hist[off + t];
+            if (c) atomicAdd(&ps.p[q].count[t], c);
+        }
+        off += ps.p[q].tiles;
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+tp_scan9_kernel(TpProjSet9 ps) {
+    __shared__ uint32_t lds[1024 / WAVE];
+    const TpProj pj = ps.p[blockIdx.x];
+    uint32_t carry = 0;
+    for (int base = 0; base < pj.tiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < pj.tiles ? pj.count[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = tp_block_scan(v, lds, tot);
+        if (i < pj.tiles) {
+            pj.start[i] = carry + ex;
+            pj.cursor[i] = 0;
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) pj.start[pj.tiles] = carry;
+}
+
+// grid g (0..2) has RTg channels per projection (0 = grid absent); its projection q owns columns
+// base_g + q * RTg .. + RTg of the span that starts at column span0 (a multiple of 4; rows 16-byte aligned)
+template <int RA, int RB, int RC>
+__global__ void __launch_bounds__(TP_THREADS)
+tp_scatter9_kernel(int64_t V, const float* __restrict__ coords, int cs, const float* __restrict__ grad, int ld, int span0,
+                   TpProjSet9 ps) {
+    constexpr int SPAN = 3 * (RA + RB + RC);
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    int total = 0;
+    for (int q = 0; q < ps.n; ++q) total += ps.p[q].tiles;
+    for (int t = threadIdx.x; t < total; t += TP_THREADS) hist[t] = 0;
+    __syncthreads();
+    for (int r = 0; r < TP_ROUNDS; ++r) {
+        const int64_t i = (int64_t)blockIdx.x * TP_PER_WG + r * TP_THREADS + threadIdx.x;
+        if (i >= V) break;
+        const float x = coords[i * cs], y = coords[i * cs + 1], z = coords[i * cs + 2];
+        int off = 0;
+        for (int q = 0; q < ps.n; ++q) {
+            const int t = tp_tile_of(tp_pick(x, y, z, ps.p[q].cx), tp_pick(x, y, z, ps.p[q].cy), ps.p[q].A, ps.p[q].B, ps.p[q].tb);
+            if (t >= 0) atomicAdd(&hist[off + t], 1u);
+            off += ps.p[q].tiles;
+        }
+    }
+    __syncthreads();
+    {
+        int off = 0;
+        for (int q = 0; q < ps.n; ++q) {
+            for (int t = threadIdx.x; t < ps.p[q].tiles; t += TP_THREADS) {
+                const uint32_t c = hist[off + t];
+                if (c) hist[off + t] = ps.p[q].start[t] + atomicAdd(&ps.p[q].cursor[t], c);
+            }
+            off += ps.p[q].tiles;
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < TP_ROUNDS; ++r) {
+        const int64_t i = (int64_t)blockIdx.x * TP_PER_WG + r * TP_THREADS + threadIdx.x;
+        if (i >= V) break;
+        const float x = coords[i * cs], y = coords[i * cs + 1], z = coords[i * cs + 2];
+        float span[SPAN];
+        tp_load_span<SPAN, 0>(grad + (size_t)i * ld + span0, span);
+        int off = 0;
+        auto place = [&](auto rt_tag, int g, int base) {
+            constexpr int RT = decltype(rt_tag)::value, REC = tp_rec(RT);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const TpProj& pj = ps.p[3 * g + q];
+                const float gx = tp_pick(x, y, z, pj.cx), gy = tp_pick(x, y, z, pj.cy);
+                const int t = tp_tile_of(gx, gy, pj.A, pj.B, pj.tb);
+                if (t >= 0) {
+                    float v[REC];
+                    v[0] = gx;
+                    v[1] = gy;
+#pragma unroll
+                    for (int k = 0; k < REC - 2; ++k) v[2 + k] = k < RT ? span[base + q * RT + k] : 0.0f;
+                    float4* dst = (float4*)(pj.rec + (size_t)atomicAdd(&hist[off + t], 1u) * REC);
+#pragma unroll
+                    for (int k = 0; k < REC / 4; ++k) dst[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+                }
+                off += pj.tiles;
+            }
+        };
+        place(std::integral_constant<int, RA>{}, 0, 0);
+        if constexpr (RB > 0) place(std::integral_constant<int, RB>{}, 1, 3 * RA);
+        if constexpr (RC > 0) place(std::integral_constant<int, RC>{}, 2, 3 * (RA + RB));
     }
 }
 
@@ -730,6 +858,83 @@ static int tp_backward(int64_t V, const float* coords, int cs, int R, int planes
         break;
     switch (R) { SCR_TP_BWD(1) SCR_TP_BWD(2) SCR_TP_BWD(3) SCR_TP_BWD(4) SCR_TP_BWD(5) SCR_TP_BWD(6) SCR_TP_BWD(7) SCR_TP_BWD(8) SCR_TP_BWD(9) SCR_TP_BWD(10) SCR_TP_BWD(11) SCR_TP_BWD(12) SCR_TP_BWD(13) SCR_TP_BWD(14) SCR_TP_BWD(15) SCR_TP_BWD(16) }
 #undef SCR_TP_BWD
+    return 0;
+}
+
+// ---- all grids of a step at once (see tp_scatter9_kernel).  ngrids <= 3; grid g: R[g] channels per plane (the attention
+// grid arrives with its planes stacked), sizes X/Y/Z[g], first column col[g] of its 3 * R[g] gradient columns (xy, xz, yz
+// in this order); the columns of all grids are contiguous from col[0].  Returns 3 when the layout is not one the fused
+// pass handles (the caller falls back to one call per grid).
+size_t triplane_multi_scratch_bytes(int64_t V, int ngrids, const int* R, const int* X, const int* Y, const int* Z) {
+    size_t b = 0;
+    for (int g = 0; g < ngrids; ++g) b += triplane_backward_scratch_bytes(V, X[g], Y[g], Z[g], R[g]);
+    return b;
+}
+
+template <int RR, int NPX>
+static void tp_gather_launch(const TpProj& pj, float* gp, hipStream_t st) {
+    static bool big_lds[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !big_lds[dev]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)tp_cell_gather_kernel<RR, NPX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)tpn_lds_bytes<RR * NPX>());
+        if (e == hipSuccess && dev >= 0 && dev < 64) big_lds[dev] = true;
+        (void)hipGetLastError();
+    }
+    tp_cell_gather_kernel<RR, NPX><<<pj.tiles, TPN_THREADS, tpn_lds_bytes<RR * NPX>(), st>>>(pj.A, pj.B, pj.tb, pj.start, pj.rec, gp, gp);
+}
+
+int launch_triplane_backward_multi(int64_t V, const float* coords, int cs, int ngrids, const int* R, const int* X, const int* Y,
+                                   const int* Z, const int* col, const float* grad, int ld, float* const* grad_planes,
+                                   void* scratch, hipStream_t st) {
+    if (ngrids < 1 || ngrids > 3 || cs < 3) return 3;
+    if (ld % 4 != 0 || col[0] % 4 != 0 || ((uintptr_t)grad & 15) != 0) return 3;
+    for (int g = 0; g + 1 < ngrids; ++g)
+        if (col[g + 1] != col[g] + 3 * R[g]) return 3;
+    const int RA = R[0], RB = ngrids > 1 ? R[1] : 0, RC = ngrids > 2 ? R[2] : 0;
+    // the layouts of FeaturePlanes (r = channels per plane): attention grid stacked (2 r) [+ plain (r) [+ plain (r)]], or plain grids only
+    const bool known = (RA == 10 && (RB == 0 || RB == 5) && (RC == 0 || RC == 5)) || (RA == 5 && (RB == 0 || RB == 5) && (RC == 0 || RC == 5));
+    if (!known || (RC && !RB)) return 3;
+    TpProjSet9 ps;
+    ps.n = 3 * ngrids;
+    const int pairs[3][2] = {{1, 0}, {2, 0}, {2, 1}};
+    char* sc = (char*)scratch;
+    int total = 0;
+    for (int g = 0; g < ngrids; ++g) {
+        const int sizes[3][2] = {{X[g], Y[g]}, {X[g], Z[g]}, {Y[g], Z[g]}};
+        for (int q = 0; q < 3; ++q) {
+            TpProj& pj = ps.p[3 * g + q];
+            pj.cx = pairs[q][0];
+            pj.cy = pairs[q][1];
+            pj.A = sizes[q][0];
+            pj.B = sizes[q][1];
+            pj.col0 = pj.col1 = col[g] + q * R[g];
+            sc = tp_carve(pj, V, R[g], sc);
+            total += pj.tiles;
+            (void)hipMemsetAsync(pj.count, 0, (size_t)pj.tiles * 4, st);
+            (void)hipMemsetAsync(grad_planes[3 * g + q], 0, (size_t)R[g] * pj.A * pj.B * 4, st);
+        }
+    }
+    for (int q = ps.n; q < 9; ++q) ps.p[q] = ps.p[0];
+    if (total > TP_HIST_MAX_TILES) return 3;
+    if (V <= 0) return 0;
+    const unsigned nwg = (unsigned)((V + TP_PER_WG - 1) / TP_PER_WG);
+    const size_t hb = (size_t)total * 4;
+    tp_count9_kernel<<<nwg, TP_THREADS, hb, st>>>(V, coords, cs, ps);
+    tp_scan9_kernel<<<ps.n, 1024, 0, st>>>(ps);
+#define SCR_TP_S9(a, b, c) tp_scatter9_kernel<a, b, c><<<nwg, TP_THREADS, hb, st>>>(V, coords, cs, grad, ld, col[0], ps)
+    if (RA == 10) {
+        if (RC) SCR_TP_S9(10, 5, 5); else if (RB) SCR_TP_S9(10, 5, 0); else SCR_TP_S9(10, 0, 0);
+    } else {
+        if (RC) SCR_TP_S9(5, 5, 5); else if (RB) SCR_TP_S9(5, 5, 0); else SCR_TP_S9(5, 0, 0);
+    }
+#undef SCR_TP_S9
+    for (int g = 0; g < ngrids; ++g)
+        for (int q = 0; q < 3; ++q) {
+            if (R[g] == 10) tp_gather_launch<10, 1>(ps.p[3 * g + q], grad_planes[3 * g + q], st);
+            else tp_gather_launch<5, 1>(ps.p[3 * g + q], grad_planes[3 * g + q], st);
+        }
     return 0;
 }
 

@@ -261,11 +261,21 @@ class PlaneGrid(nn.Module):                   # scene/grids.py:102-201
     def fused_ok(self, xyz):
         return self.xy_plane.is_cuda and self.channels // 3 <= 8 and not xyz.requires_grad    # csrc/triplane.hip (2 R <= 16)
 
-    def sample_spec(self, xyz, col0=0):
+    def bounds_key(self):
+        """The grid's box as host floats (one device read per change of the buffers): grids with equal boxes sample at
+        the same normalised coordinates, which FeaturePlanes then computes once."""
+        ver = (self.xyz_min._version, self.xyz_max._version, self.xyz_min.data_ptr(), self.xyz_max.data_ptr())
+        if getattr(self, "_bounds_ver", None) != ver:
+            self._bounds_ver = ver
+            self._bounds = tuple(self.xyz_min.detach().cpu().tolist()) + tuple(self.xyz_max.detach().cpu().tolist())
+        return self._bounds
+
+    def sample_spec(self, xyz, col0=0, ind3=None):
         """(ind [V,3], planes, first output column of every plane) for triplane.multi_triplane_sample: what
         compute_planes_feat samples and where the reference's torch.cat puts it (scene/grids.py:165,181)."""
         R = self.channels // 3
-        ind3 = (xyz.reshape(-1, 3) - self.xyz_min) / (self.xyz_max - self.xyz_min) * 2 - 1
+        if ind3 is None:
+            ind3 = (xyz.reshape(-1, 3) - self.xyz_min) / (self.xyz_max - self.xyz_min) * 2 - 1
         if not self.TAflag:
             return ind3, (self.xy_plane, self.xz_plane, self.yz_plane), tuple(col0 + R * j for j in range(3))
         tri = self.TA(torch.cat((self.xy_plane, self.xz_plane, self.yz_plane), dim=1))   # every call (:166-168)
@@ -328,9 +338,14 @@ class FeaturePlanes(nn.Module):               # scene/gaussian_model.py:97-169
             if x.dim() == 2 and all(self.k0s[i].fused_ok(x) for i in range(L)):
                 # every active grid samples straight into its columns of one matrix (no torch.cat of the grids' outputs)
                 from .triplane import multi_triplane_sample
-                specs, col = [], 0
+                specs, col, shared = [], 0, {}
                 for i in range(L):
-                    specs.append(self.k0s[i].sample_spec(x, col))
+                    # grids with the same box sample at the same normalised coordinates: ONE tensor, which also lets the
+                    # backward of all grids run as one pass over the points
+                    key = self.k0s[i].bounds_key()
+                    spec = self.k0s[i].sample_spec(x, col, shared.get(key))
+                    shared.setdefault(key, spec[0])
+                    specs.append(spec)
                     col += self.k0s[i].get_dim()
                 feats = multi_triplane_sample(specs)
                 if Q != 0:                       # uniform noise on the plain grids' blocks only (scene/grids.py:159-181)

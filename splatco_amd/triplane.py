@@ -17,6 +17,7 @@ from .rasterizer import _stream
 # (column of ind holding grid-x -> last plane dim, column holding grid-y) for xy / xz / yz (scene/grids.py:148-150)
 _PAIRS = ((1, 0), (2, 0), (2, 1))
 CHANNEL_LAST_MIN_POINTS = 262144
+FUSE_GRIDS = True        # the backward of all grids of an op in one pass over the points when the layout allows (False: grid by grid)
 
 
 def _forward_into(out, ind, cols, planes):
@@ -90,8 +91,12 @@ class _TriPlaneSample(torch.autograd.Function):
     def backward(ctx, g):
         if g.dtype != torch.float32 or g.stride(1) != 1:     # a column block of a wider matrix is read in place
             g = g.contiguous().float()
+        inds = ctx.saved_tensors
+        fused = _backward_all(ctx, g, inds)
+        if fused is not None:
+            return fused
         grads, k = [], 0
-        for (n, cols), ind, shapes in zip(ctx.meta, ctx.saved_tensors, ctx.shapes):
+        for (n, cols), ind, shapes in zip(ctx.meta, inds, ctx.shapes):
             need = ctx.needs_input_grad[2 + k + 1:2 + k + 1 + n]
             with torch.cuda.device(ind.device):
                 gp = _backward_from(g, ind, cols, shapes) if any(need) else [None] * n
@@ -99,6 +104,43 @@ class _TriPlaneSample(torch.autograd.Function):
             grads.extend(t if nd else None for t, nd in zip(gp, need))
             k += 1 + n
         return (None, None, *grads)
+
+
+def _backward_all(ctx, g, inds):
+    """All grids of the op in ONE pass over the points (scr_triplane_backward_multi) when they were sampled at the same
+    coordinates (the same tensor), each is a plain triple, their column blocks lie back to back in standard order and
+    the library knows the channel layout; None otherwise (the caller goes grid by grid)."""
+    import ctypes as C
+    ng = len(ctx.meta)
+    if not FUSE_GRIDS or ng > 3 or any(i.data_ptr() != inds[0].data_ptr() or i.shape != inds[0].shape or i.stride() != inds[0].stride() for i in inds):
+        return None
+    R, X, Y, Z, col = [], [], [], [], []
+    for (n, cols), shapes in zip(ctx.meta, ctx.shapes):
+        r = shapes[0][1]
+        if n != 3 or tuple(cols) != (cols[0], cols[0] + r, cols[0] + 2 * r):
+            return None
+        R.append(r); X.append(shapes[0][2]); Y.append(shapes[0][3]); Z.append(shapes[1][3]); col.append(cols[0])
+    if not all(ctx.needs_input_grad[2:][j] for j in range(len(ctx.needs_input_grad) - 2) if j % 4 != 0):
+        return None                                          # a plane without a gradient: the per-grid path skips whole grids
+    ind, V = inds[0], inds[0].shape[0]
+    arr = lambda v: (C.c_int32 * ng)(*v)
+    cR, cX, cY, cZ, ccol = arr(R), arr(X), arr(Y), arr(Z), arr(col)
+    gp = [torch.empty(s, dtype=torch.float32, device=g.device) for shapes in ctx.shapes for s in shapes]
+    ptrs = (C.c_void_p * (3 * ng))(*[t.data_ptr() for t in gp])
+    with torch.cuda.device(ind.device):
+        nbytes = _C.lib.scr_triplane_backward_multi_scratch_bytes(V, ng, cR, cX, cY, cZ)
+        scratch = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=g.device)
+        rc = _C.lib.scr_triplane_backward_multi(V, ind.data_ptr(), ind.stride(0), ng, cR, cX, cY, cZ, ccol, g.data_ptr(),
+                                                g.stride(0), ptrs, scratch.data_ptr(), _stream())
+    if rc == 3:
+        return None
+    _C.check(rc)
+    out, k = [], 0
+    for (n, _), shapes in zip(ctx.meta, ctx.shapes):
+        out.append(None)
+        out.extend(gp[k:k + n])
+        k += n
+    return (None, None, *out)
 
 
 def _prep_ind(ind):
@@ -109,11 +151,13 @@ def _prep_ind(ind):
 def multi_triplane_sample(grids):
     """grids: [(ind [V,3], planes (3 or 6 tensors), cols (first output column of every plane))...]; returns the
     [V, width] matrix with every grid's samples in its columns (width = the largest column end)."""
-    meta, flat, width = [], [], 0
+    meta, flat, width, prepped = [], [], 0, {}
     for ind, planes, cols in grids:
         R = planes[0].shape[1]
         meta.append((len(planes), tuple(int(c) for c in cols)))
-        flat.append(_prep_ind(ind))
+        if id(ind) not in prepped:                           # the same coordinates for several grids stay ONE tensor
+            prepped[id(ind)] = _prep_ind(ind)
+        flat.append(prepped[id(ind)])
         flat.extend(planes)
         width = max(width, max(cols) + R)
     return _TriPlaneSample.apply(tuple(meta), width, *flat)

@@ -700,3 +700,52 @@ def test_arena_sink_gradients_equal_autograd_accumulation(n_views):
         scale = float(g0[n].abs().max())
         assert scale > 0 and float((g0[n] - g1[n]).abs().max()) <= 1e-6 * scale, n
     assert float((p0 - p1).abs().max()) <= 1e-5 * float(p0.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [(10, 5, 5), (10, 5), (10,), (5, 5, 5), (5,)])
+def test_all_grids_backward_in_one_pass(layout):
+    """scr_triplane_backward_multi: grids sampled at the same coordinates (one tensor) get their plane gradients from ONE
+    pass over the points.  Checked against the grid-by-grid path (same kernels downstream: the sums differ by the order of
+    LDS atomics only) and against F.grid_sample; V above and below the row-pair threshold of the forward."""
+    import torch.nn.functional as F
+    from splatco_amd import triplane as tp
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(sum(layout))
+    for V in (50_000, 300_001):
+        ind = torch.rand(V, 3, device=dev, generator=g) * 2.3 - 1.15
+        sizes = [(40, 48, 56), (40, 48, 56), (90, 70, 80)]
+        grids, col = [], 0
+        for gi, r in enumerate(layout):
+            X, Y, Z = sizes[gi]
+            planes = [(torch.randn(1, r, a, b, device=dev, generator=g) * 0.5).requires_grad_() for a, b in ((X, Y), (X, Z), (Y, Z))]
+            grids.append((planes, tuple(col + r * j for j in range(3))))
+            col += 3 * r
+        w = torch.randn(V, col, device=dev, generator=g)
+
+        def run(fuse):
+            tp.FUSE_GRIDS = fuse
+            try:
+                for pl, _ in grids:
+                    for p in pl:
+                        p.grad = None
+                out = tp.multi_triplane_sample([(ind, tuple(pl), cols) for pl, cols in grids])
+                (out * w).sum().backward()
+                return out.detach(), [p.grad.clone() for pl, _ in grids for p in pl]
+            finally:
+                tp.FUSE_GRIDS = True
+
+        out1, g1 = run(True)
+        out0, g0 = run(False)
+        assert torch.equal(out1, out0)
+        pairs = ((1, 0), (2, 0), (2, 1))
+        k = 0
+        for pl, cols in grids:
+            for j, p in enumerate(pl):
+                scale = float(g0[k].abs().max())
+                assert float((g1[k] - g0[k]).abs().max()) <= 2e-6 * scale, (layout, V, k)
+                p.grad = None
+                samp = F.grid_sample(p, ind[:, list(pairs[j])].view(1, 1, V, 2), mode="bilinear", align_corners=True).flatten(0, 2).T
+                (samp * w[:, cols[j]:cols[j] + p.shape[1]]).sum().backward()
+                assert float((g1[k] - p.grad).abs().max()) <= 5e-5 * float(p.grad.abs().max()) + 1e-7, (layout, V, k)
+                k += 1
