@@ -226,46 +226,48 @@ __device__ inline SplatForm splat_form(float4 r0, float4 r1) {
     f.vx = -f.b / (2.0f * f.a);
     return f;
 }
-// can the splat reach a pixel of [x0, x0+ex] x [y0, y0+ey] (inclusive pixel coordinates)?
-__device__ inline bool box_reachable(const SplatForm& f, float x0, float y0, float ex, float ey) {
-    if (!f.ok) return true;
-    const float a = f.a, b = f.b, c = f.c;
-    // d = mean - pixel
-    const float dxl = f.mx - (x0 + ex), dxh = f.mx - x0, dyl = f.my - (y0 + ey), dyh = f.my - y0;
-    float qmin, mag;
-    if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) {
-        qmin = 0.0f;
-        mag = 0.0f;
-    } else {
-        qmin = 3.0e38f;
-        mag = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            // edges: dx = dxl, dx = dxh (free dy), dy = dyl, dy = dyh (free dx)
-            const bool xe = e < 2;
-            const float fix = e == 0 ? dxl : e == 1 ? dxh : e == 2 ? dyl : dyh;
-            const float kf = xe ? a : c, kv = xe ? c : a;  // q = kf fix^2 + b fix v + kv v^2
-            const float lo = xe ? dyl : dxl, hi = xe ? dyh : dxh;
-            float v = (xe ? f.vy : f.vx) * fix;
-            v = fminf(hi, fmaxf(lo, v));
-            const float t0 = kf * fix * fix, t1 = b * fix * v, t2 = kv * v * v;
-            const float qe = t0 + t1 + t2;
-            if (qe < qmin) {
-                qmin = qe;
-                mag = fabsf(t0) + fabsf(t1) + fabsf(t2);
-            }
-        }
-    }
-    return !(qmin > f.thr + 1.0e-5f * mag);
-}
-
+// The four quadrants of a tile at once.  Same minimum as box_reachable, found with two edge minima per quadrant
+// instead of four: q is convex with its minimiser at d = 0, so over a box that does not contain 0 the minimum lies on a
+// face that is VISIBLE from 0 (from a point of any other face a step towards 0 stays inside the box and lowers q) --
+// at most the vertical edge dx = cx and the horizontal edge dy = cy, where (cx, cy) = 0 clamped into the box
+// (v_med3_f32).  A coordinate of 0 that already lies inside the box's range gives cx = 0: the "edge" dx = 0 is then just
+// another line through the box (a valid upper bound of the minimum, equal to it when 0 is inside the box: q = 0), so no
+// case distinction is left.  Everything that depends on one axis only is shared by the two quadrants of a row / column.
+// The splat is kept when either candidate stays within the threshold plus the rounding margin of its own terms.
 __device__ inline uint32_t quadrant_mask(float4 r0, float4 r1, int tile_x0, int tile_y0) {
     const SplatForm f = splat_form(r0, r1);
     if (!f.ok) return 0xfu;
+    const float x0 = (float)tile_x0, y0 = (float)tile_y0;
+    float dxl[2], dxh[2], dyl[2], dyh[2];     // d = mean - pixel over the half's columns / rows (low, high end)
+    float cx[2], cy[2], qx[2], qy[2], bcx[2], bcy[2], sy[2], sx[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        dxh[h] = f.mx - (x0 + (float)(8 * h));
+        dxl[h] = f.mx - (x0 + (float)(8 * h + 7));
+        dyh[h] = f.my - (y0 + (float)(8 * h));
+        dyl[h] = f.my - (y0 + (float)(8 * h + 7));
+        cx[h] = __builtin_amdgcn_fmed3f(0.0f, dxl[h], dxh[h]);
+        cy[h] = __builtin_amdgcn_fmed3f(0.0f, dyl[h], dyh[h]);
+        qx[h] = f.a * cx[h] * cx[h];          // the fixed coordinate's own term
+        qy[h] = f.c * cy[h] * cy[h];
+        bcx[h] = f.b * cx[h];
+        bcy[h] = f.b * cy[h];
+        sy[h] = f.vy * cx[h];                 // unclamped minimiser along the edge
+        sx[h] = f.vx * cy[h];
+    }
     uint32_t mask = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        if (box_reachable(f, (float)(tile_x0 + (q & 1) * 8), (float)(tile_y0 + (q >> 1) * 8), 7.0f, 7.0f)) mask |= 1u << q;
+    for (int q = 0; q < 4; ++q) {
+        const int hx = q & 1, hy = q >> 1;
+        const float v = __builtin_amdgcn_fmed3f(sy[hx], dyl[hy], dyh[hy]);
+        const float t1 = bcx[hx] * v, t2 = f.c * v * v;
+        const float qv = qx[hx] + t1 + t2, magv = qx[hx] + fabsf(t1) + t2;
+        const float u = __builtin_amdgcn_fmed3f(sx[hy], dxl[hx], dxh[hx]);
+        const float s1 = bcy[hy] * u, s2 = f.a * u * u;
+        const float qh = qy[hy] + s1 + s2, magh = qy[hy] + fabsf(s1) + s2;
+        const bool far = qv > __builtin_fmaf(1.0e-5f, magv, f.thr) && qh > __builtin_fmaf(1.0e-5f, magh, f.thr);
+        if (!far) mask |= 1u << q;
+    }
     return mask;
 }
 
