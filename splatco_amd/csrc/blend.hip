@@ -21,6 +21,8 @@
 // Blend arithmetic is normative where a decision hangs on it: power is evaluated as
 // fma(dx, fma(A,dx,B*dy), (C*dy)*dy) with A=-Qxx/2, B=-Qxy, C=-Qyy/2; exp() may differ from the
 // oracle's libm by 2 ulp (v_exp_f32).  Compiled with -ffp-contract=off; FMAs only where written.
+#include <type_traits>
+
 #include "common.h"
 
 namespace scr {
@@ -203,13 +205,15 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
         gather(m_next, id_next);
         load_mask_id(base + 2 * FCHUNK, m_next, id_next);
         __syncthreads();  // one-wave workgroup: orders the LDS writes above before the reads below
-        for (int k = 0; k < cnt; k += 4) {
-            // two packed pairs per iteration: all LDS reads and both exponent chains are in flight
-            // before the sequential (front-to-back) transmittance updates
-            v2f power[2], al[2];
-            float4 p3[2], p4[2];
+        // two packed pairs per group: all LDS reads and both exponent chains are in flight before the sequential
+        // (front-to-back) transmittance updates.  A chunk's last group holds one pair only in half of the chunks: NP = 1
+        // skips the missing pair (wave-uniform) instead of blending it with alpha 0.
+        auto group = [&](const int k, auto npairs) {
+            constexpr int NP = decltype(npairs)::value, NS = 2 * NP;
+            v2f power[NP], al[NP];
+            float4 p3[NP], p4[NP];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < NP; ++h) {
                 const int q = (k >> 1) + h;  // pair index; slots past cnt hold stale data and are masked below
                 const float4 p0 = sp[0][q], p1 = sp[1][q], p2 = sp[2][q];
                 p3[h] = sp[3][q];
@@ -220,37 +224,45 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
                 power[h] = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(A, dx, B * dy), (Cq * dy) * dy);
                 al[h] = o * v2f{fast_exp(power[h].x), fast_exp(power[h].y)};
             }
-            const float alpha[4] = {vmin(c099, al[0].x), vmin(c099, al[0].y), vmin(c099, al[1].x), vmin(c099, al[1].y)};
-            const float pw[4] = {power[0].x, power[0].y, power[1].x, power[1].y};
-            // lane masks (SGPR pairs): which pixels does splat u touch
-            unsigned long long hit[4], anyh = 0ull;
+            float alpha[NS], pw[NS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int h = 0; h < NP; ++h) {
+                alpha[2 * h] = vmin(c099, al[h].x); alpha[2 * h + 1] = vmin(c099, al[h].y);
+                pw[2 * h] = power[h].x; pw[2 * h + 1] = power[h].y;
+            }
+            // lane masks (SGPR pairs): which pixels does splat u touch
+            unsigned long long hit[NS], anyh = 0ull;
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
                 hit[u] = (k + u < cnt) ? (lanes(!(pw[u] > 0.0f)) & lanes(!(alpha[u] < 1.0f / 255.0f))) : 0ull;
                 anyh |= hit[u];
             }
-            if ((anyh & ~done) == 0ull) continue;
-            const float cr[4] = {p3[0].x, p3[0].y, p3[1].x, p3[1].y}, cg[4] = {p3[0].z, p3[0].w, p3[1].z, p3[1].w};
-            const float cb[4] = {p4[0].x, p4[0].y, p4[1].x, p4[1].y}, cj[4] = {p4[0].z, p4[0].w, p4[1].z, p4[1].w};
+            if ((anyh & ~done) == 0ull) return;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NS; ++u) {
+                const int h = u >> 1;
+                const float cr = (u & 1) ? p3[h].y : p3[h].x, cg = (u & 1) ? p3[h].w : p3[h].z;
+                const float cb = (u & 1) ? p4[h].y : p4[h].x, cj = (u & 1) ? p4[h].w : p4[h].z;
                 // A pixel the splat does not touch (or a finished pixel) blends it with alpha 0, which
                 // leaves T and C bit-for-bit unchanged (T * (1 - 0), fma(c, 0 * T, C)), so only the
                 // alpha and the early stop need selects.  T never drops below 1e-4 (the update that
                 // would do so is the stop), hence test_T < 1e-4 can only fire on a touching splat.
-                const unsigned long long h = hit[u] & ~done;
-                const float a = sel(h, alpha[u], 0.0f);
+                const unsigned long long hm = hit[u] & ~done;
+                const float a = sel(hm, alpha[u], 0.0f);
                 const float test_T = T * (1.0f - a);
                 const unsigned long long stop = lanes(test_T < 0.0001f);
                 done |= stop;
                 const float w = sel(stop, 0.0f, a * T);
-                C0 = __builtin_fmaf(cr[u], w, C0);
-                C1 = __builtin_fmaf(cg[u], w, C1);
-                C2 = __builtin_fmaf(cb[u], w, C2);
+                C0 = __builtin_fmaf(cr, w, C0);
+                C1 = __builtin_fmaf(cg, w, C1);
+                C2 = __builtin_fmaf(cb, w, C2);
                 T = sel(stop, T, test_T);
-                last = sel(h & ~stop, __float_as_uint(cj[u]), last);
+                last = sel(hm & ~stop, __float_as_uint(cj), last);
             }
-        }
+        };
+        int k = 0;
+        for (; k + 2 < cnt; k += 4) group(k, std::integral_constant<int, 2>{});
+        if (k < cnt) group(k, std::integral_constant<int, 1>{});
         if (~done == 0ull) break;
         __syncthreads();  // reads of this chunk finished before the next chunk overwrites LDS
     }
@@ -425,7 +437,7 @@ constexpr int BCH = 64;  // list entries per round: one per lane of each wave
 #define SCR_BWD_ACC_BUFS 2
 #endif
 #ifndef SCR_BWD_MIN_WAVES
-#define SCR_BWD_MIN_WAVES 2
+#define SCR_BWD_MIN_WAVES 5   // 96 VGPRs: five workgroups per CU (the LDS allows five); no spills
 #endif
 constexpr int ACC_BUFS = SCR_BWD_ACC_BUFS;  // 2: per-round sums double-buffered (one barrier per round)
 
@@ -557,7 +569,11 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         // round r+2 only after barrier B of round r+1, which every wave passes after its combine of r)
         const int par = ACC_BUFS == 2 ? (ci & 1) : 0;
         if (ACC_BUFS == 1) __syncthreads();  // A: the previous round's combine has read acc
-        for (int k = cnt - 1; k >= 0; k -= 4) {  // back to front, four splats per reduction
+        // back to front, four splats per reduction.  A round's first group (the last one walked) is partial in three
+        // rounds of four: its missing splats are skipped with wave-uniform branches (TAIL) instead of being blended
+        // with alpha 0 -- about 1.5 of the ~22 entries a wave holds per round; the full groups stay branch-free.
+        auto group = [&](const int k, auto tail) {
+            constexpr bool TAIL = decltype(tail)::value;
             float g[4][6];
             uint32_t jj[4];
             unsigned long long any = 0ull;
@@ -572,7 +588,12 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const bool valid = k - u >= 0;  // wave-uniform
+                if (TAIL && k - u < 0) {  // wave-uniform
+#pragma unroll
+                    for (int v = 0; v < 6; ++v) g[u][v] = 0.0f;
+                    jj[u] = 0xffffffffu;
+                    continue;
+                }
                 const float4 a = ra[u], b = rb[u];
                 const float2 c = rc[u];
                 const uint32_t j = __float_as_uint(c.y);
@@ -580,8 +601,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 const float power = __builtin_fmaf(dx, __builtin_fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy);
                 const float G = fast_exp(power);
                 const float alpha = vmin(c099, b.y * G);
-                const unsigned long long hit =
-                    valid ? (lanes((int)j < last_rel) & lanes(!(power > 0.0f)) & lanes(!(alpha < 1.0f / 255.0f))) : 0ull;
+                const unsigned long long hit = lanes((int)j < last_rel) & lanes(!(power > 0.0f)) & lanes(!(alpha < 1.0f / 255.0f));
                 // Branch-free: a splat that does not contribute to this pixel is carried through the
                 // back-to-front recurrences with alpha = 0, which leaves T and the colour-behind
                 // accumulator exactly as skipping it would (T / (1 - 0) = T; the accumulator folds
@@ -589,7 +609,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 splat_pixel_grad(ps, b, c.x, xl, sel(hit, G, 0.0f), sel(hit, alpha, 0.0f), g[u][0], g[u][1], g[u][2],
                                  g[u][3], g[u][4], g[u][5]);
                 any |= hit;
-                jj[u] = valid ? j : 0xffffffffu;
+                jj[u] = j;
             }
             float r[6], myy;
             if (any) {
@@ -608,7 +628,10 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 ((float*)&accB[par][wave][jw])[comp] = r[4];
                 if (comp == 0) accC[par][wave][jw] = myy;
             }
-        }
+        };
+        int k = cnt - 1;
+        for (; k >= 3; k -= 4) group(k, std::false_type{});
+        if (k >= 0) group(k, std::true_type{});
         // ---- the wave's entries: moments about the quadrant's origin -> about the splat's centre, in the record layout
         // the combine below and preprocess_backward_kernel read: (sum Y dx, sum Y dy, sum Y dx^2, sum Y dx dy |
         // sum Y dy^2, sum Y, c0, c1 | c2) with d = mean - pixel = (mean - origin) - (x, y).  One lane per entry.
