@@ -331,13 +331,84 @@ __device__ __forceinline__ void wave_sort(uint32_t n, unsigned long long* __rest
     }
 }
 
+// A network sorts a power of two: a tile of 538 instances pays for 1024 (880 compare-exchanges per lane at E = 16
+// against 360 at E = 8).  Tiles just above a power of two are therefore sorted as TWO runs -- the first 64 EA keys and
+// the remaining n - 64 EA <= 64 EB, each by its own network -- and the runs are merged through the wave's LDS: every lane
+// forms EA + EB consecutive outputs with one bisection along its diagonal and EA + EB compare-and-advance steps (as the
+// workgroup sort's merges do), then the outputs are transposed for coalesced stores like wave_sort's.
+// mb: 8-byte slots, one pad slot per 8 keys (a lane's EA keys start EA + 1 slots apart at EA = 8).
+__device__ __forceinline__ int split_slot(int p) { return p + (p >> 3); }
+constexpr int SPLIT_SLOTS = WAVE_SORT_MAX + WAVE_SORT_MAX / 8;
+template <int EA, int EB>
+__device__ __forceinline__ void wave_sort_split(uint32_t n, const unsigned long long* __restrict__ keys, uint32_t lo,
+                                                const FinalLists& fl, unsigned long long* __restrict__ mb) {
+    constexpr int NA = 64 * EA, NB = 64 * EB, PER = EA + EB;
+    const int lane = threadIdx.x & 63;
+    {
+        uint32_t klo[EA], khi[EA];
+        wave_sort_regs<EA>(NA, keys, klo, khi);
+#pragma unroll
+        for (int e = 0; e < EA; ++e) mb[split_slot(lane * EA + e)] = ((unsigned long long)khi[e] << 32) | klo[e];
+    }
+    {
+        uint32_t klo[EB], khi[EB];
+        wave_sort_regs<EB>(n - NA, keys + NA, klo, khi);   // missing keys are +inf padding, they stay at the end
+#pragma unroll
+        for (int e = 0; e < EB; ++e) mb[split_slot(NA + lane * EB + e)] = ((unsigned long long)khi[e] << 32) | klo[e];
+    }
+    __syncthreads();  // one-wave workgroup
+    uint32_t outk[PER];
+    {
+        auto keyA = [&](uint32_t i) { return mb[split_slot((int)i)]; };
+        auto keyB = [&](uint32_t j) { return mb[split_slot(NA + (int)j)]; };
+        const uint32_t d0 = (uint32_t)lane * PER;
+        uint32_t a = d0 > (uint32_t)NB ? d0 - NB : 0u, b = min(d0, (uint32_t)NA);
+        while (a < b) {
+            const uint32_t mid = (a + b) >> 1;
+            if (keyA(mid) < keyB(d0 - mid - 1)) a = mid + 1;
+            else b = mid;
+        }
+        uint32_t ia = a, ib = d0 - a;
+        unsigned long long x = ia < (uint32_t)NA ? keyA(ia) : ~0ull, y = ib < (uint32_t)NB ? keyB(ib) : ~0ull;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const bool takeA = x <= y;                // real keys are unique; +inf only pads run B
+            outk[k] = (uint32_t)(takeA ? x : y);      // the final lists need the low word only (id | quadrant mask)
+            if (takeA) {
+                ++ia;
+                x = ia < (uint32_t)NA ? keyA(ia) : ~0ull;
+            } else {
+                ++ib;
+                y = ib < (uint32_t)NB ? keyB(ib) : ~0ull;
+            }
+        }
+    }
+    __syncthreads();  // everybody has read the runs
+    uint32_t* tr = (uint32_t*)mb;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) tr[lane * (PER + 1) + k] = outk[k];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const uint32_t i = (uint32_t)e * 64 + lane;  // sorted position
+        if (i < n) fl.write(lo + i, tr[i + i / PER]);
+    }
+}
+
 template <bool FINAL>
 __device__ __forceinline__ void wave_sort_any(uint32_t n, unsigned long long* keys, uint32_t lo, const FinalLists& fl,
-                                              uint32_t* tr) {
+                                              unsigned long long* mb) {
+    uint32_t* tr = (uint32_t*)mb;
     if (n <= 64) wave_sort<1, FINAL>(n, keys, lo, fl, tr);
     else if (n <= 128) wave_sort<2, FINAL>(n, keys, lo, fl, tr);
     else if (n <= 256) wave_sort<4, FINAL>(n, keys, lo, fl, tr);
+    else if (FINAL && n > 256 && n <= 320) wave_sort_split<4, 1>(n, keys, lo, fl, mb);
+    else if (FINAL && n > 256 && n <= 384) wave_sort_split<4, 2>(n, keys, lo, fl, mb);
     else if (n <= 512) wave_sort<8, FINAL>(n, keys, lo, fl, tr);
+    else if (FINAL && n <= 576) wave_sort_split<8, 1>(n, keys, lo, fl, mb);
+    else if (FINAL && n <= 640) wave_sort_split<8, 2>(n, keys, lo, fl, mb);
+    else if (FINAL && n <= 768) wave_sort_split<8, 4>(n, keys, lo, fl, mb);
+    else if (FINAL) wave_sort_split<8, 8>(n, keys, lo, fl, mb);
     else wave_sort<16, FINAL>(n, keys, lo, fl, tr);
 }
 
@@ -354,8 +425,8 @@ tile_sort_wave_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, un
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
     if (n == 0 || n > (uint32_t)WAVE_SORT_MAX) return;
     const FinalLists fl{gm_base, point_list, gm_index, qmask, t % gx, t / gx};
-    __shared__ uint32_t tr[WAVE_SORT_MAX + 64];  // the wave's transposition buffer (wave_sort)
-    wave_sort_any<true>(n, keys + lo, lo, fl, tr);
+    __shared__ unsigned long long mb[SPLIT_SLOTS];  // the wave's merge / transposition buffer (wave_sort, wave_sort_split)
+    wave_sort_any<true>(n, keys + lo, lo, fl, mb);
 }
 
 // Tiles with more than 1024 instances: an eight-wave workgroup sorts a chunk of up to 8192 keys on chip --
