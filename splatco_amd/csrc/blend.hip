@@ -388,25 +388,16 @@ struct PixState {
     float T, dLp0, dLp1, dLp2;
     float behind, last_alpha, d_last;
 };
-__device__ __forceinline__ void splat_pixel_grad(PixState& s, float4 b, float cb, float xl, float G, float alpha,
+__device__ __forceinline__ void splat_pixel_grad(PixState& s, float T, float4 b, float cb, float xl, float G, float alpha,
                                                  float& g_0, float& g_x, float& g_xx, float& g_c0, float& g_c1,
                                                  float& g_c2) {
 #pragma clang fp contract(fast)
-    // transmittance in front of this splat: T / (1 - alpha), correctly rounded as the division of the reference
-    // arithmetic is -- v_rcp_f32, one Newton step, and one residual correction of the quotient (four fmas
-    // instead of the ten-instruction IEEE sequence).  The recurrence runs over hundreds to thousands of splats
-    // per pixel; its accumulated rounding is what the conic gradients of needle-like or deeply buried
-    // Gaussians amplify (tools/exp/diag_stress.py), so the last half ulp per step is worth 2 % of the kernel.
-    const float om = 1.0f - alpha;
-    float r = __builtin_amdgcn_rcpf(om);
-    r = __builtin_fmaf(__builtin_fmaf(-om, r, 1.0f), r, r);
-    const float q = s.T * r;
-    s.T = __builtin_fmaf(__builtin_fmaf(-q, om, s.T), r, q);
-    const float w = alpha * s.T;
+    // T = transmittance in front of this splat (group_transmittance)
+    const float w = alpha * T;
     s.behind = s.last_alpha * (s.d_last - s.behind) + s.behind;
     const float d = b.z * s.dLp0 + b.w * s.dLp1 + cb * s.dLp2;
     g_c0 = w * s.dLp0; g_c1 = w * s.dLp1; g_c2 = w * s.dLp2;
-    const float Y = G * (s.T * (d - s.behind));  // G * dL/dalpha  (straight-through min(0.99, .))
+    const float Y = G * (T * (d - s.behind));  // G * dL/dalpha  (straight-through min(0.99, .))
     s.last_alpha = alpha;
     s.d_last = d;
     // x-separable terms of the moments about the quadrant's origin (xl = this lane's pixel column, 0..7); the
@@ -414,6 +405,27 @@ __device__ __forceinline__ void splat_pixel_grad(PixState& s, float4 b, float cb
     g_0 = Y;
     g_x = Y * xl;
     g_xx = g_x * xl;
+}
+// Transmittance in front of each of the four splats of a group, walked back to front: T_u = T_(u-1) / (1 - alpha_u).
+// ONE division per group instead of one per splat: the front-most value is T / (om0 om1 om2 om3), correctly rounded
+// as the division of the reference arithmetic is -- v_rcp_f32, one Newton step, one residual correction of the quotient
+// (four fmas instead of the ten-instruction IEEE sequence) -- and the three behind it follow by multiplication.  The
+// recurrence that runs over the hundreds to thousands of splats of a pixel (whose accumulated rounding the conic
+// gradients of needle-like or deeply buried Gaussians amplify, tools/exp/diag_stress.py) now takes one step per group:
+// three roundings in the product and half an ulp in the quotient per FOUR splats, where the per-splat division took
+// half an ulp per splat; the other three values of a group are off that chain.  Saves 9 VALU operations and three
+// v_rcp_f32 per group.
+__device__ __forceinline__ void group_transmittance(float& T, const float (&om)[4], float (&Tu)[4]) {
+#pragma clang fp contract(off)
+    const float P = ((om[0] * om[1]) * om[2]) * om[3];
+    float r = __builtin_amdgcn_rcpf(P);
+    r = __builtin_fmaf(__builtin_fmaf(-P, r, 1.0f), r, r);
+    const float q = T * r;
+    Tu[3] = __builtin_fmaf(__builtin_fmaf(-q, P, T), r, q);
+    Tu[2] = Tu[3] * om[3];
+    Tu[1] = Tu[2] * om[2];
+    Tu[0] = Tu[1] * om[1];
+    T = Tu[3];
 }
 
 // 16-byte store to a dword-aligned address (the 36-byte gradient records): global memory on gfx950 only needs dword
@@ -586,17 +598,17 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 rb[u] = st[wave][1][k + 3 - u];
                 rc[u] = *(const float2*)&st[wave][2][k + 3 - u];
             }
+            float Gs[4], al[4], om[4], Tu[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (TAIL && k - u < 0) {  // wave-uniform
-#pragma unroll
-                    for (int v = 0; v < 6; ++v) g[u][v] = 0.0f;
+                    Gs[u] = al[u] = 0.0f;
+                    om[u] = 1.0f;
                     jj[u] = 0xffffffffu;
                     continue;
                 }
                 const float4 a = ra[u], b = rb[u];
-                const float2 c = rc[u];
-                const uint32_t j = __float_as_uint(c.y);
+                const uint32_t j = __float_as_uint(rc[u].y);
                 const float dx = a.x - pxf, dy = a.y - pyf;
                 const float power = __builtin_fmaf(dx, __builtin_fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy);
                 const float G = fast_exp(power);
@@ -606,10 +618,22 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 // back-to-front recurrences with alpha = 0, which leaves T and the colour-behind
                 // accumulator exactly as skipping it would (T / (1 - 0) = T; the accumulator folds
                 // 0 * d); only the G-weighted sums need an explicit zero.
-                splat_pixel_grad(ps, b, c.x, xl, sel(hit, G, 0.0f), sel(hit, alpha, 0.0f), g[u][0], g[u][1], g[u][2],
-                                 g[u][3], g[u][4], g[u][5]);
+                Gs[u] = sel(hit, G, 0.0f);
+                al[u] = sel(hit, alpha, 0.0f);
+                om[u] = 1.0f - al[u];
                 any |= hit;
                 jj[u] = j;
+            }
+            group_transmittance(ps.T, om, Tu);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (TAIL && k - u < 0) {
+#pragma unroll
+                    for (int v = 0; v < 6; ++v) g[u][v] = 0.0f;
+                    continue;
+                }
+                splat_pixel_grad(ps, Tu[u], rb[u], rc[u].x, xl, Gs[u], al[u], g[u][0], g[u][1], g[u][2], g[u][3], g[u][4],
+                                 g[u][5]);
             }
             float r[6], myy;
             if (any) {
