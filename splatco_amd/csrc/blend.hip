@@ -378,7 +378,7 @@ __device__ __forceinline__ float fold4(float a, float b, float c, float d) {
 //     accumulator of the reference (3 channels) becomes ONE scalar recurrence on
 //     behind = <accumulated colour behind, dL/dpixel>, started at <bg, dL/dpixel> (the background is
 //     the last layer: T_final * bg), which also absorbs the separate background term;
-//   * with Y = G * dL/dalpha, the position / conic gradients are opacity- and conic-weighted
+//   * with Y = opacity * G * dL/dalpha, the position / conic gradients are conic-weighted
 //     combinations of the five moments  sum Y dx, sum Y dy, sum Y dx^2, sum Y dx dy, sum Y dy^2;
 //     the weights are applied once per Gaussian in preprocess_backward_kernel.
 // A wave therefore reduces, per splat: the moments of Y (six: 1, x, y, x^2, xy, y^2 -- taken about the QUADRANT's
@@ -397,7 +397,7 @@ __device__ __forceinline__ void splat_pixel_grad(PixState& s, float T, float4 b,
     s.behind = s.last_alpha * (s.d_last - s.behind) + s.behind;
     const float d = b.z * s.dLp0 + b.w * s.dLp1 + cb * s.dLp2;
     g_c0 = w * s.dLp0; g_c1 = w * s.dLp1; g_c2 = w * s.dLp2;
-    const float Y = G * (T * (d - s.behind));  // G * dL/dalpha  (straight-through min(0.99, .))
+    const float Y = G * (T * (d - s.behind));  // G = opacity * exp(power) here: the unclamped alpha times dL/dalpha (straight-through min(0.99, .))
     s.last_alpha = alpha;
     s.d_last = d;
     // x-separable terms of the moments about the quadrant's origin (xl = this lane's pixel column, 0..7); the
@@ -611,15 +611,16 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 const uint32_t j = __float_as_uint(rc[u].y);
                 const float dx = a.x - pxf, dy = a.y - pyf;
                 const float power = __builtin_fmaf(dx, __builtin_fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy);
-                const float G = fast_exp(power);
-                const float alpha = vmin(c099, b.y * G);
-                const unsigned long long hit = lanes((int)j < last_rel) & lanes(!(power > 0.0f)) & lanes(!(alpha < 1.0f / 255.0f));
+                const float ar = b.y * fast_exp(power);   // alpha before the clamp: min(0.99, ar) < 1/255 <=> ar < 1/255
+                const unsigned long long hit = lanes((int)j < last_rel) & lanes(!(power > 0.0f)) & lanes(!(ar < 1.0f / 255.0f));
                 // Branch-free: a splat that does not contribute to this pixel is carried through the
                 // back-to-front recurrences with alpha = 0, which leaves T and the colour-behind
                 // accumulator exactly as skipping it would (T / (1 - 0) = T; the accumulator folds
-                // 0 * d); only the G-weighted sums need an explicit zero.
-                Gs[u] = sel(hit, G, 0.0f);
-                al[u] = sel(hit, alpha, 0.0f);
+                // 0 * d).  ONE select zeroes both the alpha and the weight of the moments: the moments are taken
+                // of Y = opacity G dL/dalpha (the unclamped alpha times dL/dalpha, straight through the clamp), which
+                // is what every consumer but dL/dopacity wants anyway (preprocess_backward_kernel divides that one).
+                Gs[u] = sel(hit, ar, 0.0f);
+                al[u] = vmin(c099, Gs[u]);
                 om[u] = 1.0f - al[u];
                 any |= hit;
                 jj[u] = j;

@@ -103,7 +103,7 @@ inline __host__ BinView bin_view(void* base, int64_t I, int64_t max_tile_instanc
 }
 
 // ---- backward scratch: one gradient record per (Gaussian, tile) instance at its Gaussian-major index: nine floats
-// (sum Y dx, sum Y dy, sum Y dx^2, sum Y dx dy | sum Y dy^2, sum Y, c0, c1 | c2), 36 bytes, back to back.  The two
+// (Y = opacity G dL/dalpha: sum Y dx, sum Y dy, sum Y dx^2, sum Y dx dy | sum Y dy^2, sum Y, c0, c1 | c2), 36 bytes, back to back.  The two
 // four-float parts are moved with dword-aligned 16-byte accesses (gfx950 global memory needs dword alignment only);
 // separate arrays per part were measured and rejected: the lone 4-byte stores cost a whole 32-byte sector each.
 struct __attribute__((packed, aligned(4))) GradQuad { float x, y, z, w; };

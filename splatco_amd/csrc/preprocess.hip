@@ -331,7 +331,7 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
         // ---- deterministic reduction of the per-(tile, Gaussian) records
         uint32_t n = tiles_touched[i];
         uint32_t off = point_offsets[i] - n;
-        float sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0;  // moments of Y = G dL/dalpha over the footprint
+        float sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0;  // moments of Y = opacity G dL/dalpha over the footprint
         // this Gaussian's records are contiguous, in tile order; four at a time so that
         // twelve loads are in flight per thread (the loop is otherwise one memory latency per record), summed in order
         const GradRec* gr = grad_rec + off;
@@ -353,12 +353,15 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
             syy += q.b.x; gop += q.b.y; gcol[0] += q.b.z; gcol[1] += q.b.w;
             gcol[2] += q.c;
         }
-        // the per-splat constants the blend kernel left out: dL/dG = opacity * dL/dalpha,
-        // dG/dmean = -G Q d with Q = (-2A, -B, -2C), dG/dQ = -G/2 d d^T (Qxy counted once: factor 1)
+        // the per-splat constants the blend kernel left out.  The moments are of Y = opacity * G * dL/dalpha, i.e.
+        // dL/dG already: dG/dmean = -G Q d with Q = (-2A, -B, -2C), dG/dQ = -G/2 d d^T (Qxy counted once: factor 1);
+        // dL/dopacity = sum G dL/dalpha = (sum Y) / opacity -- a non-zero sum means some pixel passed
+        // alpha >= 1/255 with G <= 1, so the opacity is at least 1/255 there
         const float4 ra = rec[3 * i], rb = rec[3 * i + 1];
         const float cA = ra.z, cB = ra.w, cC = rb.x, op = rb.y;
-        const float gmx = op * (2.0f * cA * sx + cB * sy), gmy = op * (2.0f * cC * sy + cB * sx);
-        const float gQxx = -0.5f * op * sxx, gQxy = -op * sxy, gQyy = -0.5f * op * syy;
+        gop = gop != 0.0f ? gop / op : 0.0f;
+        const float gmx = 2.0f * cA * sx + cB * sy, gmy = 2.0f * cC * sy + cB * sx;
+        const float gQxx = -0.5f * sxx, gQxy = -sxy, gQyy = -0.5f * syy;
         const float* V = ks.view;
         const float* Pm = ks.proj;
         float a = ps.a, b = ps.b, c = ps.c;
