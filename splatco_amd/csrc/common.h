@@ -235,6 +235,9 @@ __device__ inline SplatForm splat_form(float4 r0, float4 r1) {
 // case distinction is left.  Everything that depends on one axis only is shared by the two quadrants of a row / column.
 // The splat is kept when either candidate stays within the threshold plus the rounding margin of its own terms.
 __device__ inline uint32_t quadrant_mask(float4 r0, float4 r1, int tile_x0, int tile_y0) {
+#ifdef SCR_QMASK_ALL   // developer timing: no culling (still correct: the masks are conservative)
+    return 0xfu;
+#endif
     const SplatForm f = splat_form(r0, r1);
     if (!f.ok) return 0xfu;
     const float x0 = (float)tile_x0, y0 = (float)tile_y0;
