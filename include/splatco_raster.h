@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 14
+#define SCR_ABI_VERSION 15
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -120,6 +120,29 @@ enum {
 int scr_debug_get(int which, int64_t P, int64_t num_rendered, int32_t image_height, int32_t image_width,
                   const void* geom_buf, const void* binning_buf, const void* image_buf, void* out,
                   void* stream);
+
+/* ---- TriPlaneAttention of the level-0 grid (scene/grids.py:22-64; applied to cat(xy, xz, yz planes) on every call,
+ * scene/grids.py:166-168) without the framework's ~60 small kernels per direction and without MIOpen's 7x7 convolution.
+ * The three planes are [R, H, W] each (equal sizes), read in place; C = 3 R <= 24 stacked channels.
+ *   scr_tpa_stats          : avg[C], max[C], arg[C] (pixel of the maximum) over the pixels (ChannelAttention's pools, :28-35);
+ *                            the 15-number MLP + sigmoid that turns them into ca[C] stays with the caller.
+ *   scr_tpa_forward        : y = ca x; s = (mean_c y, max_c y) [2,H,W], am = channel of the max [H*W] uint8;
+ *                            sa = sigmoid(conv7x7(s, w[2,7,7], zero padding 3)) [H*W]; pair plane j [2R,H,W] =
+ *                            (plane j | sa * y of plane j) -- the stacked planes the tri-plane sampler takes.
+ *   scr_tpa_backward       : g_j = dL/d(pair plane j) -> d_j = dL/d(plane j) [R,H,W] (both halves, written, not added),
+ *                            dca[C], dw[2,7,7].  Needs s, am, sa of the forward.  Deterministic (ordered partial sums).
+ *   scr_tpa_backward_stats : adds the pools' gradients, d[c] += davg[c] / (H W) everywhere and dmax[c] at arg[c].
+ * scratch: scr_tpa_scratch_bytes(R, H, W) bytes for every call. */
+size_t scr_tpa_scratch_bytes(int32_t R, int32_t H, int32_t W);
+int scr_tpa_stats(int32_t R, int32_t H, int32_t W, const float* p0, const float* p1, const float* p2, float* avg,
+                  float* mx, int32_t* arg, void* scratch, void* stream);
+int scr_tpa_forward(int32_t R, int32_t H, int32_t W, const float* p0, const float* p1, const float* p2, const float* ca,
+                    const float* w, float* s, uint8_t* am, float* sa, float* pair0, float* pair1, float* pair2, void* stream);
+int scr_tpa_backward(int32_t R, int32_t H, int32_t W, const float* p0, const float* p1, const float* p2, const float* ca,
+                     const float* w, const float* s, const uint8_t* am, const float* sa, const float* g0, const float* g1,
+                     const float* g2, float* d0, float* d1, float* d2, float* dca, float* dw, void* scratch, void* stream);
+int scr_tpa_backward_stats(int32_t R, int32_t H, int32_t W, const float* davg, const float* dmax, const int32_t* arg,
+                           float* d0, float* d1, float* d2, void* stream);
 
 /* ---- fused neural-Gaussian expansion + opacity-mask compaction: the op chain of
  * gaussian_renderer/__init__.py:68-111 (mask = neural_opacity > 0; repeat / cat / boolean index /
@@ -311,7 +334,8 @@ enum {
     SCR_PROF_TILE_SORT = 4, SCR_PROF_BLEND_FORWARD = 5, SCR_PROF_BLEND_BACKWARD = 6,
     SCR_PROF_PREPROCESS_BACKWARD = 7, SCR_PROF_EXPAND = 8, SCR_PROF_EXPAND_BACKWARD = 9, SCR_PROF_PLANE_BACKWARD = 10,
     SCR_PROF_L1_SSIM = 11, SCR_PROF_L1_SSIM_BACKWARD = 12, SCR_PROF_TRIPLANE_FORWARD = 13, SCR_PROF_MLP_HEADS = 14,
-    SCR_PROF_MLP_HEADS_BACKWARD = 15, SCR_PROF_NORM_LINEAR = 16, SCR_PROF_NORM_LINEAR_BACKWARD = 17, SCR_PROF_COUNT = 18
+    SCR_PROF_MLP_HEADS_BACKWARD = 15, SCR_PROF_NORM_LINEAR = 16, SCR_PROF_NORM_LINEAR_BACKWARD = 17, SCR_PROF_PLANE_ATTENTION = 18,
+    SCR_PROF_COUNT = 19
 };
 int scr_profile_enable(int mask);
 int scr_profile_read(double* total_ms, int64_t* launches);

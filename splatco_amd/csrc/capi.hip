@@ -63,7 +63,7 @@ const char* const kProfNames[SCR_PROF_COUNT] = {
     "blend_forward_kernel", "blend_backward_kernel", "preprocess_backward_kernel", "expand_kernel",
     "expand_backward_kernel", "plane_sample_backward_kernels", "l1_ssim_forward_kernel",
     "l1_ssim_backward_kernel", "triplane_forward_kernel", "mlp_heads_kernel", "mlp_heads_backward_kernel",
-    "norm_linear_kernels", "norm_linear_backward_kernels"};
+    "norm_linear_kernels", "norm_linear_backward_kernels", "plane_attention_kernels"};
 }  // namespace
 
 // streaming copy, 16 B per lane, four loads in flight per thread, non-temporal: the shape that reaches the highest HBM
@@ -466,6 +466,58 @@ int scr_triplane_forward(int64_t V, const float* coords, int32_t cstride, const 
       rc = launch_triplane_forward(V, coords, cstride, xy, xz, yz, R, X, Y, Z, channel_last, out, ld, col_xy, col_xz, col_yz, st); }
     if (rc == 1) return fail("R = %d channels per plane exceeds the supported 16", R);
     CHECK_LAUNCH("triplane_forward_kernel", 0, st);
+    return 0;
+}
+
+// ---- plane attention of the level-0 grid (attention.hip)
+size_t scr_tpa_scratch_bytes(int32_t R, int32_t H, int32_t W) { return tpa_scratch_bytes(R, H, W); }
+
+static int tpa_bad(int32_t R, int32_t H, int32_t W) {
+    if (R <= 0 || 3 * R > 24) return fail("plane attention: 3 R stacked channels must be 3..24");
+    if (H <= 0 || W <= 0 || (int64_t)H * W >= (1ll << 31)) return fail("plane attention: bad plane size");
+    return 0;
+}
+
+int scr_tpa_stats(int32_t R, int32_t H, int32_t W, const float* p0, const float* p1, const float* p2, float* avg,
+                  float* mx, int32_t* arg, void* scratch, void* stream) {
+    if (tpa_bad(R, H, W)) return 1;
+    if (!p0 || !p1 || !p2 || !avg || !mx || !arg || !scratch) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_PLANE_ATTENTION, st); launch_tpa_stats(R, (int64_t)H * W, p0, p1, p2, avg, mx, arg, scratch, st); }
+    CHECK_LAUNCH("tpa_stats_kernels", 0, st);
+    return 0;
+}
+
+int scr_tpa_forward(int32_t R, int32_t H, int32_t W, const float* p0, const float* p1, const float* p2, const float* ca,
+                    const float* w, float* s, uint8_t* am, float* sa, float* pair0, float* pair1, float* pair2, void* stream) {
+    if (tpa_bad(R, H, W)) return 1;
+    if (!p0 || !p1 || !p2 || !ca || !w || !s || !am || !sa || !pair0 || !pair1 || !pair2) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_PLANE_ATTENTION, st); launch_tpa_forward(R, H, W, p0, p1, p2, ca, w, s, am, sa, pair0, pair1, pair2, st); }
+    CHECK_LAUNCH("tpa_apply_kernel", 0, st);
+    return 0;
+}
+
+int scr_tpa_backward(int32_t R, int32_t H, int32_t W, const float* p0, const float* p1, const float* p2, const float* ca,
+                     const float* w, const float* s, const uint8_t* am, const float* sa, const float* g0, const float* g1,
+                     const float* g2, float* d0, float* d1, float* d2, float* dca, float* dw, void* scratch, void* stream) {
+    if (tpa_bad(R, H, W)) return 1;
+    if (!p0 || !p1 || !p2 || !ca || !w || !s || !am || !sa || !g0 || !g1 || !g2 || !d0 || !d1 || !d2 || !dca || !dw || !scratch)
+        return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_PLANE_ATTENTION, st);
+      launch_tpa_backward(R, H, W, p0, p1, p2, ca, w, s, am, sa, g0, g1, g2, d0, d1, d2, dca, dw, scratch, st); }
+    CHECK_LAUNCH("tpa_bwd_kernels", 0, st);
+    return 0;
+}
+
+int scr_tpa_backward_stats(int32_t R, int32_t H, int32_t W, const float* davg, const float* dmax, const int32_t* arg,
+                           float* d0, float* d1, float* d2, void* stream) {
+    if (tpa_bad(R, H, W)) return 1;
+    if (!davg || !dmax || !arg || !d0 || !d1 || !d2) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_PLANE_ATTENTION, st); launch_tpa_backward_stats(R, (int64_t)H * W, davg, dmax, arg, d0, d1, d2, st); }
+    CHECK_LAUNCH("tpa_bwd_stats_kernel", 0, st);
     return 0;
 }
 

@@ -372,6 +372,19 @@ void launch_mlp_heads_backward(int64_t V, const float* feat, const float* anchor
                                float* d_geo_a, float* d_geo_b, float* d_w1, float* d_b1, float* d_w2o, float* d_b2o, float* d_w2c,
                                float* d_b2c, float* d_w2v, float* d_b2v, hipStream_t st);
 
+// plane attention of the level-0 grid (attention.hip)
+size_t tpa_scratch_bytes(int R, int H, int W);
+void launch_tpa_stats(int R, int64_t HW, const float* p0, const float* p1, const float* p2, float* avg, float* mx,
+                      int* arg, void* scratch, hipStream_t st);
+void launch_tpa_forward(int R, int H, int W, const float* p0, const float* p1, const float* p2, const float* ca,
+                        const float* w, float* s, uint8_t* am, float* sa, float* o0, float* o1, float* o2, hipStream_t st);
+void launch_tpa_backward(int R, int H, int W, const float* p0, const float* p1, const float* p2, const float* ca,
+                         const float* w, const float* s, const uint8_t* am, const float* sa, const float* g0,
+                         const float* g1, const float* g2, float* d0, float* d1, float* d2, float* dca, float* dw,
+                         void* scratch, hipStream_t st);
+void launch_tpa_backward_stats(int R, int64_t HW, const float* davg, const float* dmx, const int* arg, float* d0,
+                               float* d1, float* d2, hipStream_t st);
+
 size_t l1_ssim_scratch_bytes(int C, int H, int W, int with_grad);
 void launch_l1_ssim_forward(int C, int H, int W, const float* img1, const float* img2, void* scratch,
                             int with_grad, float* out2, hipStream_t st);

@@ -278,11 +278,16 @@ class PlaneGrid(nn.Module):                   # scene/grids.py:102-201
             ind3 = (xyz.reshape(-1, 3) - self.xyz_min) / (self.xyz_max - self.xyz_min) * 2 - 1
         if not self.TAflag:
             return ind3, (self.xy_plane, self.xz_plane, self.yz_plane), tuple(col0 + R * j for j in range(3))
-        tri = self.TA(torch.cat((self.xy_plane, self.xz_plane, self.yz_plane), dim=1))   # every call (:166-168)
-        xyA, xzA, yzA = torch.chunk(tri, 3, dim=1)
         # column order of :181: xy, xyA, xz, xzA, yz, yzA -- a plane and its attended twin are sampled at the same
         # positions and land side by side, so each pair is stacked into ONE plane of 2 R channels: half the random
         # cache lines per sample (the channel-last rows of the pair are adjacent), one launch instead of two
+        from . import plane_attention
+        if plane_attention.fused_ok(self.xy_plane, self.xz_plane, self.yz_plane, self.TA):
+            # the attention module and the stacking as a few streaming passes (csrc/attention.hip), every call (:166-168)
+            pairs = plane_attention.attended_pair_planes(self.xy_plane, self.xz_plane, self.yz_plane, self.TA)
+            return ind3, pairs, tuple(col0 + 2 * R * j for j in range(3))
+        tri = self.TA(torch.cat((self.xy_plane, self.xz_plane, self.yz_plane), dim=1))   # every call (:166-168)
+        xyA, xzA, yzA = torch.chunk(tri, 3, dim=1)
         return ind3, (torch.cat((self.xy_plane, xyA), dim=1), torch.cat((self.xz_plane, xzA), dim=1),
                       torch.cat((self.yz_plane, yzA), dim=1)), tuple(col0 + 2 * R * j for j in range(3))
 

@@ -749,3 +749,44 @@ def test_all_grids_backward_in_one_pass(layout):
                 (samp * w[:, cols[j]:cols[j] + p.shape[1]]).sum().backward()
                 assert float((g1[k] - p.grad).abs().max()) <= 5e-5 * float(p.grad.abs().max()) + 1e-7, (layout, V, k)
                 k += 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,H,W", [(5, 70, 70), (2, 37, 91), (5, 200, 131)])
+def test_fused_plane_attention_matches_the_torch_module(R, H, W):
+    """csrc/attention.hip against the torch TriPlaneAttention + chunk + cat chain it replaces (scene/grids.py:22-64,
+    166-181): pair planes, and the gradients of the planes, the shared MLP and the 7x7 window."""
+    import copy
+    from splatco_amd import plane_attention
+    from splatco_amd.scene_model import TriPlaneAttention
+    torch.manual_seed(R * 1000 + H)
+    dev = torch.device("cuda:0")
+    ta = TriPlaneAttention(3 * R).to(dev)
+    ta_ref = copy.deepcopy(ta)
+    planes = [(torch.randn(1, R, H, W, device=dev) * 0.5).requires_grad_(True) for _ in range(3)]
+    ref_planes = [p.detach().clone().requires_grad_(True) for p in planes]
+    assert plane_attention.fused_ok(*planes, ta)
+    out = plane_attention.attended_pair_planes(*planes, ta)
+    tri = ta_ref(torch.cat(ref_planes, dim=1))
+    ref = [torch.cat((p, a), dim=1) for p, a in zip(ref_planes, torch.chunk(tri, 3, dim=1))]
+    for o, r in zip(out, ref):
+        assert o.shape == r.shape
+        assert torch.allclose(o, r, rtol=1e-5, atol=1e-6), float((o - r).abs().max())
+    g = [torch.randn_like(o) for o in out]
+    sum((o * gi).sum() for o, gi in zip(out, g)).backward()
+    sum((r * gi).sum() for r, gi in zip(ref, g)).backward()
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm().clamp_min(1e-20))
+    for p, q in zip(planes, ref_planes):
+        assert rel(p.grad, q.grad) < 1e-4, rel(p.grad, q.grad)
+    for (n, a), (_, b) in zip(ta.named_parameters(), ta_ref.named_parameters()):
+        assert rel(a.grad, b.grad) < 2e-4, (n, rel(a.grad, b.grad))
+    # deterministic: a second backward gives the same bits
+    grads1 = [p.grad.clone() for p in planes] + [a.grad.clone() for a in ta.parameters()]
+    for t in planes + list(ta.parameters()):
+        t.grad = None
+    out = plane_attention.attended_pair_planes(*planes, ta)
+    sum((o * gi).sum() for o, gi in zip(out, g)).backward()
+    for a, b in zip(grads1, [p.grad for p in planes] + [a.grad for a in ta.parameters()]):
+        assert torch.equal(a, b)
