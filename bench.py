@@ -73,6 +73,10 @@ def algorithmic_bytes(kernel, P, I, npix, extra=None):
         # dy^T x pass + dx pass backward (x re-read by every pass: the algorithm needs the statistics first)
         "norm_linear_kernels": 4 * V * (2 * (60 + 71) + 2 * 32),
         "norm_linear_backward_kernels": 4 * V * (2 * (60 + 71) + 2 * 2 * 32 + (60 + 71)),
+        # attention of the level-0 grid (C stacked channels, HW pixels; forward + backward of one step): the planes are read
+        # by the pools, the channel reduction and the apply pass, and written twice as pair planes; backward reads the
+        # planes twice, the pair-plane gradients three halves, writes the plane gradients and updates them once more
+        "plane_attention_kernels": 4 * e.get("HW", 0) * (13 * e.get("C", 0) + 12),
     }
     return float(table.get(kernel, 0))
 
@@ -509,7 +513,9 @@ def run_anchor_config(args, rank, world, dev):
     P1 = stats["P"]
     peak = hbm_copy_peak(dev)
     V = stats.get("V", 0)
-    extra = {"N": N, "V": V, "n": V * pc.n_offsets}
+    lvl0 = pc.feat_planes._feat.k0s[0]
+    extra = {"N": N, "V": V, "n": V * pc.n_offsets, "C": lvl0.channels,
+             "HW": lvl0.xy_plane.shape[2] * lvl0.xy_plane.shape[3]}
     from splatco_amd import rasterizer as R
     I = R.last_plan[1]                                       # (Gaussian, tile) instances of the last rasterised view
     launches = {k: n / nwarm for k, (ms, n) in warm_prof.items() if n}
@@ -556,6 +562,10 @@ def run_anchor_config(args, rank, world, dev):
                              for k, ms in sorted(warm_step_ms.items(), key=lambda kv: -kv[1]) if ms > 0},
         "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
     }
+    for k, v in out["kernel_rooflines"].items():
+        if k == "blend_forward_kernel" and v["frac_of_measured_peak"] > 1.0:
+            v["note"] = ("the byte model counts every entry of every tile list; the forward stops reading a tile's list once "
+                         "all of its pixels are opaque (T < 1e-4), which at this density is long before the end")
     if allreduce_info is not None:
         out["allreduce"] = allreduce_info
     print(json.dumps(out))
