@@ -7,6 +7,11 @@ is missing or was built against another ABI version, importing this module raise
 import ctypes as C
 import os
 
+# PyTorch-ROCm carries its own libamdhip64: load it BEFORE this library, so that both use ONE HIP runtime (the library's
+# device pointers and streams are torch's).  Loaded the other way round -- e.g. build() and smoke() in one process --
+# this library binds to /opt/rocm's copy and its first HIP call fails with "no ROCm-capable device is detected".
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # developer override for A/B experiments with variant builds of the same library
 LIB_PATH = os.environ.get("SPLATCO_RASTER_LIB", os.path.join(_HERE, "csrc", "libsplatco_raster.so"))
