@@ -230,12 +230,14 @@ def pick_dominant(warm_prof):
     return (max(per_step, key=per_step.get) if per_step else "blend_backward_kernel"), kern
 
 
-def roofline_object(dom, avg_ms, ab, peak_measured, note, flops=None):
+def roofline_object(dom, avg_ms, ab, peak_measured, note, flops=None, traffic_file="hbm_traffic.json", launches=1.0):
     achieved = ab / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC-derived bytes per launch, if measured
+    tpath = os.path.join(ROOT, "profiles", traffic_file)   # PMC-derived bytes per launch (cfg1) / per step (cfg2), if measured
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get(dom)
+        if traffic is not None and launches != 1.0:
+            traffic = int(traffic / launches)
     out = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": ab,
            "avg_launch_ms": avg_ms, "peak_measured": peak_measured,
@@ -549,7 +551,8 @@ def run_anchor_config(args, rank, world, dev):
         },
         "roofline": roofline_object(dominant, kern.get(dominant, 0.0), ab, peak,
                                     "dominant among this library's kernel classes by time per step",
-                                    flops=algorithmic_flops(dominant, V)),
+                                    flops=algorithmic_flops(dominant, V), traffic_file=f"hbm_traffic_{args.config}.json",
+                                    launches=max(launches.get(dominant, 1.0), 1.0)),
         "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(warm_step_ms.items(), key=lambda kv: -kv[1])},
         # every kernel class of this library against ITS byte model (per step, all launches of the class)
         "kernel_rooflines": {k: {"ms_per_step": round(ms, 4),
@@ -562,7 +565,12 @@ def run_anchor_config(args, rank, world, dev):
                              for k, ms in sorted(warm_step_ms.items(), key=lambda kv: -kv[1]) if ms > 0},
         "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
     }
+    tpath = os.path.join(ROOT, "profiles", f"hbm_traffic_{args.config}.json")
+    pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
     for k, v in out["kernel_rooflines"].items():
+        if k in pmc:      # PMC traffic of the class per step (tools/profile_cfg_pmc.sh), measured at the default scene of the config
+            v["pmc_traffic_MB_per_step"] = round(pmc[k] / 1e6, 1)
+            v["pmc_GBps"] = round(pmc[k] / (v["ms_per_step"] * 1e-3) / 1e9, 1)
         if k == "blend_forward_kernel" and v["frac_of_measured_peak"] > 1.0:
             v["note"] = ("the byte model counts every entry of every tile list; the forward stops reading a tile's list once "
                          "all of its pixels are opaque (T < 1e-4), which at this density is long before the end")
