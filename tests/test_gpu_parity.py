@@ -278,6 +278,29 @@ def test_depth_ties_and_huge_tile(oracle, P):
     _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"])
 
 
+@pytest.mark.parametrize("P", [65, 129, 257, 320, 321, 384, 385, 513, 576, 577, 640, 641, 768, 769, 1000, 1024, 1025, 1100])
+def test_tile_sizes_around_every_wave_sort_path(oracle, P):
+    """One tile holding (about) P instances for P on both sides of every size at which the one-wave tile sort changes its
+    path (a single network of 64 E keys, or two networks + an LDS merge for tiles just above a power of two:
+    binning.hip wave_sort_any): sorted lists bit-exact."""
+    cam = synthetic_camera(96, 64)
+    rng = np.random.default_rng(P)
+    g = synthetic_gaussians(P, 96, 64, seed=3)
+    tx, ty = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+    z = rng.uniform(2, 6, P).astype(np.float32)
+    z[rng.integers(0, P, P // 8)] = 3.0            # some exact depth ties (order by id)
+    px, py = rng.uniform(37, 42, P), rng.uniform(37, 42, P)      # inside tile (2, 2), footprints of about a pixel
+    g["means3D"] = np.stack([((2 * px + 1) / 96 - 1) * tx * z, ((2 * py + 1) / 64 - 1) * ty * z, z], 1).astype(np.float32)
+    g["scales"] = np.full((P, 3), 0.002, np.float32) * z[:, None]
+    g["opacities"] = np.full((P, 1), 0.02, np.float32)
+    st = oracle_settings(oracle, cam, g["bg"])
+    f = oracle.forward(st, g["means3D"], g["opacities"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+    counts = f["ranges"][:, 1].astype(np.int64) - f["ranges"][:, 0]
+    assert counts.max() == P, "the scene is meant to put every Gaussian into one tile"
+    o = _run_gpu(cam, g, ref=f)
+    _check_forward(f, o, st)
+
+
 @pytest.mark.parametrize("P", [1, 63, 4097])
 def test_odd_sizes_and_giant_splats(oracle, P):
     """P = 1, P not a multiple of any workgroup shape, and Gaussians that cover the whole image
