@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 15
+#define SCR_ABI_VERSION 16
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -157,6 +157,11 @@ int scr_tpa_backward_stats(int32_t R, int32_t H, int32_t W, const float* davg, c
 size_t scr_expand_scratch_bytes(int64_t n_candidates);
 int scr_expand_plan(int64_t n_candidates, const float* neural_opacity, void* scratch,
                     int64_t* num_selected_host, void* stream);
+/* mask -> ascending index list (the `t[visible_mask]` index of gaussian_renderer/__init__.py:23-29; what
+ * torch.nonzero returns for a 1-D mask): plan counts the set bytes (one stream synchronisation, like scr_expand_plan),
+ * run writes index[num_set] int64.  scratch: scr_expand_scratch_bytes(n). */
+int scr_mask_index_plan(int64_t n, const uint8_t* mask, void* scratch, int64_t* num_set_host, void* stream);
+int scr_mask_index_run(int64_t n, const uint8_t* mask, const void* scratch, int64_t* index, void* stream);
 int scr_expand_run(int64_t V, int32_t k, const float* neural_opacity, const float* color,
                    const float* scale_rot, const float* offsets, const float* grid_scaling,
                    const float* anchor, const void* scratch, int32_t* out_index, uint8_t* mask_out,

@@ -21,7 +21,7 @@ SYMBOLS = [
     "scr_backward_scratch_bytes", "scr_visible_filter", "scr_mark_visible", "scr_forward_plan",
     "scr_forward_run", "scr_backward", "scr_debug_get", "scr_profile_enable", "scr_profile_read",
     "scr_profile_kernel_name", "scr_expand_scratch_bytes", "scr_expand_plan", "scr_expand_run",
-    "scr_expand_backward", "scr_plane_sample_scratch_bytes", "scr_plane_sample_backward", "scr_triplane_backward_multi_scratch_bytes", "scr_triplane_backward_multi", "scr_plane_row_pairs", "scr_triplane_forward", "scr_triplane_backward_scratch_bytes", "scr_triplane_backward",
+    "scr_expand_backward", "scr_mask_index_plan", "scr_mask_index_run", "scr_plane_sample_scratch_bytes", "scr_plane_sample_backward", "scr_triplane_backward_multi_scratch_bytes", "scr_triplane_backward_multi", "scr_plane_row_pairs", "scr_triplane_forward", "scr_triplane_backward_scratch_bytes", "scr_triplane_backward",
     "scr_l1_ssim_scratch_bytes", "scr_l1_ssim_forward", "scr_l1_ssim_backward",
     "scr_tpa_scratch_bytes", "scr_tpa_stats", "scr_tpa_forward", "scr_tpa_backward", "scr_tpa_backward_stats",
     "scr_statis_compute", "scr_statis_apply", "scr_copy_probe",
@@ -29,7 +29,7 @@ SYMBOLS = [
     "scr_norm_linear_scratch_bytes", "scr_norm_linear_forward", "scr_norm_linear_backward",
 ]
 PROF_COUNT = 19
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
 
@@ -110,6 +110,9 @@ def _load():
     lib.scr_l1_ssim_forward.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, vp]
     lib.scr_l1_ssim_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.scr_l1_ssim_forward.restype = lib.scr_l1_ssim_backward.restype = C.c_int
+    lib.scr_mask_index_plan.argtypes = [i64, vp, vp, C.POINTER(C.c_int64), vp]
+    lib.scr_mask_index_run.argtypes = [i64, vp, vp, vp, vp]
+    lib.scr_mask_index_plan.restype = lib.scr_mask_index_run.restype = C.c_int
     lib.scr_tpa_scratch_bytes.argtypes = [i32, i32, i32]
     lib.scr_tpa_scratch_bytes.restype = C.c_size_t
     lib.scr_tpa_stats.argtypes = [i32, i32, i32] + [vp] * 8

@@ -337,6 +337,41 @@ int scr_expand_plan(int64_t n, const float* neural_opacity, void* scratch, int64
     return 0;
 }
 
+// mask -> index list with the expansion's count / scan / write scheme (scratch: scr_expand_scratch_bytes(n))
+int scr_mask_index_plan(int64_t n, const uint8_t* mask, void* scratch, int64_t* num_set_host, void* stream) {
+    if (!num_set_host) return fail("num_set_host is NULL");
+    *num_set_host = 0;
+    if (n < 0) return fail("n < 0");
+    if (n == 0) return 0;
+    if (!mask || !scratch) return fail("NULL argument");
+    if (n >= (1ll << 31)) return fail("more than 2^31 mask entries");
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* wg = (uint32_t*)scratch;
+    unsigned long long* total = (unsigned long long*)((char*)scratch + align_up((expand_nwg(n) + 1) * 4));
+    Mailbox& mb = mailbox();
+    const unsigned long long seq = ++mb.seq;
+    { ProfScope ps_(SCR_PROF_EXPAND, st); launch_mask_count(n, mask, wg, total, mb.dev, seq, st); }
+    CHECK_LAUNCH("mask_count_kernel", 0, st);
+    unsigned long long t = 0;
+    if (mailbox_wait(mb, seq, false, st)) {
+        t = mb.host[0];
+    } else {
+        HIP_TRY(hipMemcpyAsync(&t, total, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    *num_set_host = (int64_t)t;
+    return 0;
+}
+
+int scr_mask_index_run(int64_t n, const uint8_t* mask, const void* scratch, int64_t* index, void* stream) {
+    if (n <= 0) return n < 0 ? fail("n < 0") : 0;
+    if (!mask || !scratch || !index) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_EXPAND, st); launch_mask_index(n, mask, (const uint32_t*)scratch, index, st); }
+    CHECK_LAUNCH("mask_index_kernel", 0, st);
+    return 0;
+}
+
 int scr_expand_run(int64_t V, int32_t k, const float* neural_opacity, const float* color,
                    const float* scale_rot, const float* offsets, const float* grid_scaling,
                    const float* anchor, const void* scratch, int32_t* out_index, uint8_t* mask_out,

@@ -326,6 +326,9 @@ void launch_preprocess_backward(int64_t P, int M, const float* means3D, const fl
 
 void launch_expand_count(int64_t n, const float* neural_opacity, uint32_t* wg_count, unsigned long long* total,
                          unsigned long long* mailbox, unsigned long long seq, hipStream_t st);
+void launch_mask_count(int64_t n, const uint8_t* mask, uint32_t* wg_count, unsigned long long* total,
+                       unsigned long long* mailbox, unsigned long long seq, hipStream_t st);
+void launch_mask_index(int64_t n, const uint8_t* mask, const uint32_t* wg_offset, int64_t* index, hipStream_t st);
 void launch_expand_run(int64_t n, int k, const float* neural_opacity, const float* color, const float* scale_rot,
                        const float* offsets, const float* grid_scaling, const float* anchor,
                        const uint32_t* wg_offset, int32_t* out_index, uint8_t* mask_out, float* xyz,

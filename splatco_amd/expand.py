@@ -67,3 +67,20 @@ def expand_compact(neural_opacity, color, scale_rot, grid_offsets, grid_scaling,
     # position of every selected candidate among the Gaussians and would otherwise recompute it with a prefix sum
     mask._scr_out_index = out_index
     return (*out, mask)
+
+
+def mask_indices(mask):
+    """Ascending indices of the set entries of a 1-D bool / uint8 mask on the GPU -- mask.nonzero().squeeze(1) without
+    torch's int64 reduction + select (0.33 ms for 20 M anchors; here one pass over the bytes and one over the index)."""
+    import ctypes as C
+    m = mask.contiguous()
+    m = m.view(torch.uint8) if m.dtype == torch.bool else m
+    assert m.dim() == 1 and m.dtype == torch.uint8 and m.is_cuda
+    n = m.shape[0]
+    scratch = torch.empty(_C.lib.scr_expand_scratch_bytes(n), dtype=torch.uint8, device=m.device)
+    cnt = C.c_int64(0)
+    _C.check(_C.lib.scr_mask_index_plan(n, m.data_ptr(), scratch.data_ptr(), C.byref(cnt), _stream()))
+    idx = torch.empty(cnt.value, dtype=torch.int64, device=m.device)
+    if cnt.value:
+        _C.check(_C.lib.scr_mask_index_run(n, m.data_ptr(), scratch.data_ptr(), idx.data_ptr(), _stream()))
+    return idx

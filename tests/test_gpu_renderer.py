@@ -790,3 +790,19 @@ def test_fused_plane_attention_matches_the_torch_module(R, H, W):
     sum((o * gi).sum() for o, gi in zip(out, g)).backward()
     for a, b in zip(grads1, [p.grad for p in planes] + [a.grad for a in ta.parameters()]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 1023, 1024, 1025, 300_001])
+def test_mask_indices_equal_nonzero(n):
+    """csrc/expand.hip mask_count / mask_index kernels against torch.nonzero (the `t[visible_mask]` index of
+    gaussian_renderer/__init__.py:23-29): same ascending int64 indices, for empty, full and ragged masks."""
+    from splatco_amd.expand import mask_indices
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(n)
+    for p in (0.0, 0.37, 1.0):
+        mask = (torch.rand(n, generator=g) < p).to(dev)
+        idx = mask_indices(mask)
+        ref = mask.nonzero(as_tuple=False).squeeze(1)
+        assert idx.dtype == torch.int64 and idx.shape == ref.shape
+        assert torch.equal(idx, ref)
