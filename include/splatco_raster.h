@@ -16,7 +16,7 @@
  *   - Plain C, no exceptions, no torch types.  Every pointer is a DEVICE pointer unless the
  *     name ends in `_host`.  All arrays are contiguous fp32 / int32 / uint32 as stated.
  *   - `stream` is a hipStream_t passed as void*.  Nothing synchronises the device; the only host waits
- *     are the ones that return a data-dependent count (scr_forward_plan: num_rendered; scr_expand_plan):
+ *     are the ones that return a data-dependent count (scr_forward_plan: num_rendered; scr_expand_plan; scr_mask_index_plan):
  *     the kernel posts the count to a pinned mailbox the calling thread polls, with a copy +
  *     hipStreamSynchronize as fallback (and a sync + error check after every kernel when settings.debug != 0).
  *   - The caller allocates every buffer (sizes from the scr_*_bytes queries), so several forward graphs
