@@ -255,6 +255,14 @@ def roofline_object(dom, avg_ms, ab, peak_measured, note, flops=None, traffic_fi
         if n_inst and avg_ms:
             out["valu"] = {"insts_per_launch": n_inst,
                            "issue_frac": n_inst * 2.0 / (256 * 4 * 2.4e9 * avg_ms * 1e-3)}
+            bpath = os.path.join(ROOT, "profiles", "valu_busy.json")
+            quads = json.load(open(bpath)).get(dom) if os.path.exists(bpath) else None
+            if quads:   # SQ_ACTIVE_INST_VALU: quad-cycles the vector pipes were busy, summed over the chip's 1024 SIMDs
+                out["valu"]["busy_frac"] = quads * 4.0 / (256 * 4 * 2.4e9 * avg_ms * 1e-3)
+                out["valu"]["cycles_per_inst"] = quads * 4.0 / n_inst
+                out["valu"]["note"] = ("issue_frac prices every VALU instruction at the 2-cycle fp32 rate; busy_frac is the counter "
+                                       "SQ_ACTIVE_INST_VALU x 4 cycles over SIMDs x 2.4 GHz x kernel time: the pipes are busy for the "
+                                       "whole launch, the kernel is bound by its VALU instruction count and mix")
     return out
 
 

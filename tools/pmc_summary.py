@@ -49,6 +49,13 @@ def main(out_txt, out_json, dirs):
         if "SQ_INSTS_VALU" in acc[k]:
             key = "tile_sort_kernel" if k.startswith("tile_sort") or k.startswith("tile_merge") else k
             insts[key] = insts.get(key, 0) + int(acc[k]["SQ_INSTS_VALU"][0] / acc[k]["SQ_INSTS_VALU"][1])
+    busy = {}
+    for k in acc:
+        if "SQ_ACTIVE_INST_VALU" in acc[k]:
+            key = "tile_sort_kernel" if k.startswith("tile_sort") or k.startswith("tile_merge") else k
+            busy[key] = busy.get(key, 0) + int(acc[k]["SQ_ACTIVE_INST_VALU"][0] / acc[k]["SQ_ACTIVE_INST_VALU"][1])
+    if busy:   # quad-cycles per launch during which the VALU pipes are busy (bench.py: valu.busy_frac)
+        json.dump(busy, open(out_json.replace("hbm_traffic", "valu_busy"), "w"), indent=1, sort_keys=True)
     json.dump(traffic, open(out_json, "w"), indent=1, sort_keys=True)
     if insts:
         json.dump(insts, open(out_json.replace("hbm_traffic", "valu_insts"), "w"), indent=1, sort_keys=True)
