@@ -50,11 +50,8 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         visible_mask = torch.ones(pc.get_anchor.shape[0], dtype=torch.bool, device=pc.get_anchor.device)
     # `t[visible_mask]` four times (:23-29) = four mask->index conversions (each a host sync) and
     # four sort-based index_put backwards; one nonzero + index_select gives the same rows
-    if visible_mask.is_cuda and visible_mask.dim() == 1 and visible_mask.dtype == torch.bool:
-        from .expand import mask_indices
-        idx = mask_indices(visible_mask)            # csrc/expand.hip: count / scan / write, one host read of the count
-    else:
-        idx = visible_mask.nonzero(as_tuple=False).squeeze(1)
+    from .expand import visible_indices
+    idx = visible_indices(visible_mask)             # on the GPU csrc/expand.hip: count / scan / write, one host read of the count
     from . import anchor_gather as _ag
     g_fea = None
     if fused_heads and _ag.supported(pc) and type(pc).get_scaling is _plain_exp_scaling():

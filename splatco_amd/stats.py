@@ -85,6 +85,7 @@ def training_statis(opacity_accum, anchor_demon, offset_gradient_accum, offset_d
                     viewspace_point_grad, opacity, update_filter, offset_selection_mask, anchor_visible_mask):
     """GaussianModel.training_statis as a function over the four accumulators (updated in place, returned)."""
     inc_op, inc_g = statis_increments(n_offsets, viewspace_point_grad, opacity, update_filter, offset_selection_mask)
-    vis_idx = anchor_visible_mask.nonzero(as_tuple=False).squeeze(1)
+    from .expand import visible_indices
+    vis_idx = visible_indices(anchor_visible_mask)
     return statis_apply(opacity_accum, anchor_demon, offset_gradient_accum, offset_denom, n_offsets, vis_idx,
                         inc_op, inc_g)

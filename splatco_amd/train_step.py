@@ -33,7 +33,8 @@ def sync_densification_stats(densifier, n_views, out, vis, device):
         with torch.no_grad():
             inc_op, inc_g = stats.statis_increments(k, out["viewspace_points"].grad, out["neural_opacity"],
                                                     out["visibility_filter"], out["selection_mask"])
-            vis_idx = vis.nonzero(as_tuple=False).squeeze(1)
+            from .expand import visible_indices
+            vis_idx = visible_indices(vis)
     if world > 1:
         head = torch.tensor([vis_idx.numel() if rank == owner else 0], dtype=torch.int64, device=device)
         dist.broadcast(head, src=owner)
