@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 16
+#define SCR_ABI_VERSION 17
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -64,7 +64,7 @@ const char* scr_last_error(void);
 size_t scr_geom_bytes(int64_t P, int32_t image_height, int32_t image_width); /* per-Gaussian state + per-tile counters */
 size_t scr_binning_bytes(int64_t num_rendered, int64_t max_tile_instances);  /* per tile-instance lists */
 size_t scr_image_bytes(int32_t image_height, int32_t image_width);           /* final_T + n_contrib */
-size_t scr_backward_scratch_bytes(int64_t num_rendered);                     /* per-instance gradient records */
+size_t scr_backward_scratch_bytes(int64_t num_rendered);                     /* per-instance gradient records + validity bytes */
 
 /* ---- visible_filter: radii_out[P] int32 (> 0 <=> visible).  Either (scales, rotations) or cov3D_precomp. */
 int scr_visible_filter(int64_t P, const float* means3D, const float* scales, const float* rotations,
@@ -97,7 +97,8 @@ int scr_forward_run(int64_t P, int64_t num_rendered, int64_t max_tile_instances,
  * at scene/gaussian_model.py:779), dL_dcolors[P,3], dL_dsh[P,M,3], dL_dopacity[P], dL_dscales[P,3],
  * dL_drotations[P,4], dL_dcov3D[P,6].  Every output element is written (zeros for culled Gaussians).
  * Deterministic: bit-identical results run to run (no floating-point atomics).  scratch: scr_backward_scratch_bytes
- * (one 36-byte gradient record per (Gaussian, tile) instance). */
+ * (one 36-byte gradient record per (Gaussian, tile) instance + one validity byte: instances no pixel of their tile
+ * can use get no record). */
 int scr_backward(int64_t P, int32_t M, int64_t num_rendered, const float* means3D, const float* scales,
                  const float* rotations, const float* cov3D_precomp, const float* shs,
                  const scr_settings* settings, const int32_t* radii, const void* geom_buf,

@@ -29,7 +29,7 @@ SYMBOLS = [
     "scr_norm_linear_scratch_bytes", "scr_norm_linear_forward", "scr_norm_linear_backward",
 ]
 PROF_COUNT = 19
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
 

@@ -232,7 +232,7 @@ preprocess_kernel(int64_t P, int M, const float* __restrict__ means3D, const flo
                   const float* __restrict__ rotations, const float* __restrict__ cov3D,
                   const float* __restrict__ opacities, const float* __restrict__ shs,
                   const float* __restrict__ colors, KSettings ks, int tiles, float4* __restrict__ rec,
-                  uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped,
+                  uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped, uint8_t* __restrict__ live,
                   uint32_t* __restrict__ block_sums, uint32_t* __restrict__ tile_count,
                   int32_t* __restrict__ radii) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // [tiles] when LDS_HIST
@@ -284,6 +284,7 @@ preprocess_kernel(int64_t P, int M, const float* __restrict__ means3D, const flo
             if (clamped) clamped[i] = 0;
         }
         tiles_touched[i] = tt;
+        live[i] = 0;           // set by the blend backward for Gaussians that receive a gradient record
         tsum += tt;
     }
     // workgroup sum of tiles_touched (wave reduction, then the wave partials through LDS)
@@ -315,6 +316,7 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
                            const int32_t* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
                            const uint32_t* __restrict__ point_offsets, const uint8_t* __restrict__ clamped,
                            const float4* __restrict__ rec, const GradRec* __restrict__ grad_rec,
+                           const uint8_t* __restrict__ rec_valid, const uint8_t* __restrict__ live,
                            float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
                            float* __restrict__ dL_dcolors, float* __restrict__ dL_dsh,
                            float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
@@ -323,7 +325,9 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
     if (i >= P) return;
     float gm[3] = {0, 0, 0}, gm2[3] = {0, 0, 0}, gcol[3] = {0, 0, 0}, gop = 0, gs[3] = {0, 0, 0},
           gq[4] = {0, 0, 0, 0}, g6[6] = {0, 0, 0, 0, 0, 0};
-    bool vis = radii[i] > 0;
+    // a Gaussian none of whose instances got a record (occluded everywhere: most of them at 20 M anchors) has all-zero
+    // gradients: nothing of it is read
+    bool vis = radii[i] > 0 && live[i] != 0;
     Proj ps;
     Foot ft;
     if (vis) vis = project(i, means3D, scales, rotations, cov3D, ks, ps, ft);
@@ -332,26 +336,31 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
         uint32_t n = tiles_touched[i];
         uint32_t off = point_offsets[i] - n;
         float sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0;  // moments of Y = opacity G dL/dalpha over the footprint
-        // this Gaussian's records are contiguous, in tile order; four at a time so that
-        // twelve loads are in flight per thread (the loop is otherwise one memory latency per record), summed in order
+        // this Gaussian's records are contiguous, in tile order; four at a time so that twelve record loads (and four
+        // validity bytes) are in flight per thread -- the loop is otherwise one memory latency per record -- summed in
+        // order.  Records the blend kernel did not write (rec_valid 0: no pixel of the tile could use the instance) stand
+        // for zeros: their bytes are loaded WITH the flags (waiting for a flag before asking for its record would put two
+        // dependent round trips where there was one; measured +30 %) and dropped by a select, never used in arithmetic.
         const GradRec* gr = grad_rec + off;
+        const uint8_t* gv_ = rec_valid + off;
+        auto add = [&](const GradRec& q, bool ok) {
+            sx += ok ? q.a.x : 0.0f; sy += ok ? q.a.y : 0.0f; sxx += ok ? q.a.z : 0.0f; sxy += ok ? q.a.w : 0.0f;
+            syy += ok ? q.b.x : 0.0f; gop += ok ? q.b.y : 0.0f; gcol[0] += ok ? q.b.z : 0.0f; gcol[1] += ok ? q.b.w : 0.0f;
+            gcol[2] += ok ? q.c : 0.0f;
+        };
         uint32_t k = 0;
         for (; k + 4 <= n; k += 4) {
             GradRec q[4];
+            uint8_t ok[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) q[j] = gr[k + j];
+            for (int j = 0; j < 4; ++j) { ok[j] = gv_[k + j]; q[j] = gr[k + j]; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                sx += q[j].a.x; sy += q[j].a.y; sxx += q[j].a.z; sxy += q[j].a.w;
-                syy += q[j].b.x; gop += q[j].b.y; gcol[0] += q[j].b.z; gcol[1] += q[j].b.w;
-                gcol[2] += q[j].c;
-            }
+            for (int j = 0; j < 4; ++j) add(q[j], ok[j] != 0);
         }
         for (; k < n; ++k) {
+            const uint8_t ok = gv_[k];
             const GradRec q = gr[k];
-            sx += q.a.x; sy += q.a.y; sxx += q.a.z; sxy += q.a.w;
-            syy += q.b.x; gop += q.b.y; gcol[0] += q.b.z; gcol[1] += q.b.w;
-            gcol[2] += q.c;
+            add(q, ok != 0);
         }
         // the per-splat constants the blend kernel left out.  The moments are of Y = opacity * G * dL/dalpha, i.e.
         // dL/dG already: dG/dmean = -G Q d with Q = (-2A, -B, -2C), dG/dQ = -G/2 d d^T (Qxy counted once: factor 1);
@@ -577,23 +586,23 @@ void launch_preprocess(int64_t P, int M, const float* means3D, const float* scal
     if (g.tiles <= LDS_HIST_MAX_TILES)
         preprocess_kernel<true><<<nblk(P, BIN_GPW), BIN_THREADS, (size_t)g.tiles * 4, st>>>(
             P, M, means3D, scales, rotations, cov3D, opacities, shs, colors, ks, g.tiles, gv.rec, gv.tiles_touched,
-            shs ? gv.clamped : nullptr, gv.block_sums, gv.tile_count, radii);
+            shs ? gv.clamped : nullptr, gv.live, gv.block_sums, gv.tile_count, radii);
     else
         preprocess_kernel<false><<<nblk(P, BIN_GPW), BIN_THREADS, 0, st>>>(
             P, M, means3D, scales, rotations, cov3D, opacities, shs, colors, ks, g.tiles, gv.rec, gv.tiles_touched,
-            shs ? gv.clamped : nullptr, gv.block_sums, gv.tile_count, radii);
+            shs ? gv.clamped : nullptr, gv.live, gv.block_sums, gv.tile_count, radii);
 }
 
 void launch_preprocess_backward(int64_t P, int M, const float* means3D, const float* scales,
                                 const float* rotations, const float* cov3D, const float* shs,
                                 const KSettings& ks, const int32_t* radii, const GeomView& gv,
-                                const BinView& bv, const GradRec* grad_rec, float* dL_dmeans3D,
+                                const BinView& bv, const GradRec* grad_rec, const uint8_t* rec_valid, float* dL_dmeans3D,
                                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh, float* dL_dopacity,
                                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, hipStream_t st) {
     if (P <= 0) return;
     preprocess_backward_kernel<<<nblk(P, PRE_BLOCK), PRE_BLOCK, 0, st>>>(
         P, M, means3D, scales, rotations, cov3D, shs, ks, radii, gv.tiles_touched, gv.point_offsets,
-        gv.clamped, gv.rec, grad_rec, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh, dL_dopacity,
+        gv.clamped, gv.rec, grad_rec, rec_valid, gv.live, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh, dL_dopacity,
         dL_dscales, dL_drotations, dL_dcov3D);
 }
 
