@@ -64,7 +64,7 @@ const char* scr_last_error(void);
 size_t scr_geom_bytes(int64_t P, int32_t image_height, int32_t image_width); /* per-Gaussian state + per-tile counters */
 size_t scr_binning_bytes(int64_t num_rendered, int64_t max_tile_instances);  /* per tile-instance lists */
 size_t scr_image_bytes(int32_t image_height, int32_t image_width);           /* final_T + n_contrib */
-size_t scr_backward_scratch_bytes(int64_t num_rendered);                     /* per-instance gradient records + validity bytes */
+size_t scr_backward_scratch_bytes(int64_t num_rendered);                     /* per-instance gradient records */
 
 /* ---- visible_filter: radii_out[P] int32 (> 0 <=> visible).  Either (scales, rotations) or cov3D_precomp. */
 int scr_visible_filter(int64_t P, const float* means3D, const float* scales, const float* rotations,
@@ -97,8 +97,8 @@ int scr_forward_run(int64_t P, int64_t num_rendered, int64_t max_tile_instances,
  * at scene/gaussian_model.py:779), dL_dcolors[P,3], dL_dsh[P,M,3], dL_dopacity[P], dL_dscales[P,3],
  * dL_drotations[P,4], dL_dcov3D[P,6].  Every output element is written (zeros for culled Gaussians).
  * Deterministic: bit-identical results run to run (no floating-point atomics).  scratch: scr_backward_scratch_bytes
- * (one 36-byte gradient record per (Gaussian, tile) instance + one validity byte: instances no pixel of their tile
- * can use get no record). */
+ * (one 36-byte gradient record per (Gaussian, tile) instance; the entries of a tile's list behind every pixel's last
+ * contributor get none -- the tile's cut key in the image buffer, written by the backward, tells which). */
 int scr_backward(int64_t P, int32_t M, int64_t num_rendered, const float* means3D, const float* scales,
                  const float* rotations, const float* cov3D_precomp, const float* shs,
                  const scr_settings* settings, const int32_t* radii, const void* geom_buf,

@@ -460,7 +460,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                       const uint8_t* __restrict__ qmask, const float4* __restrict__ rec,
                       const float* __restrict__ bg, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                      GradRec* __restrict__ grad_rec, uint8_t* __restrict__ rec_valid, uint8_t* __restrict__ live) {
+                      GradRec* __restrict__ grad_rec, unsigned long long* __restrict__ cut_key) {
     // wave-private compacted records of the round: [wave][field group][3 pad + position]; group 0/1 =
     // the first 32 bytes of the splat record, group 2 = (blue, position in round, -, -).  A group of four
     // reads slots k .. k+3 of each field group: one address register and immediate offsets.  The three
@@ -518,17 +518,26 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     const int nround = (int)((n + BCH - 1) / BCH);
     const int live_top = max_last ? (int)((max_last - 1) / BCH) : -1;  // last round with any work
 
-    // Entries no wave takes part in -- whole rounds behind every pixel's last contributor (at 20 M anchors a tile's list
-    // holds 24 k entries and its pixels are opaque after a few hundred), entries whose quadrant masks miss, entries past a
-    // wave's last contributor -- get NO record: rec_valid (one byte per instance, zeroed by the launcher) says which
-    // records exist, and preprocess_backward_kernel skips the others.  (They used to be written as zeros: 36 scattered
-    // bytes per instance, written here and read back there.)
+    // The rounds behind every pixel's last contributor get NO records (at 20 M anchors a tile's list holds 24 k entries
+    // and its pixels are opaque after a few hundred: they used to be written as zeros, 36 scattered bytes per instance,
+    // and read back).  The tile publishes the sort key (depth bits, id) of its first entry WITHOUT a record instead:
+    // the list is sorted by that key, so preprocess_backward_kernel knows from a Gaussian's own depth and index whether
+    // its instance in this tile has a record -- one 8-byte store per tile, no per-instance flags.
     (void)nround;
+    if (threadIdx.x == 0) {
+        const uint32_t c = (uint32_t)(live_top + 1) * BCH;
+        unsigned long long ck = ~0ull;      // every entry has a record
+        if (c < n) {
+            const uint32_t idc = point_list[lo + c];
+            ck = ((unsigned long long)__float_as_uint(rec[3 * (size_t)idc + 2].y) << 32) | idc;
+        }
+        cut_key[t] = ck;
+    }
 
     // ---- software pipeline over the live rounds, back to front:
     // (mask, id, slot) two rounds ahead, gathered records one round ahead
     uint32_t m_next = 0, id_next = 0, slot_next = 0;  // round ci-1
-    uint32_t m_cur = 0, slot_cur = 0, id_cur = 0;     // round ci (records in r0/r1/r2x)
+    uint32_t m_cur = 0, slot_cur = 0;                 // round ci (records in r0/r1/r2x)
     bool sel_cur = false;
     float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
     float r2x = 0.0f;
@@ -544,7 +553,6 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         sel_cur = ((m >> wave) & 1u) && i < wave_last;
         m_cur = m;
         slot_cur = slot;
-        id_cur = id;
         if (sel_cur) {
             r0 = rec[3 * (size_t)id];
             r1 = rec[3 * (size_t)id + 1];
@@ -569,7 +577,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             st[wave][1][pos + 3] = r1;
             st[wave][2][pos + 3] = make_float4(r2x, __uint_as_float((uint32_t)lane), 0.0f, 0.0f);
         }
-        const uint32_t m_this = m_cur, slot_this = slot_cur, id_this = id_cur;
+        const uint32_t m_this = m_cur, slot_this = slot_cur;
         gather(ci - 1, m_next, id_next, slot_next);
         load_meta(ci - 2, m_next, id_next, slot_next);
         // acc is double-buffered by round parity: this round's writes cannot collide with the
@@ -672,14 +680,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         __syncthreads();  // B: every wave's sums for this round are in acc
         // ---- combine: wave p (< 3) writes part p of the 36-byte gradient record of position `lane`,
         // adding the waves that took part in a fixed order
-        const uint32_t ci_i = base + lane;
-        const bool took_part = ci_i < n && ((((m_this >> 0) & 1u) && ci_i < wmax0) || (((m_this >> 1) & 1u) && ci_i < wmax1) ||
-                                            (((m_this >> 2) & 1u) && ci_i < wmax2) || (((m_this >> 3) & 1u) && ci_i < wmax3));
-        if (wave == 3 && took_part) {
-            rec_valid[slot_this] = 1;
-            live[id_this] = 1;     // this Gaussian has at least one record (every writer stores the same byte)
-        }
-        if (wave < 3 && took_part) {
+        if (wave < 3 && base + lane < n) {   // every entry of a live round gets its record (zeros if no wave took part)
             const uint32_t i = base + lane;
             float4 r = make_float4(0, 0, 0, 0);
             auto part = [&](int w) {
@@ -721,13 +722,11 @@ void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView
 }
 
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                           const float* dL_dcolor, GradRec* grad_rec, uint8_t* rec_valid, hipStream_t st) {
-    // gv.live was zeroed by the forward's preprocess kernel; a second backward of the same forward finds the bytes of
-    // the first one, which only costs the skip (rec_valid, zeroed per call, decides what is summed)
+                           const float* dL_dcolor, GradRec* grad_rec, hipStream_t st) {
     Grid g(ks.H, ks.W);
     blend_backward_kernel<<<(unsigned)blend_slots_per_xcd(g) * NUM_XCD, 256, 0, st>>>(
         ks.W, ks.H, g.gx, g.tiles, gv.tile_count, gv.total, gv.ranges, bv.point_list, bv.gm_index, bv.qmask, gv.rec, ks.bg, iv.final_T,
-        iv.n_contrib, dL_dcolor, grad_rec, rec_valid, gv.live);
+        iv.n_contrib, dL_dcolor, grad_rec, iv.cut_key);
 }
 
 }  // namespace scr

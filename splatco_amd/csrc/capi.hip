@@ -144,7 +144,7 @@ const char* scr_last_error(void) { return g_err; }
 size_t scr_geom_bytes(int64_t P, int32_t H, int32_t W) { return geom_view(nullptr, P, H, W).bytes; }
 size_t scr_binning_bytes(int64_t I, int64_t max_tile) { return bin_view(nullptr, I, max_tile).bytes; }
 size_t scr_image_bytes(int32_t H, int32_t W) { return img_view(nullptr, H, W).bytes; }
-size_t scr_backward_scratch_bytes(int64_t I) { return grad_rec_bytes(I) + align_up((size_t)(I > 0 ? I : 1)); }
+size_t scr_backward_scratch_bytes(int64_t I) { return align_up((size_t)(I > 0 ? I : 1) * sizeof(GradRec)); }
 
 int scr_visible_filter(int64_t P, const float* means3D, const float* scales, const float* rotations,
                        const float* cov3D_precomp, const scr_settings* settings, int32_t* radii_out,
@@ -263,16 +263,14 @@ int scr_backward(int64_t P, int32_t M, int64_t I, const float* means3D, const fl
     GeomView gv = geom_view((void*)geom_buf, P, ks.H, ks.W);
     BinView bv = bin_view((void*)binning_buf, I, 0);  // the lists read here come first in the layout
     ImgView iv = img_view((void*)image_buf, ks.H, ks.W);
-    uint8_t* rec_valid = (uint8_t*)scratch + grad_rec_bytes(I);
     if (I > 0) {
-        HIP_TRY(hipMemsetAsync(rec_valid, 0, (size_t)I, st));
         { ProfScope ps_(SCR_PROF_BLEND_BACKWARD, st);
-          launch_blend_backward(ks, gv, bv, iv, dL_dcolor, (GradRec*)scratch, rec_valid, st); }
+          launch_blend_backward(ks, gv, bv, iv, dL_dcolor, (GradRec*)scratch, st); }
         CHECK_LAUNCH("blend_backward_kernel", settings->debug, st);
     }
     { ProfScope ps_(SCR_PROF_PREPROCESS_BACKWARD, st);
       launch_preprocess_backward(P, M, means3D, scales, rotations, cov3D_precomp, shs, ks, radii, gv, bv,
-                                 (const GradRec*)scratch, rec_valid, dL_dmeans3D, dL_dmeans2D, shs ? nullptr : dL_dcolors,
+                                 (const GradRec*)scratch, iv.cut_key, dL_dmeans3D, dL_dmeans2D, shs ? nullptr : dL_dcolors,
                                  shs ? dL_dsh : nullptr, dL_dopacity, cov3D_precomp ? nullptr : dL_dscales,
                                  cov3D_precomp ? nullptr : dL_drotations, cov3D_precomp ? dL_dcov3D : nullptr, st); }
     CHECK_LAUNCH("preprocess_backward_kernel", settings->debug, st);

@@ -44,7 +44,6 @@ struct GeomView {
     uint32_t* tiles_touched;  // [P]
     uint32_t* point_offsets;  // [P] inclusive scan of tiles_touched (written by the scatter kernel)
     uint8_t* clamped;         // [P] bit c set when SH colour channel c was clamped at 0
-    uint8_t* live;            // [P] zeroed by the forward; the blend backward sets it for Gaussians that got a gradient record
     uint2* gm_base;           // [P] (b, rw): Gaussian-major index of the instance in tile (tx, ty) = b + ty*rw + tx
                               //     (b = first index - y0*rw - x0 mod 2^32, rw = rect width; written by the scatter kernel)
     uint32_t* block_sums;     // [ceil(P/BIN_GPW)] -> exclusive prefix after scan
@@ -67,7 +66,6 @@ inline __host__ GeomView geom_view(void* base, int64_t P, int H, int W) {
     v.tiles_touched = (uint32_t*)take((size_t)P * 4);
     v.point_offsets = (uint32_t*)take((size_t)P * 4);
     v.clamped = (uint8_t*)take((size_t)P);
-    v.live = (uint8_t*)take((size_t)P);
     v.gm_base = (uint2*)take((size_t)P * 8);
     v.block_sums = (uint32_t*)take((nblk + 1) * 4);
     v.tile_count = (uint32_t*)take((size_t)g.tiles * 4);
@@ -111,13 +109,13 @@ inline __host__ BinView bin_view(void* base, int64_t I, int64_t max_tile_instanc
 struct __attribute__((packed, aligned(4))) GradQuad { float x, y, z, w; };
 struct __attribute__((packed, aligned(4))) GradRec { GradQuad a, b; float c; };
 static_assert(sizeof(GradRec) == 36, "36-byte gradient records");
-// the backward scratch: I records, then I validity bytes (1 = the blend kernel wrote the record)
-inline __host__ __device__ size_t grad_rec_bytes(int64_t I) { return align_up((size_t)(I > 0 ? I : 1) * sizeof(GradRec)); }
 
 // ---- image buffer ----
 struct ImgView {
     float* final_T;       // [H*W]
     uint32_t* n_contrib;  // [H*W]
+    unsigned long long* cut_key;  // [tiles] written by the blend backward: sort key (depth bits << 32 | id) of the tile's first
+                                  //         list entry that got no gradient record (~0: all have one)
     size_t bytes;
 };
 
@@ -128,6 +126,7 @@ inline __host__ ImgView img_view(void* base, int H, int W) {
     auto take = [&](size_t n) { char* q = p ? p + off : nullptr; off += align_up(n); return q; };
     v.final_T = (float*)take((size_t)H * W * 4);
     v.n_contrib = (uint32_t*)take((size_t)H * W * 4);
+    v.cut_key = (unsigned long long*)take((size_t)Grid(H, W).tiles * 8);
     v.bytes = off;
     return v;
 }
@@ -320,11 +319,11 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
 void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
                           float* out_color, bool longest_first, hipStream_t st);
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                           const float* dL_dcolor, GradRec* grad_rec, uint8_t* rec_valid, hipStream_t st);
+                           const float* dL_dcolor, GradRec* grad_rec, hipStream_t st);
 void launch_preprocess_backward(int64_t P, int M, const float* means3D, const float* scales,
                                 const float* rotations, const float* cov3D, const float* shs,
                                 const KSettings& ks, const int32_t* radii, const GeomView& gv,
-                                const BinView& bv, const GradRec* grad_rec, const uint8_t* rec_valid, float* dL_dmeans3D,
+                                const BinView& bv, const GradRec* grad_rec, const unsigned long long* cut_key, float* dL_dmeans3D,
                                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh, float* dL_dopacity,
                                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, hipStream_t st);
 

@@ -232,7 +232,7 @@ preprocess_kernel(int64_t P, int M, const float* __restrict__ means3D, const flo
                   const float* __restrict__ rotations, const float* __restrict__ cov3D,
                   const float* __restrict__ opacities, const float* __restrict__ shs,
                   const float* __restrict__ colors, KSettings ks, int tiles, float4* __restrict__ rec,
-                  uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped, uint8_t* __restrict__ live,
+                  uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped,
                   uint32_t* __restrict__ block_sums, uint32_t* __restrict__ tile_count,
                   int32_t* __restrict__ radii) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // [tiles] when LDS_HIST
@@ -284,7 +284,6 @@ preprocess_kernel(int64_t P, int M, const float* __restrict__ means3D, const flo
             if (clamped) clamped[i] = 0;
         }
         tiles_touched[i] = tt;
-        live[i] = 0;           // set by the blend backward for Gaussians that receive a gradient record
         tsum += tt;
     }
     // workgroup sum of tiles_touched (wave reduction, then the wave partials through LDS)
@@ -316,7 +315,7 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
                            const int32_t* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
                            const uint32_t* __restrict__ point_offsets, const uint8_t* __restrict__ clamped,
                            const float4* __restrict__ rec, const GradRec* __restrict__ grad_rec,
-                           const uint8_t* __restrict__ rec_valid, const uint8_t* __restrict__ live,
+                           const unsigned long long* __restrict__ cut_key,
                            float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
                            float* __restrict__ dL_dcolors, float* __restrict__ dL_dsh,
                            float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
@@ -325,9 +324,10 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
     if (i >= P) return;
     float gm[3] = {0, 0, 0}, gm2[3] = {0, 0, 0}, gcol[3] = {0, 0, 0}, gop = 0, gs[3] = {0, 0, 0},
           gq[4] = {0, 0, 0, 0}, g6[6] = {0, 0, 0, 0, 0, 0};
-    // a Gaussian none of whose instances got a record (occluded everywhere: most of them at 20 M anchors) has all-zero
-    // gradients: nothing of it is read
-    bool vis = radii[i] > 0 && live[i] != 0;
+    bool vis = radii[i] > 0;
+    // depth and tile rect as the forward stored them: the record loop below needs them for its cut_key addresses, and taking
+    // them from here instead of from project() lets those loads go out while project() is still waiting for its inputs
+    const float4 r2 = rec[3 * i + 2];
     Proj ps;
     Foot ft;
     if (vis) vis = project(i, means3D, scales, rotations, cov3D, ks, ps, ft);
@@ -336,13 +336,23 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
         uint32_t n = tiles_touched[i];
         uint32_t off = point_offsets[i] - n;
         float sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0;  // moments of Y = opacity G dL/dalpha over the footprint
-        // this Gaussian's records are contiguous, in tile order; four at a time so that twelve record loads (and four
-        // validity bytes) are in flight per thread -- the loop is otherwise one memory latency per record -- summed in
-        // order.  Records the blend kernel did not write (rec_valid 0: no pixel of the tile could use the instance) stand
-        // for zeros: their bytes are loaded WITH the flags (waiting for a flag before asking for its record would put two
-        // dependent round trips where there was one; measured +30 %) and dropped by a select, never used in arithmetic.
+        // this Gaussian's records are contiguous, in tile order (the row-major walk of its tile rect); four at a time so
+        // that twelve record loads are in flight per thread -- the loop is otherwise one memory latency per record --
+        // summed in order.  A tile's list entries behind every pixel's last contributor have NO record: the blend backward
+        // left the sort key of the first such entry in cut_key[tile], and this Gaussian's key (depth bits, index) says on
+        // which side it lies.  The 8-byte keys (a 64 KB table at 1080p: cache hits) are loaded WITH the records -- waiting
+        // for the verdict before asking for the record would put two dependent round trips where there is one -- and the
+        // bytes of missing records are dropped by a select, never used in arithmetic.
         const GradRec* gr = grad_rec + off;
-        const uint8_t* gv_ = rec_valid + off;
+        const unsigned long long mykey = ((unsigned long long)__float_as_uint(r2.y) << 32) | (uint32_t)i;
+        const uint32_t rlo = __float_as_uint(r2.z), rhi = __float_as_uint(r2.w);
+        const int gxt = (ks.W + TILE - 1) / TILE, rx0 = (int)(rlo & 0xffffu), rx1 = (int)(rhi & 0xffffu);
+        int tcx = rx0, tcy = (int)(rlo >> 16);      // tile of record k
+        auto next_tile = [&]() {
+            const int t = tcy * gxt + tcx;
+            if (++tcx == rx1) { tcx = rx0; ++tcy; }
+            return t;
+        };
         auto add = [&](const GradRec& q, bool ok) {
             sx += ok ? q.a.x : 0.0f; sy += ok ? q.a.y : 0.0f; sxx += ok ? q.a.z : 0.0f; sxy += ok ? q.a.w : 0.0f;
             syy += ok ? q.b.x : 0.0f; gop += ok ? q.b.y : 0.0f; gcol[0] += ok ? q.b.z : 0.0f; gcol[1] += ok ? q.b.w : 0.0f;
@@ -351,16 +361,16 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
         uint32_t k = 0;
         for (; k + 4 <= n; k += 4) {
             GradRec q[4];
-            uint8_t ok[4];
+            unsigned long long ck[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { ok[j] = gv_[k + j]; q[j] = gr[k + j]; }
+            for (int j = 0; j < 4; ++j) { ck[j] = cut_key[next_tile()]; q[j] = gr[k + j]; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) add(q[j], ok[j] != 0);
+            for (int j = 0; j < 4; ++j) add(q[j], mykey < ck[j]);
         }
         for (; k < n; ++k) {
-            const uint8_t ok = gv_[k];
+            const unsigned long long ck = cut_key[next_tile()];
             const GradRec q = gr[k];
-            add(q, ok != 0);
+            add(q, mykey < ck);
         }
         // the per-splat constants the blend kernel left out.  The moments are of Y = opacity * G * dL/dalpha, i.e.
         // dL/dG already: dG/dmean = -G Q d with Q = (-2A, -B, -2C), dG/dQ = -G/2 d d^T (Qxy counted once: factor 1);
@@ -586,23 +596,23 @@ void launch_preprocess(int64_t P, int M, const float* means3D, const float* scal
     if (g.tiles <= LDS_HIST_MAX_TILES)
         preprocess_kernel<true><<<nblk(P, BIN_GPW), BIN_THREADS, (size_t)g.tiles * 4, st>>>(
             P, M, means3D, scales, rotations, cov3D, opacities, shs, colors, ks, g.tiles, gv.rec, gv.tiles_touched,
-            shs ? gv.clamped : nullptr, gv.live, gv.block_sums, gv.tile_count, radii);
+            shs ? gv.clamped : nullptr, gv.block_sums, gv.tile_count, radii);
     else
         preprocess_kernel<false><<<nblk(P, BIN_GPW), BIN_THREADS, 0, st>>>(
             P, M, means3D, scales, rotations, cov3D, opacities, shs, colors, ks, g.tiles, gv.rec, gv.tiles_touched,
-            shs ? gv.clamped : nullptr, gv.live, gv.block_sums, gv.tile_count, radii);
+            shs ? gv.clamped : nullptr, gv.block_sums, gv.tile_count, radii);
 }
 
 void launch_preprocess_backward(int64_t P, int M, const float* means3D, const float* scales,
                                 const float* rotations, const float* cov3D, const float* shs,
                                 const KSettings& ks, const int32_t* radii, const GeomView& gv,
-                                const BinView& bv, const GradRec* grad_rec, const uint8_t* rec_valid, float* dL_dmeans3D,
+                                const BinView& bv, const GradRec* grad_rec, const unsigned long long* cut_key, float* dL_dmeans3D,
                                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh, float* dL_dopacity,
                                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, hipStream_t st) {
     if (P <= 0) return;
     preprocess_backward_kernel<<<nblk(P, PRE_BLOCK), PRE_BLOCK, 0, st>>>(
         P, M, means3D, scales, rotations, cov3D, shs, ks, radii, gv.tiles_touched, gv.point_offsets,
-        gv.clamped, gv.rec, grad_rec, rec_valid, gv.live, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh, dL_dopacity,
+        gv.clamped, gv.rec, grad_rec, cut_key, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh, dL_dopacity,
         dL_dscales, dL_drotations, dL_dcov3D);
 }
 
