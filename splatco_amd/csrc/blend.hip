@@ -460,7 +460,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                       const uint8_t* __restrict__ qmask, const float4* __restrict__ rec,
                       const float* __restrict__ bg, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                      GradRec* __restrict__ grad_rec, unsigned long long* __restrict__ cut_key) {
+                      GradRec* __restrict__ grad_rec, unsigned long long* __restrict__ cut_key, unsigned long long stamp) {
     // wave-private compacted records of the round: [wave][field group][3 pad + position]; group 0/1 =
     // the first 32 bytes of the splat record, group 2 = (blue, position in round, -, -).  A group of four
     // reads slots k .. k+3 of each field group: one address register and immediate offsets.  The three
@@ -523,16 +523,31 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     // and read back).  The tile publishes the sort key (depth bits, id) of its first entry WITHOUT a record instead:
     // the list is sorted by that key, so preprocess_backward_kernel knows from a Gaussian's own depth and index whether
     // its instance in this tile has a record -- one 8-byte store per tile, no per-instance flags.
-    (void)nround;
+    // A tile with only a round or two to spare (the benchmark density) fills them with zero records as before and
+    // publishes "no cut"; when no tile of a call cuts, the reader skips the look-ups altogether: the word behind the table
+    // takes this call's stamp as soon as one tile does.  (A stale or uninitialised word that happened to equal the stamp
+    // would cost the reader its look-ups, never the result.)
+    constexpr int CUT_MIN_ROUNDS = 3;
+    const bool cut = nround - 1 - live_top >= CUT_MIN_ROUNDS;    // workgroup-uniform
     if (threadIdx.x == 0) {
-        const uint32_t c = (uint32_t)(live_top + 1) * BCH;
         unsigned long long ck = ~0ull;      // every entry has a record
-        if (c < n) {
-            const uint32_t idc = point_list[lo + c];
+        if (cut) {
+            const uint32_t idc = point_list[lo + (uint32_t)(live_top + 1) * BCH];
             ck = ((unsigned long long)__float_as_uint(rec[3 * (size_t)idc + 2].y) << 32) | idc;
+            cut_key[tiles] = stamp;
         }
         cut_key[t] = ck;
     }
+    if (!cut && wave < 3)
+        for (int ci = nround - 1; ci > live_top; --ci) {     // all-zero records (waves 0..2 write one part each)
+            const uint32_t i = (uint32_t)ci * BCH + lane;
+            if (i < n) {
+                GradRec& gr = grad_rec[gm_index[lo + i]];
+                if (wave == 0) store16_dword_aligned(&gr.a, make_float4(0, 0, 0, 0));
+                else if (wave == 1) store16_dword_aligned(&gr.b, make_float4(0, 0, 0, 0));
+                else gr.c = 0.0f;
+            }
+        }
 
     // ---- software pipeline over the live rounds, back to front:
     // (mask, id, slot) two rounds ahead, gathered records one round ahead
@@ -722,11 +737,11 @@ void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView
 }
 
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                           const float* dL_dcolor, GradRec* grad_rec, hipStream_t st) {
+                           const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, hipStream_t st) {
     Grid g(ks.H, ks.W);
     blend_backward_kernel<<<(unsigned)blend_slots_per_xcd(g) * NUM_XCD, 256, 0, st>>>(
         ks.W, ks.H, g.gx, g.tiles, gv.tile_count, gv.total, gv.ranges, bv.point_list, bv.gm_index, bv.qmask, gv.rec, ks.bg, iv.final_T,
-        iv.n_contrib, dL_dcolor, grad_rec, iv.cut_key);
+        iv.n_contrib, dL_dcolor, grad_rec, iv.cut_key, stamp);
 }
 
 }  // namespace scr

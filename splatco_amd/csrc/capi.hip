@@ -39,6 +39,7 @@ static int fail(const char* fmt, ...) {
     } while (0)
 
 // ---- opt-in kernel timing (scr_profile_*): hipEvent pairs on the launch stream
+#include <atomic>
 #include <vector>
 namespace {
 struct ProfRec { int idx; hipEvent_t a, b; };
@@ -263,14 +264,17 @@ int scr_backward(int64_t P, int32_t M, int64_t I, const float* means3D, const fl
     GeomView gv = geom_view((void*)geom_buf, P, ks.H, ks.W);
     BinView bv = bin_view((void*)binning_buf, I, 0);  // the lists read here come first in the layout
     ImgView iv = img_view((void*)image_buf, ks.H, ks.W);
+    // a value no earlier call of this process used (and that uninitialised memory is unlikely to hold): see blend.hip
+    static std::atomic<unsigned long long> stamp_counter{0x5ca1ab1e00000000ull};
+    const unsigned long long stamp = ++stamp_counter;
     if (I > 0) {
         { ProfScope ps_(SCR_PROF_BLEND_BACKWARD, st);
-          launch_blend_backward(ks, gv, bv, iv, dL_dcolor, (GradRec*)scratch, st); }
+          launch_blend_backward(ks, gv, bv, iv, dL_dcolor, (GradRec*)scratch, stamp, st); }
         CHECK_LAUNCH("blend_backward_kernel", settings->debug, st);
     }
     { ProfScope ps_(SCR_PROF_PREPROCESS_BACKWARD, st);
       launch_preprocess_backward(P, M, means3D, scales, rotations, cov3D_precomp, shs, ks, radii, gv, bv,
-                                 (const GradRec*)scratch, iv.cut_key, dL_dmeans3D, dL_dmeans2D, shs ? nullptr : dL_dcolors,
+                                 (const GradRec*)scratch, iv.cut_key, stamp, dL_dmeans3D, dL_dmeans2D, shs ? nullptr : dL_dcolors,
                                  shs ? dL_dsh : nullptr, dL_dopacity, cov3D_precomp ? nullptr : dL_dscales,
                                  cov3D_precomp ? nullptr : dL_drotations, cov3D_precomp ? dL_dcov3D : nullptr, st); }
     CHECK_LAUNCH("preprocess_backward_kernel", settings->debug, st);

@@ -126,7 +126,7 @@ inline __host__ ImgView img_view(void* base, int H, int W) {
     auto take = [&](size_t n) { char* q = p ? p + off : nullptr; off += align_up(n); return q; };
     v.final_T = (float*)take((size_t)H * W * 4);
     v.n_contrib = (uint32_t*)take((size_t)H * W * 4);
-    v.cut_key = (unsigned long long*)take((size_t)Grid(H, W).tiles * 8);
+    v.cut_key = (unsigned long long*)take((size_t)Grid(H, W).tiles * 8 + 8);   // [tiles] is the stamp word, see blend.hip
     v.bytes = off;
     return v;
 }
@@ -319,11 +319,12 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
 void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
                           float* out_color, bool longest_first, hipStream_t st);
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                           const float* dL_dcolor, GradRec* grad_rec, hipStream_t st);
+                           const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, hipStream_t st);
 void launch_preprocess_backward(int64_t P, int M, const float* means3D, const float* scales,
                                 const float* rotations, const float* cov3D, const float* shs,
                                 const KSettings& ks, const int32_t* radii, const GeomView& gv,
-                                const BinView& bv, const GradRec* grad_rec, const unsigned long long* cut_key, float* dL_dmeans3D,
+                                const BinView& bv, const GradRec* grad_rec, const unsigned long long* cut_key,
+                                unsigned long long stamp, float* dL_dmeans3D,
                                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh, float* dL_dopacity,
                                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, hipStream_t st);
 

@@ -13,6 +13,9 @@
 // is written in the evaluation order of DESIGN.md "Normative arithmetic" (no FMA, IEEE sqrt/div).
 #include "common.h"
 
+#ifndef SCR_PREBWD_MIN_BLOCKS
+#define SCR_PREBWD_MIN_BLOCKS 1
+#endif
 namespace scr {
 
 // ------------------------------------------------------------------ shared projection maths
@@ -308,14 +311,14 @@ preprocess_kernel(int64_t P, int M, const float* __restrict__ means3D, const flo
 // ------------------------------------------------------------------ backward: reduce + chain
 // One thread per Gaussian.  Sums its per-instance gradient records in tile order (fixed order ->
 // bit-reproducible), then differentiates the projection (recomputed from the inputs).
-__global__ void __launch_bounds__(PRE_BLOCK)
+__global__ void __launch_bounds__(PRE_BLOCK, SCR_PREBWD_MIN_BLOCKS)
 preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
                            const float* __restrict__ scales, const float* __restrict__ rotations,
                            const float* __restrict__ cov3D, const float* __restrict__ shs, KSettings ks,
                            const int32_t* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
                            const uint32_t* __restrict__ point_offsets, const uint8_t* __restrict__ clamped,
                            const float4* __restrict__ rec, const GradRec* __restrict__ grad_rec,
-                           const unsigned long long* __restrict__ cut_key,
+                           const unsigned long long* __restrict__ cut_key, unsigned long long stamp, int tiles,
                            float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
                            float* __restrict__ dL_dcolors, float* __restrict__ dL_dsh,
                            float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
@@ -359,18 +362,29 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
             gcol[2] += ok ? q.c : 0.0f;
         };
         uint32_t k = 0;
-        for (; k + 4 <= n; k += 4) {
-            GradRec q[4];
-            unsigned long long ck[4];
+        if (cut_key[tiles] == stamp) {      // wave-uniform: some tile of this call left entries without records
+            for (; k + 4 <= n; k += 4) {
+                GradRec q[4];
+                unsigned long long ck[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { ck[j] = cut_key[next_tile()]; q[j] = gr[k + j]; }
+                for (int j = 0; j < 4; ++j) { ck[j] = cut_key[next_tile()]; q[j] = gr[k + j]; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) add(q[j], mykey < ck[j]);
-        }
-        for (; k < n; ++k) {
-            const unsigned long long ck = cut_key[next_tile()];
-            const GradRec q = gr[k];
-            add(q, mykey < ck);
+                for (int j = 0; j < 4; ++j) add(q[j], mykey < ck[j]);
+            }
+            for (; k < n; ++k) {
+                const unsigned long long ck = cut_key[next_tile()];
+                const GradRec q = gr[k];
+                add(q, mykey < ck);
+            }
+        } else {                            // every instance has its record (the benchmark density): no look-ups
+            for (; k + 4 <= n; k += 4) {
+                GradRec q[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = gr[k + j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) add(q[j], true);
+            }
+            for (; k < n; ++k) add(gr[k], true);
         }
         // the per-splat constants the blend kernel left out.  The moments are of Y = opacity * G * dL/dalpha, i.e.
         // dL/dG already: dG/dmean = -G Q d with Q = (-2A, -B, -2C), dG/dQ = -G/2 d d^T (Qxy counted once: factor 1);
@@ -606,13 +620,14 @@ void launch_preprocess(int64_t P, int M, const float* means3D, const float* scal
 void launch_preprocess_backward(int64_t P, int M, const float* means3D, const float* scales,
                                 const float* rotations, const float* cov3D, const float* shs,
                                 const KSettings& ks, const int32_t* radii, const GeomView& gv,
-                                const BinView& bv, const GradRec* grad_rec, const unsigned long long* cut_key, float* dL_dmeans3D,
+                                const BinView& bv, const GradRec* grad_rec, const unsigned long long* cut_key,
+                                unsigned long long stamp, float* dL_dmeans3D,
                                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh, float* dL_dopacity,
                                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, hipStream_t st) {
     if (P <= 0) return;
     preprocess_backward_kernel<<<nblk(P, PRE_BLOCK), PRE_BLOCK, 0, st>>>(
         P, M, means3D, scales, rotations, cov3D, shs, ks, radii, gv.tiles_touched, gv.point_offsets,
-        gv.clamped, gv.rec, grad_rec, cut_key, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh, dL_dopacity,
+        gv.clamped, gv.rec, grad_rec, cut_key, stamp, Grid(ks.H, ks.W).tiles, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh, dL_dopacity,
         dL_dscales, dL_drotations, dL_dcov3D);
 }
 
