@@ -434,7 +434,7 @@ tile_sort_wave_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, un
 // consecutive outputs: one bisection along its diagonal, 16 compare-and-advance steps) make one run of them.  A tile
 // of up to 8192 instances is finished here (final lists written); a larger tile gets its 8192-chunks
 // sorted in place and goes on to the global merge passes.
-constexpr int WG_SORT_MAX = 8192;   // keys a workgroup sorts on chip: 8 waves x 1024
+constexpr int WG_SORT_MAX = SCR_WG_SORT_MAX;   // keys a workgroup sorts on chip: one wave per 1024
 constexpr int WG_SORT_THREADS = WG_SORT_MAX / 16;   // 16 keys per lane
 __device__ __forceinline__ int wg_slot(int p) { return p + (p >> 4); }  // 16 keys of a lane start 17 slots apart
 __global__ void __launch_bounds__(WG_SORT_THREADS)

@@ -27,6 +27,9 @@ constexpr int BIN_GPW = BIN_THREADS * BIN_ROUNDS;  // Gaussians per preprocess /
 #endif
 constexpr int LDS_HIST_MAX_TILES = SCR_LDS_HIST_MAX_TILES;  // per-tile LDS histogram (4 B / tile) in the CU's 160 KB of LDS (4K images: 32400 tiles)
 constexpr int ID_BITS = 28;             // sort key = depth:32 | id:28 | quadrant mask:4  ->  P < 2^28
+#ifndef SCR_WG_SORT_MAX
+#define SCR_WG_SORT_MAX 8192              // keys an on-chip workgroup sort takes (binning.hip tile_sort_wg_kernel)
+#endif
 constexpr int REC_F = 12;               // floats per splat record (48 B, three float4)
 constexpr int GRAD_F = 9;               // floats per per-instance gradient record (GradRec)
 
@@ -96,7 +99,7 @@ inline __host__ BinView bin_view(void* base, int64_t I, int64_t max_tile_instanc
     v.point_list = (uint32_t*)take(n * 4);
     v.gm_index = (uint32_t*)take(n * 4);
     v.qmask = (uint8_t*)take(n);
-    const bool merge = max_tile_instances > 8192;  // WG_SORT_MAX (binning.hip): tiles above it take global merge passes
+    const bool merge = max_tile_instances > SCR_WG_SORT_MAX;  // tiles above one workgroup sort chunk (binning.hip) take global merge passes
     v.keys2 = merge ? (unsigned long long*)take(n * 8) : nullptr;
     v.bytes = off;
     return v;
