@@ -702,7 +702,7 @@ int scr_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, co
 int scr_statis_compute(int64_t V, int32_t k, const float* neural_opacity, const int32_t* out_index,
                        const uint8_t* update_filter, const float* viewspace_grad, int32_t grad_stride,
                        float* inc_opacity, float* inc_grad, void* stream) {
-    if (V < 0 || k <= 0 || grad_stride < 2) return fail("bad V / k / grad_stride");
+    if (V < 0 || k <= 0 || k > 256 || grad_stride < 2) return fail("bad V / k (1..256) / grad_stride");
     if (V == 0) return 0;
     if (!neural_opacity || !out_index || !inc_opacity || !inc_grad) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;

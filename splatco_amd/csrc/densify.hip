@@ -20,22 +20,30 @@
 namespace scr {
 
 __global__ void __launch_bounds__(256)
-statis_compute_kernel(int64_t V, int k, const float* __restrict__ neural_opacity, const int32_t* __restrict__ out_index,
+statis_compute_kernel(int64_t V, int k, int per, const float* __restrict__ neural_opacity, const int32_t* __restrict__ out_index,
                       const uint8_t* __restrict__ update_filter, const float* __restrict__ grad, int gstride,
                       float* __restrict__ inc_opacity, float* __restrict__ inc_grad) {
-    // one thread per candidate; the k candidates of an anchor are summed by the thread of slot 0
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= V * k) return;
-    const int32_t p = out_index[c];
-    float g = -1.0f;
-    if (p >= 0 && update_filter[p]) {
-        const float gx = grad[(size_t)p * gstride], gy = grad[(size_t)p * gstride + 1];
-        g = sqrtf(gx * gx + gy * gy);
+    // one thread per candidate; a workgroup takes per = (256 / k) * k candidates -- whole anchors -- so that every load is
+    // coalesced and the k opacities of an anchor meet in LDS (a thread that walked its anchor's k values alone read
+    // 40 bytes per lane with six lanes of a wave active)
+    __shared__ float op[256];
+    const int64_t c = (int64_t)blockIdx.x * per + threadIdx.x;
+    const bool in = (int)threadIdx.x < per && c < V * k;
+    float g = -1.0f, o = 0.0f;
+    if (in) {
+        const int32_t p = out_index[c];
+        o = fmaxf(neural_opacity[c], 0.0f);
+        if (p >= 0 && update_filter[p]) {
+            const float gx = grad[(size_t)p * gstride], gy = grad[(size_t)p * gstride + 1];
+            g = sqrtf(gx * gx + gy * gy);
+        }
+        inc_grad[c] = g;
     }
-    inc_grad[c] = g;
-    if (c % k == 0) {
+    op[threadIdx.x] = o;
+    __syncthreads();
+    if (in && threadIdx.x % k == 0) {
         float s = 0.0f;
-        for (int j = 0; j < k; ++j) s += fmaxf(neural_opacity[c + j], 0.0f);
+        for (int j = 0; j < k; ++j) s += op[threadIdx.x + j];     // slot order, as before
         inc_opacity[c / k] = s;
     }
 }
@@ -66,8 +74,10 @@ void launch_statis_compute(int64_t V, int k, const float* neural_opacity, const 
                            float* inc_grad, hipStream_t st) {
     const int64_t n = V * k;
     if (n <= 0) return;
-    statis_compute_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(V, k, neural_opacity, out_index, update_filter,
-                                                                     grad, gstride, inc_opacity, inc_grad);
+    const int per = k <= 256 ? (256 / k) * k : 0;
+    if (!per) return;      // scr_statis_compute rejects k > 256
+    statis_compute_kernel<<<(unsigned)((n + per - 1) / per), 256, 0, st>>>(V, k, per, neural_opacity, out_index, update_filter,
+                                                                         grad, gstride, inc_opacity, inc_grad);
 }
 
 void launch_statis_apply(int64_t V, int k, const int64_t* visible_index, const float* inc_opacity, const float* inc_grad,
