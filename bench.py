@@ -379,6 +379,7 @@ def run_anchor_config(args, rank, world, dev):
     from splatco_amd import _C
     from splatco_amd.densify import AnchorDensifier
     from splatco_amd.multiview import GradArena
+    from splatco_amd.losses import scaling_reg
     from splatco_amd.renderer import prefilter_voxel, render
     from splatco_amd.synthetic import ANCHOR_CONFIGS, synthetic_anchor_model, synthetic_views
     from splatco_amd.train_step import collaborative_step
@@ -419,7 +420,7 @@ def run_anchor_config(args, rank, world, dev):
                 p.grad = None
             vis = prefilter_voxel(views[0], pc, pipe, bg)
             out = render(views[0], pc, pipe, bg, visible_mask=vis, retain_grad=True)
-            loss = (out["render"] - target).abs().mean() + 0.01 * out["scaling"].prod(dim=1).mean()
+            loss = (out["render"] - target).abs().mean() + 0.01 * scaling_reg(out["scaling"])
             loss.backward()
             stats["P"], stats["V"] = out["radii"].shape[0], int(out["selection_mask"].numel() // pc.n_offsets)
             stats["rendered"] = out["radii"]

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 17
+#define SCR_ABI_VERSION 18
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -239,6 +239,13 @@ int scr_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img1, cons
 int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2,
                          const void* scratch, const float* g_l1, const float* g_ssim, float* dimg1,
                          void* stream);
+
+/* The loss's scaling regulariser, mean_p(scaling[p,0] scaling[p,1] scaling[p,2]) (train.py:192-196:
+ * `scaling.prod(dim=1).mean()`) -> out[1], and its gradient dscaling[P,3] = g[0] / P * (products of the other two).
+ * One streaming pass per direction, ordered partial sums (deterministic); no host read. */
+size_t scr_scaling_reg_scratch_bytes(int64_t P);
+int scr_scaling_reg_forward(int64_t P, const float* scaling, void* scratch, float* out, void* stream);
+int scr_scaling_reg_backward(int64_t P, const float* scaling, const float* g, float* dscaling, void* stream);
 
 /* ---- the head of generate_neural_gaussians (gaussian_renderer/__init__.py:23-31) for the reference's sizes (feat 32, 10 offsets):
  * the four visible-anchor gathers, exp(_scaling) and the [V,71] concatenation in one pass.  visible_index[V] int64 = the

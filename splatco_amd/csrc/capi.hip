@@ -587,6 +587,27 @@ int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, con
     return 0;
 }
 
+// ---- scaling regulariser of the per-view loss (ssim.hip)
+size_t scr_scaling_reg_scratch_bytes(int64_t P) { return scaling_reg_scratch_bytes(P); }
+
+int scr_scaling_reg_forward(int64_t P, const float* scaling, void* scratch, float* out, void* stream) {
+    if (P <= 0) return fail("P <= 0");
+    if (!scaling || !scratch || !out) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_L1_SSIM, st); launch_scaling_reg_forward(P, scaling, scratch, out, st); }
+    CHECK_LAUNCH("scaling_reg_partial_kernel", 0, st);
+    return 0;
+}
+
+int scr_scaling_reg_backward(int64_t P, const float* scaling, const float* g, float* dscaling, void* stream) {
+    if (P <= 0) return fail("P <= 0");
+    if (!scaling || !g || !dscaling) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_L1_SSIM_BACKWARD, st); launch_scaling_reg_backward(P, scaling, g, dscaling, st); }
+    CHECK_LAUNCH("scaling_reg_backward_kernel", 0, st);
+    return 0;
+}
+
 // ---- visible-anchor gather (anchor_gather.hip)
 int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anchor_feat, const float* anchor,
                       const float* offset, const float* scaling, float* feat_out, float* anchor_out, float* offsets_out,

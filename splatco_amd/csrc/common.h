@@ -396,6 +396,9 @@ void launch_tpa_backward_stats(int R, int64_t HW, const float* davg, const float
                                float* d1, float* d2, hipStream_t st);
 
 size_t l1_ssim_scratch_bytes(int C, int H, int W, int with_grad);
+size_t scaling_reg_scratch_bytes(int64_t P);
+void launch_scaling_reg_forward(int64_t P, const float* s, void* scratch, float* out, hipStream_t st);
+void launch_scaling_reg_backward(int64_t P, const float* s, const float* g, float* ds, hipStream_t st);
 void launch_l1_ssim_forward(int C, int H, int W, const float* img1, const float* img2, void* scratch,
                             int with_grad, float* out2, hipStream_t st);
 void launch_l1_ssim_backward(int C, int H, int W, const float* img1, const float* img2, const void* scratch,

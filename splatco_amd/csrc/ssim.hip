@@ -198,4 +198,58 @@ void launch_l1_ssim_backward(int C, int H, int W, const float* img1, const float
                                                   (float)(1.0 / ((double)C * H * W)), dimg1);
 }
 
+// ------------------------------------------------------------------ scaling regulariser of the per-view loss
+// mean_p(s[p,0] s[p,1] s[p,2]) (train.py:192-196: scaling.prod(dim=1).mean()) and its gradient.  torch's prod backward
+// counts the zeros of its input first -- a compare, an int64 reduction at 60 GB/s and a host read -- before a division
+// pass; here: one streaming pass per direction, partial sums per workgroup added in order by one more workgroup.
+constexpr int SREG_ROWS = 2048;      // rows per workgroup
+__global__ void __launch_bounds__(256)
+scaling_reg_partial_kernel(int64_t P, const float* __restrict__ s, double* __restrict__ partial) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const int64_t r0 = (int64_t)blockIdx.x * SREG_ROWS;
+    for (int64_t r = r0 + threadIdx.x; r < min(P, r0 + SREG_ROWS); r += 256)
+        acc += (double)((s[3 * r] * s[3 * r + 1]) * s[3 * r + 2]);      // the product in binary32, as torch.prod forms it
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, WAVE);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(1024)
+scaling_reg_finish_kernel(int nb, const double* __restrict__ partial, double inv_n, float* __restrict__ out) {
+    __shared__ double red[16];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 1024) acc += partial[b];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, WAVE);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        out[0] = (float)(t * inv_n);
+    }
+}
+__global__ void __launch_bounds__(256)
+scaling_reg_backward_kernel(int64_t P, const float* __restrict__ s, const float* __restrict__ g, float inv_n,
+                            float* __restrict__ ds) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= P) return;
+    const float a = s[3 * r], b = s[3 * r + 1], c = s[3 * r + 2], w = g[0] * inv_n;
+    ds[3 * r] = w * (b * c);
+    ds[3 * r + 1] = w * (a * c);
+    ds[3 * r + 2] = w * (a * b);
+}
+
+size_t scaling_reg_scratch_bytes(int64_t P) { return align_up((size_t)((P + SREG_ROWS - 1) / SREG_ROWS + 1) * 8); }
+void launch_scaling_reg_forward(int64_t P, const float* s, void* scratch, float* out, hipStream_t st) {
+    const int nb = (int)((P + SREG_ROWS - 1) / SREG_ROWS);
+    scaling_reg_partial_kernel<<<nb, 256, 0, st>>>(P, s, (double*)scratch);
+    scaling_reg_finish_kernel<<<1, 1024, 0, st>>>(nb, (const double*)scratch, 1.0 / (double)P, out);
+}
+void launch_scaling_reg_backward(int64_t P, const float* s, const float* g, float* ds, hipStream_t st) {
+    scaling_reg_backward_kernel<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(P, s, g, (float)(1.0 / (double)P), ds);
+}
+
 }  // namespace scr

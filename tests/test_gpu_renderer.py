@@ -806,3 +806,23 @@ def test_mask_indices_equal_nonzero(n):
         ref = mask.nonzero(as_tuple=False).squeeze(1)
         assert idx.dtype == torch.int64 and idx.shape == ref.shape
         assert torch.equal(idx, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 2049, 300_000])
+def test_scaling_regulariser_matches_torch_prod(P):
+    """csrc/ssim.hip scaling_reg_* against scaling.prod(dim=1).mean() (train.py:192-196), value and gradient, incl. rows
+    with zeros (where torch's backward takes its special path)."""
+    from splatco_amd.losses import scaling_reg
+    dev = torch.device("cuda:0")
+    torch.manual_seed(P)
+    s = (torch.rand(P, 3, device=dev) * 0.2)
+    if P > 10:
+        s[3, 1] = 0.0
+        s[7] = 0.0
+    a, b = s.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    la, lb = scaling_reg(a), b.prod(dim=1).mean()
+    assert torch.allclose(la, lb, rtol=1e-5, atol=1e-9)
+    (la * 3.0).backward()
+    (lb * 3.0).backward()
+    assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-12)

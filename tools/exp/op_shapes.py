@@ -3,6 +3,7 @@ import sys, types
 import torch
 from torch.profiler import ProfilerActivity, profile
 sys.path.insert(0, ".")
+from splatco_amd.losses import scaling_reg
 from splatco_amd.renderer import prefilter_voxel, render
 from splatco_amd.synthetic import ANCHOR_CONFIGS, synthetic_anchor_model, synthetic_views
 dev = torch.device("cuda:0")
@@ -17,7 +18,7 @@ def step():
         p.grad = None
     vis = prefilter_voxel(view, pc, pipe, bg)
     out = render(view, pc, pipe, bg, visible_mask=vis, retain_grad=True)
-    ((out["render"] - gt).abs().mean() + 0.01 * out["scaling"].prod(dim=1).mean()).backward()
+    ((out["render"] - gt).abs().mean() + 0.01 * scaling_reg(out["scaling"])).backward()
 for _ in range(3):
     step()
 torch.cuda.synchronize()

@@ -11,6 +11,7 @@ from torch.profiler import ProfilerActivity, profile
 sys.path.insert(0, ".")
 from splatco_amd.densify import AnchorDensifier
 from splatco_amd.multiview import GradArena
+from splatco_amd.losses import scaling_reg
 from splatco_amd.renderer import prefilter_voxel, render
 from splatco_amd.synthetic import ANCHOR_CONFIGS, synthetic_anchor_model, synthetic_views
 from splatco_amd.train_step import collaborative_step
@@ -35,7 +36,7 @@ def main(cfg="cfg2", anchors=0, steps=3, order="random"):
                 p.grad = None
             vis = prefilter_voxel(views[0], pc, pipe, bg)
             out = render(views[0], pc, pipe, bg, visible_mask=vis, retain_grad=True)
-            ((out["render"] - gts[0]).abs().mean() + 0.01 * out["scaling"].prod(dim=1).mean()).backward()
+            ((out["render"] - gts[0]).abs().mean() + 0.01 * scaling_reg(out["scaling"])).backward()
     else:
         groups = [{"params": [getattr(pc, "_" + n)], "lr": 1e-4, "name": n} for n in ("anchor", "offset", "anchor_feat", "scaling")]
         groups.append({"params": [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad], "lr": 1e-3, "name": "mlp_and_feat_planes"})
