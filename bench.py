@@ -402,7 +402,8 @@ def run_anchor_config(args, rank, world, dev):
 
     if train:
         groups = [{"params": [getattr(pc, "_" + n)], "lr": 1e-4, "name": n} for n in ("anchor", "offset", "anchor_feat", "scaling")]
-        rest = [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad]
+        idle = {id(p) for p in pc.feat_planes._feat.inactive_parameters()}     # plane levels above activate_level: grad None in the reference
+        rest = [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad and id(p) not in idle]
         groups.append({"params": rest, "lr": 1e-3, "name": "mlp_and_feat_planes"})
         opt = torch.optim.Adam(groups, eps=1e-15, fused=True)      # one pass over parameter / gradient / moments per tensor
         den = AnchorDensifier(pc, opt, seed=seed)

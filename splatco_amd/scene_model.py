@@ -334,6 +334,14 @@ class FeaturePlanes(nn.Module):               # scene/gaussian_model.py:97-169
             self.models.append(nn.Sequential(nn.BatchNorm1d(d), TallLinear(d, out_dim)))
             self.CTX_models.append(nn.Sequential(nn.BatchNorm1d(71), TallLinear(71, out_dim)))
 
+    def inactive_parameters(self):
+        """Parameters of the levels above activate_level: forward() does not touch them, so they never receive a gradient.
+        The reference leaves their .grad None and torch.optim skips them; a training loop that pre-allocates gradients
+        (multiview.GradArena) should leave them out of its parameter list -- at the default sizes the 2800^2 level is 470 MB
+        of zeros per step to clear, to all-reduce and to run Adam over."""
+        L = self.activate_level + 1
+        return [p for mods in (self.k0s[L:], self.models[L:], self.CTX_models[L:]) for m in mods for p in m.parameters()]
+
     def forward(self, x, g_fea, Q=0, parts=False):
         """parts=True: return the two 32-column halves (plane branch, attribute branch) instead of their
         concatenation, when they exist as separate matrices (the fused MLP heads read them as they are)."""

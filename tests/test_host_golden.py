@@ -181,3 +181,22 @@ def test_fused_norm_linear_matches_batchnorm_linear_chain(level):
             assert torch.allclose(p.grad, q.grad, rtol=1e-7, atol=1e-11), (n, (p.grad - q.grad).abs().max())
     for (n, p), (_, q) in zip(a.named_buffers(), b.named_buffers()):
         assert torch.allclose(p.double(), q.double(), rtol=1e-10, atol=1e-12), n
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_inactive_plane_levels_never_receive_a_gradient(level):
+    """FeaturePlanes.inactive_parameters(): exactly the parameters forward() leaves without a gradient at this
+    activate_level (the reference's optimizer skips them: .grad stays None; scene/gaussian_model.py:160-166)."""
+    from splatco_amd.scene_model import FeaturePlanes
+    torch.manual_seed(level)
+    fp = FeaturePlanes([16, 16, 16], torch.tensor([-1.0, -1, -1]), torch.tensor([1.0, 1, 1]), feat_dim=15)
+    fp.activate_level = level
+    x, g = torch.rand(64, 3) * 1.6 - 0.8, torch.randn(64, 71)
+    fp(x, g, 0).sum().backward()
+    idle = {id(p) for p in fp.inactive_parameters()}
+    for n, p in fp.named_parameters():
+        if id(p) in idle:
+            assert p.grad is None, n
+        else:
+            assert p.grad is not None, n
+    assert len(idle) > 0        # the finest plane level is idle at every activate_level the reference reaches

@@ -23,16 +23,11 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-from torch.utils._python_dispatch import TorchDispatchMode
-import traceback
-class Spy(TorchDispatchMode):
-    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
-        big_int = [a for a in args if isinstance(a, torch.Tensor) and a.is_cuda and a.numel() > 100000 and a.dtype in (torch.bool, torch.int64, torch.int32, torch.uint8)]
-        name = str(func)
-        if big_int and any(s in name for s in ("sum", "nonzero", "any", "all", "max", "min", "count", "cumsum", "unique", "sort")):
-            print("SPY", name, [(tuple(a.shape), a.dtype) for a in big_int], "".join(traceback.format_stack(limit=7)[:-1])[-700:])
-        return func(*args, **(kwargs or {}))
-with Spy():
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step()
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.self_device_time_total > 30 and not e.key.startswith(("void", "scr::", "_"))]
+rows.sort(key=lambda e: -e.self_device_time_total)
+for e in rows[:40]:
+    print(f"{e.key[:40]:40s} {e.self_device_time_total / 1e3:7.3f} ms x{e.count:3d}  {str(e.input_shapes)[:120]}")
 sys.exit(0)

@@ -39,7 +39,8 @@ def main(cfg="cfg2", anchors=0, steps=3, order="random"):
             ((out["render"] - gts[0]).abs().mean() + 0.01 * scaling_reg(out["scaling"])).backward()
     else:
         groups = [{"params": [getattr(pc, "_" + n)], "lr": 1e-4, "name": n} for n in ("anchor", "offset", "anchor_feat", "scaling")]
-        groups.append({"params": [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad], "lr": 1e-3, "name": "mlp_and_feat_planes"})
+        idle = {id(p) for p in pc.feat_planes._feat.inactive_parameters()}
+        groups.append({"params": [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad and id(p) not in idle], "lr": 1e-3, "name": "mlp_and_feat_planes"})
         opt = torch.optim.Adam(groups, eps=1e-15, fused=True)
         den = AnchorDensifier(pc, opt, seed=seed)
         arena = GradArena([p for grp in groups for p in grp["params"]])
