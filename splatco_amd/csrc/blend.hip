@@ -369,6 +369,30 @@ __device__ __forceinline__ float fold4(float a, float b, float c, float d) {
     return __uint_as_float(q[0]) + __uint_as_float(q[1]);               // rows: A, C, B, D
 }
 
+// fold4 for Y with the x-moments for free.  A lane's pixel column is x = 4 x2 + 2 x1 + x0 with (x2, x1, x0) = lane bits
+// (5, 4, 3).  The permlane32 swap that folds x2 away leaves the x2 = 1 halves in its second result, the permlane16 swap the
+// x1 = 1 rows: sums of Y over those half-spaces, which is all that sum Y x and sum Y x^2 need --
+//   sum Y x   = 4 H2 + 2 H1 + H0,   sum Y x^2 = 16 H2 + 4 H1 + H0 + 16 H21 + 8 H20 + 4 H10
+// (H_b = sum of Y over x_b = 1, H_bc over x_b = x_c = 1).  The x0 level is row_fold6's 8-lane step: it gets per-lane values
+// whose sum over x0 is the moment (x0f = this lane's x0 as a float selects the H.0 terms).  Four swaps and four adds for Y
+// instead of nine and nine for (Y, Y x, Y x^2), and no per-pixel multiplications by x.
+__device__ __forceinline__ void fold4_moments(float a, float b, float c, float d, float x0f, float& s0, float& s1,
+                                              float& s2) {
+    auto ab = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    auto cd = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(d), false, false);
+    const float sab = __uint_as_float(ab[0]) + __uint_as_float(ab[1]);   // x2 folded away
+    const float scd = __uint_as_float(cd[0]) + __uint_as_float(cd[1]);
+    auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(sab), __float_as_uint(scd), false, false);
+    auto q2 = __builtin_amdgcn_permlane16_swap(ab[1], cd[1], false, false);   // the x2 = 1 halves, folded over x1
+    const float H1 = __uint_as_float(q[1]), H21 = __uint_as_float(q2[1]);
+    const float M0 = __uint_as_float(q[0]) + H1;                          // rows: A, C, B, D
+    const float H2 = __uint_as_float(q2[0]) + H21;
+    s0 = M0;
+    s1 = __builtin_fmaf(x0f, M0, __builtin_fmaf(4.0f, H2, 2.0f * H1));
+    s2 = __builtin_fmaf(x0f, __builtin_fmaf(8.0f, H2, __builtin_fmaf(4.0f, H1, M0)),
+                        __builtin_fmaf(16.0f, H21, __builtin_fmaf(16.0f, H2, 4.0f * H1)));
+}
+
 // Per-pixel gradient terms of one splat (back-to-front recurrences).  Not decision bearing, so the
 // compiler may contract mul+add pairs here (fewer VALU issues); the tolerance is the gradient bar of
 // the parity tests (rel-L2 <= 1e-4 vs the oracle).
@@ -388,9 +412,8 @@ struct PixState {
     float T, dLp0, dLp1, dLp2;
     float behind, last_alpha, d_last;
 };
-__device__ __forceinline__ void splat_pixel_grad(PixState& s, float T, float4 b, float cb, float xl, float G, float alpha,
-                                                 float& g_0, float& g_x, float& g_xx, float& g_c0, float& g_c1,
-                                                 float& g_c2) {
+__device__ __forceinline__ void splat_pixel_grad(PixState& s, float T, float4 b, float cb, float G, float alpha,
+                                                 float& g_0, float& g_c0, float& g_c1, float& g_c2) {
 #pragma clang fp contract(fast)
     // T = transmittance in front of this splat (group_transmittance)
     const float w = alpha * T;
@@ -400,11 +423,9 @@ __device__ __forceinline__ void splat_pixel_grad(PixState& s, float T, float4 b,
     const float Y = G * (T * (d - s.behind));  // G = opacity * exp(power) here: the unclamped alpha times dL/dalpha (straight-through min(0.99, .))
     s.last_alpha = alpha;
     s.d_last = d;
-    // x-separable terms of the moments about the quadrant's origin (xl = this lane's pixel column, 0..7); the
-    // y-dependent ones are made from row sums inside the reduction (row_fold6)
+    // the moments of Y about the quadrant's origin are made INSIDE the reduction: the x-dependent ones from the halves
+    // the first two folding levels leave behind (fold4_moments), the y-dependent ones from row sums (row_fold6)
     g_0 = Y;
-    g_x = Y * xl;
-    g_xx = g_x * xl;
 }
 // Transmittance in front of each of the four splats of a group, walked back to front: T_u = T_(u-1) / (1 - alpha_u).
 // ONE division per group instead of one per splat: the front-most value is T / (om0 om1 om2 om3), correctly rounded
@@ -488,7 +509,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     const int px = qx0 + (lane >> 3), py = qy0 + (lane & 7);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const float xl = (float)(lane >> 3), yl = (float)(lane & 7), yl2 = yl * yl;
+    const float x0f = (float)((lane >> 3) & 1), yl = (float)(lane & 7), yl2 = yl * yl;
     const float qx0f = (float)qx0, qy0f = (float)qy0;
     const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
     const uint32_t last = inside ? n_contrib[pix] : 0u;
@@ -605,7 +626,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         // with alpha 0 -- about 1.5 of the ~22 entries a wave holds per round; the full groups stay branch-free.
         auto group = [&](const int k, auto tail) {
             constexpr bool TAIL = decltype(tail)::value;
-            float g[4][6];
+            float g[4][4];      // Y and the three colour terms of each splat
             uint32_t jj[4];
             unsigned long long any = 0ull;
             // all four records first (one LDS round trip per group instead of four)
@@ -649,16 +670,16 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             for (int u = 0; u < 4; ++u) {
                 if (TAIL && k - u < 0) {
 #pragma unroll
-                    for (int v = 0; v < 6; ++v) g[u][v] = 0.0f;
+                    for (int v = 0; v < 4; ++v) g[u][v] = 0.0f;
                     continue;
                 }
-                splat_pixel_grad(ps, Tu[u], rb[u], rc[u].x, xl, Gs[u], al[u], g[u][0], g[u][1], g[u][2], g[u][3], g[u][4],
-                                 g[u][5]);
+                splat_pixel_grad(ps, Tu[u], rb[u], rc[u].x, Gs[u], al[u], g[u][0], g[u][1], g[u][2], g[u][3]);
             }
             float r[6], myy;
             if (any) {
+                fold4_moments(g[0][0], g[1][0], g[2][0], g[3][0], x0f, r[0], r[1], r[2]);
 #pragma unroll
-                for (int v = 0; v < 6; ++v) r[v] = fold4(g[0][v], g[1][v], g[2][v], g[3][v]);
+                for (int v = 0; v < 3; ++v) r[3 + v] = fold4(g[0][1 + v], g[1][1 + v], g[2][1 + v], g[3][1 + v]);
                 row_fold6(r, yl, yl2, myy);
             } else {
                 r[0] = r[4] = myy = 0.0f;
