@@ -388,9 +388,9 @@ __device__ __forceinline__ void fold4_moments(float a, float b, float c, float d
     const float M0 = __uint_as_float(q[0]) + H1;                          // rows: A, C, B, D
     const float H2 = __uint_as_float(q2[0]) + H21;
     s0 = M0;
-    s1 = __builtin_fmaf(x0f, M0, __builtin_fmaf(4.0f, H2, 2.0f * H1));
-    s2 = __builtin_fmaf(x0f, __builtin_fmaf(8.0f, H2, __builtin_fmaf(4.0f, H1, M0)),
-                        __builtin_fmaf(16.0f, H21, __builtin_fmaf(16.0f, H2, 4.0f * H1)));
+    const float t = __builtin_fmaf(4.0f, H2, H1), u = t + H1;            // 4 H2 + H1, 4 H2 + 2 H1
+    s1 = __builtin_fmaf(x0f, M0, u);
+    s2 = __builtin_fmaf(x0f, __builtin_fmaf(2.0f, u, M0), __builtin_fmaf(16.0f, H21, 4.0f * t));
 }
 
 // Per-pixel gradient terms of one splat (back-to-front recurrences).  Not decision bearing, so the
