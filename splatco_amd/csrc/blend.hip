@@ -10,13 +10,13 @@
 // Forward: waves are independent -> one-wave workgroups, no barriers; the next chunk's masks,
 // ids and records are in flight while the current chunk is blended.
 // Backward: the four waves of a tile share one workgroup.  Per (tile, Gaussian) gradient moments are
-// reduced on chip -- a folding reduction inside the wave (permlane swaps, then bank-masked DPP adds that
-// pack two values per register), one LDS slot per (wave, splat), a fixed-order add over the waves that
-// took part -- and written ONCE as a 36-byte
-// record at the instance's Gaussian-major index (so the per-Gaussian reduction reads its records
-// contiguously).  No floating-point atomics:
-// results are bit-reproducible.  The per-Gaussian sum over tiles happens in
-// preprocess_backward_kernel.
+// reduced on chip -- a folding reduction inside the wave (permlane swaps whose left-over halves give the
+// x-moments, then bank-masked DPP adds that pack two values per register and make the y-moments from row
+// sums), one LDS slot per (wave, splat), a fixed-order add over the waves that took part -- and written
+// ONCE as a 36-byte record at the instance's Gaussian-major index (so the per-Gaussian reduction reads its
+// records contiguously).  Rounds behind every pixel's last contributor get no records: the tile leaves the
+// sort key of its first entry without one (cut_key).  No floating-point atomics: results are
+// bit-reproducible.  The per-Gaussian sum over tiles happens in preprocess_backward_kernel.
 //
 // Blend arithmetic is normative where a decision hangs on it: power is evaluated as
 // fma(dx, fma(A,dx,B*dy), (C*dy)*dy) with A=-Qxx/2, B=-Qxy, C=-Qyy/2; exp() may differ from the
