@@ -200,3 +200,18 @@ def test_inactive_plane_levels_never_receive_a_gradient(level):
         else:
             assert p.grad is not None, n
     assert len(idle) > 0        # the finest plane level is idle at every activate_level the reference reaches
+
+
+def test_host_fallbacks_of_the_small_ops():
+    """On host tensors the wrappers of the small HIP ops take the torch expressions they replace (the reference's own
+    lines: train.py:192-196 `scaling.prod(dim=1).mean()`, gaussian_renderer/__init__.py:23-29 `t[visible_mask]`)."""
+    from splatco_amd.expand import visible_indices
+    from splatco_amd.losses import scaling_reg
+    torch.manual_seed(0)
+    s = torch.rand(100, 3, requires_grad=True)
+    r = scaling_reg(s)
+    assert torch.equal(r, s.prod(dim=1).mean())
+    r.backward()
+    assert s.grad is not None and s.grad.shape == s.shape
+    m = torch.rand(1000) < 0.3
+    assert torch.equal(visible_indices(m), m.nonzero(as_tuple=False).squeeze(1))
