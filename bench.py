@@ -296,7 +296,8 @@ def run_cfg1(args, rank, world, dev):
         img, radii = rast(means2D=means2D, **params)
         img.backward(dL)
         if world > 1:
-            allreduce_gradients(leaves)                       # SUM, one flat bucket (train.py:198,240)
+            allreduce_gradients(leaves, agree="once")         # SUM, in place on the operator's gradient arena (train.py:198,240);
+                                                              # the ranks agree on the path once, not with a host read per step
         state["radii"], state["img"] = radii, img
         return radii
 
@@ -335,8 +336,8 @@ def run_cfg1(args, rank, world, dev):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         # bookkeeping (outside the timed region): the gradient all-reduce on its own, SURVEY.md 8(e)
-        bucket = allreduce_gradients(leaves)
-        ms = time_allreduce(lambda: allreduce_gradients(leaves), dev)
+        bucket = allreduce_gradients(leaves, agree="once")
+        ms = time_allreduce(lambda: allreduce_gradients(leaves, agree="once"), dev)
         allreduce_info = allreduce_report(bucket.numel() * bucket.element_size(), ms, world,
                                           what=f"{P}x14 fp32 per-Gaussian gradients, one in-place all-reduce of the operator's arena")
     if rank != 0:

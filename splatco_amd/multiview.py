@@ -62,11 +62,18 @@ def _agree(flag: bool, signature: int, device) -> bool:
     return bool(t[0].item()) and int(t[1].item()) == -int(t[2].item())
 
 
-def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = None) -> torch.Tensor:
+_AGREED = {}      # parameter identities -> (local flag, local signature, agreed decision) of the first call (agree="once")
+
+
+def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = None, agree: str = "always") -> torch.Tensor:
     """SUM-all-reduce the .grad of every tensor in `params` through one flat bucket, in place.
     Parameters without a gradient on this rank contribute zeros (a rank whose views do not see
     an anchor still takes part).  Returns the bucket (reusable).  Every rank must pass the same
-    parameters in the same order.  (The training step uses GradArena instead: no packing at all.)"""
+    parameters in the same order.  (The training step uses GradArena instead: no packing at all.)
+    agree: "always" -- the ranks agree on the in-place / packed path with a small MIN all-reduce and a host read on every
+    call; "once" -- on the first call for these parameters only (a loop whose ranks run the same program: the host read
+    would otherwise stand between every backward pass and its gradient exchange); a rank whose own situation changes
+    afterwards raises instead of exchanging misaligned data."""
     params = [p for p in params if p is not None and p.requires_grad]
     if not params:
         return bucket
@@ -80,7 +87,18 @@ def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = N
         order = sorted(range(len(params)), key=lambda i: params[i].grad.storage_offset())
         for i in order:
             sig = (sig * 1000003 + i + 1) % (1 << 61)
-    if _agree(arena is not None, sig, dev):
+    if agree == "once":
+        key = tuple(id(p) for p in params)
+        seen = _AGREED.get(key)
+        if seen is None:
+            seen = _AGREED[key] = (arena is not None, sig, _agree(arena is not None, sig, dev))
+        elif seen[:2] != (arena is not None, sig):
+            raise RuntimeError("allreduce_gradients(agree='once'): this rank's gradient layout changed after the ranks agreed "
+                               "on the exchange path; call with agree='always'")
+        in_place = seen[2]
+    else:
+        in_place = _agree(arena is not None, sig, dev)
+    if in_place:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(arena, op=dist.ReduceOp.SUM)
         return arena
