@@ -59,7 +59,8 @@ def _agree(flag: bool, signature: int, device) -> bool:
         return flag
     t = torch.tensor([1 if flag else 0, signature, -signature], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return bool(t[0].item()) and int(t[1].item()) == -int(t[2].item())
+    f, a, b = t.tolist()      # one host read
+    return bool(f) and int(a) == -int(b)
 
 
 _AGREED = {}      # parameter identities -> (local flag, local signature, agreed decision) of the first call (agree="once")
