@@ -341,7 +341,9 @@ int scr_copy_probe(const void* src, void* dst, size_t bytes, void* stream);
  * event pair costs a few microseconds of stream time, so a benchmark times only the class it
  * reports).  scr_profile_read() waits for the recorded events, ADDS the elapsed time and
  * launch count of each kernel class since the last read into total_ms[SCR_PROF_COUNT] /
- * launches[SCR_PROF_COUNT], and resets. */
+ * launches[SCR_PROF_COUNT], and resets.
+ * NOT thread-safe: the event pool is process-global and unlocked.  Enable / read it from the one host thread that
+ * makes the library's calls (the product never enables it; bench.py and tools/ do). */
 enum {
     SCR_PROF_FILTER = 0, SCR_PROF_PREPROCESS = 1, SCR_PROF_PLAN_SCAN = 2, SCR_PROF_SCATTER = 3,
     SCR_PROF_TILE_SORT = 4, SCR_PROF_BLEND_FORWARD = 5, SCR_PROF_BLEND_BACKWARD = 6,

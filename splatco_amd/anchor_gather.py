@@ -7,6 +7,11 @@ from . import _C
 from .rasterizer import _stream
 
 
+import os
+
+_DEBUG = bool(int(os.environ.get("SPLATCO_DEBUG", "0")))      # debug checks that cost a device pass + a host read
+
+
 def supported(pc):
     try:
         return bool(pc._anchor_feat.is_cuda and pc._anchor_feat.shape[1] == 32 and pc._offset.shape[1:] == (10, 3)
@@ -15,17 +20,35 @@ def supported(pc):
         return False
 
 
+def fused_gather_taken(pc, fused_heads=True):
+    """THE predicate for "render() sends this model's per-anchor parameters through the fused gather": the renderer
+    (generate_neural_gaussians) and whoever attaches a gradient sink (multiview.GradArena.sink) must decide alike -- a
+    sink attached to a model that then takes the index_select path would have autograd ADD into gradient memory the
+    arena did not clear.  The fused kernel reproduces get_scaling = exp(_scaling) (scene/gaussian_model.py:397-399)
+    only, so a subclass that overrides the property is not eligible."""
+    if not (fused_heads and supported(pc)):
+        return False
+    from .scene_model import AnchorGaussianModel
+    return type(pc).get_scaling is AnchorGaussianModel.get_scaling
+
+
 class GradSink:
     """Where the backward of the gather writes the gradients of (_anchor_feat, _anchor, _offset, _scaling) directly: the
     parameters' own .grad memory (views of multiview.GradArena's buffer).  Every gradient of those four parameters comes
     through this one op, and its kernel overwrites EVERY element (zeros for invisible anchors), so the first view of a
     step needs neither a zero-filled buffer nor autograd's `grad += new` pass over 71 floats per anchor (5.7 GB read
     twice and written once at 20 M anchors); further views of the same step add in the kernel.  `fresh` is set by the
-    owner at the start of a step and cleared by the first write."""
+    owner at the start of a step and cleared by the first write.
+    `pending` counts the forward passes of the step whose backward has not run yet; the backward that brings it to zero
+    is the one after which the four gradients are FINAL.  If `ranges` ([(n0, n1)] anchor ranges, 64-aligned starts) and
+    `on_range` are set, that last backward runs one launch per range and calls on_range(r) behind each, so the owner can
+    put range r's exchange on the wire while range r + 1 is computed (multiview.GradArena)."""
 
     def __init__(self, feat, anchor, offset, scaling):
         self.tensors = (feat, anchor, offset, scaling)
         self.fresh = True
+        self.pending = 0
+        self.ranges, self.on_range = None, None
 
 
 class _AnchorGather(torch.autograd.Function):
@@ -45,6 +68,8 @@ class _AnchorGather(torch.autograd.Function):
                                                   off.data_ptr(), gs.data_ptr(), g_fea.data_ptr(), 72, _stream()))
         ctx.save_for_backward(idx, gs)
         ctx.N, ctx.sink = N, sink
+        if sink is not None:
+            sink.pending += 1
         return feat, anc, off, gs, g_fea
 
     @staticmethod
@@ -62,19 +87,29 @@ class _AnchorGather(torch.autograd.Function):
         d_feat, d_anc, d_off, d_gs = p(d_feat), p(d_anc), p(d_off), p(d_gs)
         ptr = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
         sink = ctx.sink
+        ranges = [(0, N)]
         if sink is not None:
             g_feat, g_anchor, g_offset, g_scaling = sink.tensors
             accumulate = 0 if sink.fresh else 1
             sink.fresh = False
+            sink.pending -= 1
+            if sink.pending == 0 and sink.ranges and sink.on_range is not None:
+                ranges = sink.ranges                # the gradients are final after this pass: hand them over range by range
         else:
             new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
             g_feat, g_anchor, g_offset, g_scaling = new(N, 32), new(N, 3), new(N, 10, 3), new(N, 6)
             accumulate = 0
-        if N:
-            with torch.cuda.device(dev):
-                _C.check(_C.lib.scr_anchor_gather_backward(N, V, inv.data_ptr(), ptr(gs), ptr(d_feat), ptr(d_anc), ptr(d_off),
-                                                           ptr(d_gs), ptr(d_g_fea), ldg, g_feat.data_ptr(), g_anchor.data_ptr(),
-                                                           g_offset.data_ptr(), g_scaling.data_ptr(), accumulate, _stream()))
+        with torch.cuda.device(dev):
+            for r, (n0, n1) in enumerate(ranges):
+                # a range is the same kernel on offset pointers: a workgroup owns 64 consecutive anchors, their visible
+                # ones own consecutive upstream rows wherever the range starts (n0 is a multiple of 64)
+                if n1 > n0:
+                    _C.check(_C.lib.scr_anchor_gather_backward(
+                        n1 - n0, V, inv.data_ptr() + 8 * n0, ptr(gs), ptr(d_feat), ptr(d_anc), ptr(d_off), ptr(d_gs),
+                        ptr(d_g_fea), ldg, g_feat.data_ptr() + 4 * 32 * n0, g_anchor.data_ptr() + 4 * 3 * n0,
+                        g_offset.data_ptr() + 4 * 30 * n0, g_scaling.data_ptr() + 4 * 6 * n0, accumulate, _stream(dev)))
+                if sink is not None and ranges is sink.ranges:
+                    sink.on_range(r)
         if sink is not None:
             return None, None, None, None, None, None        # written where the optimiser reads them
         return None, None, g_feat, g_anchor, g_offset, g_scaling
@@ -82,8 +117,12 @@ class _AnchorGather(torch.autograd.Function):
 
 def gather_anchors(pc, idx):
     """(feat [V,32], anchor [V,3], grid_offsets [V,10,3], grid_scaling [V,6] = exp(_scaling), g_fea [V,71]) of the
-    visible anchors idx [V] (int64, ascending).  With pc._grad_sink set (train_step.collaborative_step with a GradArena)
+    visible anchors idx [V] (int64, STRICTLY ASCENDING and duplicate-free: what visible_indices returns; any other list
+    gives wrong gradients -- SPLATCO_DEBUG=1 checks it, at the price of a host read).  With pc._grad_sink set (train_step.collaborative_step with a GradArena)
     the gradients of the four parameters go straight into their .grad memory."""
+    if _DEBUG and idx.numel() > 1 and not bool((idx[1:] > idx[:-1]).all()):
+        raise RuntimeError("gather_anchors: the index list must be strictly ascending (visible_indices of a mask); the "
+                           "backward kernel hands the visible anchors of 64 consecutive anchors consecutive upstream rows")
     sink = getattr(pc, "_grad_sink", None)
     if sink is not None and not torch.is_grad_enabled():
         sink = None                                 # no backward will come

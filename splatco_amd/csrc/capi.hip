@@ -1,6 +1,8 @@
 // splatco_amd/csrc/capi.hip -- the C-ABI of include/splatco_raster.h over the gfx950 kernels.
-// No global state: every buffer is caller-owned (several forward graphs are alive
-// at once in the mv loop of train.py:171-240).
+// Every data buffer is caller-owned (several forward graphs are alive at once in the mv loop of
+// train.py:171-240).  Process-lifetime state of the library, all of it below: a thread-local error string, one pinned
+// 64-byte mailbox per calling host thread + a process-wide stamp counter for the plan read-backs, a per-device flag for
+// the dynamic-LDS attribute, and the opt-in profiling event pool (g_prof_*; single-threaded, see the header).
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>

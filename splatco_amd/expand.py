@@ -23,17 +23,19 @@ class _ExpandCompact(torch.autograd.Function):
         n = V * k
         scratch = torch.empty(max(_C.lib.scr_expand_scratch_bytes(n), 1), dtype=torch.uint8, device=dev)
         cnt = C.c_int64(0)
-        _C.check(_C.lib.scr_expand_plan(n, _ptr(neural_opacity), scratch.data_ptr(), C.byref(cnt), _stream()))
+        with torch.cuda.device(dev):           # kernels launch on the CURRENT device: make it the tensors' device
+            _C.check(_C.lib.scr_expand_plan(n, _ptr(neural_opacity), scratch.data_ptr(), C.byref(cnt), _stream(dev)))
         P = int(cnt.value)
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         xyz, col, opa, sca, rot = new(P, 3), new(P, 3), new(P, 1), new(P, 3), new(P, 4)
         out_index = torch.empty(n, dtype=torch.int32, device=dev)
         mask = torch.empty(n, dtype=torch.bool, device=dev)
         if n:
-            _C.check(_C.lib.scr_expand_run(V, k, _ptr(neural_opacity), _ptr(color), _ptr(scale_rot), _ptr(offsets),
-                                           _ptr(grid_scaling), _ptr(anchor), scratch.data_ptr(), out_index.data_ptr(),
-                                           mask.data_ptr(), _ptr(xyz), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot),
-                                           _stream()))
+            with torch.cuda.device(dev):
+                _C.check(_C.lib.scr_expand_run(V, k, _ptr(neural_opacity), _ptr(color), _ptr(scale_rot), _ptr(offsets),
+                                               _ptr(grid_scaling), _ptr(anchor), scratch.data_ptr(), out_index.data_ptr(),
+                                               mask.data_ptr(), _ptr(xyz), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot),
+                                               _stream(dev)))
         ctx.save_for_backward(scale_rot, offsets, grid_scaling, out_index)
         ctx.dims = (V, k)
         ctx.mark_non_differentiable(mask, out_index)
@@ -50,11 +52,12 @@ class _ExpandCompact(torch.autograd.Function):
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         d_no, d_col, d_sr, d_off, d_gs, d_an = new(n, 1), new(n, 3), new(n, 7), new(V, k, 3), new(V, 6), new(V, 3)
         if n:
-            _C.check(_C.lib.scr_expand_backward(V, k, _ptr(scale_rot), _ptr(offsets), _ptr(grid_scaling),
-                                                out_index.data_ptr(), _ptr(g_xyz), _ptr(g_col), _ptr(g_opa),
-                                                _ptr(g_sca), _ptr(g_rot), d_no.data_ptr(), d_col.data_ptr(),
-                                                d_sr.data_ptr(), d_off.data_ptr(), d_gs.data_ptr(), d_an.data_ptr(),
-                                                _stream()))
+            with torch.cuda.device(dev):
+                _C.check(_C.lib.scr_expand_backward(V, k, _ptr(scale_rot), _ptr(offsets), _ptr(grid_scaling),
+                                                    out_index.data_ptr(), _ptr(g_xyz), _ptr(g_col), _ptr(g_opa),
+                                                    _ptr(g_sca), _ptr(g_rot), d_no.data_ptr(), d_col.data_ptr(),
+                                                    d_sr.data_ptr(), d_off.data_ptr(), d_gs.data_ptr(), d_an.data_ptr(),
+                                                    _stream(dev)))
         return d_no, d_col, d_sr, d_off, d_gs, d_an, None
 
 
@@ -86,8 +89,9 @@ def mask_indices(mask):
     n = m.shape[0]
     scratch = torch.empty(_C.lib.scr_expand_scratch_bytes(n), dtype=torch.uint8, device=m.device)
     cnt = C.c_int64(0)
-    _C.check(_C.lib.scr_mask_index_plan(n, m.data_ptr(), scratch.data_ptr(), C.byref(cnt), _stream()))
-    idx = torch.empty(cnt.value, dtype=torch.int64, device=m.device)
-    if cnt.value:
-        _C.check(_C.lib.scr_mask_index_run(n, m.data_ptr(), scratch.data_ptr(), idx.data_ptr(), _stream()))
+    with torch.cuda.device(m.device):          # the plan call reads its count back on the host: one synchronisation
+        _C.check(_C.lib.scr_mask_index_plan(n, m.data_ptr(), scratch.data_ptr(), C.byref(cnt), _stream(m.device)))
+        idx = torch.empty(cnt.value, dtype=torch.int64, device=m.device)
+        if cnt.value:
+            _C.check(_C.lib.scr_mask_index_run(n, m.data_ptr(), scratch.data_ptr(), idx.data_ptr(), _stream(m.device)))
     return idx

@@ -57,8 +57,9 @@ class _L1Ssim(torch.autograd.Function):
         C, H, W = x.shape
         scratch = torch.empty(_C.lib.scr_l1_ssim_scratch_bytes(C, H, W, int(need)), dtype=torch.uint8, device=x.device)
         out = torch.empty(2, dtype=torch.float32, device=x.device)
-        _C.check(_C.lib.scr_l1_ssim_forward(C, H, W, x.data_ptr(), y.data_ptr(), scratch.data_ptr(), int(need),
-                                            out.data_ptr(), _stream()))
+        with torch.cuda.device(x.device):      # kernels launch on the CURRENT device: make it the tensors' device
+            _C.check(_C.lib.scr_l1_ssim_forward(C, H, W, x.data_ptr(), y.data_ptr(), scratch.data_ptr(), int(need),
+                                                out.data_ptr(), _stream(x.device)))
         ctx.save_for_backward(x, y, scratch)
         ctx.have_maps = need
         return out[0], out[1]
@@ -74,8 +75,9 @@ class _L1Ssim(torch.autograd.Function):
         g_l1 = g_l1.contiguous().float().reshape(1)
         g_ssim = g_ssim.contiguous().float().reshape(1)
         dx = torch.empty_like(x)
-        _C.check(_C.lib.scr_l1_ssim_backward(C, H, W, x.data_ptr(), y.data_ptr(), scratch.data_ptr(),
-                                             g_l1.data_ptr(), g_ssim.data_ptr(), dx.data_ptr(), _stream()))
+        with torch.cuda.device(x.device):
+            _C.check(_C.lib.scr_l1_ssim_backward(C, H, W, x.data_ptr(), y.data_ptr(), scratch.data_ptr(),
+                                                 g_l1.data_ptr(), g_ssim.data_ptr(), dx.data_ptr(), _stream(x.device)))
         return dx, None
 
 
@@ -98,7 +100,8 @@ class _ScalingReg(torch.autograd.Function):
         P = s.shape[0]
         scratch = torch.empty(_C.lib.scr_scaling_reg_scratch_bytes(P), dtype=torch.uint8, device=s.device)
         out = torch.empty(1, dtype=torch.float32, device=s.device)
-        _C.check(_C.lib.scr_scaling_reg_forward(P, s.data_ptr(), scratch.data_ptr(), out.data_ptr(), _stream()))
+        with torch.cuda.device(s.device):
+            _C.check(_C.lib.scr_scaling_reg_forward(P, s.data_ptr(), scratch.data_ptr(), out.data_ptr(), _stream(s.device)))
         ctx.save_for_backward(s)
         return out.reshape(())
 
@@ -109,7 +112,8 @@ class _ScalingReg(torch.autograd.Function):
         (s,) = ctx.saved_tensors
         g = g.contiguous().float().reshape(1)
         d = torch.empty_like(s)
-        _C.check(_C.lib.scr_scaling_reg_backward(s.shape[0], s.data_ptr(), g.data_ptr(), d.data_ptr(), _stream()))
+        with torch.cuda.device(s.device):
+            _C.check(_C.lib.scr_scaling_reg_backward(s.shape[0], s.data_ptr(), g.data_ptr(), d.data_ptr(), _stream(s.device)))
         return d
 
 

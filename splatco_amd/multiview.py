@@ -63,7 +63,19 @@ def _agree(flag: bool, signature: int, device) -> bool:
     return bool(f) and int(a) == -int(b)
 
 
-_AGREED = {}      # parameter identities -> (local flag, local signature, agreed decision) of the first call (agree="once")
+class _Agreement:
+    """What agree="once" remembers: the tensors it was made for (weakly -- densification and sort_anchors replace
+    parameters and CPython reuses ids, so an id()-keyed table would hand a new parameter set a stale decision), this
+    rank's (flag, signature) at the time, and the decision the ranks reached."""
+    __slots__ = ("refs", "local", "decision", "__weakref__")
+
+    def __init__(self, params, local, decision):
+        import weakref
+        self.refs = tuple(weakref.ref(p) for p in params)
+        self.local, self.decision = local, decision
+
+    def covers(self, params):
+        return len(self.refs) == len(params) and all(r() is p for r, p in zip(self.refs, params))
 
 
 def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = None, agree: str = "always") -> torch.Tensor:
@@ -89,14 +101,18 @@ def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = N
         for i in order:
             sig = (sig * 1000003 + i + 1) % (1 << 61)
     if agree == "once":
-        key = tuple(id(p) for p in params)
-        seen = _AGREED.get(key)
-        if seen is None:
-            seen = _AGREED[key] = (arena is not None, sig, _agree(arena is not None, sig, dev))
-        elif seen[:2] != (arena is not None, sig):
+        # the agreement lives ON the first parameter (an attribute of the tensor object): it dies with the tensors it was
+        # made for, nothing grows when a caller passes fresh leaves every step
+        seen = getattr(params[0], "_scr_agreement", None)
+        if seen is None or not seen.covers(params):
+            seen = _Agreement(params, (arena is not None, sig), _agree(arena is not None, sig, dev))
+            params[0]._scr_agreement = seen
+        elif seen.local != (arena is not None, sig):
+            # rank-local: the peers are already inside their all_reduce and will block there until this process dies
+            # (the launcher tears the job down); a caller whose ranks may diverge must use agree="always"
             raise RuntimeError("allreduce_gradients(agree='once'): this rank's gradient layout changed after the ranks agreed "
                                "on the exchange path; call with agree='always'")
-        in_place = seen[2]
+        in_place = seen.decision
     else:
         in_place = _agree(arena is not None, sig, dev)
     if in_place:
@@ -138,18 +154,24 @@ class GradArena:
     .grad), the collective runs on slices of the same memory, and the optimiser reads the reduced values where
     they are.  Per step: zero() -> backward -> reduce() -> optimizer.step().
 
-    The exchange is issued in pieces (one per parameter, large parameters split into `chunk_bytes` pieces, every
-    piece an independent collective that RCCL can spread over the xGMI links), either
-      * from post-accumulate hooks, as soon as autograd has finished a parameter's gradient -- the tail of the
-        backward pass (MLP weights and planes finish before the per-anchor tensors) overlaps the transfers; or
-      * all at once by reduce() when hooks are off.
+    The exchange is issued in UNITS: one per parameter (split into `chunk_bytes` pieces, every piece an independent
+    collective that RCCL can spread over the xGMI links); the four per-anchor parameters written through the gradient
+    sink (see sink()) form `anchor_ranges` units instead, one per range of anchors, each holding that range's slice of
+    all four.  A unit becomes READY when its gradient is final on this rank -- a parameter's post-accumulate hook, or
+    the sink's per-range callback from the last anchor-gather backward of the step -- and reduce() declares the rest
+    ready.  Collectives are matched across ranks by ISSUE ORDER, so the order must not depend on what happened on a
+    rank: units are issued strictly in one agreed order, as far as the contiguous ready prefix reaches.  The first
+    exchange runs in index order from reduce(); the ranks then agree on the order for all later steps (hook order as
+    observed, MIN over ranks of the positions, so every rank derives the same permutation from the same reduced
+    vector; sink ranges next; parameters nobody saw a gradient for last).  A rank without local views -- no hook fires,
+    everything goes out from reduce() -- therefore issues exactly the sequence the others do.
     mode "all_reduce": dist.all_reduce(SUM) per piece.  mode "rs_ag": reduce_scatter_tensor + all_gather_into_tensor
     on a piece padded to a multiple of the world size (on the point-to-point xGMI mesh every rank then owns 1/world
     of the sum and all 7 links carry traffic in both phases).
     Every rank must build the arena from the same parameters in the same order (the layout is that order)."""
 
     def __init__(self, params: Sequence[torch.Tensor], chunk_bytes: int = 256 << 20, mode: str = "all_reduce",
-                 overlap: bool = True):
+                 overlap: bool = True, anchor_ranges: int = 8):
         self.params = [p for p in params if p is not None and p.requires_grad]
         assert self.params, "no trainable parameters"
         assert mode in ("all_reduce", "rs_ag")
@@ -160,24 +182,68 @@ class GradArena:
         self.mode, self.overlap = mode, overlap
         rank, world = world_info()
         self.world = world
-        align = 64 * max(world, 1)                       # elements: every parameter starts on a 256-byte, world-divisible boundary
+        self.align = align = 64 * max(world, 1)          # elements: every parameter starts on a 256-byte, world-divisible boundary
         self.offsets, total = [], 0
         for p in self.params:
             self.offsets.append(total)
             total += (p.numel() + align - 1) // align * align
         self.flat = torch.zeros(total, dtype=dt, device=dev)
         self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
-        chunk = max(align, chunk_bytes // self.itemsize // align * align)
-        self.pieces = []                                  # per parameter: [(start, stop) of padded pieces]
-        for o, p in zip(self.offsets, self.params):
-            end = o + (p.numel() + align - 1) // align * align
-            self.pieces.append([(a, min(a + chunk, end)) for a in range(o, end, chunk)])
+        self.chunk = max(align, chunk_bytes // self.itemsize // align * align)
+        self.anchor_ranges = max(1, int(anchor_ranges))
+        self._sink, self._sink_ids = None, ()
         self._work, self._handles, self._pending = [], [], []
-        self._fired = [False] * len(self.params)
+        self._layout()
         self.bind()
         if overlap and world > 1:
             for i, p in enumerate(self.params):
                 self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    # ---- units ---------------------------------------------------------------------------------------------------
+    def _split(self, a, end):
+        return [(x, min(x + self.chunk, end)) for x in range(a, end, self.chunk)]
+
+    def _layout(self):
+        """Units of the exchange for the current sink: ("p", i) per parameter outside the sink, ("s", r) per anchor
+        range of the sink.  Every quantity here depends on shapes only, so all ranks build the same table."""
+        align = self.align
+        padded = lambda p: (p.numel() + align - 1) // align * align
+        self.units, self.unit_pieces, self.sink_ranges = [], [], []
+        for i, (o, p) in enumerate(zip(self.offsets, self.params)):
+            if i not in self._sink_ids:
+                self.units.append(("p", i))
+                self.unit_pieces.append(self._split(o, o + padded(p)))
+        if self._sink_ids:
+            N = self.params[self._sink_ids[0]].shape[0]
+            step = -(-N // self.anchor_ranges)
+            step = max(align, (step + align - 1) // align * align)   # anchors per range: slices stay world-divisible
+            n0 = 0
+            while n0 < N:
+                self.sink_ranges.append((n0, min(N, n0 + step)))
+                n0 += step
+            for r, (n0, n1) in enumerate(self.sink_ranges):
+                pieces = []
+                for i in self._sink_ids:
+                    p, o = self.params[i], self.offsets[i]
+                    w = p.numel() // max(N, 1)
+                    end = o + padded(p) if n1 == N else o + n1 * w     # the last range takes the parameter's padding
+                    pieces += self._split(o + n0 * w, end)
+                self.units.append(("s", r))
+                self.unit_pieces.append(pieces)
+        self._unit_of_param = {u[1]: k for k, u in enumerate(self.units) if u[0] == "p"}
+        self._unit_of_range = {u[1]: k for k, u in enumerate(self.units) if u[0] == "s"}
+        self._order = None                                   # agreed issue order (unit numbers); None until agreed
+        self._begin_step()
+
+    def _begin_step(self):
+        self._ready = [False] * len(self.units)
+        self._issued = [False] * len(self.units)
+        self._cursor, self._fire_log = 0, []
+
+    @property
+    def pieces(self):
+        """Per unit: [(start, stop)] of its collectives in the flat buffer."""
+        return self.unit_pieces
 
     def bind(self):
         for p, v in zip(self.params, self.views):
@@ -186,43 +252,56 @@ class GradArena:
     def sink(self, pc):
         """Lets the fused anchor gather write the gradients of pc's four per-anchor parameters straight into their
         arena views (anchor_gather.GradSink): zero() then skips those 71 floats per anchor and autograd's accumulation
-        pass over them disappears.  Returns the sink (also kept as self._sink), or None when the gather is not the fused
-        one or a parameter is missing from the arena."""
+        pass over them disappears; the LAST gather backward of a step runs range by range and reports every finished
+        range, so that range's exchange is on the wire while the next is computed.  Returns the sink (also kept as
+        self._sink), or None when the renderer would not take the fused gather for this model or a parameter is
+        missing from the arena.  Every rank must call this alike (it changes the unit table)."""
         from . import anchor_gather as _ag
-        self._sink, self._sink_ids = None, ()
         ps = [getattr(pc, n, None) for n in ("_anchor_feat", "_anchor", "_offset", "_scaling")]
+        return self.attach_sink(ps if _ag.fused_gather_taken(pc) else None)
+
+    def attach_sink(self, per_anchor_params):
+        """sink() for an explicit list of per-anchor parameters [N, ...] (all with the same N), or None to detach."""
+        from .anchor_gather import GradSink
+        self._sink, self._sink_ids = None, ()
         ids = {id(p): i for i, p in enumerate(self.params)}
-        if not _ag.supported(pc) or any(p is None or id(p) not in ids for p in ps):
-            return None
-        self._sink = _ag.GradSink(*[self.views[ids[id(p)]] for p in ps])
-        self._sink_ids = tuple(ids[id(p)] for p in ps)
+        ps = per_anchor_params
+        if ps is not None and all(p is not None and id(p) in ids for p in ps):
+            self._sink_ids = tuple(ids[id(p)] for p in ps)
+            self._sink = GradSink(*[self.views[i] for i in self._sink_ids])
+        self._layout()
+        if self._sink is not None:
+            self._sink.ranges = list(self.sink_ranges) if (self.overlap and self.world > 1) else None
+            self._sink.on_range = self._range_done
         return self._sink
 
     def zero(self):
         """Start of a step: clear the arena and make sure every .grad still aliases it.  Parameters written through
         the sink are overwritten by the first view's backward: they are not cleared here."""
-        sink = getattr(self, "_sink", None)
+        sink = self._sink
         if sink is None:
             self.flat.zero_()
         else:
             for i, v in enumerate(self.views):
                 if i not in self._sink_ids:
                     v.zero_()
-            sink.fresh = True
-        self._fired = [False] * len(self.params)
+            sink.fresh, sink.pending = True, 0
+        self._begin_step()
         self.bind()
 
     def _settle_sink(self):
         # no view of this step wrote through the sink (a rank without views): its parameters still hold the previous
         # step's gradients
-        sink = getattr(self, "_sink", None)
+        sink = self._sink
         if sink is not None and sink.fresh:
             for i in self._sink_ids:
                 self.views[i].zero_()
             sink.fresh = False
 
-    def _issue(self, i):
-        for a, b in self.pieces[i]:
+    # ---- issue ---------------------------------------------------------------------------------------------------
+    def _issue(self, k):
+        self._issued[k] = True
+        for a, b in self.unit_pieces[k]:
             piece = self.flat[a:b]
             if self.mode == "all_reduce":
                 self._work.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
@@ -232,29 +311,72 @@ class GradArena:
                 self._work.append(dist.reduce_scatter_tensor(mine, piece, op=dist.ReduceOp.SUM, async_op=True))
                 self._pending.append((piece, mine))
 
+    def _flush(self):
+        """Issue the contiguous ready prefix of the agreed order (nothing before the order is agreed)."""
+        if self._order is None or self.world == 1:
+            return
+        while self._cursor < len(self._order) and self._ready[self._order[self._cursor]]:
+            self._issue(self._order[self._cursor])
+            self._cursor += 1
+
     def _make_hook(self, i):
         def hook(param):
             if param.grad is not self.views[i] and param.grad.data_ptr() != self.views[i].data_ptr():
                 self.views[i].copy_(param.grad)           # autograd replaced the tensor (never seen; kept correct)
                 param.grad = self.views[i]
-            self._fired[i] = True
-            self._issue(i)
+            k = self._unit_of_param.get(i)
+            if k is not None and not self._ready[k]:
+                self._ready[k] = True
+                self._fire_log.append(k)
+                self._flush()
         return hook
+
+    def _range_done(self, r):
+        """anchor_gather's last backward of the step finished anchor range r (its kernel is queued on the current
+        stream; the collective waits for it there)."""
+        k = self._unit_of_range.get(r)
+        if k is not None and not self._ready[k]:
+            self._ready[k] = True
+            self._flush()
+
+    def _agree_order(self):
+        """One small MIN all-reduce + host read, after the FIRST exchange of a unit table: position of every parameter
+        unit in this rank's hook log (len(units) where no hook fired) -> the same permutation on every rank; then the
+        sink's ranges in order; then the units no rank saw a gradient for (they only ever go out from reduce())."""
+        n = len(self.units)
+        pos = [n] * n
+        for j, k in enumerate(self._fire_log):
+            pos[k] = j
+        flags = [1 if u[0] == "s" else 0 for u in self.units]
+        t = torch.tensor(pos + flags + [-f for f in flags], dtype=torch.int64, device=self.flat.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        t = t.tolist()
+        pos, fmin, fneg = t[:n], t[n:2 * n], t[2 * n:]
+        if any(a != -b for a, b in zip(fmin, fneg)):
+            raise RuntimeError("GradArena: the ranks attached different gradient sinks (the unit tables differ)")
+        fired = sorted((k for k in range(n) if not flags[k] and pos[k] < n), key=lambda k: (pos[k], k))
+        silent = [k for k in range(n) if not flags[k] and pos[k] >= n]
+        self._order = fired + [k for k in range(n) if flags[k]] + silent
 
     def reduce(self):
         """SUM over ranks of everything in the arena; returns when the reduced gradients are usable on the current
-        stream.  Parameters whose hook did not fire (no gradient on this rank: zeros) are exchanged now."""
+        stream.  Units that were not issued during the backward pass (no gradient on this rank: zeros; or behind one
+        that was not ready) are exchanged now, in the agreed order."""
         self._settle_sink()
         if self.world > 1:
-            for i in range(len(self.params)):
-                if not (self.overlap and self._fired[i]):
-                    self._issue(i)
+            order = self._order if self._order is not None else list(range(len(self.units)))
+            for k in order[self._cursor:] if self._order is not None else order:
+                assert not self._issued[k]
+                self._issue(k)
+            self._cursor = len(order)
             for w in self._work:
                 w.wait()
             self._work = [dist.all_gather_into_tensor(piece, mine, async_op=True) for piece, mine in self._pending]
             for w in self._work:
                 w.wait()
             self._work, self._pending = [], []
+            if self._order is None and self.overlap:
+                self._agree_order()
         return self.flat
 
     def nbytes(self):

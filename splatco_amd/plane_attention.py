@@ -24,6 +24,11 @@ def _channel_mlp(avg, mx, w1, w2):
 class _AttendedPairs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xy, xz, yz, w1, w2, wc):
+        with torch.cuda.device(xy.device):     # kernels launch on the CURRENT device: make it the tensors' device
+            return _AttendedPairs._forward(ctx, xy, xz, yz, w1, w2, wc)
+
+    @staticmethod
+    def _forward(ctx, xy, xz, yz, w1, w2, wc):
         R, H, W = xy.shape[1], xy.shape[2], xy.shape[3]
         dev, C3 = xy.device, 3 * R
         planes = [p.detach().contiguous().float() for p in (xy, xz, yz)]
@@ -46,6 +51,11 @@ class _AttendedPairs(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g0, g1, g2):
+        with torch.cuda.device(g0.device):
+            return _AttendedPairs._backward(ctx, g0, g1, g2)
+
+    @staticmethod
+    def _backward(ctx, g0, g1, g2):
         p0, p1, p2, w1, w2, wcc, avg, mx, arg, ca, s, am, sa = ctx.saved_tensors
         R, H, W = ctx.dims
         dev, C3 = p0.device, 3 * R

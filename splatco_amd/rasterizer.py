@@ -251,10 +251,10 @@ class GaussianRasterizer(nn.Module):
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
-            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+            raise ValueError('GaussianRasterizer: pass either shs or colors_precomp (one of them, not both, not neither)')
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
-            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+            raise ValueError('GaussianRasterizer: pass either scales + rotations or cov3D_precomp (one form of the covariance, not both, not neither)')
         empty = torch.Tensor([])
         return rasterize_gaussians(
             means3D, means2D, empty if shs is None else shs, empty if colors_precomp is None else colors_precomp,
@@ -264,7 +264,7 @@ class GaussianRasterizer(nn.Module):
     def visible_filter(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
-            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+            raise ValueError('GaussianRasterizer: pass either scales + rotations or cov3D_precomp (one form of the covariance, not both, not neither)')
         with torch.no_grad():
             cs = _CSettings(self.raster_settings)
             means3D = _dev_f32(means3D, "means3D")

@@ -29,12 +29,6 @@ def _mlp_heads(pc, x):
     return tuple(h[2:](x_) for h, x_ in zip(heads, parts))
 
 
-def _plain_exp_scaling():
-    """The get_scaling property the fused gather reproduces (1.0 * exp(_scaling), scene/gaussian_model.py:397-399)."""
-    from .scene_model import AnchorGaussianModel
-    return AnchorGaussianModel.get_scaling
-
-
 def _parts_capable():
     from .scene_model import GaussianLearner
     return GaussianLearner
@@ -54,10 +48,15 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     idx = visible_indices(visible_mask)             # on the GPU csrc/expand.hip: count / scan / write, one host read of the count
     from . import anchor_gather as _ag
     g_fea = None
-    if fused_heads and _ag.supported(pc) and type(pc).get_scaling is _plain_exp_scaling():
+    if _ag.fused_gather_taken(pc, fused_heads):
         # the four gathers, exp(_scaling) and the [V,71] concatenation of :23-31 as one pass (csrc/anchor_gather.hip)
         feat, anchor, grid_offsets, grid_scaling, g_fea = _ag.gather_anchors(pc, idx)
     else:
+        if getattr(pc, "_grad_sink", None) is not None and torch.is_grad_enabled():
+            # autograd would ADD these gradients into arena memory that zero() skipped for the sink
+            raise RuntimeError("a gradient sink is attached (train_step.collaborative_step with a GradArena) but this "
+                               "render does not take the fused anchor gather (fused_heads=False or a model whose "
+                               "get_scaling is not exp(_scaling)): detach the sink or render through the fused path")
         feat = pc._anchor_feat.index_select(0, idx)
         anchor = pc.get_anchor.index_select(0, idx)
         grid_offsets = pc._offset.index_select(0, idx)

@@ -38,7 +38,8 @@ def _forward_into(out, ind, cols, planes):
             def pairs(p):
                 p = p.contiguous()
                 rp = torch.empty(p.shape[2] - 1, p.shape[3], 2, R, dtype=torch.float32, device=p.device)
-                _C.check(_C.lib.scr_plane_row_pairs(R, p.shape[2], p.shape[3], p.data_ptr(), rp.data_ptr(), _stream()))
+                with torch.cuda.device(p.device):
+                    _C.check(_C.lib.scr_plane_row_pairs(R, p.shape[2], p.shape[3], p.data_ptr(), rp.data_ptr(), _stream(p.device)))
                 return rp
             xy, xz, yz = pairs(xy), pairs(xz), pairs(yz)
         else:
@@ -195,7 +196,8 @@ class _PlaneSample(torch.autograd.Function):
         g = g.contiguous().float()
         grad_plane = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
         scratch = torch.empty(_C.lib.scr_plane_sample_scratch_bytes(V, A, B, R), dtype=torch.uint8, device=g.device)
-        _C.check(_C.lib.scr_plane_sample_backward(V, grid.data_ptr(), 2, 0, 1, R, A, B, 1, g.data_ptr(), g.data_ptr(),
-                                                  g.stride(0), grad_plane.data_ptr(), grad_plane.data_ptr(),
-                                                  scratch.data_ptr(), _stream()))
+        with torch.cuda.device(g.device):
+            _C.check(_C.lib.scr_plane_sample_backward(V, grid.data_ptr(), 2, 0, 1, R, A, B, 1, g.data_ptr(), g.data_ptr(),
+                                                      g.stride(0), grad_plane.data_ptr(), grad_plane.data_ptr(),
+                                                      scratch.data_ptr(), _stream(g.device)))
         return grad_plane, None

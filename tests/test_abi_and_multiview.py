@@ -161,6 +161,67 @@ for mode, overlap in (("all_reduce", True), ("rs_ag", True), ("all_reduce", Fals
             assert torch.allclose(p.grad, w, rtol=1e-10, atol=1e-12), (mode, overlap, rank)
     arena.close()
 for p in params: p.grad = None
+# ---- a rank WITHOUT views (world > number of views): its hooks never fire, everything goes out from reduce(); the other
+# rank's hooks fire in backward order [2, 1, 0].  Collectives are matched by issue order, so the arena must issue in one
+# agreed order on both (three equal-size parameters: a mismatch would sum different parameters without any error)
+eq = [torch.full((64,), float(j + 1), dtype=torch.float64, requires_grad=True) for j in range(3)]
+for mode in ("all_reduce", "rs_ag"):
+    arena = GradArena(eq, chunk_bytes=256, mode=mode, overlap=True)
+    for it in range(3):                                     # step 0 agrees on the order, steps 1.. issue from the hooks
+        arena.zero()
+        if rank == 0:
+            h = eq[0] * 1.0
+            h = h + eq[1] * 10.0                             # graph order makes the hook order 2, 1, 0
+            h = h + eq[2] * 100.0
+            h.sum().backward()
+            if it:
+                assert arena._cursor == 3, arena._cursor     # all three went out during the backward pass
+        arena.reduce()
+        for j, w in enumerate((1.0, 10.0, 100.0)):
+            assert torch.equal(eq[j].grad, torch.full((64,), w, dtype=torch.float64)), (mode, it, rank, j, eq[j].grad[:2])
+    assert arena._order is not None
+    arena.close()
+for p in eq: p.grad = None
+# ---- the per-anchor exchange in anchor RANGES (the sink's units) equals the unchunked exchange bit for bit, whether the
+# ranges are reported during the step (rank 0) or only declared final by reduce() (rank 1), and in both collective shapes
+Na = 1000
+pa = [torch.zeros(Na, w, dtype=torch.float32, requires_grad=True) for w in (32, 3, 30, 6)]
+other = torch.zeros(77, dtype=torch.float32, requires_grad=True)
+gen = torch.Generator().manual_seed(7 + rank)
+vals = [torch.randn(Na, w, generator=gen) for w in (32, 3, 30, 6)]
+oval = torch.randn(77, generator=gen)
+results = {}
+for mode in ("all_reduce", "rs_ag"):
+    for nr in (1, 4):
+        arena = GradArena([other] + pa, chunk_bytes=4096, mode=mode, overlap=True, anchor_ranges=nr)
+        sink = arena.attach_sink(pa)
+        assert sink is not None and len(arena.sink_ranges) == (1 if nr == 1 else 4) and sink.ranges == arena.sink_ranges
+        assert all(n0 % 64 == 0 for n0, _ in sink.ranges) and sink.ranges[-1][1] == Na
+        for it in range(2):
+            arena.zero()
+            (other * oval).sum().backward()                  # an ordinary parameter: its hook fires
+            for r, (n0, n1) in enumerate(sink.ranges):       # what anchor_gather's last backward does, range by range
+                for t, v in zip(sink.tensors, vals):
+                    t[n0:n1] = v[n0:n1]
+                sink.fresh = False
+                if rank == 0:
+                    sink.on_range(r)
+            if it and rank == 0:
+                assert arena._cursor == len(arena.units)     # everything was on the wire before reduce()
+            arena.reduce()
+        results[(mode, nr)] = arena.flat.clone()
+        arena.close()
+both = [torch.zeros_like(v) for v in vals]
+for b, v in zip(both, vals):
+    g2 = [torch.zeros_like(v) for _ in range(world)]
+    dist.all_gather(g2, v)
+    b.copy_(g2[0] + g2[1])
+for key, flat in results.items():
+    assert torch.equal(flat, results[("all_reduce", 1)]), key
+a1 = GradArena([other] + pa, anchor_ranges=1)
+for i, b in zip(range(1, 5), both):
+    assert torch.equal(results[("all_reduce", 4)][a1.offsets[i]:a1.offsets[i] + b.numel()].view_as(b), b)
+a1.close()
 # ---- densification statistics of the LAST view reach every rank; identically seeded growth -> identical anchors
 import splatco_amd.stats as stats
 from torch_restatements import statis_increments_torch, statis_apply_torch
