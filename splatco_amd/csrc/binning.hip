@@ -55,16 +55,27 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(uint32_t nblk, uint32_t
     // mailbox (optional): four words of pinned host memory the GPU can write -- (I, seq, max tile count, seq).
     // The host spins on the two stamps instead of sleeping in a stream synchronisation.
     __shared__ uint32_t lds[1024 / WAVE + 1];
+    __shared__ unsigned long long wide[1024 / WAVE];
     if (blockIdx.x == 0) {
-        unsigned long long carry = 0;
+        // the 32-bit prefixes are what the scatter kernel uses; the TOTAL is formed in 64 bits from the (saturated)
+        // workgroup sums, so that num_rendered >= 2^32 shows up on the host instead of wrapping
+        unsigned long long carry = 0, mine = 0;
         for (uint32_t base = 0; base < nblk; base += 1024) {
             uint32_t i = base + threadIdx.x;
             uint32_t v = i < nblk ? block_sums[i] : 0u, tot;
             uint32_t ex = block_exclusive_scan<1024>(v, lds, tot);
             if (i < nblk) block_sums[i] = (uint32_t)carry + ex;
             carry += tot;
+            mine += v;
         }
+#pragma unroll
+        for (int d = WAVE / 2; d > 0; d >>= 1) mine += (unsigned long long)__shfl_down((long long)mine, d, WAVE);
+        __syncthreads();
+        if ((threadIdx.x & (WAVE - 1)) == 0) wide[threadIdx.x / WAVE] = mine;
+        __syncthreads();
         if (threadIdx.x == 0) {
+            carry = 0;
+            for (int w = 0; w < 1024 / WAVE; ++w) carry += wide[w];
             total[0] = carry;
             if (mailbox) {
                 mailbox[0] = carry;

@@ -185,10 +185,10 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
     plan_host[0] = plan_host[1] = 0;
     if (!geom_buf) return fail("geom_buf is NULL");
     if ((shs != nullptr) == (colors_precomp != nullptr))
-        return fail("Please provide exactly one of either SHs or precomputed colors!");
+        return fail("pass either shs or colors_precomp (one of them, not both, not neither)");
     if (((scales != nullptr) || (rotations != nullptr)) == (cov3D_precomp != nullptr) || ((scales != nullptr) != (rotations != nullptr)))
         if (!(cov3D_precomp && !scales && !rotations) && !(scales && rotations && !cov3D_precomp))
-            return fail("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+            return fail("pass either scales + rotations or cov3D_precomp (one form of the covariance)");
     if (P > 0 && (!means3D || !opacities || !radii_out)) return fail("means3D / opacities / radii_out is NULL");
     if (P >= (1ll << ID_BITS)) return fail("P = %lld exceeds the 2^%d Gaussians a sort key can index", (long long)P, ID_BITS);
     if (shs && (M < (settings->sh_degree + 1) * (settings->sh_degree + 1)))
@@ -221,7 +221,10 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
         HIP_TRY(hipMemcpyAsync(total, gv.total, 16, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    if (total[0] >= (1ull << 32)) return fail("num_rendered = %llu does not fit 32-bit instance indices", total[0]);
+    // per-workgroup sums saturate at 2^32 - 1 (preprocess_kernel) and the scan adds them in 64 bits: any total at or above
+    // 2^32 - 1 means "does not fit" (the prefix values are meaningless then; nothing has been written through them yet)
+    if (total[0] >= 0xFFFFFFFFull)
+        return fail("num_rendered >= 2^32 - 1 (counted %llu): the (Gaussian, tile) instances do not fit 32-bit indices", total[0]);
     plan_host[0] = (int64_t)total[0];
     plan_host[1] = (int64_t)total[1];
     return 0;

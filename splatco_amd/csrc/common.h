@@ -8,6 +8,13 @@
 
 namespace scr {
 
+// min(a + b, 2^32 - 1)
+__host__ __device__ __forceinline__ uint32_t sat_add_u32(uint32_t a, uint32_t b) {
+    const uint32_t s = a + b;
+    return s < a ? 0xFFFFFFFFu : s;
+}
+
+
 constexpr int TILE = SCR_TILE;          // 16x16 pixels
 constexpr int TILE_PIX = TILE * TILE;   // 256
 constexpr int WAVE = 64;                // CDNA wavefront

@@ -287,18 +287,20 @@ preprocess_kernel(int64_t P, int M, const float* __restrict__ means3D, const flo
             if (clamped) clamped[i] = 0;
         }
         tiles_touched[i] = tt;
-        tsum += tt;
+        tsum = sat_add_u32(tsum, tt);
     }
-    // workgroup sum of tiles_touched (wave reduction, then the wave partials through LDS)
+    // workgroup sum of tiles_touched (wave reduction, then the wave partials through LDS).  SATURATING: 4096 Gaussians
+    // times a million-tile image passes 2^32, and a wrapped sum would slip under the host's num_rendered guard
+    // (min(sum, 2^32 - 1) is the same in any order of additions)
     uint32_t s = tsum;
 #pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) s += __shfl_down(s, d, WAVE);
+    for (int d = WAVE / 2; d > 0; d >>= 1) s = sat_add_u32(s, (uint32_t)__shfl_down(s, d, WAVE));
     if ((threadIdx.x & (WAVE - 1)) == 0) wave_sum[threadIdx.x / WAVE] = s;
     __syncthreads();  // also: every LDS histogram update of the workgroup is done
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
 #pragma unroll
-        for (int w = 0; w < BIN_THREADS / WAVE; ++w) tot += wave_sum[w];
+        for (int w = 0; w < BIN_THREADS / WAVE; ++w) tot = sat_add_u32(tot, wave_sum[w]);
         block_sums[blockIdx.x] = tot;
     }
     if (LDS_HIST)

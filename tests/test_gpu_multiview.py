@@ -1,0 +1,313 @@
+"""GPU tests of the multi-view branch at the sizes BASELINE.json names for it, on the ONE GPU of the test box:
+
+  * sharded == sequential ON THE HIP PATH: two ranks on one device over gloo run train_step.collaborative_step with a
+    GradArena (gradient sink, hook-issued pieces, per-anchor exchange in anchor ranges), the cross-view consistency term
+    and a densifier; every rank then replays the reference's sequential mv loop (train.py:171-240: all views, summed
+    losses + pairwise term, ONE backward; training_statis of the last view, train.py:264-266) with the same kernels.
+  * configs[3] per-GPU reality: 5 M anchors, mv = 4 views rendered one after another on one GPU -- four live rasterizer
+    graphs, one backward -- which is exactly how the reference executes --mv 4.
+  * configs[4] per-rank size: 20 M anchors, one view: prefilter radii bit-exact against the OpenMP oracle at N = 20 M and
+    the full training step.
+  * num_rendered >= 2^32 is refused (capi.hip, scr_forward_plan) instead of wrapping.
+"""
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from util import oracle_settings
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SHARDED_WORKER = r'''
+import os, sys, types, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from splatco_amd import stats
+from splatco_amd.densify import AnchorDensifier
+from splatco_amd.expand import visible_indices
+from splatco_amd.losses import view_loss
+from splatco_amd.multiview import GradArena, pair_consistency
+from splatco_amd.renderer import prefilter_voxel, render
+from splatco_amd.synthetic import synthetic_anchor_model, synthetic_views
+from splatco_amd.train_step import collaborative_step
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
+bg = torch.ones(3, device=dev)
+W, H, N, MV = 640, 360, 200_000, 4
+views = [v.to(dev) for v in synthetic_views(MV, W, H)]
+g = torch.Generator(device=dev).manual_seed(5)
+base = torch.rand(3, H, W, device=dev, generator=g)
+gts = [(base + 0.02 * i).clamp(0, 1) for i in range(MV)]           # alike enough for SSIM > 0.6: every pair counts
+
+
+def make():
+    pc = synthetic_anchor_model(N, 9, dev, plane_size=256)
+    idle = {id(p) for p in pc.feat_planes._feat.inactive_parameters()}
+    groups = [{"params": [getattr(pc, "_" + n)], "lr": 1e-4, "name": n} for n in ("anchor", "offset", "anchor_feat", "scaling")]
+    rest = [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad and id(p) not in idle]
+    groups.append({"params": rest, "lr": 1e-3, "name": "mlp_and_feat_planes"})
+    opt = torch.optim.Adam(groups, eps=1e-15)
+    den = AnchorDensifier(pc, opt, voxel_size=0.01, seed=77)
+    return pc, [p for grp in groups for p in grp["params"]], den
+
+
+def sequential(pc, params, den, cw):
+    """The reference's loop: every view on this one process, one backward, statistics of the last view."""
+    for p in params:
+        p.grad = None
+    total, outs = None, []
+    for cam, gt in zip(views, gts):
+        vis = prefilter_voxel(cam, pc, pipe, bg)
+        out = render(cam, pc, pipe, bg, visible_mask=vis, retain_grad=True)
+        loss = view_loss(out["render"], gt, out["scaling"])
+        total = loss if total is None else total + loss
+        outs.append((out, vis))
+    own, cross = 0.0, 0.0
+    if cw:
+        for i in range(MV):
+            for j in range(i + 1, MV):
+                t = pair_consistency(outs[i][0]["render"], gts[i], outs[j][0]["render"], gts[j])
+                assert t is not None
+                total = total + cw * t
+                if i % world == j % world:
+                    own = own + cw * t.detach()
+                else:
+                    cross = cross + cw * t.detach()
+    total.backward()
+    out, vis = outs[-1]
+    with torch.no_grad():
+        inc_op, inc_g = stats.statis_increments(den.n_offsets, out["viewspace_points"].grad, out["neural_opacity"],
+                                                out["visibility_filter"], out["selection_mask"])
+        den.apply_statis(visible_indices(vis), inc_op, inc_g)
+    return total.detach(), own, cross
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+
+
+for mode, cw in (("all_reduce", 0.05), ("rs_ag", 0.0)):
+    pc_a, params_a, den_a = make()
+    pc_b, params_b, den_b = make()
+    assert all(torch.equal(a, b) for a, b in zip(params_a, params_b))
+    arena = GradArena(params_a, chunk_bytes=4 << 20, mode=mode, anchor_ranges=4)       # several pieces per large parameter
+    for it in range(2):         # step 0 goes out from reduce() and agrees on the order; step 1 issues from the hooks / ranges
+        loss_a, out_a, _ = collaborative_step(pc_a, views, gts, pipe, bg, consistency_weight=cw, densifier=den_a, arena=arena)
+        loss_b, own, cross = sequential(pc_b, params_b, den_b, cw)
+    assert arena._order is not None and arena._sink is not None and len(arena.sink_ranges) == 4
+    assert arena._cursor == len(arena.units)
+    worst = 0.0
+    for i, (pa, pb) in enumerate(zip(params_a, params_b)):
+        assert pa.grad is not None and pb.grad is not None and pa.grad.data_ptr() == arena.views[i].data_ptr()
+        r = rel(pa.grad, pb.grad)
+        worst = max(worst, r)
+        # the sum over views is formed in another order (per rank, then across ranks) and nothing else differs
+        assert r <= 1e-6, (mode, i, tuple(pa.shape), r)
+    # losses: a cross-rank pair is evaluated by both owners (each differentiates its own image): it counts twice in the
+    # sum of the local losses
+    tl = loss_a.clone().double()
+    dist.all_reduce(tl)
+    want = float(loss_b) + float(cross)
+    assert abs(float(tl) - want) <= 1e-6 * abs(want), (float(tl), want)
+    # densification statistics: the last view's (rendered by rank 1) on every rank
+    for name in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"):
+        a, b = getattr(den_a, name), getattr(den_b, name)
+        if cw == 0.0:
+            assert torch.equal(a, b), (mode, name)              # same kernels, same dL/dpixel: bit for bit
+        else:
+            assert rel(a, b) <= 1e-5, (mode, name, rel(a, b))   # the pairwise term reaches the image in another order
+    for d in (den_a, den_b):
+        d.offset_denom += 50
+        d.anchor_demon += 90
+    den_a.adjust_anchor(iteration=100, check_interval=100, grad_threshold=float(den_a.offset_gradient_accum.mean() / 52))
+    n_new = pc_a._anchor.shape[0]
+    assert n_new != N, "adjust_anchor changed nothing: the comparison below would be empty"
+    state = torch.cat([t.detach().reshape(-1).float() for t in (pc_a._anchor, pc_a._anchor_feat, pc_a._offset, pc_a._scaling,
+                                                                den_a.offset_denom, den_a.opacity_accum, den_a.anchor_demon,
+                                                                den_a.offset_gradient_accum)])
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([state.numel()], device=dev))
+    assert all(int(s) == state.numel() for s in sizes), sizes
+    both = [torch.zeros_like(state) for _ in range(world)]
+    dist.all_gather(both, state)
+    assert all(torch.equal(both[0], b) for b in both), "replicas diverged after adjust_anchor"
+    if cw == 0.0:
+        den_b.adjust_anchor(iteration=100, check_interval=100, grad_threshold=float(den_b.offset_gradient_accum.mean() / 52))
+        assert pc_b._anchor.shape[0] == n_new and torch.equal(pc_a._anchor, pc_b._anchor) and torch.equal(pc_a._offset, pc_b._offset)
+    print(f"[rank {rank}] {mode} consistency {cw}: worst gradient rel-L2 {worst:.2e}, anchors {N} -> {n_new}", flush=True)
+    arena.close()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_sharded_step_equals_the_sequential_loop_on_the_hip_path(tmp_path):
+    script = tmp_path / "sharded_worker.py"
+    script.write_text(SHARDED_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29641", str(script), ROOT],
+                       capture_output=True, text=True, env=env, timeout=1500)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
+    assert r.stdout.count("ok") == 2
+
+
+def _train_setup(pc, seed, mode="all_reduce"):
+    from splatco_amd.densify import AnchorDensifier
+    from splatco_amd.multiview import GradArena
+    groups = [{"params": [getattr(pc, "_" + n)], "lr": 1e-4, "name": n} for n in ("anchor", "offset", "anchor_feat", "scaling")]
+    idle = {id(p) for p in pc.feat_planes._feat.inactive_parameters()}
+    rest = [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad and id(p) not in idle]
+    groups.append({"params": rest, "lr": 1e-3, "name": "mlp_and_feat_planes"})
+    opt = torch.optim.Adam(groups, eps=1e-15, fused=True)
+    den = AnchorDensifier(pc, opt, seed=seed)
+    arena = GradArena([p for grp in groups for p in grp["params"]], mode=mode)
+    return opt, den, arena
+
+
+def _check_param_grads(pc):
+    planes = pc.feat_planes._feat.k0s
+    for name, p in [("anchor", pc._anchor), ("offset", pc._offset), ("feat", pc._anchor_feat), ("scaling", pc._scaling),
+                    ("mlp_opacity", pc.mlp_opacity[0].weight), ("mlp_cov", pc.mlp_cov[0].weight),
+                    ("mlp_color", pc.mlp_color[2].weight), ("plane L0 (attention)", planes[0].xy_plane),
+                    ("plane L1", planes[1].xz_plane), ("plane L2 (1400)", planes[2].yz_plane)]:
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0, name
+    assert planes[3].xy_plane.grad is None            # the 2800^2 level is never sampled
+
+
+def test_cfg3_5M_anchors_mv4_sequential_views_on_one_gpu():
+    """configs[3] as the REFERENCE executes it (train.py:171-240): the four views of --mv 4 rendered one after another on
+    one GPU, four rasterizer graphs alive, one backward; here through collaborative_step at world size 1 with the gradient
+    arena, the densifier and the optimiser."""
+    from splatco_amd.renderer import prefilter_voxel, render
+    from splatco_amd.synthetic import ANCHOR_CONFIGS, synthetic_anchor_model, synthetic_views
+    from splatco_amd.train_step import collaborative_step
+    dev = torch.device("cuda:0")
+    N, mv, seed = ANCHOR_CONFIGS["cfg3"]
+    assert (N, mv) == (5_000_000, 4)
+    pc = synthetic_anchor_model(N, seed, dev)
+    opt, den, arena = _train_setup(pc, seed)
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
+    bg = torch.ones(3, device=dev)
+    views = [v.to(dev) for v in synthetic_views(mv)]
+    g = torch.Generator(device=dev).manual_seed(100 + seed)
+    gts = [torch.rand(3, 1080, 1920, device=dev, generator=g) for _ in views]
+    torch.cuda.reset_peak_memory_stats()
+    before = pc._anchor.detach().clone()
+    loss, out, _ = collaborative_step(pc, views, gts, pipe, bg, densifier=den, arena=arena)       # no optimiser: look at the gradients
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    P = out["radii"].shape[0]
+    print(f"[cfg3] 5 M anchors, mv = 4 sequential views: last view {P} Gaussians, loss {float(loss):.4f}, "
+          f"peak memory {peak:.1f} GiB (four live graphs + 1.42 GB arena)")
+    assert torch.isfinite(loss) and out["render"].shape == (3, 1080, 1920) and P > 10_000_000
+    _check_param_grads(pc)
+    assert arena._sink is not None and pc._anchor.grad.data_ptr() == arena._sink.tensors[1].data_ptr()
+    assert float(den.anchor_demon.sum()) > 0 and float(den.offset_denom.sum()) > 0        # the last view's statistics arrived
+    # the gradient of four views is the sum of four single-view gradients (a second arena step per view)
+    total = torch.zeros_like(pc._anchor_feat)
+    for v, gt in zip(views, gts):
+        collaborative_step(pc, [v], [gt], pipe, bg, arena=arena)
+        total += pc._anchor_feat.grad
+    collaborative_step(pc, views, gts, pipe, bg, arena=arena)
+    err = float((pc._anchor_feat.grad - total).norm() / total.norm())
+    assert err <= 1e-6, err
+    # bit-reproducible image of the last view
+    with torch.no_grad():
+        vis = prefilter_voxel(views[-1], pc, pipe, bg)
+        again = render(views[-1], pc, pipe, bg, visible_mask=vis)["render"]
+    assert torch.equal(again, out["render"].detach())
+    # and the full step with the optimiser moves the anchors
+    collaborative_step(pc, views, gts, pipe, bg, optimizer=opt, densifier=den, arena=arena)
+    torch.cuda.synchronize()
+    assert torch.isfinite(pc._anchor).all() and not torch.equal(pc._anchor.detach(), before)
+
+
+def test_cfg4_20M_anchors_one_view_per_rank(oracle):
+    """configs[4] per-rank work: 20 M anchors, one 1080p view: anchor visibility bit-exact against the oracle at N = 20 M,
+    then the full training step (prefilter, render, loss, backward into the arena, statistics, Adam)."""
+    from splatco_amd.rasterizer import GaussianRasterizer
+    from splatco_amd import rasterizer as R
+    from splatco_amd.renderer import _settings
+    from splatco_amd.synthetic import ANCHOR_CONFIGS, synthetic_anchor_model, synthetic_views
+    from splatco_amd.train_step import collaborative_step
+    dev = torch.device("cuda:0")
+    N, mv, seed = ANCHOR_CONFIGS["cfg4"]
+    assert (N, mv) == (20_000_000, 8)
+    pc = synthetic_anchor_model(N, seed, dev)
+    cam = synthetic_views(1)[0]
+    bg = torch.ones(3, device=dev)
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
+    st = oracle_settings(oracle, cam, np.ones(3, np.float32))
+    oracle.use_threads(True)
+    try:
+        with torch.no_grad():
+            want = oracle.visible_filter(st, pc.get_anchor.cpu().numpy(), pc.get_scaling[:, :3].cpu().numpy(),
+                                         pc.get_rotation.cpu().numpy())
+            got = GaussianRasterizer(_settings(cam.to(dev), bg, 1.0, False)).visible_filter(
+                means3D=pc.get_anchor, scales=pc.get_scaling[:, :3], rotations=pc.get_rotation)
+    finally:
+        oracle.use_threads(False)
+    assert np.array_equal(got.cpu().numpy(), want), "visible_filter radii at N = 20M"
+    assert int((want > 0).sum()) > 15_000_000
+    del want, got
+    opt, den, arena = _train_setup(pc, seed)
+    gt = torch.rand(3, 1080, 1920, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + seed))
+    before = pc._anchor_feat.detach().clone()
+    torch.cuda.reset_peak_memory_stats()
+    loss, out, _ = collaborative_step(pc, [cam.to(dev)], [gt], pipe, bg, densifier=den, arena=arena)
+    torch.cuda.synchronize()
+    P, I = out["radii"].shape[0], R.last_plan[1]
+    print(f"[cfg4] 20 M anchors, one view: {P} Gaussians, {I} tile instances ({I / 2**32:.3f} of the 2^32 index space), "
+          f"largest tile {R.last_plan[2]}, loss {float(loss):.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    assert P > 50_000_000 and 100_000_000 < I < 2 ** 32
+    assert torch.isfinite(loss) and torch.isfinite(out["render"]).all()
+    _check_param_grads(pc)
+    gvs = out["viewspace_points"].grad
+    assert gvs is not None and torch.isfinite(gvs).all() and gvs[:, :2].abs().sum() > 0
+    assert float(den.anchor_demon.sum()) > 0
+    loss2, _, _ = collaborative_step(pc, [cam.to(dev)], [gt], pipe, bg, optimizer=opt, densifier=den, arena=arena)
+    torch.cuda.synchronize()
+    assert float(loss2) == float(loss)                       # same parameters, deterministic forward: the same loss bit for bit
+    assert torch.isfinite(pc._anchor_feat).all() and not torch.equal(pc._anchor_feat.detach(), before)
+
+
+def test_more_than_2_32_tile_instances_is_an_error_not_a_wrap():
+    """capi.hip (scr_forward_plan): instance indices are 32-bit; a scene whose (Gaussian, tile) count reaches 2^32 must be
+    refused.  4 160 giant splats over a 16 384 x 16 384 image = 1 048 576 tiles each: 4.36e9 instances -- one workgroup
+    of 4 096 Gaussians alone passes 2^32 (the per-workgroup sums saturate instead of wrapping)."""
+    from splatco_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from splatco_amd.synthetic import synthetic_camera
+    dev = torch.device("cuda:0")
+    S, P = 16384, 4160
+    cam = synthetic_camera(S, S)
+    import math
+    tx = math.tan(cam.FoVx * 0.5)
+    rs = GaussianRasterizationSettings(S, S, tx, tx, torch.ones(3, device=dev), 1.0, cam.world_view_transform.to(dev),
+                                       cam.full_proj_transform.to(dev), 1, cam.camera_center.to(dev), False, False)
+    means = torch.tensor([[0.0, 0.0, 5.0]], device=dev).repeat(P, 1)
+    scales = torch.full((P, 3), 50.0, device=dev)
+    rots = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=dev).repeat(P, 1)
+    op = torch.full((P, 1), 0.5, device=dev)
+    col = torch.rand(P, 3, device=dev)
+    with pytest.raises(RuntimeError, match="num_rendered"):
+        GaussianRasterizer(rs)(means3D=means, means2D=torch.zeros(P, 3, device=dev), opacities=op, colors_precomp=col,
+                               scales=scales, rotations=rots)
+    # one Gaussian fewer than a workgroup's worth below the limit still plans and renders (4 095 x 2^20 < 2^32 - 1)
+    # -- not run: 4.29e9 instances would need 73 GB of binning state; the planning arithmetic is what is under test
+    # a second call after the refusal works (no state was left behind)
+    rs2 = rs._replace(image_height=64, image_width=64)
+    img, radii = GaussianRasterizer(rs2)(means3D=means[:8], means2D=torch.zeros(8, 3, device=dev), opacities=op[:8],
+                                         colors_precomp=col[:8], scales=scales[:8], rotations=rots[:8])
+    assert img.shape == (3, 64, 64) and torch.isfinite(img).all() and int((radii > 0).sum()) == 8
