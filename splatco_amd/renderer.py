@@ -62,10 +62,17 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         grid_offsets = pc._offset.index_select(0, idx)
         grid_scaling = pc.get_scaling.index_select(0, idx)
     V, k = anchor.shape[0], pc.n_offsets
-    if getattr(pc, "use_feat_bank", False) or getattr(pc, "appearance_dim", 0) > 0:
-        raise NotImplementedError("feature bank / appearance embedding are off on the benchmarked path")
+    if getattr(pc, "use_feat_bank", False):
+        # dead in the reference too: its feature-bank MLP is built for 3 + 1 inputs (scene/gaussian_model.py:308-309) and
+        # fed 3 + 1 + 64 columns (gaussian_renderer/__init__.py:41-43) -- the branch stops with a shape error there
+        raise NotImplementedError("use_feat_bank: the reference's own branch cannot run (4-input MLP fed 68 columns)")
+    appearance_dim = int(getattr(pc, "appearance_dim", 0) or 0)
     from . import mlp_heads as _mh
-    plain = not (pc.add_opacity_dist or pc.add_color_dist or pc.add_cov_dist)
+    # the benchmarked configuration (README.md:93: --appearance_dim 0, no feature bank, no distance inputs): the three
+    # heads read the same [V, 99] input.  The reference's CODE default is appearance_dim = 32
+    # (arguments/__init__.py:76): that runs through the framework's GEMMs below, op for op as
+    # gaussian_renderer/__init__.py:40-93
+    plain = not (pc.add_opacity_dist or pc.add_color_dist or pc.add_cov_dist or appearance_dim > 0)
     if g_fea is None:
         g_fea = torch.concat((feat, anchor, grid_offsets.reshape(V, -1), grid_scaling), dim=1)
     use_fused = plain and fused_heads and _mh.supported(pc, feat, feat, feat)
@@ -97,7 +104,11 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         cat_local_view = torch.cat([feat, ob_view, ob_dist, geo_fea], dim=1)
         cat_local_view_wodist = torch.cat([feat, ob_view, geo_fea], dim=1)
         neural_opacity = pc.get_opacity_mlp(cat_local_view if pc.add_opacity_dist else cat_local_view_wodist)
-        color = pc.get_color_mlp(cat_local_view if pc.add_color_dist else cat_local_view_wodist)
+        color_in = cat_local_view if pc.add_color_dist else cat_local_view_wodist
+        if appearance_dim > 0:                               # per-camera appearance code on the colour head (:55-58,76-80)
+            camera_indicies = torch.full((V,), int(viewpoint_camera.uid), dtype=torch.long, device=anchor.device)
+            color_in = torch.cat([color_in, pc.get_appearance(camera_indicies)], dim=1)
+        color = pc.get_color_mlp(color_in)
         scale_rot = pc.get_cov_mlp(cat_local_view if pc.add_cov_dist else cat_local_view_wodist)
     neural_opacity = neural_opacity.reshape([-1, 1])
     color = color.reshape([V * k, 3])

@@ -119,8 +119,11 @@ def save_mlp_checkpoints(model, path, mode="unite"):                            
     if mode != "unite":
         raise NotImplementedError("only the reference's default 'unite' checkpoint (checkpoints.pth) is written")
     os.makedirs(path, exist_ok=True)
-    torch.save({"opacity_mlp": model.mlp_opacity.state_dict(), "cov_mlp": model.mlp_cov.state_dict(),
-                "color_mlp": model.mlp_color.state_dict()}, os.path.join(path, "checkpoints.pth"))
+    ck = {"opacity_mlp": model.mlp_opacity.state_dict(), "cov_mlp": model.mlp_cov.state_dict(),
+          "color_mlp": model.mlp_color.state_dict()}
+    if getattr(model, "appearance_dim", 0) > 0 and getattr(model, "embedding_appearance", None) is not None:
+        ck["appearance"] = model.embedding_appearance.state_dict()            # :1054-1060
+    torch.save(ck, os.path.join(path, "checkpoints.pth"))
 
 
 def load_mlp_checkpoints(model, path, mode="unite"):                              # :1065-1090
@@ -130,6 +133,10 @@ def load_mlp_checkpoints(model, path, mode="unite"):                            
     model.mlp_opacity.load_state_dict(ck["opacity_mlp"])
     model.mlp_cov.load_state_dict(ck["cov_mlp"])
     model.mlp_color.load_state_dict(ck["color_mlp"])
+    if getattr(model, "appearance_dim", 0) > 0:                               # :1087-1088
+        if getattr(model, "embedding_appearance", None) is None:
+            model.set_appearance(ck["appearance"]["embedding.weight"].shape[0])
+        model.embedding_appearance.load_state_dict(ck["appearance"])
     return model
 
 

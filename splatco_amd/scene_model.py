@@ -414,6 +414,19 @@ def morton_order(anchor, bits=10):
     return torch.argsort(code, stable=True)
 
 
+class AppearanceEmbedding(nn.Module):
+    """Per-camera appearance code (scene/embedding.py:52-80): a lookup table whose state_dict key is
+    `embedding.weight`, as in the reference's checkpoints ('appearance', scene/gaussian_model.py:1052-1059)."""
+
+    def __init__(self, num_cameras, dim):
+        super().__init__()
+        self.in_dim, self.out_dim = num_cameras, dim
+        self.embedding = nn.Embedding(num_cameras, dim)
+
+    def forward(self, idx):
+        return self.embedding(idx)
+
+
 class AnchorGaussianModel(nn.Module):
     """The attributes of the reference's GaussianModel that render() / prefilter_voxel() touch
     (scene/gaussian_model.py:253-337,396-432), with the same names."""
@@ -421,9 +434,9 @@ class AnchorGaussianModel(nn.Module):
     def __init__(self, feat_dim=32, n_offsets=10, appearance_dim=0, plane_size=2800, num_channels=15,
                  use_feat_bank=False, add_opacity_dist=False, add_cov_dist=False, add_color_dist=False):
         super().__init__()
-        if use_feat_bank or appearance_dim > 0:
-            raise NotImplementedError("use_feat_bank / appearance embedding are off on the benchmarked path "
-                                      "(arguments/__init__.py:57, README.md:93 --appearance_dim 0)")
+        if use_feat_bank:
+            raise NotImplementedError("use_feat_bank: dead in the reference (its 4-input feature-bank MLP, scene/gaussian_model.py:"
+                                      "308-309, is fed 68 columns at gaussian_renderer/__init__.py:41-43 and stops with a shape error)")
         self.feat_dim, self.n_offsets, self.appearance_dim, self.use_feat_bank = feat_dim, n_offsets, appearance_dim, use_feat_bank
         self.add_opacity_dist, self.add_cov_dist, self.add_color_dist = add_opacity_dist, add_cov_dist, add_color_dist
         od, cd, kd = int(add_opacity_dist), int(add_cov_dist), int(add_color_dist)
@@ -433,6 +446,9 @@ class AnchorGaussianModel(nn.Module):
                                      TallLinear(feat_dim, 7 * n_offsets))
         self.mlp_color = nn.Sequential(TallLinear(feat_dim + 3 + kd + appearance_dim + 64, feat_dim), nn.ReLU(True),
                                        TallLinear(feat_dim, 3 * n_offsets), nn.Sigmoid())
+        # off on the benchmarked path (README.md:93 --appearance_dim 0, arguments/__init__.py:57); the reference's code
+        # defaults (appearance_dim = 32, arguments/__init__.py:76) run through the unfused heads of renderer.py
+        self.embedding_appearance = None                                         # set_appearance(num_cameras), :390-392
         self.feat_planes = GaussianLearner(plane_size, num_channels)
         self._anchor = nn.Parameter(torch.empty(0, 3))
         self._offset = nn.Parameter(torch.empty(0, n_offsets, 3))
@@ -460,12 +476,18 @@ class AnchorGaussianModel(nn.Module):
     # the reference's eval()/train() touch only the three MLP heads; BatchNorm in FeaturePlanes
     # stays in train mode forever (scene/gaussian_model.py:350-366)
     def eval(self):
-        self.mlp_opacity.eval(); self.mlp_cov.eval(); self.mlp_color.eval()
-        return self
+        return self.train(False)
 
     def train(self, mode=True):
         self.mlp_opacity.train(mode); self.mlp_cov.train(mode); self.mlp_color.train(mode)
+        if self.embedding_appearance is not None:
+            self.embedding_appearance.train(mode)
         return self
+
+    def set_appearance(self, num_cameras):                   # scene/gaussian_model.py:390-392
+        if self.appearance_dim > 0:
+            dev = self.mlp_color[0].weight.device
+            self.embedding_appearance = AppearanceEmbedding(num_cameras, self.appearance_dim).to(dev)
 
     # ---- memory layout: anchors in spatial (Morton) order.  Nothing in the reference depends on the order of the
     # anchors (it only breaks exact depth ties); on MI355X it decides whether the tri-plane samples, the gradient
@@ -497,6 +519,13 @@ class AnchorGaussianModel(nn.Module):
     @property
     def get_rotation(self):
         return self.rotation_activation(self._rotation)
+
+    @property
+    def get_appearance(self):
+        if self.embedding_appearance is None:
+            raise RuntimeError("appearance_dim > 0: call set_appearance(num_cameras) first (the reference does so in "
+                               "Scene.__init__, scene/__init__.py)")
+        return self.embedding_appearance
 
     @property
     def get_opacity_mlp(self):

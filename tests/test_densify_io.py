@@ -124,6 +124,37 @@ def test_ply_layout_and_round_trip(tmp_path):
     assert other._anchor.requires_grad and other._rotation.requires_grad and other._opacity.requires_grad   # as :706-712
 
 
+def test_ply_equals_what_the_reference_hands_to_plyfile(tmp_path):
+    """tests/golden/ply_layout.npz: the structured array the REFERENCE's save_ply (scene/gaussian_model.py:640-673) built
+    and passed to PlyElement.describe(elements, 'vertex') / PlyData([el]).write(path), recorded by a stand-in for the
+    absent plyfile package (tools/make_golden.py), plus what the reference's load_ply_sparse_gaussian (:675-712) made of
+    that element.  save_ply here must write the same properties in the same order with the same bytes, and the loader
+    must return the reference loader's tensors."""
+    from splatco_amd import scene_io
+    from splatco_amd.scene_model import AnchorGaussianModel
+    d = np.load(os.path.join(GOLD, "ply_layout.npz"))
+    t = lambda n: torch.tensor(d[n])
+    pc = AnchorGaussianModel(feat_dim=32, n_offsets=int(d["n_offsets"]), plane_size=8, num_channels=15)
+    pc.set_anchors(t("anchor"), t("offset"), t("anchor_feat"), t("scaling"), t("rotation"), t("opacity"))
+    path = str(tmp_path / "point_cloud" / "iteration_7" / "point_cloud.ply")
+    scene_io.save_ply(pc, path)
+    head, payload = open(path, "rb").read().split(b"end_header\n", 1)
+    lines = [l for l in head.decode().split("\n") if l]
+    N = d["anchor"].shape[0]
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", f"element {str(d['element_name'])} {N}"]
+    assert [l.split()[-1] for l in lines[3:]] == [str(n) for n in d["field_names"]]           # names AND order
+    assert all(l.split()[:2] == ["property", "float"] for l in lines[3:]) and set(str(f) for f in d["field_formats"]) == {"<f4"}
+    assert int(d["itemsize"]) == 4 * len(d["field_names"])
+    assert payload == d["payload"].tobytes()                                                   # the reference's bytes
+    other = AnchorGaussianModel(feat_dim=32, n_offsets=int(d["n_offsets"]), plane_size=8, num_channels=15)
+    scene_io.load_ply_sparse_gaussian(other, path)
+    for n in ("anchor", "offset", "anchor_feat", "scaling", "rotation", "opacity"):
+        got = getattr(other, "_" + n)
+        assert np.array_equal(got.detach().numpy(), d["loaded." + n]), n
+        assert bool(got.requires_grad) == bool(d["loaded." + n + ".requires_grad"]), n
+        assert np.array_equal(d["loaded." + n], d[n]), n                                       # and the reference round-trips itself
+
+
 def test_ply_reader_accepts_ascii_and_permuted_properties(tmp_path):
     from splatco_amd import scene_io
     p = tmp_path / "a.ply"

@@ -826,3 +826,42 @@ def test_scaling_regulariser_matches_torch_prod(P):
     (la * 3.0).backward()
     (lb * 3.0).backward()
     assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("training", [True, False])
+def test_appearance_embedding_path_on_the_gpu(training):
+    """The reference's code default appearance_dim = 32 (arguments/__init__.py:76) on the device: fused anchor gather,
+    HIP tri-plane / BatchNorm-Linear / expansion kernels, the three heads as GEMMs (the colour head's input carries the
+    camera's code, gaussian_renderer/__init__.py:55-58,76-80) -- against the fixture captured from the reference, then a
+    render() whose backward reaches the embedding row of that camera only."""
+    from test_host_golden import _appearance_model
+    from splatco_amd.renderer import generate_neural_gaussians, prefilter_voxel, render
+    dev = torch.device("cuda:0")
+    pc, d = _appearance_model(dict(np.load(os.path.join(GOLD, "neural_gaussians_app.npz"))))
+    pc = pc.to(dev)
+    pc.train(training)
+    cam = types.SimpleNamespace(camera_center=torch.tensor(d["camera_center"], device=dev), uid=int(d["uid"]))
+    with torch.no_grad():
+        res = generate_neural_gaussians(cam, pc, torch.tensor(d["visible_mask"], device=dev), is_training=training)
+    names = ["xyz", "color", "opacity", "scaling", "rot", "neural_opacity", "mask"][:len(res)]
+    tag = "train" if training else "eval"
+    for n, v in zip(names, res):
+        want = d[f"{tag}.{n}"]
+        assert tuple(v.shape) == want.shape, n
+        if v.dtype == torch.bool:
+            np.testing.assert_array_equal(v.cpu().numpy(), want)
+        else:
+            np.testing.assert_allclose(v.cpu().numpy(), want, rtol=1e-4, atol=1e-5, err_msg=n)
+    if training:
+        view = look_at_camera(eye=(0.3, -0.2, -4.5), target=(0, 0, 0), up=(0, -1, 0), FoVx=math.radians(60), width=200,
+                              height=120, uid=int(d["uid"])).to(dev)
+        pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
+        bg = torch.ones(3, device=dev)
+        vis = prefilter_voxel(view, pc, pipe, bg)
+        out = render(view, pc, pipe, bg, visible_mask=vis, retain_grad=True)
+        out["render"].square().mean().backward()
+        g = pc.embedding_appearance.embedding.weight.grad
+        assert g is not None and g[int(d["uid"])].abs().sum() > 0
+        assert all(float(g[i].abs().sum()) == 0.0 for i in range(g.shape[0]) if i != int(d["uid"]))
+        assert pc._anchor_feat.grad is not None and pc._anchor_feat.grad.abs().sum() > 0

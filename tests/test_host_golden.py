@@ -46,7 +46,7 @@ def test_losses():
 
 
 def _load_prefixed(module, d, prefix):
-    sd = {k[len(prefix):]: torch.tensor(d[k]) for k in d.files if k.startswith(prefix) and ".out" not in k}
+    sd = {k[len(prefix):]: torch.tensor(d[k]) for k in (d.files if hasattr(d, "files") else d) if k.startswith(prefix) and ".out" not in k}
     missing, unexpected = module.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected
     assert all("num_batches_tracked" in m for m in missing), missing
@@ -129,6 +129,58 @@ def test_generate_neural_gaussians(level, training):
             np.testing.assert_array_equal(v.numpy(), want)
         else:
             np.testing.assert_allclose(v.numpy(), want, rtol=2e-5, atol=2e-6, err_msg=n)
+
+
+def _appearance_model(d, pre="app."):
+    from splatco_amd.scene_model import AnchorGaussianModel
+    sub = {k[len(pre):]: v for k, v in d.items() if k.startswith(pre)}
+    pc = AnchorGaussianModel(feat_dim=32, n_offsets=int(sub["n_offsets"]), appearance_dim=32, plane_size=40, num_channels=15)
+    pc.set_appearance(sub["embedding_appearance.embedding.weight"].shape[0])
+    for name in ("mlp_opacity", "mlp_cov", "mlp_color", "embedding_appearance", "feat_planes"):
+        _load_prefixed(getattr(pc, name), sub, name + ".")
+    pc.set_anchors(torch.tensor(sub["anchor"]), torch.tensor(sub["offset"]), torch.tensor(sub["anchor_feat"]),
+                   torch.tensor(sub["scaling"]))
+    pc.feat_planes.Q0 = 0
+    pc.feat_planes._feat.activate_level = 2
+    return pc, sub
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_generate_neural_gaussians_with_the_appearance_embedding(training):
+    """appearance_dim = 32 is the default of the reference's argument parser (arguments/__init__.py:76; the README's
+    command line passes 0): per-camera code concatenated to the colour head's input (gaussian_renderer/__init__.py:55-58,
+    76-80, scene/embedding.py).  Fixture captured from the reference's own generate_neural_gaussians."""
+    from splatco_amd.renderer import generate_neural_gaussians
+    pc, d = _appearance_model(_npz("neural_gaussians_app.npz"))
+    assert pc.mlp_color[0].in_features == 32 + 3 + 32 + 64
+    pc.train(training)
+    cam = types.SimpleNamespace(camera_center=torch.tensor(d["camera_center"]), uid=int(d["uid"]))
+    with torch.no_grad():
+        res = generate_neural_gaussians(cam, pc, torch.tensor(d["visible_mask"]), is_training=training, expand=expand_torch_chain)
+    names = ["xyz", "color", "opacity", "scaling", "rot", "neural_opacity", "mask"][:len(res)]
+    tag = "train" if training else "eval"
+    for n, v in zip(names, res):
+        want = d[f"{tag}.{n}"]
+        assert tuple(v.shape) == want.shape, n
+        if v.dtype == torch.bool:
+            np.testing.assert_array_equal(v.numpy(), want)
+        else:
+            np.testing.assert_allclose(v.numpy(), want, rtol=2e-5, atol=2e-6, err_msg=n)
+    # another camera's code changes the colours and nothing else
+    cam2 = types.SimpleNamespace(camera_center=cam.camera_center, uid=0)
+    with torch.no_grad():
+        other = generate_neural_gaussians(cam2, pc, torch.tensor(d["visible_mask"]), is_training=training, expand=expand_torch_chain)
+    assert torch.equal(other[0], res[0]) and not torch.equal(other[1], res[1])
+    # before set_appearance the reference dies at `None(camera_indicies)` (nothing in it calls set_appearance); here a message
+    pc.embedding_appearance = None
+    with pytest.raises(RuntimeError, match="set_appearance"):
+        generate_neural_gaussians(cam, pc, torch.tensor(d["visible_mask"]), is_training=training, expand=expand_torch_chain)
+
+
+def test_feature_bank_is_refused_with_the_reason():
+    from splatco_amd.scene_model import AnchorGaussianModel
+    with pytest.raises(NotImplementedError, match="68 columns"):
+        AnchorGaussianModel(use_feat_bank=True, plane_size=8)
 
 
 def test_training_statis_restatement():

@@ -18,6 +18,13 @@ Fixtures (all float32 / int, a few hundred KB in total):
                  appearance_dim=0, Q0=0, train and eval variants, activate_level 0 and 2
                  (gaussian_renderer/__init__.py:18-116) + every state_dict it needs
   training_statis.npz  GaussianModel.training_statis on small seeded masks (scene/gaussian_model.py:761-782)
+  neural_gaussians_app.npz  the same call with the reference's CODE defaults that the README command line switches off:
+                 appearance_dim = 32 (arguments/__init__.py:76; per-camera code on the colour head,
+                 gaussian_renderer/__init__.py:55-58,76-80, scene/embedding.py); N = 256 anchors, camera uid 3 of 5
+  ply_layout.npz what the reference's save_ply (scene/gaussian_model.py:640-673) hands to plyfile for the model of
+                 neural_gaussians.npz: the structured array's field names, its bytes and the element name, recorded by
+                 a stand-in for PlyElement.describe / PlyData.write (plyfile is not installed here); and what the
+                 reference's load_ply_sparse_gaussian (:675-712) makes of that element
   densify.npz    GaussianModel.adjust_anchor (anchor_growing + prune_anchor, optimizer state surgery) and
                  compute_curvature on small seeded models (scene/gaussian_model.py:784-997,1092-1110)
 """
@@ -236,6 +243,136 @@ def make_neural_gaussians():
                         offset_gradient_accum=f32(pc.offset_gradient_accum), offset_denom=f32(pc.offset_denom))
 
 
+def _ref_model(extra_args, N, seed):
+    import scene.gaussian_model as gm
+    from arguments import ModelParams
+
+    def get_offsets_cpu(self, resolutions_list, dim=3):
+        offsets_list, offsets = [0], 0
+        for r in resolutions_list:
+            offsets += r ** dim
+            offsets_list.append(offsets)
+        return torch.tensor(resolutions_list, dtype=torch.int), torch.tensor(offsets_list, dtype=torch.int)
+
+    gm.FeaturePlanes.get_offsets = get_offsets_cpu
+    parser = argparse.ArgumentParser()
+    mp = ModelParams(parser)
+    ds = mp.extract(parser.parse_args(["--num_channels", "15", "--plane_size", "40"] + extra_args))
+    torch.manual_seed(seed)
+    pc = gm.GaussianModel(ds.feat_dim, ds.n_offsets, ds.voxel_size, ds.update_depth, ds.update_init_factor,
+                          ds.update_hierachy_factor, ds.use_feat_bank, ds.appearance_dim, ds.ratio,
+                          ds.add_opacity_dist, ds.add_cov_dist, ds.add_color_dist, model_params=ds)
+    k = ds.n_offsets
+    g = torch.Generator().manual_seed(seed + 3)
+    pc._anchor = (torch.rand(N, 3, generator=g) * 3.6 - 1.8)
+    pc._offset = torch.randn(N, k, 3, generator=g) * 0.5
+    pc._anchor_feat = torch.randn(N, 32, generator=g) * 0.5
+    pc._scaling = torch.randn(N, 6, generator=g) * 0.3 - 3.0
+    pc._rotation = torch.randn(N, 4, generator=g)
+    pc._opacity = torch.randn(N, 1, generator=g)
+    pc.feat_planes.Q0 = 0
+    with torch.no_grad():
+        for m in list(pc.mlp_opacity) + list(pc.mlp_cov) + list(pc.mlp_color):
+            if isinstance(m, torch.nn.Linear):
+                m.weight.mul_(3.0)
+    return pc, ds, g
+
+
+def make_neural_gaussians_appearance():
+    """appearance_dim = 32 is the default of the reference's argument parser; the embedding itself only exists after
+    GaussianModel.set_appearance(num_cameras), which nothing in the reference calls (so the default command line stops
+    at gaussian_renderer/__init__.py:58 with `None(camera_indicies)`): the fixture calls it as a dataset loader would."""
+    import gaussian_renderer as gr
+    out = {}
+    names = ["xyz", "color", "opacity", "scaling", "rot", "neural_opacity", "mask"]
+    # (use_feat_bank = True cannot be captured: the reference concatenates ob_view, ob_dist AND the 64 geo features into the
+    # feature-bank MLP's input, gaussian_renderer/__init__.py:41-43, which was built for 3 + 1 columns,
+    # scene/gaussian_model.py:308-309 -- the branch stops with a shape error, checked here on 2026-10-02)
+    for case, extra in (("app", []),):
+        pc, ds, g = _ref_model(extra, 256, 20 + len(extra))
+        assert ds.appearance_dim == 32 and pc.use_feat_bank == bool(extra)
+        pc.set_appearance(5)
+        cam = types.SimpleNamespace(camera_center=torch.tensor([0.3, -0.2, -4.5]), uid=3)
+        vis = torch.rand(256, generator=g) > 0.25
+        pre = case + "."
+        out.update({pre + "anchor": f32(pc._anchor), pre + "offset": f32(pc._offset), pre + "anchor_feat": f32(pc._anchor_feat),
+                    pre + "scaling": f32(pc._scaling), pre + "camera_center": f32(cam.camera_center),
+                    pre + "uid": np.int64(cam.uid), pre + "visible_mask": vis.numpy(), pre + "n_offsets": np.int64(ds.n_offsets)})
+        out.update(sd_np(pre + "mlp_opacity.", pc.mlp_opacity))
+        out.update(sd_np(pre + "mlp_cov.", pc.mlp_cov))
+        out.update(sd_np(pre + "mlp_color.", pc.mlp_color))
+        out.update(sd_np(pre + "embedding_appearance.", pc.embedding_appearance))
+        if pc.use_feat_bank:
+            out.update(sd_np(pre + "mlp_feature_bank.", pc.mlp_feature_bank))
+        out.update({f"{pre}feat_planes.{kk}": v.detach().cpu().numpy() for kk, v in pc.feat_planes.state_dict().items()
+                    if "num_batches_tracked" not in kk})
+        pc.feat_planes._feat.activate_level = 2
+        for training in (True, False):
+            pc.mlp_opacity.train(training); pc.mlp_cov.train(training); pc.mlp_color.train(training)
+            with torch.no_grad():
+                res = gr.generate_neural_gaussians(cam, pc, vis, is_training=training)
+            tag = f"{pre}{'train' if training else 'eval'}"
+            for nme, v in zip(names, res):
+                out[f"{tag}.{nme}"] = v.numpy() if v.dtype == torch.bool else f32(v)
+    np.savez_compressed(os.path.join(OUT, "neural_gaussians_app.npz"), **out)
+
+
+def make_ply_layout():
+    """save_ply / load_ply_sparse_gaussian of the reference with a recording stand-in for plyfile."""
+    import scene.gaussian_model as gm
+    rec = {}
+
+    class Element:
+        def __init__(self, data, name):
+            self.data, self.name = data, name
+            self.properties = [types.SimpleNamespace(name=n) for n in data.dtype.names]
+
+        def __getitem__(self, key):
+            return self.data[key]
+
+    class PlyElement:
+        @staticmethod
+        def describe(data, name):
+            rec["element"] = Element(np.array(data, copy=True), name)
+            return rec["element"]
+
+    class PlyData:
+        def __init__(self, elements):
+            self.elements = list(elements)
+
+        def write(self, path):
+            rec["written_to"] = path
+
+        @staticmethod
+        def read(path):
+            return PlyData([rec["element"]])
+
+    gm.PlyElement, gm.PlyData = PlyElement, PlyData
+    gm.mkdir_p = lambda p: None
+    pc, ds, _ = _ref_model(["--appearance_dim", "0"], 37, 40)
+    pc.save_ply("/nonexistent/point_cloud/iteration_7/point_cloud.ply")
+    el = rec["element"]
+    assert rec["written_to"].endswith("point_cloud.ply") and el.name == "vertex"
+    out = {"element_name": np.array(el.name), "field_names": np.array(el.data.dtype.names),
+           "field_formats": np.array([el.data.dtype.fields[n][0].str for n in el.data.dtype.names]),
+           "itemsize": np.int64(el.data.dtype.itemsize), "payload": np.frombuffer(el.data.tobytes(), np.uint8),
+           "anchor": f32(pc._anchor), "offset": f32(pc._offset), "anchor_feat": f32(pc._anchor_feat),
+           "scaling": f32(pc._scaling), "rotation": f32(pc._rotation), "opacity": f32(pc._opacity),
+           "n_offsets": np.int64(ds.n_offsets)}
+    # the reference's reader on the element its writer produced (torch.tensor(..., device="cuda") -> host)
+    real_tensor = torch.tensor
+    torch.tensor = lambda *a, **k: real_tensor(*a, **{kk: v for kk, v in k.items() if kk != "device"})
+    try:
+        other = gm.GaussianModel.__new__(gm.GaussianModel)
+        other.load_ply_sparse_gaussian("ignored")
+    finally:
+        torch.tensor = real_tensor
+    for n in ("anchor", "offset", "anchor_feat", "scaling", "rotation", "opacity"):
+        out["loaded." + n] = f32(getattr(other, "_" + n))
+        out["loaded." + n + ".requires_grad"] = np.bool_(getattr(other, "_" + n).requires_grad)
+    np.savez_compressed(os.path.join(OUT, "ply_layout.npz"), **out)
+
+
 def make_densify():
     """GaussianModel.adjust_anchor / anchor_growing / prune_anchor / compute_curvature
     (scene/gaussian_model.py:784-997,1092-1110) on a small seeded model, CPU.  The reference hard-codes
@@ -314,10 +451,10 @@ def make_densify():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
-    make_cameras()
-    make_losses()
-    make_planegrid()
-    make_neural_gaussians()
-    make_densify()
+    makers = {"cameras": make_cameras, "losses": make_losses, "planegrid": make_planegrid,
+              "neural_gaussians": make_neural_gaussians, "neural_gaussians_app": make_neural_gaussians_appearance,
+              "ply_layout": make_ply_layout, "densify": make_densify}
+    for name in (sys.argv[1:] or list(makers)):          # densify patches torch.zeros / torch.ones: keep it last
+        makers[name]()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
