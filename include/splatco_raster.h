@@ -255,7 +255,10 @@ int scr_scaling_reg_backward(int64_t P, const float* scaling, const float* g, fl
  * the upstream gradients of the five outputs (any may be NULL) and overwrites EVERY element of the four parameter
  * gradients [N,32] / [N,3] / [N,30] / [N,6] (zeros for invisible anchors; d exp applied): no atomics, no memset.
  * accumulate != 0: ADDS to what the four arrays hold instead (a further view of the same step writing into the same
- * gradient buffers: the caller hands the parameters' .grad memory itself, multiview.GradArena.sink). */
+ * gradient buffers: the caller hands the parameters' .grad memory itself, multiview.GradArena.sink).
+ * A RANGE of anchors [n0, n0 + N) with n0 a multiple of 64 is the same call on offset pointers (inverse_index + n0, the
+ * four gradient arrays + n0 rows; the upstream arrays and V -- their total row count -- unchanged): the sharded step
+ * finishes the per-anchor gradients range by range so that a range's exchange overlaps the next range's kernel. */
 int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anchor_feat, const float* anchor,
                       const float* offset, const float* scaling, float* feat_out, float* anchor_out, float* offsets_out,
                       float* grid_scaling_out, float* g_fea_out, int32_t g_fea_ld, void* stream);

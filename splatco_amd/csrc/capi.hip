@@ -633,7 +633,7 @@ int scr_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inverse_inde
                                const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                const float* d_g_fea, int32_t g_fea_ld, float* g_anchor_feat, float* g_anchor,
                                float* g_offset, float* g_scaling, int32_t accumulate, void* stream) {
-    if (N < 0 || V < 0 || V > N) return fail("bad sizes");
+    if (N < 0 || V < 0) return fail("bad sizes");      // V may exceed N: N can be a range of the anchors (see the header)
     if (g_fea_ld != 71 && g_fea_ld != 72) return fail("g_fea row stride must be 71 (packed) or 72 (16-byte aligned rows)");
     if (N == 0) return 0;
     if (!inverse_index || !g_anchor_feat || !g_anchor || !g_offset || !g_scaling) return fail("NULL argument");
