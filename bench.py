@@ -104,7 +104,20 @@ def launch_ranks(args):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
-    sys.exit(subprocess.run(cmd, env=env).returncode)
+    # the ranks get their own session = their own process group, so that a hang (a rank that died inside a collective
+    # leaves its peers blocked forever) ends in a non-zero exit after --timeout instead of holding the node
+    import signal
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        sys.exit(proc.wait(timeout=args.timeout))
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: --gpus {args.gpus} did not finish within {args.timeout:.0f} s: killing the ranks", file=sys.stderr)
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)      # exactly the group started above
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        sys.exit(124)
 
 
 def make_view(rank, W, H):
@@ -218,10 +231,40 @@ def time_allreduce(fn, dev, reps=5):
 
 def allreduce_report(nbytes, ms, world, **more):
     alg = nbytes / (ms * 1e-3) / 1e9
-    out = {"bytes": int(nbytes), "ms": ms, "algbw_GBps": alg, "busbw_GBps": alg * 2 * (world - 1) / world,
-           "xgmi_link_peak_GBps": XGMI_LINK_GBS}
+    bus = alg * 2 * (world - 1) / world
+    # xGMI is a point-to-point mesh: a ring sends a GPU's whole bus traffic over ONE link (bus rate = that link's rate),
+    # a direct / all-to-all schedule spreads it over the world - 1 links to its peers
+    out = {"bytes": int(nbytes), "ms": ms, "algbw_GBps": alg, "busbw_GBps": bus,
+           "xgmi_link_peak_GBps": XGMI_LINK_GBS, "per_link_GBps_if_ring": bus, "frac_of_one_link": bus / XGMI_LINK_GBS,
+           "per_link_GBps_if_all_links": bus / max(world - 1, 1),
+           "frac_of_all_links": bus / (XGMI_LINK_GBS * max(world - 1, 1))}
     out.update(more)
     return out
+
+
+def exposed_exchange(step, state, steps, ms_with, ms_alone, dev):
+    """How much of the gradient exchange the step could NOT hide: the same K steps once more with the exchange switched
+    off (state["exchange"] = False; every rank the same program, same barriers), MAX over ranks.
+    exposed = step with - step without; overlapped = the exchange's stand-alone time - exposed (>= 0)."""
+    import torch.distributed as dist
+    state["exchange"] = False
+    for _ in range(2):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    state["exchange"] = True
+    ms_without = float(t.item())
+    exp_ms = ms_with - ms_without
+    return {"ms_per_step_with_exchange": ms_with, "ms_per_step_without_exchange": ms_without, "exposed_ms": exp_ms,
+            "exchange_alone_ms": ms_alone, "overlapped_ms": max(0.0, ms_alone - max(exp_ms, 0.0)) if ms_alone else None,
+            "note": "without = the same steps with the gradient exchange skipped (timed after the headline region)"}
 
 
 def pick_dominant(warm_prof):
@@ -230,17 +273,62 @@ def pick_dominant(warm_prof):
     return (max(per_step, key=per_step.get) if per_step else "blend_backward_kernel"), kern
 
 
+# kernel class -> the sources its code comes from (csrc/): a PMC reading is only valid for the code it was taken on
+KERNEL_SOURCES = {
+    "blend_forward_kernel": ("blend.hip", "common.h"), "blend_backward_kernel": ("blend.hip", "common.h"),
+    "preprocess_kernel": ("preprocess.hip", "common.h"), "preprocess_backward_kernel": ("preprocess.hip", "common.h"),
+    "filter_kernel": ("preprocess.hip", "common.h"), "plan_scan_kernel": ("binning.hip", "common.h"),
+    "scatter_kernel": ("binning.hip", "common.h"), "tile_sort_kernel": ("binning.hip", "common.h"),
+    "expand_kernel": ("expand.hip", "common.h"), "expand_backward_kernel": ("expand.hip", "common.h"),
+    "triplane_forward_kernel": ("triplane.hip", "common.h"), "plane_sample_backward_kernels": ("triplane.hip", "common.h"),
+    "l1_ssim_forward_kernel": ("ssim.hip", "common.h"), "l1_ssim_backward_kernel": ("ssim.hip", "common.h"),
+    "mlp_heads_kernel": ("mlp_heads.hip", "common.h"), "mlp_heads_backward_kernel": ("mlp_heads.hip", "common.h"),
+    "norm_linear_kernels": ("normlinear.hip", "common.h"), "norm_linear_backward_kernels": ("normlinear.hip", "common.h"),
+    "plane_attention_kernels": ("attention.hip", "common.h"),
+}
+
+
+def source_hashes(names=None):
+    """sha256[:16] of the kernel sources (they travel with the repository, so the GPU box can check them)."""
+    import hashlib
+    d = os.path.join(ROOT, "splatco_amd", "csrc")
+    names = names or sorted(f for f in os.listdir(d) if f.endswith((".hip", ".h")))
+    return {n: hashlib.sha256(open(os.path.join(d, n), "rb").read()).hexdigest()[:16] for n in names if os.path.exists(os.path.join(d, n))}
+
+
+def profile_value(fname, kernel):
+    """A number a profiling run left under profiles/ (PMC traffic, VALU counters), WITH its provenance -- or (None, why)
+    when the file is missing, carries no provenance (profiles/provenance.json, written by the tools that produce the
+    file), or was collected on other kernel code than the one that is running now."""
+    path = os.path.join(ROOT, "profiles", fname)
+    if not os.path.exists(path):
+        return None, None
+    table = json.load(open(path))
+    prov = table.get("_provenance")                  # written by tools/pmc_summary.py / pmc_cfg_summary.py (tools/provenance.py)
+    if prov is None:
+        return None, {"file": f"profiles/{fname}", "dropped": "no provenance recorded in this file"}
+    need = KERNEL_SOURCES.get(kernel, ("common.h",))
+    now = source_hashes(need)
+    then = prov.get("sources", {})
+    stale = [n for n in need if then.get(n) != now.get(n)]
+    if stale:
+        return None, {"file": f"profiles/{fname}", "collected_at_git": prov.get("git"), "dropped":
+                      f"stale: {', '.join(stale)} changed since the counters were collected"}
+    return table.get(kernel), {"file": f"profiles/{fname}", "collected_at_git": prov.get("git"), "collected": prov.get("date"),
+                               "command": prov.get("command"), "sources": {n: then[n] for n in need}}
+
+
 def roofline_object(dom, avg_ms, ab, peak_measured, note, flops=None, traffic_file="hbm_traffic.json", launches=1.0):
     achieved = ab / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", traffic_file)   # PMC-derived bytes per launch (cfg1) / per step (cfg2), if measured
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(dom)
-        if traffic is not None and launches != 1.0:
-            traffic = int(traffic / launches)
+    # PMC-derived bytes per launch (cfg1) / per step (cfg2): only if collected on THIS kernel code
+    traffic, traffic_src = profile_value(traffic_file, dom)
+    if traffic is not None and launches != 1.0:
+        traffic = int(traffic / launches)
     out = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": ab,
-           "avg_launch_ms": avg_ms, "peak_measured": peak_measured,
+           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+           "algorithmic_bytes_per_launch": ab,
+           "avg_launch_ms": avg_ms, "avg_launch_ms_source": "HIP events on the launch stream inside this run's timed region",
+           "peak_measured": peak_measured,
            "frac_of_measured": (achieved / peak_measured) if peak_measured else None, "note": note}
     if flops:      # a kernel whose floor is the matrix pipe, not HBM: the roofline that bounds it (the HBM view stays beside it)
         tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms else 0.0
@@ -249,20 +337,37 @@ def roofline_object(dom, avg_ms, ab, peak_measured, note, flops=None, traffic_fi
                     "hbm_view": {"achieved_GBps": achieved, "frac": achieved / HBM_PEAK_GBS,
                                  "frac_of_measured": (achieved / peak_measured) if peak_measured else None}})
         out.pop("frac_of_measured", None)
-    vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
-    if os.path.exists(vpath):
-        n_inst = json.load(open(vpath)).get(dom)
-        if n_inst and avg_ms:
-            out["valu"] = {"insts_per_launch": n_inst,
-                           "issue_frac": n_inst * 2.0 / (256 * 4 * 2.4e9 * avg_ms * 1e-3)}
-            bpath = os.path.join(ROOT, "profiles", "valu_busy.json")
-            quads = json.load(open(bpath)).get(dom) if os.path.exists(bpath) else None
-            if quads:   # SQ_ACTIVE_INST_VALU: quad-cycles the vector pipes were busy, summed over the chip's 1024 SIMDs
-                out["valu"]["busy_frac"] = quads * 4.0 / (256 * 4 * 2.4e9 * avg_ms * 1e-3)
-                out["valu"]["cycles_per_inst"] = quads * 4.0 / n_inst
-                out["valu"]["note"] = ("issue_frac prices every VALU instruction at the 2-cycle fp32 rate; busy_frac is the counter "
-                                       "SQ_ACTIVE_INST_VALU x 4 cycles over SIMDs x 2.4 GHz x kernel time: the pipes are busy for the "
-                                       "whole launch, the kernel is bound by its VALU instruction count and mix")
+    out["valu"] = valu_object(dom, avg_ms)
+    if out["valu"] is None:
+        out.pop("valu")
+    return out
+
+
+def valu_object(dom, avg_ms):
+    """The VALU view of a kernel that is not HBM-bound, from counters collected on this kernel code (else dropped) and
+    the calibration of profiles/valu_calibration.json (tools/exp/valu_calib.hip under rocprofv3: what the counter
+    SQ_ACTIVE_INST_VALU reads per SIMD and shader cycle when a pure v_fma_f32 stream keeps the vector pipe saturated, and
+    the shader clock the probes ran at).  valu_frac = the kernel's counter rate / the saturated rate: <= 1 by construction
+    if the probe saturates the pipe."""
+    n_inst, src_i = profile_value("valu_insts.json", dom)
+    quads, src_b = profile_value("valu_busy.json", dom)
+    if not avg_ms or (n_inst is None and quads is None):
+        return {"dropped": (src_i or src_b or {}).get("dropped")} if (src_i or src_b) else None
+    cpath = os.path.join(ROOT, "profiles", "valu_calibration.json")
+    cal = json.load(open(cpath)) if os.path.exists(cpath) else None
+    out = {"insts_per_launch": n_inst, "source": src_i or src_b}
+    if cal and quads and cal.get("busy_quads_per_cycle_per_simd_saturated"):
+        mhz, sat = cal["shader_clock_MHz"], cal["busy_quads_per_cycle_per_simd_saturated"]
+        cycles = avg_ms * 1e-3 * mhz * 1e6
+        out.update({
+            "valu_frac": quads / (1024 * cycles * sat), "active_quads_per_launch": quads,
+            "cycles_per_inst": (quads / sat) / n_inst if n_inst else None,
+            "calibration": {"file": "profiles/valu_calibration.json", "shader_clock_MHz": mhz,
+                            "counter_per_simd_cycle_when_saturated": sat, "probe": cal.get("saturating_probe")},
+            "note": "valu_frac = SQ_ACTIVE_INST_VALU of the kernel / (1024 SIMDs x kernel shader cycles x the counter's rate under a "
+                    "saturating v_fma_f32 stream): the fraction of the launch during which the vector pipes were issuing; "
+                    "cycles_per_inst = that busy time per VALU instruction (plain fp32 2, DPP / compares / selects 4-5, "
+                    "transcendentals and permlane swaps 8: the calibration file lists the measured costs)"})
     return out
 
 
@@ -295,7 +400,7 @@ def run_cfg1(args, rank, world, dev):
         means2D.grad = None          # the reference makes a fresh screenspace tensor per render (:133)
         img, radii = rast(means2D=means2D, **params)
         img.backward(dL)
-        if world > 1:
+        if world > 1 and state.get("exchange", True):
             allreduce_gradients(leaves, agree="once")         # SUM, in place on the operator's gradient arena (train.py:198,240);
                                                               # the ranks agree on the path once, not with a host read per step
         state["radii"], state["img"] = radii, img
@@ -330,7 +435,7 @@ def run_cfg1(args, rank, world, dev):
     elapsed = time.perf_counter() - t0
     prof = _C.profile_read()
     _C.profile_enable(False)
-    allreduce_info = None
+    allreduce_info, exposed = None, None
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -340,8 +445,9 @@ def run_cfg1(args, rank, world, dev):
         ms = time_allreduce(lambda: allreduce_gradients(leaves, agree="once"), dev)
         allreduce_info = allreduce_report(bucket.numel() * bucket.element_size(), ms, world,
                                           what=f"{P}x14 fp32 per-Gaussian gradients, one in-place all-reduce of the operator's arena")
+        exposed = exposed_exchange(step, state, args.steps, elapsed / args.steps * 1e3, ms, dev)
     if rank != 0:
-        return
+        return None
     with torch.no_grad():
         _, _, st = R.rasterize_forward(R._CSettings(rast.raster_settings), params["means3D"].detach(),
                                        params["opacities"].detach(), params["scales"].detach(),
@@ -369,9 +475,25 @@ def run_cfg1(args, rank, world, dev):
     }
     if allreduce_info is not None:
         out["allreduce"] = allreduce_info
+    if exposed is not None:
+        out["exchange"] = exposed
+    hip_image = state["img"].detach().cpu().numpy()
+    if world == 1 and not args.no_cfg2:
+        # the largest single-GPU configuration (BASELINE.json configs[2]) measured by the same process, after the headline:
+        # cfg1 stays the line's metric / value, cfg2 rides along so that it is timed under the driver's clock too
+        del params, leaves, means2D, dL, st
+        state.clear()
+        torch.cuda.empty_cache()
+        sub = argparse.Namespace(**vars(args))
+        sub.config, sub.steps, sub.warmup, sub.anchors = "cfg2", 5, 3, 0
+        c2 = run_anchor_config(sub, rank, world, dev)
+        out["cfg2"] = {k: c2[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "stages", "roofline",
+                                          "kernel_ms_per_step", "peak_mem_GiB", "time_settle_steps")}
+        out["cfg2"]["kernel_rooflines"] = {k: {kk: v[kk] for kk in ("ms_per_step", "GBps", "frac_of_measured_peak") if kk in v}
+                                           for k, v in c2["kernel_rooflines"].items()}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"], out["psnr_match_db"] = cpu_baseline(g, cam, dev, state["img"].detach().cpu().numpy())
-    print(json.dumps(out))
+        out["cpu_baseline"], out["psnr_match_db"] = cpu_baseline(g, cam, dev, hip_image)
+    return out
 
 
 # ------------------------------------------------------------------ cfg2..4: the anchor scenes
@@ -411,6 +533,7 @@ def run_anchor_config(args, rank, world, dev):
         arena = GradArena([p for grp in groups for p in grp["params"]], mode=args.exchange)
 
         def step():
+            arena.world = world if stats.get("exchange", True) else 1      # 1: reduce() and the hooks issue no collective
             loss, out, _ = collaborative_step(pc, views, gts, pipe, bg, optimizer=opt, densifier=den, arena=arena)
             stats["P"], stats["V"] = out["radii"].shape[0], int(out["selection_mask"].numel() // pc.n_offsets)
             stats["rendered"] = out["radii"]
@@ -495,7 +618,7 @@ def run_anchor_config(args, rank, world, dev):
     prof = _C.profile_read()
     _C.profile_enable(False)
     Pt = torch.tensor([stats["P"]], device=dev, dtype=torch.float64)
-    allreduce_info = None
+    allreduce_info, exposed = None, None
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -514,9 +637,13 @@ def run_anchor_config(args, rank, world, dev):
                 arena.nbytes(), ms_ar if args.exchange == "all_reduce" else ms_rs, world,
                 what=f"gradient arena: {N} anchors x 71 fp32 + planes + MLPs, exchanged in place in "
                      f"{sum(len(p) for p in arena.pieces)} pieces of <= 256 MiB, issued from autograd hooks",
-                mode=args.exchange, ms_all_reduce_pieces=ms_ar, ms_reduce_scatter_all_gather=ms_rs)
+                mode=args.exchange, ms_all_reduce_pieces=ms_ar, ms_reduce_scatter_all_gather=ms_rs,
+                units=len(arena.units), anchor_ranges=len(arena.sink_ranges),
+                issue_order_agreed=arena._order is not None)
+            exposed = exposed_exchange(step, stats, args.steps, elapsed / args.steps * 1e3,
+                                       ms_ar if args.exchange == "all_reduce" else ms_rs, dev)
     if rank != 0:
-        return
+        return None
     step_s = elapsed / args.steps
     P_all = float(Pt.item())
     kern = dict(warm_kern)
@@ -576,18 +703,22 @@ def run_anchor_config(args, rank, world, dev):
                              for k, ms in sorted(warm_step_ms.items(), key=lambda kv: -kv[1]) if ms > 0},
         "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
     }
-    tpath = os.path.join(ROOT, "profiles", f"hbm_traffic_{args.config}.json")
-    pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
     for k, v in out["kernel_rooflines"].items():
-        if k in pmc:      # PMC traffic of the class per step (tools/profile_cfg_pmc.sh), measured at the default scene of the config
-            v["pmc_traffic_MB_per_step"] = round(pmc[k] / 1e6, 1)
-            v["pmc_GBps"] = round(pmc[k] / (v["ms_per_step"] * 1e-3) / 1e9, 1)
+        # PMC traffic of the class per step (tools/profile_cfg_pmc.sh) at the default scene of the config -- only if it
+        # was collected on the kernel code that is running now
+        t_pmc, _src = profile_value(f"hbm_traffic_{args.config}.json", k) if not args.anchors else (None, None)
+        if t_pmc is not None:
+            v["pmc_traffic_MB_per_step"] = round(t_pmc / 1e6, 1)
+            v["pmc_GBps"] = round(t_pmc / (v["ms_per_step"] * 1e-3) / 1e9, 1)
+            v["pmc_collected_at_git"] = _src.get("collected_at_git")
         if k == "blend_forward_kernel" and v["frac_of_measured_peak"] > 1.0:
             v["note"] = ("the byte model counts every entry of every tile list; the forward stops reading a tile's list once "
                          "all of its pixels are opaque (T < 1e-4), which at this density is long before the end")
     if allreduce_info is not None:
         out["allreduce"] = allreduce_info
-    print(json.dumps(out))
+    if exposed is not None:
+        out["exchange"] = exposed
+    return out
 
 
 def main():
@@ -602,6 +733,9 @@ def main():
     ap.add_argument("--exchange", choices=["all_reduce", "rs_ag"], default="all_reduce",
                     help="shape of the gradient exchange of cfg3/cfg4 (GradArena)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cfg2", action="store_true", help="cfg1 at N = 1: skip the cfg2 block that rides along on the line")
+    ap.add_argument("--timeout", type=float, default=1500.0,
+                    help="--gpus N > 1 started by this script: kill the ranks and exit non-zero after this many seconds")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 20 if args.config == "cfg1" else 5
@@ -633,9 +767,15 @@ def main():
         else:
             dist.init_process_group(backend)
     if args.config == "cfg1":
-        run_cfg1(args, rank, world, dev)
+        out = run_cfg1(args, rank, world, dev)
     else:
-        run_anchor_config(args, rank, world, dev)
+        out = run_anchor_config(args, rank, world, dev)
+    if out is not None:                                      # rank 0
+        if world > 1:
+            out["ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
+                            "devices": torch.cuda.device_count()}
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -110,8 +110,11 @@ for mode, cw in (("all_reduce", 0.05), ("rs_ag", 0.0)):
         assert pa.grad is not None and pb.grad is not None and pa.grad.data_ptr() == arena.views[i].data_ptr()
         r = rel(pa.grad, pb.grad)
         worst = max(worst, r)
-        # the sum over views is formed in another order (per rank, then across ranks) and nothing else differs
-        assert r <= 1e-6, (mode, i, tuple(pa.shape), r)
+        # the sum over views is formed in another order (per rank, then across ranks) and nothing else differs: 1e-6 for
+        # the per-anchor tensors, the planes and the weight matrices; the handful of parameters with a few dozen elements
+        # (attention MLP / window weights, biases) are each a sum over millions of signed terms, where the same
+        # reordering shows at 1e-5 of the (cancelled) result
+        assert r <= (1e-6 if pa.numel() >= 1000 else 2e-5), (mode, i, tuple(pa.shape), r)
     # losses: a cross-rank pair is evaluated by both owners (each differentiates its own image): it counts twice in the
     # sum of the local losses
     tl = loss_a.clone().double()

@@ -10,7 +10,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from provenance import stamp
 
 CLASSES = (  # kernel-name prefix -> bench.py kernel class (capi.hip kProfNames)
     ("filter_kernel", "filter_kernel"), ("preprocess_backward", "preprocess_backward_kernel"),
@@ -58,7 +62,10 @@ def main(out_txt, out_json, d_fetch, d_write):
             by_class[cls] += t
             f.write(f"{k:34s} {nf[k] / steps:13.1f} {fetch[k] * 1024 / steps / 1e6:10.1f} {write.get(k, 0) * 1024 / steps / 1e6:10.1f} "
                     f"{t / 1e6:11.1f}  {cls}\n")
-    json.dump({k: int(v) for k, v in by_class.items()}, open(out_json, "w"), indent=1, sort_keys=True)
+    table = {k: int(v) for k, v in by_class.items()}
+    table["_provenance"] = stamp("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --config <cfg> --steps 3 "
+                                 "--warmup 2 --no-cpu-baseline (tools/profile_cfg_pmc.sh); bytes per step by kernel class")
+    json.dump(table, open(out_json, "w"), indent=1, sort_keys=True)
     print(open(out_txt).read())
 
 

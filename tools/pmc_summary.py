@@ -10,7 +10,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from provenance import stamp
 
 
 def short(name):
@@ -54,10 +58,14 @@ def main(out_txt, out_json, dirs):
         if "SQ_ACTIVE_INST_VALU" in acc[k]:
             key = "tile_sort_kernel" if k.startswith("tile_sort") or k.startswith("tile_merge") else k
             busy[key] = busy.get(key, 0) + int(acc[k]["SQ_ACTIVE_INST_VALU"][0] / acc[k]["SQ_ACTIVE_INST_VALU"][1])
-    if busy:   # quad-cycles per launch during which the VALU pipes are busy (bench.py: valu.busy_frac)
+    prov = stamp("rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python3 bench.py --steps 20 --warmup 5 "
+                 "--no-cpu-baseline (tools/profile_round.sh); averages per launch")
+    for table in (traffic, insts, busy):
+        table["_provenance"] = prov
+    if len(busy) > 1:   # quad-cycles per launch during which the VALU pipes are busy (bench.py: valu.valu_frac)
         json.dump(busy, open(out_json.replace("hbm_traffic", "valu_busy"), "w"), indent=1, sort_keys=True)
     json.dump(traffic, open(out_json, "w"), indent=1, sort_keys=True)
-    if insts:
+    if len(insts) > 1:
         json.dump(insts, open(out_json.replace("hbm_traffic", "valu_insts"), "w"), indent=1, sort_keys=True)
     print(open(out_txt).read())
 

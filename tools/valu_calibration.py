@@ -15,7 +15,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from provenance import stamp
 
 SIMDS = 1024
 
@@ -57,6 +61,7 @@ def main(out_txt, out_json, bare, dirs):
     out["shader_clock_MHz"] = sum(r["shader_clock_MHz"] for r in rows) / max(len(rows), 1)
     out["cycles_per_inst"] = {k: e["cycles_per_inst_per_simd"] for k, e in out["forms"].items()}
     out["counter_per_inst"] = {k: e["active_per_inst"] for k, e in out["forms"].items()}
+    out["_provenance"] = stamp("tools/profile_valu_calib.sh: tools/exp/valu_calib bare + 2 rocprofv3 --pmc passes")
     open(out_txt, "w").write("\n".join(lines) + "\n")
     json.dump(out, open(out_json, "w"), indent=1, sort_keys=True)
     print("\n".join(lines))
