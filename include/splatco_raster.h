@@ -116,7 +116,9 @@ enum {
     SCR_DBG_POINT_LIST = 3,    /* uint32[I] sorted Gaussian ids  binning */
     SCR_DBG_N_CONTRIB = 4,     /* uint32[H*W]        image  */
     SCR_DBG_FINAL_T = 5,       /* float[H*W]         image  */
-    SCR_DBG_SPLAT_RECORDS = 6  /* float[P][12]: mx,my,-Qxx/2,-Qxy,-Qyy/2,opacity,r,g,b,depth,rect bits x2   geom */
+    SCR_DBG_SPLAT_RECORDS = 6, /* float[P][12]: mx,my,-Qxx/2,-Qxy,-Qyy/2,opacity,r,g,b,depth,rect bits x2   geom */
+    SCR_DBG_QMASK = 7,         /* uint8[I]  quadrant mask of every sorted list entry (bit q: the splat can reach quadrant q)  binning */
+    SCR_DBG_GM_INDEX = 8       /* uint32[I] Gaussian-major index of every sorted list entry (where its gradient record goes)   binning */
 };
 int scr_debug_get(int which, int64_t P, int64_t num_rendered, int32_t image_height, int32_t image_width,
                   const void* geom_buf, const void* binning_buf, const void* image_buf, void* out,

@@ -32,7 +32,8 @@ SYMBOLS = [
 PROF_COUNT = 19
 ABI_VERSION = 18
 
-DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS = range(7)
+(DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS, DBG_QMASK,
+ DBG_GM_INDEX) = range(9)
 
 
 class Settings(C.Structure):

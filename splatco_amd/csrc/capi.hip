@@ -303,6 +303,11 @@ int scr_debug_get(int which, int64_t P, int64_t I, int32_t H, int32_t W, const v
         if (!binning_buf) return fail("binning_buf is NULL");
         src = bin_view((void*)binning_buf, I, 0).point_list;
         bytes = (size_t)I * 4;
+    } else if (which == SCR_DBG_QMASK || which == SCR_DBG_GM_INDEX) {
+        if (!binning_buf) return fail("binning_buf is NULL");
+        BinView bv = bin_view((void*)binning_buf, I, 0);
+        src = which == SCR_DBG_QMASK ? (const void*)bv.qmask : (const void*)bv.gm_index;
+        bytes = which == SCR_DBG_QMASK ? (size_t)I : (size_t)I * 4;
     } else if (which == SCR_DBG_N_CONTRIB || which == SCR_DBG_FINAL_T) {
         if (!image_buf) return fail("image_buf is NULL");
         ImgView iv = img_view((void*)image_buf, H, W);

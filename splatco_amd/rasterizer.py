@@ -92,6 +92,7 @@ class RasterState:
             _C.DBG_N_CONTRIB: ((self.cs.H, self.cs.W), torch.int32),
             _C.DBG_FINAL_T: ((self.cs.H, self.cs.W), torch.float32),
             _C.DBG_SPLAT_RECORDS: ((self.P, 12), torch.float32),
+            _C.DBG_QMASK: ((self.I,), torch.uint8), _C.DBG_GM_INDEX: ((self.I,), torch.int32),
         }
         shape, dt = shapes[which]
         out = torch.empty(shape, dtype=dt, device=dev)

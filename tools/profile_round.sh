@@ -17,7 +17,7 @@ fi
 $T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${TAG}_fetch -o fetch -- python3 $B > $OUT/pmc_$TAG.log 2>&1
 $T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${TAG}_write -o write -- python3 $B >> $OUT/pmc_$TAG.log 2>&1
 $T rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_${TAG}_sq1 -o sq1 -- python3 $B >> $OUT/pmc_$TAG.log 2>&1
-$T rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_${TAG}_sq2 -o sq2 -- python3 $B >> $OUT/pmc_$TAG.log 2>&1
+$T rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_${TAG}_sq2 -o sq2 -- python3 $B >> $OUT/pmc_$TAG.log 2>&1
 cd $REPO
 tail -1 $OUT/bench_$TAG.log
 find $OUT/prof_$TAG -name "*.db" | head -2
