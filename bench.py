@@ -728,8 +728,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3", "cfg4"], default="cfg1")
     ap.add_argument("--anchors", type=int, default=0, help="override the anchor count of cfg2..4 (developer runs)")
-    ap.add_argument("--anchor-order", choices=["random", "morton"], default="random",
-                    help="memory order of the anchors of cfg2..4: as drawn (random in space) or Morton-sorted")
+    ap.add_argument("--anchor-order", choices=["random", "morton"], default="morton",
+                    help="memory order of the anchors of cfg2..4: Morton-sorted (what AnchorDensifier.sort_anchors keeps; the "
+                         "reference's own initial order is the sorted np.unique order of create_from_pcd, "
+                         "scene/gaussian_model.py:449) or as drawn (random in space: the stated worst case for every gather)")
     ap.add_argument("--exchange", choices=["all_reduce", "rs_ag"], default="all_reduce",
                     help="shape of the gradient exchange of cfg3/cfg4 (GradArena)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(uint32_t nblk, uint32_t
 template <bool LDS_HIST>
 __global__ void __launch_bounds__(BIN_THREADS)
 scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec, uint2* __restrict__ gm_base,
-               const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
+               uint32_t* __restrict__ live_bits, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
                uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ ranges,
                uint32_t* __restrict__ cursor, unsigned long long* __restrict__ keys) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // [tiles] when LDS_HIST
@@ -176,12 +176,17 @@ scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec, uin
         const uint32_t klo = (uint32_t)i << 4;
         const float4 r0 = rec[3 * i], r1 = rec[3 * i + 1];
         const unsigned long long khi = (unsigned long long)dbits[r] << 32;
+        uint32_t live = 0, kbit = 1;     // bit k: tile k of this walk has a reachable quadrant (k < 32; later tiles: re-tested by the reader)
         for (int ty = rlo[r] >> 16; ty < (int)(rhi[r] >> 16); ++ty)
             for (int tx = rlo[r] & 0xffff; tx < (int)(rhi[r] & 0xffff); ++tx) {
                 const uint32_t t = (uint32_t)(ty * gx + tx);
                 const uint32_t slot = LDS_HIST ? atomicAdd(&hist[t], 1u) : ranges[2 * t] + atomicAdd(&cursor[t], 1u);
-                keys[slot] = khi | klo | quadrant_mask(r0, r1, tx * TILE, ty * TILE);
+                const uint32_t qm = quadrant_mask(r0, r1, tx * TILE, ty * TILE);
+                keys[slot] = khi | klo | qm;
+                live |= qm ? kbit : 0u;
+                kbit <<= 1;               // 0 from the 33rd tile on
             }
+        live_bits[i] = live;
     }
 }
 
@@ -281,15 +286,17 @@ constexpr int WAVE_SORT_MAX = 1024;
 struct FinalLists {
     const uint2* gm_base;
     uint32_t* point_list;
-    uint32_t* gm_index;
+    uint32_t* gm_index;     // nullptr: deep lists (common.h deep_lists) -- the blend backward takes the index from gm_base itself
     uint8_t* qmask;
     int tx, ty;  // this tile
     __device__ __forceinline__ void write(uint32_t i, uint32_t klo) const {
         const uint32_t id = klo >> 4;
-        const uint2 b = gm_base[id];  // 8 B per Gaussian: an XCD's band of tiles keeps its share in L2
         point_list[i] = id;
         qmask[i] = (uint8_t)(klo & 15u);
-        gm_index[i] = b.x + (uint32_t)ty * b.y + (uint32_t)tx;
+        if (gm_index) {               // kernel-uniform
+            const uint2 b = gm_base[id];  // 8 B per Gaussian: an XCD's band of tiles keeps its share in L2
+            gm_index[i] = b.x + (uint32_t)ty * b.y + (uint32_t)tx;
+        }
     }
 };
 
@@ -675,20 +682,21 @@ void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const Bi
     }
     if (g.tiles <= LDS_HIST_MAX_TILES)
         scatter_kernel<true><<<nb, BIN_THREADS, (size_t)g.tiles * 4, st>>>(
-            P, g.gx, g.tiles, gv.rec, gv.gm_base, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor,
-            bv.keys);
+            P, g.gx, g.tiles, gv.rec, gv.gm_base, gv.live_bits, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges,
+            gv.cursor, bv.keys);
     else
         scatter_kernel<false><<<nb, BIN_THREADS, 0, st>>>(
-            P, g.gx, g.tiles, gv.rec, gv.gm_base, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges, gv.cursor,
-            bv.keys);
+            P, g.gx, g.tiles, gv.rec, gv.gm_base, gv.live_bits, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges,
+            gv.cursor, bv.keys);
 }
 
 void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, int64_t max_tile_instances,
-                      hipStream_t st) {
+                      bool with_gm_index, hipStream_t st) {
+    uint32_t* const gm_index = with_gm_index ? bv.gm_index : nullptr;
     Grid g(ks.H, ks.W);
     const unsigned gt = (unsigned)xcd_grid(g.tiles);
     if (max_tile_instances <= 0) return;
-    tile_sort_wave_kernel<<<gt, 64, 0, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.gm_base, bv.point_list, bv.gm_index,
+    tile_sort_wave_kernel<<<gt, 64, 0, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.gm_base, bv.point_list, gm_index,
                                              bv.qmask);
     if (max_tile_instances <= WAVE_SORT_MAX) return;
     const unsigned chunks = (unsigned)((max_tile_instances + WG_SORT_MAX - 1) / WG_SORT_MAX);
@@ -702,7 +710,7 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
         (void)hipGetLastError();
     }
     tile_sort_wg_kernel<<<dim3(gt, chunks), WG_SORT_THREADS, lds, st>>>(g.tiles, g.gx, gv.ranges, bv.keys, gv.gm_base, bv.point_list,
-                                                                        bv.gm_index, bv.qmask);
+                                                                        gm_index, bv.qmask);
     if (chunks <= 1) return;
     unsigned passes = 0;
     while ((1u << passes) < chunks) ++passes;
@@ -711,7 +719,7 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
         const unsigned long long* src = (p & 1u) ? bv.keys2 : bv.keys;  // data of pass p lives in buffer (p & 1)
         unsigned long long* dst = (p & 1u) ? bv.keys : bv.keys2;
         tile_merge_path_kernel<<<dim3(gt, segs), 256, 0, st>>>(g.tiles, g.gx, p, gv.ranges, src, dst, gv.gm_base,
-                                                               bv.point_list, bv.gm_index, bv.qmask);
+                                                               bv.point_list, gm_index, bv.qmask);
     }
 }
 

@@ -478,6 +478,7 @@ __global__ void __launch_bounds__(256, SCR_BWD_MIN_WAVES)
 blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const unsigned long long* __restrict__ total,
                       const uint32_t* __restrict__ ranges,
                       const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ gm_index,
+                      const uint2* __restrict__ gm_base,
                       const uint8_t* __restrict__ qmask, const float4* __restrict__ rec,
                       const float* __restrict__ bg, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
@@ -559,11 +560,18 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         }
         cut_key[t] = ck;
     }
+    // Gaussian-major index of a list entry = where its gradient record goes
+    const uint32_t tile_x = (uint32_t)(t % gx), tile_y = (uint32_t)(t / gx);
+    auto gm_of = [&](uint32_t pos, uint32_t id) -> uint32_t {
+        if (gm_index) return gm_index[pos];           // kernel-uniform: the tile sort materialised it
+        const uint2 b = gm_base[id];      // deep lists: 8 B per Gaussian (scatter_kernel), index of its rect walk's origin + rect width
+        return b.x + tile_y * b.y + tile_x;
+    };
     if (!cut && wave < 3)
         for (int ci = nround - 1; ci > live_top; --ci) {     // all-zero records (waves 0..2 write one part each)
             const uint32_t i = (uint32_t)ci * BCH + lane;
-            if (i < n) {
-                GradRec& gr = grad_rec[gm_index[lo + i]];
+            if (i < n && qmask[lo + i] != 0) {     // mask 0: no record (see the combine below)
+                GradRec& gr = grad_rec[gm_of(lo + i, point_list[lo + i])];
                 if (wave == 0) store16_dword_aligned(&gr.a, make_float4(0, 0, 0, 0));
                 else if (wave == 1) store16_dword_aligned(&gr.b, make_float4(0, 0, 0, 0));
                 else gr.c = 0.0f;
@@ -582,7 +590,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         const bool have = ci >= 0 && i < n;
         m = have ? qmask[lo + i] : 0u;
         id = have ? point_list[lo + i] : 0u;
-        slot = have ? gm_index[lo + i] : 0u;
+        slot = have ? gm_of(lo + i, id) : 0u;
     };
     auto gather = [&](int ci, uint32_t m, uint32_t id, uint32_t slot) {
         const uint32_t i = (uint32_t)ci * BCH + lane;
@@ -716,7 +724,11 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         __syncthreads();  // B: every wave's sums for this round are in acc
         // ---- combine: wave p (< 3) writes part p of the 36-byte gradient record of position `lane`,
         // adding the waves that took part in a fixed order
-        if (wave < 3 && base + lane < n) {   // every entry of a live round gets its record (zeros if no wave took part)
+        // Every entry of a live round that SOME quadrant can reach gets its record (zeros if no wave took part).  An entry
+        // with quadrant mask 0 -- the splat's rect covers the tile, its alpha >= 1/255 ellipse does not: a third of the
+        // instances at the benchmark density -- gets none: the scatter kernel left that verdict per Gaussian in live_bits
+        // and preprocess_backward_kernel does not read what was not written
+        if (wave < 3 && base + lane < n && m_this != 0) {
             const uint32_t i = base + lane;
             float4 r = make_float4(0, 0, 0, 0);
             auto part = [&](int w) {
@@ -758,11 +770,13 @@ void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView
 }
 
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                           const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, hipStream_t st) {
+                           const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, bool gm_from_base,
+                           hipStream_t st) {
     Grid g(ks.H, ks.W);
     blend_backward_kernel<<<(unsigned)blend_slots_per_xcd(g) * NUM_XCD, 256, 0, st>>>(
-        ks.W, ks.H, g.gx, g.tiles, gv.tile_count, gv.total, gv.ranges, bv.point_list, bv.gm_index, bv.qmask, gv.rec, ks.bg, iv.final_T,
-        iv.n_contrib, dL_dcolor, grad_rec, iv.cut_key, stamp);
+        ks.W, ks.H, g.gx, g.tiles, gv.tile_count, gv.total, gv.ranges, bv.point_list, gm_from_base ? nullptr : bv.gm_index, gv.gm_base,
+        bv.qmask, gv.rec, ks.bg,
+        iv.final_T, iv.n_contrib, dL_dcolor, grad_rec, iv.cut_key, stamp);
 }
 
 }  // namespace scr

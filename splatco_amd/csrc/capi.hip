@@ -242,7 +242,7 @@ int scr_forward_run(int64_t P, int64_t I, int64_t max_tile, const scr_settings* 
     if (I > 0) {
         { ProfScope ps_(SCR_PROF_SCATTER, st); launch_scatter(P, ks, gv, bv, st); }
         CHECK_LAUNCH("scatter_kernel", settings->debug, st);
-        { ProfScope ps_(SCR_PROF_TILE_SORT, st); launch_tile_sort(ks, gv, bv, max_tile, st); }
+        { ProfScope ps_(SCR_PROF_TILE_SORT, st); launch_tile_sort(ks, gv, bv, max_tile, !deep_lists(I, Grid(ks.H, ks.W).tiles), st); }
         CHECK_LAUNCH("tile_sort_kernel", settings->debug, st);
     }
     { ProfScope ps_(SCR_PROF_BLEND_FORWARD, st); launch_blend_forward(ks, gv, bv, iv, out_color, 2 * max_tile * (int64_t)Grid(ks.H, ks.W).tiles > 3 * I, st); }
@@ -274,7 +274,7 @@ int scr_backward(int64_t P, int32_t M, int64_t I, const float* means3D, const fl
     const unsigned long long stamp = ++stamp_counter;
     if (I > 0) {
         { ProfScope ps_(SCR_PROF_BLEND_BACKWARD, st);
-          launch_blend_backward(ks, gv, bv, iv, dL_dcolor, (GradRec*)scratch, stamp, st); }
+          launch_blend_backward(ks, gv, bv, iv, dL_dcolor, (GradRec*)scratch, stamp, deep_lists(I, Grid(ks.H, ks.W).tiles), st); }
         CHECK_LAUNCH("blend_backward_kernel", settings->debug, st);
     }
     { ProfScope ps_(SCR_PROF_PREPROCESS_BACKWARD, st);
@@ -306,6 +306,8 @@ int scr_debug_get(int which, int64_t P, int64_t I, int32_t H, int32_t W, const v
     } else if (which == SCR_DBG_QMASK || which == SCR_DBG_GM_INDEX) {
         if (!binning_buf) return fail("binning_buf is NULL");
         BinView bv = bin_view((void*)binning_buf, I, 0);
+        if (which == SCR_DBG_GM_INDEX && deep_lists(I, g.tiles))
+            return fail("gm_index is not materialised for deep tile lists (I > 8192 per tile on average)");
         src = which == SCR_DBG_QMASK ? (const void*)bv.qmask : (const void*)bv.gm_index;
         bytes = which == SCR_DBG_QMASK ? (size_t)I : (size_t)I * 4;
     } else if (which == SCR_DBG_N_CONTRIB || which == SCR_DBG_FINAL_T) {

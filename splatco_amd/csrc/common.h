@@ -56,6 +56,9 @@ struct GeomView {
     uint8_t* clamped;         // [P] bit c set when SH colour channel c was clamped at 0
     uint2* gm_base;           // [P] (b, rw): Gaussian-major index of the instance in tile (tx, ty) = b + ty*rw + tx
                               //     (b = first index - y0*rw - x0 mod 2^32, rw = rect width; written by the scatter kernel)
+    uint32_t* live_bits;      // [P] bit k: the k-th tile of the Gaussian's rect walk (row-major) can be reached by one of its
+                              //     quadrants (quadrant mask != 0), k < 32; written by the scatter kernel.  An instance whose bit
+                              //     is clear gets no gradient record (blend backward) and none is read (preprocess backward)
     uint32_t* block_sums;     // [ceil(P/BIN_GPW)] -> exclusive prefix after scan
     uint32_t* tile_count;     // [tiles] instances per tile (preprocess -> plan scan); afterwards the blend launches' tile order
     uint32_t* ranges;         // [tiles][2] (start, end)
@@ -77,6 +80,7 @@ inline __host__ GeomView geom_view(void* base, int64_t P, int H, int W) {
     v.point_offsets = (uint32_t*)take((size_t)P * 4);
     v.clamped = (uint8_t*)take((size_t)P);
     v.gm_base = (uint2*)take((size_t)P * 8);
+    v.live_bits = (uint32_t*)take((size_t)P * 4);
     v.block_sums = (uint32_t*)take((nblk + 1) * 4);
     v.tile_count = (uint32_t*)take((size_t)g.tiles * 4);
     v.ranges = (uint32_t*)take((size_t)g.tiles * 8);
@@ -85,6 +89,14 @@ inline __host__ GeomView geom_view(void* base, int64_t P, int H, int W) {
     v.bytes = off;
     return v;
 }
+
+// Deep tile lists (MatrixCity scale: tens of thousands of entries per tile, a few hundred of them in front of the pixels'
+// last contributors): the tile sort does not materialise gm_index -- one 8-byte gm_base gather per instance, most of them
+// for entries the backward pass never visits -- and the blend backward derives the index of the entries it does visit
+// from gm_base itself.  With every entry live (the benchmark density) the sort's coalesced gm_index is the cheaper way
+// round (measured both ways: tile sort 5.1 -> 4.0 ms at 20 M anchors; blend backward +4 % at cfg1 / cfg2).
+// Both passes derive the choice from the same two numbers.
+inline __host__ bool deep_lists(int64_t I, int tiles) { return I > (int64_t)8192 * tiles; }
 
 // ---- binning buffer: per (Gaussian, tile) instance lists ----
 struct BinView {
@@ -325,11 +337,12 @@ void launch_plan_scans(int64_t P, const KSettings& ks, const GeomView& gv, unsig
                        unsigned long long seq, hipStream_t st);
 void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const BinView& bv, hipStream_t st);
 void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, int64_t max_tile_instances,
-                      hipStream_t st);
+                      bool with_gm_index, hipStream_t st);
 void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
                           float* out_color, bool longest_first, hipStream_t st);
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                           const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, hipStream_t st);
+                           const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, bool gm_from_base,
+                           hipStream_t st);
 void launch_preprocess_backward(int64_t P, int M, const float* means3D, const float* scales,
                                 const float* rotations, const float* cov3D, const float* shs,
                                 const KSettings& ks, const int32_t* radii, const GeomView& gv,

@@ -318,7 +318,8 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
                            const float* __restrict__ scales, const float* __restrict__ rotations,
                            const float* __restrict__ cov3D, const float* __restrict__ shs, KSettings ks,
                            const int32_t* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
-                           const uint32_t* __restrict__ point_offsets, const uint8_t* __restrict__ clamped,
+                           const uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ live_bits,
+                           const uint8_t* __restrict__ clamped,
                            const float4* __restrict__ rec, const GradRec* __restrict__ grad_rec,
                            const unsigned long long* __restrict__ cut_key, unsigned long long stamp, int tiles,
                            float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
@@ -353,8 +354,18 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
         const uint32_t rlo = __float_as_uint(r2.z), rhi = __float_as_uint(r2.w);
         const int gxt = (ks.W + TILE - 1) / TILE, rx0 = (int)(rlo & 0xffffu), rx1 = (int)(rhi & 0xffffu);
         int tcx = rx0, tcy = (int)(rlo >> 16);      // tile of record k
-        auto next_tile = [&]() {
+        // An instance no quadrant of its tile can reach (quadrant mask 0: the splat's rect covers the tile, its ellipse at
+        // the alpha >= 1/255 level does not -- a third of the instances at the benchmark density) has NO record: the blend
+        // backward skipped it.  The scatter kernel left the verdicts of the first 32 tiles of the walk in live_bits; for
+        // the rare larger rects the same test on the same record is repeated here (same function, same inputs, same
+        // compiler flags: bit for bit the same decision).
+        const uint32_t lbits = live_bits[i];
+        const float4 qa = rec[3 * i], qb = rec[3 * i + 1];
+        uint32_t kwalk = 0;
+        auto next_tile = [&](bool& live) {
             const int t = tcy * gxt + tcx;
+            live = kwalk < 32u ? ((lbits >> kwalk) & 1u) != 0u : quadrant_mask(qa, qb, tcx * TILE, tcy * TILE) != 0u;
+            ++kwalk;
             if (++tcx == rx1) { tcx = rx0; ++tcy; }
             return t;
         };
@@ -363,30 +374,38 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
             syy += ok ? q.b.x : 0.0f; gop += ok ? q.b.y : 0.0f; gcol[0] += ok ? q.b.z : 0.0f; gcol[1] += ok ? q.b.w : 0.0f;
             gcol[2] += ok ? q.c : 0.0f;
         };
+        const GradRec none = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, 0.0f};
         uint32_t k = 0;
         if (cut_key[tiles] == stamp) {      // wave-uniform: some tile of this call left entries without records
             for (; k + 4 <= n; k += 4) {
                 GradRec q[4];
                 unsigned long long ck[4];
+                bool live[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { ck[j] = cut_key[next_tile()]; q[j] = gr[k + j]; }
+                for (int j = 0; j < 4; ++j) { ck[j] = cut_key[next_tile(live[j])]; q[j] = live[j] ? gr[k + j] : none; }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) add(q[j], mykey < ck[j]);
+                for (int j = 0; j < 4; ++j) add(q[j], live[j] && mykey < ck[j]);
             }
             for (; k < n; ++k) {
-                const unsigned long long ck = cut_key[next_tile()];
-                const GradRec q = gr[k];
-                add(q, mykey < ck);
+                bool live;
+                const unsigned long long ck = cut_key[next_tile(live)];
+                const GradRec q = live ? gr[k] : none;
+                add(q, live && mykey < ck);
             }
-        } else {                            // every instance has its record (the benchmark density): no look-ups
+        } else {                            // every live instance has its record (the benchmark density): no look-ups
             for (; k + 4 <= n; k += 4) {
                 GradRec q[4];
+                bool live[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) q[j] = gr[k + j];
+                for (int j = 0; j < 4; ++j) { next_tile(live[j]); q[j] = live[j] ? gr[k + j] : none; }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) add(q[j], true);
+                for (int j = 0; j < 4; ++j) add(q[j], live[j]);
             }
-            for (; k < n; ++k) add(gr[k], true);
+            for (; k < n; ++k) {
+                bool live;
+                next_tile(live);
+                add(live ? gr[k] : none, live);
+            }
         }
         // the per-splat constants the blend kernel left out.  The moments are of Y = opacity * G * dL/dalpha, i.e.
         // dL/dG already: dG/dmean = -G Q d with Q = (-2A, -B, -2C), dG/dQ = -G/2 d d^T (Qxy counted once: factor 1);
@@ -628,7 +647,7 @@ void launch_preprocess_backward(int64_t P, int M, const float* means3D, const fl
                                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, hipStream_t st) {
     if (P <= 0) return;
     preprocess_backward_kernel<<<nblk(P, PRE_BLOCK), PRE_BLOCK, 0, st>>>(
-        P, M, means3D, scales, rotations, cov3D, shs, ks, radii, gv.tiles_touched, gv.point_offsets,
+        P, M, means3D, scales, rotations, cov3D, shs, ks, radii, gv.tiles_touched, gv.point_offsets, gv.live_bits,
         gv.clamped, gv.rec, grad_rec, cut_key, stamp, Grid(ks.H, ks.W).tiles, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh, dL_dopacity,
         dL_dscales, dL_drotations, dL_dcov3D);
 }

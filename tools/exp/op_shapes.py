@@ -25,7 +25,7 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step()
     torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.self_device_time_total > 50]
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.self_device_time_total > 8 and not e.key.startswith(("void", "scr::", "_", "Memcpy", "Memset"))]
 rows.sort(key=lambda e: -e.self_device_time_total)
-for e in rows[:45]:
+for e in rows[:90]:
     print(f"{e.key[:42]:42s} {e.self_device_time_total / 1e3:7.3f} ms x{e.count:3d}  {str(e.input_shapes)[:110]}")

@@ -59,7 +59,7 @@ def main(out_txt, out_json, dirs):
             key = "tile_sort_kernel" if k.startswith("tile_sort") or k.startswith("tile_merge") else k
             busy[key] = busy.get(key, 0) + int(acc[k]["SQ_ACTIVE_INST_VALU"][0] / acc[k]["SQ_ACTIVE_INST_VALU"][1])
     prov = stamp("rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python3 bench.py --steps 20 --warmup 5 "
-                 "--no-cpu-baseline (tools/profile_round.sh); averages per launch")
+                 "--no-cpu-baseline --no-cfg2 (tools/profile_round.sh); averages per launch")
     for table in (traffic, insts, busy):
         table["_provenance"] = prov
     if len(busy) > 1:   # quad-cycles per launch during which the VALU pipes are busy (bench.py: valu.valu_frac)
