@@ -162,9 +162,11 @@ int scr_expand_plan(int64_t n_candidates, const float* neural_opacity, void* scr
                     int64_t* num_selected_host, void* stream);
 /* mask -> ascending index list (the `t[visible_mask]` index of gaussian_renderer/__init__.py:23-29; what
  * torch.nonzero returns for a 1-D mask): plan counts the set bytes (one stream synchronisation, like scr_expand_plan),
- * run writes index[num_set] int64.  scratch: scr_expand_scratch_bytes(n). */
+ * run writes index[num_set] int64 and, when `inverse` is not NULL, inverse[n] int64 = the position of entry i in the
+ * index list, -1 where the mask is clear (what scr_anchor_gather_backward takes as inverse_index: the framework builds
+ * it with a fill, an arange and an index_put).  scratch: scr_expand_scratch_bytes(n). */
 int scr_mask_index_plan(int64_t n, const uint8_t* mask, void* scratch, int64_t* num_set_host, void* stream);
-int scr_mask_index_run(int64_t n, const uint8_t* mask, const void* scratch, int64_t* index, void* stream);
+int scr_mask_index_run(int64_t n, const uint8_t* mask, const void* scratch, int64_t* index, int64_t* inverse, void* stream);
 int scr_expand_run(int64_t V, int32_t k, const float* neural_opacity, const float* color,
                    const float* scale_rot, const float* offsets, const float* grid_scaling,
                    const float* anchor, const void* scratch, int32_t* out_index, uint8_t* mask_out,
@@ -279,6 +281,27 @@ int scr_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inverse_inde
  * aligned rows take the wide-load path).  Sums over the rows are formed per workgroup and combined in a fixed order:
  * bit-reproducible.  Scratch from scr_norm_linear_scratch_bytes(V), the same block for forward and backward. */
 size_t scr_norm_linear_scratch_bytes(int64_t V);
+/* Normalised tri-plane sample coordinates of contiguous xyz[V,3] in the box [lo, hi] (host floats):
+ * out = (xyz - lo) / (hi - lo) * 2 - 1 (scene/grids.py:146), the same IEEE operations in the same order as the four
+ * elementwise passes of the reference, in one. */
+int scr_box_coords(int64_t V, const float* xyz, const float* lo_host, const float* hi_host, float* out, void* stream);
+/* The parameter side of the same fold.  FeaturePlanes sums L <= 4 pairs Linear_i(BatchNorm_i(.)) (scene/gaussian_model.py:
+ * 149-169): pair i reads columns [cols[i], cols[i] + widths[i]) of the d-column input (the plane branch) or all of it
+ * (cols[i] = 0, widths[i] = d: the attribute branch).  scr_norm_fold builds G[32, d] and c[32] from the pairs' parameters
+ * (G[r, cols_i + j] += W_i[r, j] gamma_i[j];  c[r] = sum_i (W_i[r, :] . beta_i + b_i[r])), scr_norm_fold_backward turns
+ * dG / dc into the gradients of the 4 L parameter tensors, scr_norm_running_stats applies nn.BatchNorm1d's running-statistics
+ * update (momentum form) for all pairs from the batch mean / biased variance and n rows.  One single-workgroup launch each;
+ * the `_host` arguments are HOST arrays of L widths / column offsets / DEVICE pointers. */
+int scr_norm_fold(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host, const void* const* lin_weight_host,
+                  const void* const* lin_bias_host, const void* const* bn_weight_host, const void* const* bn_bias_host, float* G,
+                  float* c, void* stream);
+int scr_norm_fold_backward(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host,
+                           const void* const* lin_weight_host, const void* const* bn_weight_host, const void* const* bn_bias_host,
+                           const float* dG, const float* dc, void* const* d_lin_weight_host, void* const* d_lin_bias_host,
+                           void* const* d_bn_weight_host, void* const* d_bn_bias_host, void* stream);
+int scr_norm_running_stats(int32_t L, const int32_t* widths_host, const int32_t* cols_host, const float* momentum_host,
+                           void* const* running_mean_host, void* const* running_var_host, void* const* num_batches_host,
+                           const float* mean, const float* var, int64_t n, void* stream);
 int scr_norm_linear_forward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* G, const float* c, float eps,
                             float* y, float* mean, float* var, float* inv, void* scratch, void* stream);
 int scr_norm_linear_backward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* G,

@@ -28,6 +28,7 @@ SYMBOLS = [
     "scr_statis_compute", "scr_statis_apply", "scr_copy_probe",
     "scr_knn", "scr_knn_curvature", "scr_anchor_gather", "scr_anchor_gather_backward", "scr_mlp_heads_hidden_bytes", "scr_mlp_heads_partial_bytes", "scr_mlp_heads_forward", "scr_mlp_heads_backward",
     "scr_norm_linear_scratch_bytes", "scr_norm_linear_forward", "scr_norm_linear_backward",
+    "scr_norm_fold", "scr_norm_fold_backward", "scr_norm_running_stats", "scr_box_coords",
 ]
 PROF_COUNT = 19
 ABI_VERSION = 18
@@ -106,6 +107,13 @@ def _load():
     lib.scr_norm_linear_forward.restype = C.c_int
     lib.scr_norm_linear_backward.argtypes = [i64, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.scr_norm_linear_backward.restype = C.c_int
+    lib.scr_box_coords.argtypes = [i64, vp, vp, vp, vp, vp]
+    lib.scr_box_coords.restype = C.c_int
+    lib.scr_norm_fold.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.scr_norm_fold_backward.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.scr_norm_running_stats.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    for f in ("scr_norm_fold", "scr_norm_fold_backward", "scr_norm_running_stats"):
+        getattr(lib, f).restype = C.c_int
     lib.scr_plane_sample_backward.restype = C.c_int
     lib.scr_l1_ssim_scratch_bytes.argtypes = [i32, i32, i32, i32]
     lib.scr_l1_ssim_scratch_bytes.restype = C.c_size_t
@@ -118,7 +126,7 @@ def _load():
     lib.scr_scaling_reg_backward.argtypes = [i64, vp, vp, vp, vp]
     lib.scr_scaling_reg_forward.restype = lib.scr_scaling_reg_backward.restype = C.c_int
     lib.scr_mask_index_plan.argtypes = [i64, vp, vp, C.POINTER(C.c_int64), vp]
-    lib.scr_mask_index_run.argtypes = [i64, vp, vp, vp, vp]
+    lib.scr_mask_index_run.argtypes = [i64, vp, vp, vp, vp, vp]
     lib.scr_mask_index_plan.restype = lib.scr_mask_index_run.restype = C.c_int
     lib.scr_tpa_scratch_bytes.argtypes = [i32, i32, i32]
     lib.scr_tpa_scratch_bytes.restype = C.c_size_t

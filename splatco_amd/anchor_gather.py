@@ -66,7 +66,10 @@ class _AnchorGather(torch.autograd.Function):
                 _C.check(_C.lib.scr_anchor_gather(V, idx.data_ptr(), anchor_feat.data_ptr(), anchor.data_ptr(),
                                                   offset.data_ptr(), scaling.data_ptr(), feat.data_ptr(), anc.data_ptr(),
                                                   off.data_ptr(), gs.data_ptr(), g_fea.data_ptr(), 72, _stream()))
-        ctx.save_for_backward(idx, gs)
+        inv = getattr(idx, "_scr_inverse", None)       # left by expand.mask_indices: position of every anchor in idx, -1 = invisible
+        if inv is not None and (inv.shape != (N,) or inv.device != dev):
+            inv = None
+        ctx.save_for_backward(idx, gs, *(() if inv is None else (inv,)))
         ctx.N, ctx.sink = N, sink
         if sink is not None:
             sink.pending += 1
@@ -74,10 +77,13 @@ class _AnchorGather(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_feat, d_anc, d_off, d_gs, d_g_fea):
-        idx, gs = ctx.saved_tensors
+        idx, gs, *rest = ctx.saved_tensors
         N, V, dev = ctx.N, idx.numel(), idx.device
-        inv = torch.full((N,), -1, dtype=torch.long, device=dev)
-        inv[idx] = torch.arange(V, device=dev)
+        if rest:
+            inv = rest[0]
+        else:
+            inv = torch.full((N,), -1, dtype=torch.long, device=dev)
+            inv[idx] = torch.arange(V, device=dev)
         p = lambda t: None if t is None else t.contiguous().float()
         ldg = 71
         if d_g_fea is not None and d_g_fea.dtype == torch.float32 and d_g_fea.stride() == (72, 1):

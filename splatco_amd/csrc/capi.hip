@@ -379,11 +379,11 @@ int scr_mask_index_plan(int64_t n, const uint8_t* mask, void* scratch, int64_t* 
     return 0;
 }
 
-int scr_mask_index_run(int64_t n, const uint8_t* mask, const void* scratch, int64_t* index, void* stream) {
+int scr_mask_index_run(int64_t n, const uint8_t* mask, const void* scratch, int64_t* index, int64_t* inverse, void* stream) {
     if (n <= 0) return n < 0 ? fail("n < 0") : 0;
-    if (!mask || !scratch || !index) return fail("NULL argument");
+    if (!mask || !scratch || (!index && !inverse)) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
-    { ProfScope ps_(SCR_PROF_EXPAND, st); launch_mask_index(n, mask, (const uint32_t*)scratch, index, st); }
+    { ProfScope ps_(SCR_PROF_EXPAND, st); launch_mask_index(n, mask, (const uint32_t*)scratch, index, inverse, st); }
     CHECK_LAUNCH("mask_index_kernel", 0, st);
     return 0;
 }
@@ -648,6 +648,58 @@ int scr_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inverse_inde
     launch_anchor_gather_backward(N, V, inverse_index, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea, g_fea_ld,
                                   g_anchor_feat, g_anchor, g_offset, g_scaling, accumulate, (hipStream_t)stream);
     CHECK_LAUNCH("anchor_gather_backward_kernel", 0, (hipStream_t)stream);
+    return 0;
+}
+
+// ---- normalised tri-plane coordinates of contiguous xyz[V,3] in the box [lo, hi] (triplane.hip)
+int scr_box_coords(int64_t V, const float* xyz, const float* lo_host, const float* hi_host, float* out, void* stream) {
+    if (V < 0) return fail("V < 0");
+    if (V == 0) return 0;
+    if (!xyz || !lo_host || !hi_host || !out) return fail("NULL argument");
+    launch_box_coords(V, xyz, lo_host, hi_host, out, (hipStream_t)stream);
+    CHECK_LAUNCH("box_coords_kernel", 0, (hipStream_t)stream);
+    return 0;
+}
+
+// ---- the parameter side of the fold: G, c from the pairs' weights, their gradients back, running statistics (normlinear.hip)
+int scr_norm_fold(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host, const void* const* lin_weight_host,
+                  const void* const* lin_bias_host, const void* const* bn_weight_host, const void* const* bn_bias_host, float* G,
+                  float* c, void* stream) {
+    if (!widths_host || !cols_host || !lin_weight_host || !lin_bias_host || !bn_weight_host || !bn_bias_host || !G || !c)
+        return fail("NULL argument");
+    if (launch_nl_fold(L, d, widths_host, cols_host, (const float* const*)lin_weight_host, (const float* const*)lin_bias_host,
+                       (const float* const*)bn_weight_host, (const float* const*)bn_bias_host, G, c, (hipStream_t)stream))
+        return fail("scr_norm_fold: 1 <= L <= 4 pairs, column blocks inside [0, d), d <= 80");
+    CHECK_LAUNCH("nl_fold_kernel", 0, (hipStream_t)stream);
+    return 0;
+}
+
+int scr_norm_fold_backward(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host,
+                           const void* const* lin_weight_host, const void* const* bn_weight_host, const void* const* bn_bias_host,
+                           const float* dG, const float* dc, void* const* d_lin_weight_host, void* const* d_lin_bias_host,
+                           void* const* d_bn_weight_host, void* const* d_bn_bias_host, void* stream) {
+    if (!widths_host || !cols_host || !lin_weight_host || !bn_weight_host || !bn_bias_host || !dG || !dc || !d_lin_weight_host ||
+        !d_lin_bias_host || !d_bn_weight_host || !d_bn_bias_host)
+        return fail("NULL argument");
+    if (launch_nl_fold_backward(L, d, widths_host, cols_host, (const float* const*)lin_weight_host,
+                                (const float* const*)bn_weight_host, (const float* const*)bn_bias_host, dG, dc,
+                                (float* const*)d_lin_weight_host, (float* const*)d_lin_bias_host, (float* const*)d_bn_weight_host,
+                                (float* const*)d_bn_bias_host, (hipStream_t)stream))
+        return fail("scr_norm_fold_backward: 1 <= L <= 4 pairs, column blocks inside [0, d), d <= 80");
+    CHECK_LAUNCH("nl_fold_backward_kernel", 0, (hipStream_t)stream);
+    return 0;
+}
+
+int scr_norm_running_stats(int32_t L, const int32_t* widths_host, const int32_t* cols_host, const float* momentum_host,
+                           void* const* running_mean_host, void* const* running_var_host, void* const* num_batches_host,
+                           const float* mean, const float* var, int64_t n, void* stream) {
+    if (!widths_host || !cols_host || !momentum_host || !running_mean_host || !running_var_host || !mean || !var)
+        return fail("NULL argument");
+    if (launch_nl_running_stats(L, widths_host, cols_host, momentum_host, (float* const*)running_mean_host,
+                                (float* const*)running_var_host, (long long* const*)num_batches_host, mean, var, n,
+                                (hipStream_t)stream))
+        return fail("scr_norm_running_stats: 1 <= L <= 4");
+    CHECK_LAUNCH("nl_running_stats_kernel", 0, (hipStream_t)stream);
     return 0;
 }
 

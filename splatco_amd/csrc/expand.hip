@@ -99,7 +99,7 @@ mask_count_kernel(int64_t n, const uint8_t* __restrict__ mask, uint32_t* __restr
 }
 __global__ void __launch_bounds__(EXP_THREADS)
 mask_index_kernel(int64_t n, const uint8_t* __restrict__ mask, const uint32_t* __restrict__ wg_offset,
-                  int64_t* __restrict__ index) {
+                  int64_t* __restrict__ index, int64_t* __restrict__ inverse) {
     __shared__ uint32_t wcnt[EXP_ITEMS][EXP_THREADS / WAVE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     bool keep[EXP_ITEMS];
@@ -119,7 +119,9 @@ mask_index_kernel(int64_t n, const uint8_t* __restrict__ mask, const uint32_t* _
         uint32_t before = 0;
 #pragma unroll
         for (int q = 0; q < EXP_THREADS / WAVE; ++q) before += q < w ? wcnt[r][q] : 0u;
-        if (keep[r]) index[base + before + below[r]] = (int64_t)blockIdx.x * EXP_PER_WG + r * EXP_THREADS + threadIdx.x;
+        const int64_t i = (int64_t)blockIdx.x * EXP_PER_WG + r * EXP_THREADS + threadIdx.x;
+        if (keep[r]) index[base + before + below[r]] = i;
+        if (inverse && i < n) inverse[i] = keep[r] ? (int64_t)(base + before + below[r]) : -1ll;
 #pragma unroll
         for (int q = 0; q < EXP_THREADS / WAVE; ++q) base += wcnt[r][q];
     }
@@ -274,9 +276,10 @@ void launch_mask_count(int64_t n, const uint8_t* mask, uint32_t* wg_count, unsig
     mask_count_kernel<<<nwg, EXP_THREADS, 0, st>>>(n, mask, wg_count);
     expand_scan_kernel<<<1, 1024, 0, st>>>(nwg, wg_count, total, mailbox, seq);
 }
-void launch_mask_index(int64_t n, const uint8_t* mask, const uint32_t* wg_offset, int64_t* index, hipStream_t st) {
+void launch_mask_index(int64_t n, const uint8_t* mask, const uint32_t* wg_offset, int64_t* index, int64_t* inverse,
+                       hipStream_t st) {
     const uint32_t nwg = (uint32_t)((n + EXP_PER_WG - 1) / EXP_PER_WG);
-    mask_index_kernel<<<nwg, EXP_THREADS, 0, st>>>(n, mask, wg_offset, index);
+    mask_index_kernel<<<nwg, EXP_THREADS, 0, st>>>(n, mask, wg_offset, index, inverse);
 }
 
 void launch_expand_run(int64_t n, int k, const float* neural_opacity, const float* color, const float* scale_rot,

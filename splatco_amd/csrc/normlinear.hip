@@ -427,4 +427,136 @@ int launch_norm_linear_backward(int64_t V, int d, const float* x, int ldx, const
     return 0;
 }
 
+// ------------------------------------------------------------------ folding the BatchNorm / Linear parameters
+// FeaturePlanes sums L <= 4 pairs Linear_i(BatchNorm_i(.)) over its active levels.  With batch statistics the pairs fold
+// into ONE weight matrix G [32, d] and one bias c [32] (scene_model._norm_linear):
+//   pair i sees columns [col_i, col_i + d_i) of the input (the plane branch: the levels' samples side by side) or the
+//   whole input (col_i = 0, d_i = d: the attribute branch, every level reads g_fea):
+//     G[r, col_i + j] += W_i[r, j] * gamma_i[j]          c[r] = sum_i ( sum_j W_i[r, j] * beta_i[j] + b_i[r] )
+// In the framework that is ~15 kernels on 32 x 71 numbers per branch and twice that on the way back, each a launch of
+// its own (4.5 us of GPU time apiece: 0.45 ms of a 23.5 ms cfg2 step).  Here: one single-workgroup kernel per direction;
+// fixed order of additions (pair 0 first): deterministic.
+struct NlFoldArgs {
+    int L, d;
+    int dd[4], col[4];
+    const float* W[4];      // [32, d_i]
+    const float* b[4];      // [32]
+    const float* gamma[4];  // [d_i]
+    const float* beta[4];   // [d_i]
+    float* dW[4];           // backward outputs (same shapes)
+    float* db[4];
+    float* dgamma[4];
+    float* dbeta[4];
+};
+
+__global__ void __launch_bounds__(256) nl_fold_kernel(NlFoldArgs a, float* __restrict__ G, float* __restrict__ c) {
+    for (int e = threadIdx.x; e < 32 * a.d; e += 256) {
+        const int r = e / a.d, col = e - r * a.d;
+        float g = 0.0f;
+        for (int i = 0; i < a.L; ++i) {
+            const int j = col - a.col[i];
+            if (j >= 0 && j < a.dd[i]) g += a.W[i][r * a.dd[i] + j] * a.gamma[i][j];
+        }
+        G[e] = g;
+    }
+    if (threadIdx.x < 32) {
+        const int r = threadIdx.x;
+        float acc = 0.0f;
+        for (int i = 0; i < a.L; ++i) {
+            float dot = 0.0f;
+            for (int j = 0; j < a.dd[i]; ++j) dot += a.W[i][r * a.dd[i] + j] * a.beta[i][j];
+            acc += dot + a.b[i][r];
+        }
+        c[r] = acc;
+    }
+}
+
+// dW_i[r, j] = dG[r, col_i + j] * gamma_i[j] + dc[r] * beta_i[j];  db_i = dc;
+// dgamma_i[j] = sum_r dG[r, col_i + j] * W_i[r, j];  dbeta_i[j] = sum_r dc[r] * W_i[r, j]
+__global__ void __launch_bounds__(256) nl_fold_backward_kernel(NlFoldArgs a, const float* __restrict__ dG,
+                                                               const float* __restrict__ dc) {
+    for (int i = 0; i < a.L; ++i) {
+        const int di = a.dd[i];
+        for (int e = threadIdx.x; e < 32 * di; e += 256) {
+            const int r = e / di, j = e - r * di;
+            a.dW[i][e] = dG[r * a.d + a.col[i] + j] * a.gamma[i][j] + dc[r] * a.beta[i][j];
+        }
+        for (int j = threadIdx.x; j < di; j += 256) {
+            float sg = 0.0f, sb = 0.0f;
+            for (int r = 0; r < 32; ++r) {
+                const float w = a.W[i][r * di + j];
+                sg += dG[r * a.d + a.col[i] + j] * w;
+                sb += dc[r] * w;
+            }
+            a.dgamma[i][j] = sg;
+            a.dbeta[i][j] = sb;
+        }
+        if (threadIdx.x < 32) a.db[i][threadIdx.x] = dc[threadIdx.x];
+    }
+}
+
+// running statistics of the L BatchNorms after a training-mode forward (nn.BatchNorm1d with a momentum):
+//   running_mean = (1 - m) running_mean + m mean;  running_var = (1 - m) running_var + m var n / (n - 1);  batches += 1
+struct NlRunArgs {
+    int L;
+    int dd[4], col[4];
+    float momentum[4];
+    float* run_mean[4];
+    float* run_var[4];
+    long long* batches[4];
+};
+__global__ void __launch_bounds__(256) nl_running_stats_kernel(NlRunArgs a, const float* __restrict__ mean,
+                                                               const float* __restrict__ var, float unbias) {
+    for (int i = 0; i < a.L; ++i) {
+        const float m = a.momentum[i];
+        for (int j = threadIdx.x; j < a.dd[i]; j += 256) {
+            a.run_mean[i][j] = a.run_mean[i][j] * (1.0f - m) + m * mean[a.col[i] + j];
+            a.run_var[i][j] = a.run_var[i][j] * (1.0f - m) + m * (var[a.col[i] + j] * unbias);
+        }
+        if (threadIdx.x == 0 && a.batches[i]) *a.batches[i] += 1;
+    }
+}
+
+int launch_nl_fold(int L, int d, const int* dd, const int* col, const float* const* W, const float* const* b,
+                   const float* const* gamma, const float* const* beta, float* G, float* c, hipStream_t st) {
+    if (L < 1 || L > 4 || d < 1 || d > NL_DP) return 1;
+    NlFoldArgs a = {};
+    a.L = L; a.d = d;
+    for (int i = 0; i < L; ++i) {
+        if (dd[i] < 1 || col[i] < 0 || col[i] + dd[i] > d) return 1;
+        a.dd[i] = dd[i]; a.col[i] = col[i]; a.W[i] = W[i]; a.b[i] = b[i]; a.gamma[i] = gamma[i]; a.beta[i] = beta[i];
+    }
+    nl_fold_kernel<<<1, 256, 0, st>>>(a, G, c);
+    return 0;
+}
+
+int launch_nl_fold_backward(int L, int d, const int* dd, const int* col, const float* const* W, const float* const* gamma,
+                            const float* const* beta, const float* dG, const float* dc, float* const* dW, float* const* db,
+                            float* const* dgamma, float* const* dbeta, hipStream_t st) {
+    if (L < 1 || L > 4 || d < 1 || d > NL_DP) return 1;
+    NlFoldArgs a = {};
+    a.L = L; a.d = d;
+    for (int i = 0; i < L; ++i) {
+        if (dd[i] < 1 || col[i] < 0 || col[i] + dd[i] > d) return 1;
+        a.dd[i] = dd[i]; a.col[i] = col[i]; a.W[i] = W[i]; a.gamma[i] = gamma[i]; a.beta[i] = beta[i];
+        a.dW[i] = dW[i]; a.db[i] = db[i]; a.dgamma[i] = dgamma[i]; a.dbeta[i] = dbeta[i];
+    }
+    nl_fold_backward_kernel<<<1, 256, 0, st>>>(a, dG, dc);
+    return 0;
+}
+
+int launch_nl_running_stats(int L, const int* dd, const int* col, const float* momentum, float* const* run_mean,
+                            float* const* run_var, long long* const* batches, const float* mean, const float* var, int64_t n,
+                            hipStream_t st) {
+    if (L < 1 || L > 4) return 1;
+    NlRunArgs a = {};
+    a.L = L;
+    for (int i = 0; i < L; ++i) {
+        a.dd[i] = dd[i]; a.col[i] = col[i]; a.momentum[i] = momentum[i];
+        a.run_mean[i] = run_mean[i]; a.run_var[i] = run_var[i]; a.batches[i] = batches ? batches[i] : nullptr;
+    }
+    nl_running_stats_kernel<<<1, 256, 0, st>>>(a, mean, var, (float)((double)n / (double)(n > 1 ? n - 1 : 1)));
+    return 0;
+}
+
 }  // namespace scr

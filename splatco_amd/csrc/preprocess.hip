@@ -362,10 +362,16 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
         const uint32_t lbits = live_bits[i];
         const float4 qa = rec[3 * i], qb = rec[3 * i + 1];
         uint32_t kwalk = 0;
-        auto next_tile = [&](bool& live) {
+        auto next_tile = [&](bool& live) {      // the first 32 tiles of the walk: a bit test, nothing that branches
             const int t = tcy * gxt + tcx;
-            live = kwalk < 32u ? ((lbits >> kwalk) & 1u) != 0u : quadrant_mask(qa, qb, tcx * TILE, tcy * TILE) != 0u;
+            live = ((lbits >> (kwalk & 31u)) & 1u) != 0u;
             ++kwalk;
+            if (++tcx == rx1) { tcx = rx0; ++tcy; }
+            return t;
+        };
+        auto next_tile_far = [&](bool& live) {  // beyond them (rects of more than 32 tiles: rare): the test itself
+            const int t = tcy * gxt + tcx;
+            live = quadrant_mask(qa, qb, tcx * TILE, tcy * TILE) != 0u;
             if (++tcx == rx1) { tcx = rx0; ++tcy; }
             return t;
         };
@@ -374,38 +380,52 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
             syy += ok ? q.b.x : 0.0f; gop += ok ? q.b.y : 0.0f; gcol[0] += ok ? q.b.z : 0.0f; gcol[1] += ok ? q.b.w : 0.0f;
             gcol[2] += ok ? q.c : 0.0f;
         };
-        const GradRec none = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, 0.0f};
+        // The loads stay unconditional and four in flight per thread; the bytes of a record that was never written (dead
+        // instance, or behind its tile's cut) are dropped by the select in add(), never used in arithmetic.  Measured at
+        // cfg1 against the 0.0735 ms of summing every record: a predicated load per record 0.103 ms (the compiler closes
+        // each with its own wait), dead loads redirected to one shared address 0.081 ms (a hot spot on one L2 channel), to
+        // the Gaussian's own first record 0.079 - 0.089 ms (the address select sits in front of every load); as below
+        // 0.075 ms -- what the verdicts buy is the blend backward's stores (a third of its 36-byte records), not reads.
+#define SCR_PB_SRC(live_, p_) (p_)
         uint32_t k = 0;
-        if (cut_key[tiles] == stamp) {      // wave-uniform: some tile of this call left entries without records
-            for (; k + 4 <= n; k += 4) {
+        const uint32_t nb = n < 32u ? n : 32u;      // records whose verdict is in lbits
+        const bool any_cut = cut_key[tiles] == stamp;
+        if (any_cut) {                      // wave-uniform: some tile of this call left entries without records
+            for (; k + 4 <= nb; k += 4) {
                 GradRec q[4];
                 unsigned long long ck[4];
                 bool live[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { ck[j] = cut_key[next_tile(live[j])]; q[j] = live[j] ? gr[k + j] : none; }
+                for (int j = 0; j < 4; ++j) { ck[j] = cut_key[next_tile(live[j])]; q[j] = *SCR_PB_SRC(live[j], gr + k + j); }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) add(q[j], live[j] && mykey < ck[j]);
             }
-            for (; k < n; ++k) {
+            for (; k < nb; ++k) {
                 bool live;
                 const unsigned long long ck = cut_key[next_tile(live)];
-                const GradRec q = live ? gr[k] : none;
+                const GradRec q = *SCR_PB_SRC(live, gr + k);
                 add(q, live && mykey < ck);
             }
         } else {                            // every live instance has its record (the benchmark density): no look-ups
-            for (; k + 4 <= n; k += 4) {
+            for (; k + 4 <= nb; k += 4) {
                 GradRec q[4];
                 bool live[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { next_tile(live[j]); q[j] = live[j] ? gr[k + j] : none; }
+                for (int j = 0; j < 4; ++j) { next_tile(live[j]); q[j] = *SCR_PB_SRC(live[j], gr + k + j); }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) add(q[j], live[j]);
             }
-            for (; k < n; ++k) {
+            for (; k < nb; ++k) {
                 bool live;
                 next_tile(live);
-                add(live ? gr[k] : none, live);
+                add(*SCR_PB_SRC(live, gr + k), live);
             }
+        }
+        for (; k < n; ++k) {                // tiles 32.. of a large rect
+            bool live;
+            const int t = next_tile_far(live);
+            const unsigned long long ck = any_cut ? cut_key[t] : ~0ull;
+            if (live) add(gr[k], mykey < ck);
         }
         // the per-splat constants the blend kernel left out.  The moments are of Y = opacity * G * dL/dalpha, i.e.
         // dL/dG already: dG/dmean = -G Q d with Q = (-2A, -B, -2C), dG/dQ = -G/2 d d^T (Qxy counted once: factor 1);

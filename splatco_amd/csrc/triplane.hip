@@ -968,4 +968,23 @@ int tp_debug_ticks(unsigned long long* out) {
 }
 #endif
 
+// ---- normalised sample coordinates: ind = (xyz - lo) / (hi - lo) * 2 - 1 (scene/grids.py:146), the framework's four
+// elementwise passes over [V, 3] as one; the same IEEE operations in the same order, so the same bits
+__global__ void __launch_bounds__(256) box_coords_kernel(int64_t n3, const float* __restrict__ xyz, float lo0, float lo1,
+                                                         float lo2, float hi0, float hi1, float hi2, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    const float den0 = hi0 - lo0, den1 = hi1 - lo1, den2 = hi2 - lo2;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n3; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % 3);
+        const float lo = c == 0 ? lo0 : c == 1 ? lo1 : lo2, den = c == 0 ? den0 : c == 1 ? den1 : den2;
+        out[e] = ((xyz[e] - lo) / den) * 2.0f - 1.0f;
+    }
+}
+void launch_box_coords(int64_t V, const float* xyz, const float* lo, const float* hi, float* out, hipStream_t st) {
+    if (V <= 0) return;
+    const int64_t n3 = 3 * V;
+    const unsigned grid = (unsigned)((n3 + 255) / 256 < 65536 ? (n3 + 255) / 256 : 65536);
+    box_coords_kernel<<<grid, 256, 0, st>>>(n3, xyz, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], out);
+}
+
 }  // namespace scr

@@ -79,9 +79,12 @@ def visible_indices(mask):
     return mask.nonzero(as_tuple=False).squeeze(1)
 
 
-def mask_indices(mask):
+def mask_indices(mask, inverse=True):
     """Ascending indices of the set entries of a 1-D bool / uint8 mask on the GPU -- mask.nonzero().squeeze(1) without
-    torch's int64 reduction + select (0.33 ms for 20 M anchors; here one pass over the bytes and one over the index)."""
+    torch's int64 reduction + select (0.33 ms for 20 M anchors; here one pass over the bytes and one over the index).
+    inverse: the same pass also leaves the inverse map (position in the list, -1 where the mask is clear) on the result as
+    `._scr_inverse`: the fused anchor gather's backward wants it and would otherwise build it with a fill, an arange and
+    an index_put."""
     import ctypes as C
     m = mask.contiguous()
     m = m.view(torch.uint8) if m.dtype == torch.bool else m
@@ -92,6 +95,10 @@ def mask_indices(mask):
     with torch.cuda.device(m.device):          # the plan call reads its count back on the host: one synchronisation
         _C.check(_C.lib.scr_mask_index_plan(n, m.data_ptr(), scratch.data_ptr(), C.byref(cnt), _stream(m.device)))
         idx = torch.empty(cnt.value, dtype=torch.int64, device=m.device)
-        if cnt.value:
-            _C.check(_C.lib.scr_mask_index_run(n, m.data_ptr(), scratch.data_ptr(), idx.data_ptr(), _stream(m.device)))
+        inv = torch.empty(n, dtype=torch.int64, device=m.device) if inverse and n else None
+        if n and (cnt.value or inv is not None):
+            _C.check(_C.lib.scr_mask_index_run(n, m.data_ptr(), scratch.data_ptr(), idx.data_ptr() if cnt.value else None,
+                                               inv.data_ptr() if inv is not None else None, _stream(m.device)))
+    if inv is not None:
+        idx._scr_inverse = inv
     return idx

@@ -139,13 +139,11 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, visible_m
     is_training = pc.get_color_mlp.training
     out = generate_neural_gaussians(viewpoint_camera, pc, visible_mask, is_training=is_training)
     xyz, color, opacity, scaling, rot = out[:5]
-    # zero tensor whose .grad receives the screen-space mean gradient (:133-138)
-    screenspace_points = torch.zeros_like(xyz, dtype=pc.get_anchor.dtype, requires_grad=True) + 0
-    if retain_grad:
-        try:
-            screenspace_points.retain_grad()
-        except Exception:
-            pass
+    # zero tensor whose .grad receives the screen-space mean gradient (:133-138).  The reference makes it a non-leaf
+    # (`zeros_like(..., requires_grad=True) + 0` + retain_grad()); a leaf carries the same .grad after backward() without
+    # the extra pass over [P, 3] forward and the accumulate-into-retained-copy backward (retain_grad=True is accepted
+    # and means nothing more)
+    screenspace_points = torch.zeros_like(xyz, dtype=pc.get_anchor.dtype, requires_grad=True)
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, bg_color, scaling_modifier, pipe.debug))
     rendered_image, radii = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=color,
                                        opacities=opacity, scales=scaling, rotations=rot, cov3D_precomp=None)
@@ -164,6 +162,11 @@ def prefilter_voxel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, 
         # scale / rotation path is live
         raise NotImplementedError("compute_cov3D_python is not a live path of the reference's prefilter_voxel")
     with torch.no_grad():
-        radii_pure = rasterizer.visible_filter(means3D=pc.get_anchor, scales=pc.get_scaling[:, :3],
+        from .scene_model import AnchorGaussianModel
+        if type(pc).get_scaling is AnchorGaussianModel.get_scaling:
+            scales = torch.exp(pc._scaling[:, :3])      # = get_scaling[:, :3] without exp of the other three columns + a strided copy
+        else:
+            scales = pc.get_scaling[:, :3]
+        radii_pure = rasterizer.visible_filter(means3D=pc.get_anchor, scales=scales,
                                                rotations=pc.get_rotation, cov3D_precomp=None)
     return radii_pure > 0

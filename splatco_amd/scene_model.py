@@ -171,6 +171,65 @@ class _NormLinearFn(torch.autograd.Function):
         return dx, H, sdy, None
 
 
+def _ptr_table(tensors):
+    import ctypes as C
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class _NormFold(torch.autograd.Function):
+    """(G [32, d], c [32]) of sum_i Linear_i(BatchNorm_i(.)) from the pairs' parameters, as ONE launch per direction
+    (csrc/normlinear.hip nl_fold_kernel / nl_fold_backward_kernel) instead of ~15 framework kernels on 32 x 71 numbers
+    forward and twice that backward.  tensors = (W_0, b_0, gamma_0, beta_0, W_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, d, widths, cols, *tensors):
+        import ctypes as C
+        from . import _C
+        from .rasterizer import _stream
+        L, dev = len(widths), tensors[0].device
+        ts = [t.detach().contiguous().float() for t in tensors]
+        W, b, ga, be = ts[0::4], ts[1::4], ts[2::4], ts[3::4]
+        G, c = torch.empty(32, d, device=dev), torch.empty(32, device=dev)
+        wi, ci = (C.c_int32 * L)(*widths), (C.c_int32 * L)(*cols)
+        with torch.cuda.device(dev):
+            _C.check(_C.lib.scr_norm_fold(L, d, wi, ci, _ptr_table(W), _ptr_table(b), _ptr_table(ga), _ptr_table(be),
+                                          G.data_ptr(), c.data_ptr(), _stream(dev)))
+        ctx.save_for_backward(*W, *ga, *be)
+        ctx.meta = (d, tuple(widths), tuple(cols))
+        return G, c
+
+    @staticmethod
+    def backward(ctx, dG, dc):
+        import ctypes as C
+        from . import _C
+        from .rasterizer import _stream
+        d, widths, cols = ctx.meta
+        L = len(widths)
+        saved = ctx.saved_tensors
+        W, ga, be = saved[:L], saved[L:2 * L], saved[2 * L:]
+        dev = W[0].device
+        dG = torch.zeros(32, d, device=dev) if dG is None else dG.contiguous().float()
+        dc = torch.zeros(32, device=dev) if dc is None else dc.contiguous().float()
+        dW = [torch.empty_like(w) for w in W]
+        db = [torch.empty(32, device=dev) for _ in range(L)]
+        dga, dbe = [torch.empty_like(g) for g in ga], [torch.empty_like(g) for g in be]
+        wi, ci = (C.c_int32 * L)(*widths), (C.c_int32 * L)(*cols)
+        with torch.cuda.device(dev):
+            _C.check(_C.lib.scr_norm_fold_backward(L, d, wi, ci, _ptr_table(W), _ptr_table(ga), _ptr_table(be), dG.data_ptr(),
+                                                   dc.data_ptr(), _ptr_table(dW), _ptr_table(db), _ptr_table(dga),
+                                                   _ptr_table(dbe), _stream(dev)))
+        out = []
+        for i in range(L):
+            out += [dW[i], db[i], dga[i], dbe[i]]
+        return (None, None, None, *out)
+
+
+def _fold_on_device(x, bns, linears):
+    return (x.is_cuda and x.dtype == torch.float32 and 1 <= len(bns) <= 4 and x.shape[1] <= 80
+            and all(l.out_features == 32 and l.bias is not None and l.weight.dtype == torch.float32 for l in linears)
+            and all(bn.affine for bn in bns))
+
+
 def _norm_linear(x, bns, linears):
     """sum_i Linear_i(BatchNorm_i(x_i)) where x = cat_i(x_i) column-wise (bns[i] normalises its own column
     block; pass the same block twice -- offsets repeat -- is not supported) OR every BatchNorm_i sees the
@@ -178,17 +237,39 @@ def _norm_linear(x, bns, linears):
     nn.BatchNorm1d.forward does in training mode."""
     d = x.shape[1]
     shared = all(bn.num_features == d for bn in bns)
-    if shared:      # same input through every pair: the folded weights simply add up
+    if not shared:
+        assert sum(bn.num_features for bn in bns) == d
+    widths = [bn.num_features for bn in bns]
+    cols = [0] * len(bns) if shared else [sum(widths[:i]) for i in range(len(bns))]
+    on_device = _fold_on_device(x, bns, linears)
+    if on_device:
+        # one launch builds G and c from the 4 L parameter tensors (and one takes their gradients back)
+        G, c = _NormFold.apply(d, tuple(widths), tuple(cols),
+                               *[t for bn, lin in zip(bns, linears) for t in (lin.weight, lin.bias, bn.weight, bn.bias)])
+    elif shared:    # same input through every pair: the folded weights simply add up
         G = sum(lin.weight * bn.weight for bn, lin in zip(bns, linears))
         c = sum(lin.weight @ bn.bias + lin.bias for bn, lin in zip(bns, linears))
     else:
-        assert sum(bn.num_features for bn in bns) == d
         G = torch.cat([lin.weight * bn.weight for bn, lin in zip(bns, linears)], dim=1)
         c = sum(lin.weight @ bn.bias + lin.bias for bn, lin in zip(bns, linears))
     assert all(bn.eps == bns[0].eps for bn in bns)
     y, mean, var = _NormLinearFn.apply(x, G, c, bns[0].eps)
     with torch.no_grad():
-        n, off = x.shape[0], 0
+        n = x.shape[0]
+        track = [bn for bn in bns if bn.track_running_stats and bn.training]
+        if on_device and len(track) == len(bns) and all(bn.momentum is not None for bn in bns) and mean.is_cuda:
+            # nn.BatchNorm1d's running-statistics update for all pairs in one launch (six tiny kernels per BatchNorm otherwise)
+            import ctypes as C
+            from . import _C
+            from .rasterizer import _stream
+            L = len(bns)
+            with torch.cuda.device(x.device):
+                _C.check(_C.lib.scr_norm_running_stats(
+                    L, (C.c_int32 * L)(*widths), (C.c_int32 * L)(*cols), (C.c_float * L)(*[float(bn.momentum) for bn in bns]),
+                    _ptr_table([bn.running_mean for bn in bns]), _ptr_table([bn.running_var for bn in bns]),
+                    _ptr_table([bn.num_batches_tracked for bn in bns]), mean.data_ptr(), var.data_ptr(), n, _stream(x.device)))
+            return y
+        off = 0
         for bn in bns:
             m, v = (mean, var) if shared else (mean[off:off + bn.num_features], var[off:off + bn.num_features])
             off += 0 if shared else bn.num_features
@@ -270,12 +351,29 @@ class PlaneGrid(nn.Module):                   # scene/grids.py:102-201
             self._bounds = tuple(self.xyz_min.detach().cpu().tolist()) + tuple(self.xyz_max.detach().cpu().tolist())
         return self._bounds
 
+    def box_coords(self, xyz):
+        """(xyz - xyz_min) / (xyz_max - xyz_min) * 2 - 1 (scene/grids.py:146) for [..., 3] points; on the device one pass
+        (scr_box_coords: the same IEEE operations in the same order) instead of four."""
+        p = xyz.reshape(-1, 3)
+        if p.is_cuda and p.dtype == torch.float32 and not p.requires_grad and p.shape[0] > 0:
+            import ctypes as C
+            from . import _C
+            from .rasterizer import _stream
+            b = self.bounds_key()
+            p = p.contiguous()
+            out = torch.empty_like(p)
+            with torch.cuda.device(p.device):
+                _C.check(_C.lib.scr_box_coords(p.shape[0], p.data_ptr(), (C.c_float * 3)(*b[:3]), (C.c_float * 3)(*b[3:]),
+                                               out.data_ptr(), _stream(p.device)))
+            return out
+        return (p - self.xyz_min) / (self.xyz_max - self.xyz_min) * 2 - 1
+
     def sample_spec(self, xyz, col0=0, ind3=None):
         """(ind [V,3], planes, first output column of every plane) for triplane.multi_triplane_sample: what
         compute_planes_feat samples and where the reference's torch.cat puts it (scene/grids.py:165,181)."""
         R = self.channels // 3
         if ind3 is None:
-            ind3 = (xyz.reshape(-1, 3) - self.xyz_min) / (self.xyz_max - self.xyz_min) * 2 - 1
+            ind3 = self.box_coords(xyz)
         if not self.TAflag:
             return ind3, (self.xy_plane, self.xz_plane, self.yz_plane), tuple(col0 + R * j for j in range(3))
         # column order of :181: xy, xyA, xz, xzA, yz, yzA -- a plane and its attended twin are sampled at the same
@@ -514,11 +612,21 @@ class AnchorGaussianModel(nn.Module):
 
     @property
     def get_scaling(self):
-        return 1.0 * torch.exp(self._scaling)
+        return torch.exp(self._scaling)          # the reference's `1.0 * exp(.)` (scene/gaussian_model.py:397-399): the same bits
 
     @property
     def get_rotation(self):
-        return self.rotation_activation(self._rotation)
+        # normalize(_rotation), scene/gaussian_model.py:405-407.  The anchors' rotation never receives a gradient
+        # (requires_grad False in the reference): the normalised copy is kept until the parameter is written or replaced
+        # instead of two passes over [N, 4] in every prefilter_voxel call
+        r = self._rotation
+        key = (id(r), r._version, r.data_ptr(), tuple(r.shape))
+        if getattr(self, "_rot_key", None) != key or r.requires_grad:
+            out = self.rotation_activation(r)
+            if r.requires_grad:
+                return out
+            self._rot_key, self._rot_norm = key, out.detach()
+        return self._rot_norm
 
     @property
     def get_appearance(self):

@@ -865,3 +865,80 @@ def test_appearance_embedding_path_on_the_gpu(training):
         assert g is not None and g[int(d["uid"])].abs().sum() > 0
         assert all(float(g[i].abs().sum()) == 0.0 for i in range(g.shape[0]) if i != int(d["uid"]))
         assert pc._anchor_feat.grad is not None and pc._anchor_feat.grad.abs().sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shared", [False, True])
+def test_norm_fold_kernels_match_the_framework_chain(shared):
+    """scene_model._norm_linear on the device: the fold of L (BatchNorm, Linear) pairs into (G, c), its backward and the
+    running-statistics update run as single launches (csrc/normlinear.hip nl_fold_* / nl_running_stats_kernel).  Checked
+    against nn.BatchNorm1d -> Linear module by module in float64 (scene/gaussian_model.py:149-169): output, every
+    parameter gradient, input gradient, running_mean / running_var / num_batches_tracked."""
+    from splatco_amd import scene_model as sm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3 + shared)
+    widths = (71, 71, 71) if shared else (30, 15, 15)
+    V, d = 20011, (71 if shared else 60)
+    bns = [torch.nn.BatchNorm1d(w).to(dev) for w in widths]
+    lins = [sm.TallLinear(w, 32).to(dev) for w in widths]
+    with torch.no_grad():
+        for bn in bns:
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.3)
+            bn.running_mean.normal_()
+            bn.running_var.uniform_(0.5, 2.0)
+    x = (torch.randn(V, d, device=dev) * 0.7 + 0.3).requires_grad_()
+    w = torch.randn(V, 32, device=dev)
+    ref_b = [torch.nn.BatchNorm1d(wd).double() for wd in widths]
+    ref_l = [torch.nn.Linear(wd, 32).double() for wd in widths]
+    for a, b in zip(bns + lins, ref_b + ref_l):
+        b.load_state_dict({k: v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu() for k, v in a.state_dict().items()})
+    y = sm._norm_linear(x, bns, lins)
+    (y * w).sum().backward()
+    x64 = x.detach().cpu().double().requires_grad_()
+    off, y64 = 0, 0
+    for bn, lin, wd in zip(ref_b, ref_l, widths):
+        y64 = y64 + lin(bn(x64 if shared else x64[:, off:off + wd]))
+        off += 0 if shared else wd
+    (y64 * w.cpu().double()).sum().backward()
+
+    def close(a, b, tol, name):
+        scale = max(float(b.abs().max()), 1e-6)
+        err = float((a.detach().cpu().double() - b).abs().max()) / scale
+        assert err <= tol, (name, err)
+
+    close(y, y64.detach(), 2e-5, "y")
+    close(x.grad, x64.grad, 5e-5, "dx")
+    for i, (bn, lin, rb, rl) in enumerate(zip(bns, lins, ref_b, ref_l)):
+        close(lin.weight.grad, rl.weight.grad, 5e-5, f"dW{i}")
+        close(lin.bias.grad, rl.bias.grad, 5e-5, f"db{i}")
+        close(bn.weight.grad, rb.weight.grad, 5e-5, f"dgamma{i}")
+        close(bn.bias.grad, rb.bias.grad, 5e-5, f"dbeta{i}")
+        close(bn.running_mean, rb.running_mean, 1e-5, f"running_mean{i}")
+        close(bn.running_var, rb.running_var, 1e-5, f"running_var{i}")
+        assert int(bn.num_batches_tracked) == int(rb.num_batches_tracked) == 1
+
+
+@pytest.mark.gpu
+def test_box_coords_and_inverse_index_equal_the_framework_ops():
+    """Two small fusions of the anchor path: PlaneGrid.box_coords == the reference's four elementwise passes
+    (scene/grids.py:146) BIT FOR BIT (same IEEE operations, same order), and mask_indices' inverse map == the
+    fill + arange + index_put the gather's backward used to build."""
+    from splatco_amd.expand import mask_indices
+    from splatco_amd.scene_model import PlaneGrid
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    pg = PlaneGrid(15, [24, 24, 24], [-2.0, -1.5, -2.5], [2.0, 2.25, 1.75]).to(dev)
+    for V in (1, 7, 100_003):
+        xyz = torch.randn(V, 3, device=dev, generator=g) * 3
+        want = (xyz - pg.xyz_min) / (pg.xyz_max - pg.xyz_min) * 2 - 1
+        assert torch.equal(pg.box_coords(xyz), want)
+    for n in (1, 63, 64, 4097, 1_000_003):
+        m = torch.rand(n, device=dev, generator=g) < 0.4
+        idx = mask_indices(m)
+        assert torch.equal(idx, m.nonzero().squeeze(1))
+        inv = torch.full((n,), -1, dtype=torch.long, device=dev)
+        inv[idx] = torch.arange(idx.numel(), device=dev)
+        assert torch.equal(idx._scr_inverse, inv)
+    empty = mask_indices(torch.zeros(100, dtype=torch.bool, device=dev))
+    assert empty.numel() == 0 and torch.all(empty._scr_inverse == -1)
