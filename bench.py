@@ -344,30 +344,52 @@ def roofline_object(dom, avg_ms, ab, peak_measured, note, flops=None, traffic_fi
 
 
 def valu_object(dom, avg_ms):
-    """The VALU view of a kernel that is not HBM-bound, from counters collected on this kernel code (else dropped) and
-    the calibration of profiles/valu_calibration.json (tools/exp/valu_calib.hip under rocprofv3: what the counter
-    SQ_ACTIVE_INST_VALU reads per SIMD and shader cycle when a pure v_fma_f32 stream keeps the vector pipe saturated, and
-    the shader clock the probes ran at).  valu_frac = the kernel's counter rate / the saturated rate: <= 1 by construction
-    if the probe saturates the pipe."""
+    """The VALU view of a kernel that is not HBM-bound, from counters collected on this kernel code (else dropped) and the
+    calibration of profiles/valu_calibration.json (tools/exp/valu_calib.hip, bare and under rocprofv3 --pmc).  What the
+    calibration established: SQ_ACTIVE_INST_VALU counts issue PASSES, not busy cycles -- 1 per plain / DPP / compare /
+    select instruction, 2 per transcendental or permlane swap -- and a SIMD sustains 0.44 passes per shader cycle of pure
+    v_fma_f32 (2.3 cycles each) but only 0.23 - 0.25 of the 4-cycle forms (DPP, v_cmp -> SGPR pair, v_cndmask with an SGPR
+    mask) and of the two-pass forms; the clock a kernel runs at comes from GRBM_GUI_ACTIVE (DVFS: 1.8 - 2.4 GHz).
+      valu_frac        = modelled issue cycles / kernel cycles, with the calibrated cost of each class and the kernel's
+                         counts: two-pass instructions = ACTIVE - INSTS, 4-cycle forms = their share of the inner loop's
+                         ISA (profiles/*isa_mix*), the rest plain.  <= 1: the classes' costs are the saturated ones.
+      vs_mix_probe     = the kernel's passes per SIMD-cycle / those of a pure-VALU loop with the same instruction mix at
+                         saturating occupancy: how close the kernel is to a loop that does nothing but issue VALU work."""
     n_inst, src_i = profile_value("valu_insts.json", dom)
-    quads, src_b = profile_value("valu_busy.json", dom)
-    if not avg_ms or (n_inst is None and quads is None):
-        return {"dropped": (src_i or src_b or {}).get("dropped")} if (src_i or src_b) else None
+    passes, src_b = profile_value("valu_busy.json", dom)
+    gui, _ = profile_value("gui_active.json", dom)
+    if not avg_ms or n_inst is None or passes is None:
+        why = (src_i or src_b or {}).get("dropped")
+        return {"dropped": why} if why else None
     cpath = os.path.join(ROOT, "profiles", "valu_calibration.json")
     cal = json.load(open(cpath)) if os.path.exists(cpath) else None
-    out = {"insts_per_launch": n_inst, "source": src_i or src_b}
-    if cal and quads and cal.get("busy_quads_per_cycle_per_simd_saturated"):
-        mhz, sat = cal["shader_clock_MHz"], cal["busy_quads_per_cycle_per_simd_saturated"]
-        cycles = avg_ms * 1e-3 * mhz * 1e6
-        out.update({
-            "valu_frac": quads / (1024 * cycles * sat), "active_quads_per_launch": quads,
-            "cycles_per_inst": (quads / sat) / n_inst if n_inst else None,
-            "calibration": {"file": "profiles/valu_calibration.json", "shader_clock_MHz": mhz,
-                            "counter_per_simd_cycle_when_saturated": sat, "probe": cal.get("saturating_probe")},
-            "note": "valu_frac = SQ_ACTIVE_INST_VALU of the kernel / (1024 SIMDs x kernel shader cycles x the counter's rate under a "
-                    "saturating v_fma_f32 stream): the fraction of the launch during which the vector pipes were issuing; "
-                    "cycles_per_inst = that busy time per VALU instruction (plain fp32 2, DPP / compares / selects 4-5, "
-                    "transcendentals and permlane swaps 8: the calibration file lists the measured costs)"})
+    out = {"insts_per_launch": n_inst, "issue_passes_per_launch": passes, "source": src_i or src_b}
+    if not cal:
+        return out
+    f = cal["forms"]
+    rate = lambda key: f[key]["busy_quads_per_cycle_per_simd"]      # passes per SIMD and shader cycle of a saturated probe
+    mhz = gui / 8.0 / (avg_ms * 1e3) if gui else cal["shader_clock_MHz"]
+    cycles = avg_ms * 1e-3 * mhz * 1e6                                   # per SIMD
+    c_plain = 1.0 / rate("v_fma_f32 @8")
+    c_four = 1.0 / min(rate("v_add_f32 dpp row_shr @5"), rate("v_cmp_lt_f32 -> sgpr pair @5"), rate("v_cndmask_b32_e64 sgpr mask @5"))
+    c_two_pass = 2.0 / min(rate("v_exp_f32 @5"), rate("v_permlane32_swap @5"))
+    four_share = {"blend_backward_kernel": 41.0 / 217.0, "blend_forward_kernel": 0.12}.get(dom, 0.0)   # DPP + compares + selects
+    n_two = max(passes - n_inst, 0)
+    n_four = four_share * n_inst
+    n_plain = max(n_inst - n_two - n_four, 0)
+    modelled = (n_plain * c_plain + n_four * c_four + n_two * c_two_pass) / 1024.0
+    mix = max(v["busy_quads_per_cycle_per_simd"] for k, v in f.items() if k.startswith("blend-backward mix"))
+    out.update({
+        "shader_clock_MHz": round(mhz, 0), "clock_source": "GRBM_GUI_ACTIVE / 8 XCDs / launch time" if gui else "calibration probes",
+        "valu_frac": modelled / cycles, "modelled_issue_cycles_per_simd": modelled, "kernel_cycles_per_simd": cycles,
+        "class_cycles": {"plain": round(c_plain, 2), "dpp_cmp_select": round(c_four, 2), "transcendental_permlane": round(c_two_pass, 2)},
+        "class_counts": {"plain": int(n_plain), "dpp_cmp_select": int(n_four), "transcendental_permlane": int(n_two)},
+        "passes_per_simd_cycle": passes / (1024.0 * cycles), "passes_per_simd_cycle_pure_fma": rate("v_fma_f32 @8"),
+        "passes_per_simd_cycle_mix_probe": mix, "vs_mix_probe": passes / (1024.0 * cycles) / mix,
+        "calibration": "profiles/valu_calibration.json (+ .txt)",
+        "note": "VALU-issue bound when valu_frac is near 1: the remaining time is the issue slots the SALU / LDS / waits take "
+                "from the vector pipe; SQ_ACTIVE_INST_VALU is an instruction-pass count (round 2 read it as busy quad-cycles: "
+                "hence its 1.10)"})
     return out
 
 

@@ -371,7 +371,7 @@ def _fp64_on_fp32_records(oracle, st, f):
 CERTIFY = 1e-5         # a gradient row is "pinned by binary32" when the fp32 oracle's own row is this close to fp64
 
 
-def stress_case(oracle, rng, verbose=False):
+def stress_case(oracle, rng, verbose=False, info=None):
     """One randomised scene against the oracle.  Forward: the bars of _check_forward.  Gradients, per tensor:
       (a) rel-L2 <= 1e-4 vs the fp32 oracle over ALL Gaussians -- or, where that fails,
       (b) the same bar over the Gaussians whose gradient binary32 pins at all: rows for which the fp32 oracle itself
@@ -434,18 +434,50 @@ def stress_case(oracle, rng, verbose=False):
                      f"{d_o32 / max(np.linalg.norm(ref[loose]), 1e-300):.1e}, 2-ulp noise floor "
                      f"{d_noise / max(np.linalg.norm(ref[loose]), 1e-300):.1e} from fp64 there), pinned rows {e_pinned:.1e};")
             if e32[k] > GRAD_TOL:
+                if info is not None:
+                    info.setdefault("branch_b", {})[k] = {"all_rows": e32[k], "unpinned_rows": int(loose.sum()),
+                                                           "visible_rows": int(vis.sum()), "pinned_rel_l2": e_pinned}
                 assert e_pinned <= GRAD_TOL, (k, "rows pinned by fp32", e_pinned)
                 assert d_dev <= 10.0 * max(d_o32, d_noise), (k, "ill-conditioned rows vs fp64: device", d_dev, "fp32 oracle", d_o32,
                                                              "noise floor", d_noise)
     ranges = f["ranges"]
+    if info is not None:
+        info.update({"P": int(g["means3D"].shape[0]), "visible": int((f["radii"] > 0).sum()), "worst": float(worst),
+                     "image": f"{cam.image_width}x{cam.image_height}", "I": int(f["num_rendered"])})
     return (f"P={g['means3D'].shape[0]} {cam.image_width}x{cam.image_height} I={f['num_rendered']} "
             f"max tile={(ranges[:, 1].astype(np.int64) - ranges[:, 0]).max()} vis={(f['radii'] > 0).sum()} "
             f"worst grad {worst:.1e}" + (" |" + note if note else ""))
 
 
+# What the stress set may lean on branch (b) of stress_case (bars measured over seeds 0-4 on the round-3 kernels,
+# profiles/r03_stress.txt, with head-room): per scene at most UNPINNED_MAX of the visible Gaussians may be rows that
+# binary32 does not pin, and per seed at most B_SCENES_MAX of the ten scenes may need the branch at all.
+UNPINNED_MAX = 0.20
+B_SCENES_MAX = 8
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4])
 def test_randomised_stress_scenes(oracle, seed):
-    """50 seeded scenes of the randomised stress set (tools/stress_parity.py runs more of the same)."""
+    """50 seeded scenes of the randomised stress set (tools/stress_parity.py runs more of the same).  Every scene's
+    outcome -- worst rel-L2 over all rows, which tensors needed branch (b), how many rows fp32 does not pin -- goes to
+    the report file named by SPLATCO_STRESS_REPORT (committed as profiles/r03_stress.txt), and the use of branch (b) is
+    bounded by asserts."""
     rng = np.random.default_rng(seed)
+    lines, b_scenes = [], 0
     for it in range(10):
-        print(f"[stress {seed}/{it}] " + stress_case(oracle, rng))
+        info = {}
+        print(f"[stress {seed}/{it}] " + stress_case(oracle, rng, info=info))
+        bb = info.get("branch_b", {})
+        frac = max((v["unpinned_rows"] / max(v["visible_rows"], 1) for v in bb.values()), default=0.0)
+        b_scenes += bool(bb)
+        lines.append(f"seed {seed} scene {it}: P={info['P']} {info['image']} I={info['I']} visible={info['visible']} worst rel-L2 over all rows "
+                     f"{info['worst']:.2e} -> " + ("branch (a): 1e-4 over all rows" if not bb else
+                     "branch (b) for " + ", ".join(f"{k} (all rows {v['all_rows']:.1e}, pinned rows {v['pinned_rel_l2']:.1e}, "
+                                                   f"{v['unpinned_rows']} of {v['visible_rows']} rows unpinned)" for k, v in bb.items())))
+        assert frac <= UNPINNED_MAX, (seed, it, "fraction of visible rows not pinned by binary32", frac)
+    lines.append(f"seed {seed}: {b_scenes} of 10 scenes used branch (b)")
+    path = os.environ.get("SPLATCO_STRESS_REPORT")
+    if path:
+        with open(path, "a") as fh:
+            fh.write("\n".join(lines) + "\n")
+    assert b_scenes <= B_SCENES_MAX, (seed, b_scenes)

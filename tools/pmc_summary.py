@@ -58,10 +58,17 @@ def main(out_txt, out_json, dirs):
         if "SQ_ACTIVE_INST_VALU" in acc[k]:
             key = "tile_sort_kernel" if k.startswith("tile_sort") or k.startswith("tile_merge") else k
             busy[key] = busy.get(key, 0) + int(acc[k]["SQ_ACTIVE_INST_VALU"][0] / acc[k]["SQ_ACTIVE_INST_VALU"][1])
+    gui = {}
+    for k in acc:
+        if "GRBM_GUI_ACTIVE" in acc[k]:    # GPU-active cycles summed over the 8 XCDs: / 8 / kernel time = the clock the kernel ran at
+            key = "tile_sort_kernel" if k.startswith("tile_sort") or k.startswith("tile_merge") else k
+            gui[key] = gui.get(key, 0) + int(acc[k]["GRBM_GUI_ACTIVE"][0] / acc[k]["GRBM_GUI_ACTIVE"][1])
     prov = stamp("rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python3 bench.py --steps 20 --warmup 5 "
                  "--no-cpu-baseline --no-cfg2 (tools/profile_round.sh); averages per launch")
-    for table in (traffic, insts, busy):
+    for table in (traffic, insts, busy, gui):
         table["_provenance"] = prov
+    if len(gui) > 1:
+        json.dump(gui, open(out_json.replace("hbm_traffic", "gui_active"), "w"), indent=1, sort_keys=True)
     if len(busy) > 1:   # quad-cycles per launch during which the VALU pipes are busy (bench.py: valu.valu_frac)
         json.dump(busy, open(out_json.replace("hbm_traffic", "valu_busy"), "w"), indent=1, sort_keys=True)
     json.dump(traffic, open(out_json, "w"), indent=1, sort_keys=True)
