@@ -450,7 +450,9 @@ struct NlFoldArgs {
 };
 
 __global__ void __launch_bounds__(256) nl_fold_kernel(NlFoldArgs a, float* __restrict__ G, float* __restrict__ c) {
-    for (int e = threadIdx.x; e < 32 * a.d; e += 256) {
+    // grid: one workgroup per 256 elements of G; the last workgroup also forms c (8 lanes per row, fixed-order shuffle sum)
+    const int e = (int)blockIdx.x * 256 + threadIdx.x;
+    if (e < 32 * a.d) {
         const int r = e / a.d, col = e - r * a.d;
         float g = 0.0f;
         for (int i = 0; i < a.L; ++i) {
@@ -459,15 +461,18 @@ __global__ void __launch_bounds__(256) nl_fold_kernel(NlFoldArgs a, float* __res
         }
         G[e] = g;
     }
-    if (threadIdx.x < 32) {
-        const int r = threadIdx.x;
+    if (blockIdx.x == gridDim.x - 1) {
+        const int r = threadIdx.x >> 3, sub = threadIdx.x & 7;
         float acc = 0.0f;
         for (int i = 0; i < a.L; ++i) {
             float dot = 0.0f;
-            for (int j = 0; j < a.dd[i]; ++j) dot += a.W[i][r * a.dd[i] + j] * a.beta[i][j];
+            for (int j = sub; j < a.dd[i]; j += 8) dot += a.W[i][r * a.dd[i] + j] * a.beta[i][j];
+            dot += __shfl_xor(dot, 1, 64);
+            dot += __shfl_xor(dot, 2, 64);
+            dot += __shfl_xor(dot, 4, 64);
             acc += dot + a.b[i][r];
         }
-        c[r] = acc;
+        if (sub == 0) c[r] = acc;
     }
 }
 
@@ -475,12 +480,14 @@ __global__ void __launch_bounds__(256) nl_fold_kernel(NlFoldArgs a, float* __res
 // dgamma_i[j] = sum_r dG[r, col_i + j] * W_i[r, j];  dbeta_i[j] = sum_r dc[r] * W_i[r, j]
 __global__ void __launch_bounds__(256) nl_fold_backward_kernel(NlFoldArgs a, const float* __restrict__ dG,
                                                                const float* __restrict__ dc) {
-    for (int i = 0; i < a.L; ++i) {
-        const int di = a.dd[i];
-        for (int e = threadIdx.x; e < 32 * di; e += 256) {
-            const int r = e / di, j = e - r * di;
-            a.dW[i][e] = dG[r * a.d + a.col[i] + j] * a.gamma[i][j] + dc[r] * a.beta[i][j];
-        }
+    // grid: (ceil(32 d_max / 256), L): workgroup (x, i) writes 256 elements of dW_i; x == 0 also the column sums of pair i
+    const int i = (int)blockIdx.y, di = a.dd[i];
+    const int e = (int)blockIdx.x * 256 + threadIdx.x;
+    if (e < 32 * di) {
+        const int r = e / di, j = e - r * di;
+        a.dW[i][e] = dG[r * a.d + a.col[i] + j] * a.gamma[i][j] + dc[r] * a.beta[i][j];
+    }
+    if (blockIdx.x == 0) {
         for (int j = threadIdx.x; j < di; j += 256) {
             float sg = 0.0f, sb = 0.0f;
             for (int r = 0; r < 32; ++r) {
@@ -526,7 +533,7 @@ int launch_nl_fold(int L, int d, const int* dd, const int* col, const float* con
         if (dd[i] < 1 || col[i] < 0 || col[i] + dd[i] > d) return 1;
         a.dd[i] = dd[i]; a.col[i] = col[i]; a.W[i] = W[i]; a.b[i] = b[i]; a.gamma[i] = gamma[i]; a.beta[i] = beta[i];
     }
-    nl_fold_kernel<<<1, 256, 0, st>>>(a, G, c);
+    nl_fold_kernel<<<(32 * d + 255) / 256, 256, 0, st>>>(a, G, c);
     return 0;
 }
 
@@ -541,7 +548,7 @@ int launch_nl_fold_backward(int L, int d, const int* dd, const int* col, const f
         a.dd[i] = dd[i]; a.col[i] = col[i]; a.W[i] = W[i]; a.gamma[i] = gamma[i]; a.beta[i] = beta[i];
         a.dW[i] = dW[i]; a.db[i] = db[i]; a.dgamma[i] = dgamma[i]; a.dbeta[i] = dbeta[i];
     }
-    nl_fold_backward_kernel<<<1, 256, 0, st>>>(a, dG, dc);
+    nl_fold_backward_kernel<<<dim3((32 * d + 255) / 256, L), 256, 0, st>>>(a, dG, dc);
     return 0;
 }
 

@@ -973,17 +973,29 @@ int tp_debug_ticks(unsigned long long* out) {
 __global__ void __launch_bounds__(256) box_coords_kernel(int64_t n3, const float* __restrict__ xyz, float lo0, float lo1,
                                                          float lo2, float hi0, float hi1, float hi2, float* __restrict__ out) {
 #pragma clang fp contract(off)
-    const float den0 = hi0 - lo0, den1 = hi1 - lo1, den2 = hi2 - lo2;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n3; e += (int64_t)gridDim.x * 256) {
-        const int c = (int)(e % 3);
-        const float lo = c == 0 ? lo0 : c == 1 ? lo1 : lo2, den = c == 0 ? den0 : c == 1 ? den1 : den2;
-        out[e] = ((xyz[e] - lo) / den) * 2.0f - 1.0f;
+    // four points = twelve floats = three 16-byte accesses per thread: the component of float j of the group is j % 3
+    const float lo[3] = {lo0, lo1, lo2}, den[3] = {hi0 - lo0, hi1 - lo1, hi2 - lo2};
+    const int64_t groups = n3 / 12;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < groups; q += (int64_t)gridDim.x * 256) {
+        const float4* src = (const float4*)(xyz + 12 * q);
+        float4 v[3] = {src[0], src[1], src[2]};
+        float* f = (float*)v;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) f[j] = ((f[j] - lo[j % 3]) / den[j % 3]) * 2.0f - 1.0f;
+        float4* dst = (float4*)(out + 12 * q);
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
     }
+    if (blockIdx.x == 0)        // the tail (fewer than four points)
+        for (int64_t e = 12 * groups + threadIdx.x; e < n3; e += 256) {
+            const int c = (int)(e % 3);
+            out[e] = ((xyz[e] - lo[c]) / den[c]) * 2.0f - 1.0f;
+        }
 }
 void launch_box_coords(int64_t V, const float* xyz, const float* lo, const float* hi, float* out, hipStream_t st) {
     if (V <= 0) return;
-    const int64_t n3 = 3 * V;
-    const unsigned grid = (unsigned)((n3 + 255) / 256 < 65536 ? (n3 + 255) / 256 : 65536);
+    const int64_t n3 = 3 * V, groups = n3 / 12;
+    const int64_t want = (groups + 255) / 256;
+    const unsigned grid = (unsigned)(want < 1 ? 1 : want < 16384 ? want : 16384);
     box_coords_kernel<<<grid, 256, 0, st>>>(n3, xyz, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], out);
 }
 

@@ -449,11 +449,14 @@ def stress_case(oracle, rng, verbose=False, info=None):
             f"worst grad {worst:.1e}" + (" |" + note if note else ""))
 
 
-# What the stress set may lean on branch (b) of stress_case (bars measured over seeds 0-4 on the round-3 kernels,
-# profiles/r03_stress.txt, with head-room): per scene at most UNPINNED_MAX of the visible Gaussians may be rows that
-# binary32 does not pin, and per seed at most B_SCENES_MAX of the ten scenes may need the branch at all.
-UNPINNED_MAX = 0.20
-B_SCENES_MAX = 8
+# How far the stress set may lean on branch (b) of stress_case.  Measured over seeds 0-4 on the round-3 kernels
+# (profiles/r03_stress.txt): 27 of the 50 scenes need the branch for at least one tensor (4 - 6 per seed); the rows that
+# binary32 does not pin are at most 21 % of the visible Gaussians in scenes with more than 1000 of them (15 % above
+# 5000) and up to 33 % in the tiny ones (197 Gaussians: 30-odd rows).  The bars below are those figures with head-room;
+# a kernel change that pushes more of the set into the branch fails here instead of passing silently.
+UNPINNED_MAX = 0.25            # of the visible Gaussians, scenes with >= 1000 of them
+UNPINNED_MAX_SMALL = 0.40      # scenes with fewer
+B_SCENES_MAX = 7               # of the ten scenes of a seed
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4])
@@ -463,7 +466,7 @@ def test_randomised_stress_scenes(oracle, seed):
     the report file named by SPLATCO_STRESS_REPORT (committed as profiles/r03_stress.txt), and the use of branch (b) is
     bounded by asserts."""
     rng = np.random.default_rng(seed)
-    lines, b_scenes = [], 0
+    lines, b_scenes, over = [], 0, []
     for it in range(10):
         info = {}
         print(f"[stress {seed}/{it}] " + stress_case(oracle, rng, info=info))
@@ -474,10 +477,11 @@ def test_randomised_stress_scenes(oracle, seed):
                      f"{info['worst']:.2e} -> " + ("branch (a): 1e-4 over all rows" if not bb else
                      "branch (b) for " + ", ".join(f"{k} (all rows {v['all_rows']:.1e}, pinned rows {v['pinned_rel_l2']:.1e}, "
                                                    f"{v['unpinned_rows']} of {v['visible_rows']} rows unpinned)" for k, v in bb.items())))
-        assert frac <= UNPINNED_MAX, (seed, it, "fraction of visible rows not pinned by binary32", frac)
+        over.append((it, frac)) if frac > (UNPINNED_MAX if info["visible"] >= 1000 else UNPINNED_MAX_SMALL) else None
     lines.append(f"seed {seed}: {b_scenes} of 10 scenes used branch (b)")
     path = os.environ.get("SPLATCO_STRESS_REPORT")
     if path:
         with open(path, "a") as fh:
             fh.write("\n".join(lines) + "\n")
+    assert not over, (seed, "scenes whose fraction of visible rows not pinned by binary32 exceeds the bar", over)
     assert b_scenes <= B_SCENES_MAX, (seed, b_scenes)
