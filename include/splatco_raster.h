@@ -290,18 +290,21 @@ int scr_box_coords(int64_t V, const float* xyz, const float* lo_host, const floa
  * (cols[i] = 0, widths[i] = d: the attribute branch).  scr_norm_fold builds G[32, d] and c[32] from the pairs' parameters
  * (G[r, cols_i + j] += W_i[r, j] gamma_i[j];  c[r] = sum_i (W_i[r, :] . beta_i + b_i[r])), scr_norm_fold_backward turns
  * dG / dc into the gradients of the 4 L parameter tensors, scr_norm_running_stats applies nn.BatchNorm1d's running-statistics
- * update (momentum form) for all pairs from the batch mean / biased variance and n rows.  One single-workgroup launch each;
- * the `_host` arguments are HOST arrays of L widths / column offsets / DEVICE pointers. */
-int scr_norm_fold(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host, const void* const* lin_weight_host,
-                  const void* const* lin_bias_host, const void* const* bn_weight_host, const void* const* bn_bias_host, float* G,
-                  float* c, void* stream);
-int scr_norm_fold_backward(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host,
+ * update (momentum form) for all pairs from the batch mean / biased variance and n rows.  A few small launches each;
+ * the `_host` arguments are HOST arrays of L widths / column offsets / DEVICE pointers.  col_at_host (NULL = identity):
+ * d bytes, col_at[j] = the column of the input matrix (hence of G, mean, var) that holds reference column j -- for a
+ * caller that keeps its input columns in another order than the reference's concatenation (two grids' planes stacked
+ * and sampled together land interleaved). */
+int scr_norm_fold(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host, const uint8_t* col_at_host,
+                  const void* const* lin_weight_host, const void* const* lin_bias_host, const void* const* bn_weight_host,
+                  const void* const* bn_bias_host, float* G, float* c, void* stream);
+int scr_norm_fold_backward(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host, const uint8_t* col_at_host,
                            const void* const* lin_weight_host, const void* const* bn_weight_host, const void* const* bn_bias_host,
                            const float* dG, const float* dc, void* const* d_lin_weight_host, void* const* d_lin_bias_host,
                            void* const* d_bn_weight_host, void* const* d_bn_bias_host, void* stream);
-int scr_norm_running_stats(int32_t L, const int32_t* widths_host, const int32_t* cols_host, const float* momentum_host,
-                           void* const* running_mean_host, void* const* running_var_host, void* const* num_batches_host,
-                           const float* mean, const float* var, int64_t n, void* stream);
+int scr_norm_running_stats(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host, const uint8_t* col_at_host,
+                           const float* momentum_host, void* const* running_mean_host, void* const* running_var_host,
+                           void* const* num_batches_host, const float* mean, const float* var, int64_t n, void* stream);
 int scr_norm_linear_forward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* G, const float* c, float eps,
                             float* y, float* mean, float* var, float* inv, void* scratch, void* stream);
 int scr_norm_linear_backward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* G,

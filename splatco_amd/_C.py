@@ -109,9 +109,9 @@ def _load():
     lib.scr_norm_linear_backward.restype = C.c_int
     lib.scr_box_coords.argtypes = [i64, vp, vp, vp, vp, vp]
     lib.scr_box_coords.restype = C.c_int
-    lib.scr_norm_fold.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.scr_norm_fold_backward.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.scr_norm_running_stats.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.scr_norm_fold.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.scr_norm_fold_backward.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.scr_norm_running_stats.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     for f in ("scr_norm_fold", "scr_norm_fold_backward", "scr_norm_running_stats"):
         getattr(lib, f).restype = C.c_int
     lib.scr_plane_sample_backward.restype = C.c_int

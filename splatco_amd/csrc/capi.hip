@@ -662,26 +662,27 @@ int scr_box_coords(int64_t V, const float* xyz, const float* lo_host, const floa
 }
 
 // ---- the parameter side of the fold: G, c from the pairs' weights, their gradients back, running statistics (normlinear.hip)
-int scr_norm_fold(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host, const void* const* lin_weight_host,
+int scr_norm_fold(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host, const uint8_t* col_at_host,
+                  const void* const* lin_weight_host,
                   const void* const* lin_bias_host, const void* const* bn_weight_host, const void* const* bn_bias_host, float* G,
                   float* c, void* stream) {
     if (!widths_host || !cols_host || !lin_weight_host || !lin_bias_host || !bn_weight_host || !bn_bias_host || !G || !c)
         return fail("NULL argument");
-    if (launch_nl_fold(L, d, widths_host, cols_host, (const float* const*)lin_weight_host, (const float* const*)lin_bias_host,
+    if (launch_nl_fold(L, d, widths_host, cols_host, col_at_host, (const float* const*)lin_weight_host, (const float* const*)lin_bias_host,
                        (const float* const*)bn_weight_host, (const float* const*)bn_bias_host, G, c, (hipStream_t)stream))
-        return fail("scr_norm_fold: 1 <= L <= 4 pairs, column blocks inside [0, d), d <= 80");
+        return fail("scr_norm_fold: 1 <= L <= 4 pairs, column blocks inside [0, d), d <= 80, col_at a permutation of 0 .. d-1");
     CHECK_LAUNCH("nl_fold_kernel", 0, (hipStream_t)stream);
     return 0;
 }
 
-int scr_norm_fold_backward(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host,
+int scr_norm_fold_backward(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host, const uint8_t* col_at_host,
                            const void* const* lin_weight_host, const void* const* bn_weight_host, const void* const* bn_bias_host,
                            const float* dG, const float* dc, void* const* d_lin_weight_host, void* const* d_lin_bias_host,
                            void* const* d_bn_weight_host, void* const* d_bn_bias_host, void* stream) {
     if (!widths_host || !cols_host || !lin_weight_host || !bn_weight_host || !bn_bias_host || !dG || !dc || !d_lin_weight_host ||
         !d_lin_bias_host || !d_bn_weight_host || !d_bn_bias_host)
         return fail("NULL argument");
-    if (launch_nl_fold_backward(L, d, widths_host, cols_host, (const float* const*)lin_weight_host,
+    if (launch_nl_fold_backward(L, d, widths_host, cols_host, col_at_host, (const float* const*)lin_weight_host,
                                 (const float* const*)bn_weight_host, (const float* const*)bn_bias_host, dG, dc,
                                 (float* const*)d_lin_weight_host, (float* const*)d_lin_bias_host, (float* const*)d_bn_weight_host,
                                 (float* const*)d_bn_bias_host, (hipStream_t)stream))
@@ -690,12 +691,13 @@ int scr_norm_fold_backward(int32_t L, int32_t d, const int32_t* widths_host, con
     return 0;
 }
 
-int scr_norm_running_stats(int32_t L, const int32_t* widths_host, const int32_t* cols_host, const float* momentum_host,
+int scr_norm_running_stats(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host, const uint8_t* col_at_host,
+                           const float* momentum_host,
                            void* const* running_mean_host, void* const* running_var_host, void* const* num_batches_host,
                            const float* mean, const float* var, int64_t n, void* stream) {
     if (!widths_host || !cols_host || !momentum_host || !running_mean_host || !running_var_host || !mean || !var)
         return fail("NULL argument");
-    if (launch_nl_running_stats(L, widths_host, cols_host, momentum_host, (float* const*)running_mean_host,
+    if (launch_nl_running_stats(L, d, widths_host, cols_host, col_at_host, momentum_host, (float* const*)running_mean_host,
                                 (float* const*)running_var_host, (long long* const*)num_batches_host, mean, var, n,
                                 (hipStream_t)stream))
         return fail("scr_norm_running_stats: 1 <= L <= 4");

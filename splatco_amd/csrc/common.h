@@ -328,14 +328,15 @@ __device__ inline uint32_t quadrant_mask(float4 r0, float4 r1, int tile_x0, int 
 
 // launchers (defined in the .hip files)
 void launch_box_coords(int64_t V, const float* xyz, const float* lo, const float* hi, float* out, hipStream_t st);
-int launch_nl_fold(int L, int d, const int* dd, const int* col, const float* const* W, const float* const* b,
-                   const float* const* gamma, const float* const* beta, float* G, float* c, hipStream_t st);
-int launch_nl_fold_backward(int L, int d, const int* dd, const int* col, const float* const* W, const float* const* gamma,
-                            const float* const* beta, const float* dG, const float* dc, float* const* dW, float* const* db,
-                            float* const* dgamma, float* const* dbeta, hipStream_t st);
-int launch_nl_running_stats(int L, const int* dd, const int* col, const float* momentum, float* const* run_mean,
-                            float* const* run_var, long long* const* batches, const float* mean, const float* var, int64_t n,
-                            hipStream_t st);
+int launch_nl_fold(int L, int d, const int* dd, const int* col, const unsigned char* col_at, const float* const* W,
+                   const float* const* b, const float* const* gamma, const float* const* beta, float* G, float* c,
+                   hipStream_t st);
+int launch_nl_fold_backward(int L, int d, const int* dd, const int* col, const unsigned char* col_at, const float* const* W,
+                            const float* const* gamma, const float* const* beta, const float* dG, const float* dc,
+                            float* const* dW, float* const* db, float* const* dgamma, float* const* dbeta, hipStream_t st);
+int launch_nl_running_stats(int L, int d, const int* dd, const int* col, const unsigned char* col_at, const float* momentum,
+                            float* const* run_mean, float* const* run_var, long long* const* batches, const float* mean,
+                            const float* var, int64_t n, hipStream_t st);
 void launch_filter(int64_t P, const float* means3D, const float* scales, const float* rotations,
                    const float* cov3D, const KSettings& ks, int32_t* radii, hipStream_t st);
 void launch_mark_visible(int64_t P, const float* means3D, const float* view, uint8_t* out, hipStream_t st);

@@ -438,6 +438,8 @@ int launch_norm_linear_backward(int64_t V, int d, const float* x, int ldx, const
 // fixed order of additions (pair 0 first): deterministic.
 struct NlFoldArgs {
     int L, d;
+    unsigned char at[NL_DP];   // column of G (and of the input matrix) that holds reference column j: identity unless the caller
+                               // keeps its input columns in another order (FeaturePlanes stacks two grids' planes)
     int dd[4], col[4];
     const float* W[4];      // [32, d_i]
     const float* b[4];      // [32]
@@ -453,13 +455,13 @@ __global__ void __launch_bounds__(256) nl_fold_kernel(NlFoldArgs a, float* __res
     // grid: one workgroup per 256 elements of G; the last workgroup also forms c (8 lanes per row, fixed-order shuffle sum)
     const int e = (int)blockIdx.x * 256 + threadIdx.x;
     if (e < 32 * a.d) {
-        const int r = e / a.d, col = e - r * a.d;
+        const int r = e / a.d, col = e - r * a.d;      // col: reference column
         float g = 0.0f;
         for (int i = 0; i < a.L; ++i) {
             const int j = col - a.col[i];
             if (j >= 0 && j < a.dd[i]) g += a.W[i][r * a.dd[i] + j] * a.gamma[i][j];
         }
-        G[e] = g;
+        G[r * a.d + a.at[col]] = g;
     }
     if (blockIdx.x == gridDim.x - 1) {
         const int r = threadIdx.x >> 3, sub = threadIdx.x & 7;
@@ -485,14 +487,14 @@ __global__ void __launch_bounds__(256) nl_fold_backward_kernel(NlFoldArgs a, con
     const int e = (int)blockIdx.x * 256 + threadIdx.x;
     if (e < 32 * di) {
         const int r = e / di, j = e - r * di;
-        a.dW[i][e] = dG[r * a.d + a.col[i] + j] * a.gamma[i][j] + dc[r] * a.beta[i][j];
+        a.dW[i][e] = dG[r * a.d + a.at[a.col[i] + j]] * a.gamma[i][j] + dc[r] * a.beta[i][j];
     }
     if (blockIdx.x == 0) {
         for (int j = threadIdx.x; j < di; j += 256) {
             float sg = 0.0f, sb = 0.0f;
             for (int r = 0; r < 32; ++r) {
                 const float w = a.W[i][r * di + j];
-                sg += dG[r * a.d + a.col[i] + j] * w;
+                sg += dG[r * a.d + a.at[a.col[i] + j]] * w;
                 sb += dc[r] * w;
             }
             a.dgamma[i][j] = sg;
@@ -506,6 +508,7 @@ __global__ void __launch_bounds__(256) nl_fold_backward_kernel(NlFoldArgs a, con
 //   running_mean = (1 - m) running_mean + m mean;  running_var = (1 - m) running_var + m var n / (n - 1);  batches += 1
 struct NlRunArgs {
     int L;
+    unsigned char at[NL_DP];
     int dd[4], col[4];
     float momentum[4];
     float* run_mean[4];
@@ -517,18 +520,32 @@ __global__ void __launch_bounds__(256) nl_running_stats_kernel(NlRunArgs a, cons
     for (int i = 0; i < a.L; ++i) {
         const float m = a.momentum[i];
         for (int j = threadIdx.x; j < a.dd[i]; j += 256) {
-            a.run_mean[i][j] = a.run_mean[i][j] * (1.0f - m) + m * mean[a.col[i] + j];
-            a.run_var[i][j] = a.run_var[i][j] * (1.0f - m) + m * (var[a.col[i] + j] * unbias);
+            const int at = a.at[a.col[i] + j];
+            a.run_mean[i][j] = a.run_mean[i][j] * (1.0f - m) + m * mean[at];
+            a.run_var[i][j] = a.run_var[i][j] * (1.0f - m) + m * (var[at] * unbias);
         }
         if (threadIdx.x == 0 && a.batches[i]) *a.batches[i] += 1;
     }
 }
 
-int launch_nl_fold(int L, int d, const int* dd, const int* col, const float* const* W, const float* const* b,
-                   const float* const* gamma, const float* const* beta, float* G, float* c, hipStream_t st) {
+static bool nl_set_perm(unsigned char (&at)[NL_DP], int d, const unsigned char* col_at) {
+    bool seen[NL_DP] = {};
+    for (int j = 0; j < d; ++j) {
+        const int t = col_at ? col_at[j] : j;
+        if (t >= d || seen[t]) return false;       // not a permutation of 0 .. d-1
+        seen[t] = true;
+        at[j] = (unsigned char)t;
+    }
+    return true;
+}
+
+int launch_nl_fold(int L, int d, const int* dd, const int* col, const unsigned char* col_at, const float* const* W,
+                   const float* const* b, const float* const* gamma, const float* const* beta, float* G, float* c,
+                   hipStream_t st) {
     if (L < 1 || L > 4 || d < 1 || d > NL_DP) return 1;
     NlFoldArgs a = {};
     a.L = L; a.d = d;
+    if (!nl_set_perm(a.at, d, col_at)) return 1;
     for (int i = 0; i < L; ++i) {
         if (dd[i] < 1 || col[i] < 0 || col[i] + dd[i] > d) return 1;
         a.dd[i] = dd[i]; a.col[i] = col[i]; a.W[i] = W[i]; a.b[i] = b[i]; a.gamma[i] = gamma[i]; a.beta[i] = beta[i];
@@ -537,12 +554,13 @@ int launch_nl_fold(int L, int d, const int* dd, const int* col, const float* con
     return 0;
 }
 
-int launch_nl_fold_backward(int L, int d, const int* dd, const int* col, const float* const* W, const float* const* gamma,
-                            const float* const* beta, const float* dG, const float* dc, float* const* dW, float* const* db,
-                            float* const* dgamma, float* const* dbeta, hipStream_t st) {
+int launch_nl_fold_backward(int L, int d, const int* dd, const int* col, const unsigned char* col_at, const float* const* W,
+                            const float* const* gamma, const float* const* beta, const float* dG, const float* dc,
+                            float* const* dW, float* const* db, float* const* dgamma, float* const* dbeta, hipStream_t st) {
     if (L < 1 || L > 4 || d < 1 || d > NL_DP) return 1;
     NlFoldArgs a = {};
     a.L = L; a.d = d;
+    if (!nl_set_perm(a.at, d, col_at)) return 1;
     for (int i = 0; i < L; ++i) {
         if (dd[i] < 1 || col[i] < 0 || col[i] + dd[i] > d) return 1;
         a.dd[i] = dd[i]; a.col[i] = col[i]; a.W[i] = W[i]; a.gamma[i] = gamma[i]; a.beta[i] = beta[i];
@@ -552,12 +570,15 @@ int launch_nl_fold_backward(int L, int d, const int* dd, const int* col, const f
     return 0;
 }
 
-int launch_nl_running_stats(int L, const int* dd, const int* col, const float* momentum, float* const* run_mean,
-                            float* const* run_var, long long* const* batches, const float* mean, const float* var, int64_t n,
-                            hipStream_t st) {
-    if (L < 1 || L > 4) return 1;
+int launch_nl_running_stats(int L, int d, const int* dd, const int* col, const unsigned char* col_at, const float* momentum,
+                            float* const* run_mean, float* const* run_var, long long* const* batches, const float* mean,
+                            const float* var, int64_t n, hipStream_t st) {
+    if (L < 1 || L > 4 || d < 1 || d > NL_DP) return 1;
     NlRunArgs a = {};
     a.L = L;
+    if (!nl_set_perm(a.at, d, col_at)) return 1;
+    for (int i = 0; i < L; ++i)
+        if (dd[i] < 1 || col[i] < 0 || col[i] + dd[i] > d) return 1;
     for (int i = 0; i < L; ++i) {
         a.dd[i] = dd[i]; a.col[i] = col[i]; a.momentum[i] = momentum[i];
         a.run_mean[i] = run_mean[i]; a.run_var[i] = run_var[i]; a.batches[i] = batches ? batches[i] : nullptr;

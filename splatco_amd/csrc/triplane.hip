@@ -894,7 +894,8 @@ int launch_triplane_backward_multi(int64_t V, const float* coords, int cs, int n
         if (col[g + 1] != col[g] + 3 * R[g]) return 3;
     const int RA = R[0], RB = ngrids > 1 ? R[1] : 0, RC = ngrids > 2 ? R[2] : 0;
     // the layouts of FeaturePlanes (r = channels per plane): attention grid stacked (2 r) [+ plain (r) [+ plain (r)]], or plain grids only
-    const bool known = (RA == 10 && (RB == 0 || RB == 5) && (RC == 0 || RC == 5)) || (RA == 5 && (RB == 0 || RB == 5) && (RC == 0 || RC == 5));
+    // (15: the attention grid's pair planes with the same-size plain grid's plane stacked on them, one record / gather per projection)
+    const bool known = ((RA == 10 || RA == 5) && (RB == 0 || RB == 5) && (RC == 0 || RC == 5)) || (RA == 15 && (RB == 0 || RB == 5) && RC == 0);
     if (!known || (RC && !RB)) return 3;
     TpProjSet9 ps;
     ps.n = 3 * ngrids;
@@ -924,7 +925,9 @@ int launch_triplane_backward_multi(int64_t V, const float* coords, int cs, int n
     tp_count9_kernel<<<nwg, TP_THREADS, hb, st>>>(V, coords, cs, ps);
     tp_scan9_kernel<<<ps.n, 1024, 0, st>>>(ps);
 #define SCR_TP_S9(a, b, c) tp_scatter9_kernel<a, b, c><<<nwg, TP_THREADS, hb, st>>>(V, coords, cs, grad, ld, col[0], ps)
-    if (RA == 10) {
+    if (RA == 15) {
+        if (RB) SCR_TP_S9(15, 5, 0); else SCR_TP_S9(15, 0, 0);
+    } else if (RA == 10) {
         if (RC) SCR_TP_S9(10, 5, 5); else if (RB) SCR_TP_S9(10, 5, 0); else SCR_TP_S9(10, 0, 0);
     } else {
         if (RC) SCR_TP_S9(5, 5, 5); else if (RB) SCR_TP_S9(5, 5, 0); else SCR_TP_S9(5, 0, 0);
@@ -932,7 +935,8 @@ int launch_triplane_backward_multi(int64_t V, const float* coords, int cs, int n
 #undef SCR_TP_S9
     for (int g = 0; g < ngrids; ++g)
         for (int q = 0; q < 3; ++q) {
-            if (R[g] == 10) tp_gather_launch<10, 1>(ps.p[3 * g + q], grad_planes[3 * g + q], st);
+            if (R[g] == 15) tp_gather_launch<15, 1>(ps.p[3 * g + q], grad_planes[3 * g + q], st);
+            else if (R[g] == 10) tp_gather_launch<10, 1>(ps.p[3 * g + q], grad_planes[3 * g + q], st);
             else tp_gather_launch<5, 1>(ps.p[3 * g + q], grad_planes[3 * g + q], st);
         }
     return 0;

@@ -9,12 +9,18 @@ state_dicts load unchanged (tests/golden/neural_gaussians.npz was captured from 
 Out of scope here: optimiser, densification, PLY io, entropy models, the
 dead Spatial_CTX grids.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 NORM_LINEAR_HIP = True       # _NormLinearFn on the GPU: csrc/normlinear.hip (False: the torch ops, kept as the checker's other leg)
 FUSE_NORM_LINEAR = True      # FeaturePlanes: fold the train-mode BatchNorms into their Linears (see _NormLinearFn)
+# Measured and left off (round 3, cfg2, anchors in Morton order): tri-plane forward 1.58 -> 2.00 ms (60 floats per sample and
+# plane keep fewer threads in flight than the line requests saved are worth once the gathers are mostly L2 hits), plane
+# backward 2.31 -> 2.25 ms, step 22.7 -> 23.1 ms.  tests/test_gpu_renderer.py keeps the path checked.
+STACK_LEVEL0 = os.environ.get("SPLATCO_STACK_LEVEL0", "0") != "0"   # FeaturePlanes: sample the attention grid and the same-size plain grid of level 0 as one stacked grid
 
 
 class _TallLinearFn(torch.autograd.Function):
@@ -182,20 +188,21 @@ class _NormFold(torch.autograd.Function):
     forward and twice that backward.  tensors = (W_0, b_0, gamma_0, beta_0, W_1, ...)."""
 
     @staticmethod
-    def forward(ctx, d, widths, cols, *tensors):
+    def forward(ctx, d, widths, cols, col_at, *tensors):
         import ctypes as C
         from . import _C
         from .rasterizer import _stream
         L, dev = len(widths), tensors[0].device
+        at = None if col_at is None else (C.c_uint8 * d)(*col_at)
         ts = [t.detach().contiguous().float() for t in tensors]
         W, b, ga, be = ts[0::4], ts[1::4], ts[2::4], ts[3::4]
         G, c = torch.empty(32, d, device=dev), torch.empty(32, device=dev)
         wi, ci = (C.c_int32 * L)(*widths), (C.c_int32 * L)(*cols)
         with torch.cuda.device(dev):
-            _C.check(_C.lib.scr_norm_fold(L, d, wi, ci, _ptr_table(W), _ptr_table(b), _ptr_table(ga), _ptr_table(be),
+            _C.check(_C.lib.scr_norm_fold(L, d, wi, ci, at, _ptr_table(W), _ptr_table(b), _ptr_table(ga), _ptr_table(be),
                                           G.data_ptr(), c.data_ptr(), _stream(dev)))
         ctx.save_for_backward(*W, *ga, *be)
-        ctx.meta = (d, tuple(widths), tuple(cols))
+        ctx.meta = (d, tuple(widths), tuple(cols), None if col_at is None else tuple(col_at))
         return G, c
 
     @staticmethod
@@ -203,8 +210,9 @@ class _NormFold(torch.autograd.Function):
         import ctypes as C
         from . import _C
         from .rasterizer import _stream
-        d, widths, cols = ctx.meta
+        d, widths, cols, col_at = ctx.meta
         L = len(widths)
+        at = None if col_at is None else (C.c_uint8 * d)(*col_at)
         saved = ctx.saved_tensors
         W, ga, be = saved[:L], saved[L:2 * L], saved[2 * L:]
         dev = W[0].device
@@ -215,13 +223,13 @@ class _NormFold(torch.autograd.Function):
         dga, dbe = [torch.empty_like(g) for g in ga], [torch.empty_like(g) for g in be]
         wi, ci = (C.c_int32 * L)(*widths), (C.c_int32 * L)(*cols)
         with torch.cuda.device(dev):
-            _C.check(_C.lib.scr_norm_fold_backward(L, d, wi, ci, _ptr_table(W), _ptr_table(ga), _ptr_table(be), dG.data_ptr(),
+            _C.check(_C.lib.scr_norm_fold_backward(L, d, wi, ci, at, _ptr_table(W), _ptr_table(ga), _ptr_table(be), dG.data_ptr(),
                                                    dc.data_ptr(), _ptr_table(dW), _ptr_table(db), _ptr_table(dga),
                                                    _ptr_table(dbe), _stream(dev)))
         out = []
         for i in range(L):
             out += [dW[i], db[i], dga[i], dbe[i]]
-        return (None, None, None, *out)
+        return (None, None, None, None, *out)
 
 
 def _fold_on_device(x, bns, linears):
@@ -230,11 +238,14 @@ def _fold_on_device(x, bns, linears):
             and all(bn.affine for bn in bns))
 
 
-def _norm_linear(x, bns, linears):
+def _norm_linear(x, bns, linears, col_at=None):
     """sum_i Linear_i(BatchNorm_i(x_i)) where x = cat_i(x_i) column-wise (bns[i] normalises its own column
     block; pass the same block twice -- offsets repeat -- is not supported) OR every BatchNorm_i sees the
     whole x (len(bns) == len(linears), all of width x.shape[1]).  Updates the running statistics as
-    nn.BatchNorm1d.forward does in training mode."""
+    nn.BatchNorm1d.forward does in training mode.
+    col_at (sequence of d ints, a permutation): x keeps the reference's column j at column col_at[j] (FeaturePlanes
+    samples two same-size grids as one and gets their features interleaved); G, the batch statistics and the running
+    statistics follow."""
     d = x.shape[1]
     shared = all(bn.num_features == d for bn in bns)
     if not shared:
@@ -244,7 +255,7 @@ def _norm_linear(x, bns, linears):
     on_device = _fold_on_device(x, bns, linears)
     if on_device:
         # one launch builds G and c from the 4 L parameter tensors (and one takes their gradients back)
-        G, c = _NormFold.apply(d, tuple(widths), tuple(cols),
+        G, c = _NormFold.apply(d, tuple(widths), tuple(cols), None if col_at is None else tuple(int(v) for v in col_at),
                                *[t for bn, lin in zip(bns, linears) for t in (lin.weight, lin.bias, bn.weight, bn.bias)])
     elif shared:    # same input through every pair: the folded weights simply add up
         G = sum(lin.weight * bn.weight for bn, lin in zip(bns, linears))
@@ -252,6 +263,10 @@ def _norm_linear(x, bns, linears):
     else:
         G = torch.cat([lin.weight * bn.weight for bn, lin in zip(bns, linears)], dim=1)
         c = sum(lin.weight @ bn.bias + lin.bias for bn, lin in zip(bns, linears))
+    at_idx = None
+    if col_at is not None and not on_device:      # G[:, col_at[j]] = G_ref[:, j]
+        at_idx = torch.as_tensor(list(col_at), dtype=torch.long, device=x.device)
+        G = torch.zeros_like(G).index_copy(1, at_idx, G)
     assert all(bn.eps == bns[0].eps for bn in bns)
     y, mean, var = _NormLinearFn.apply(x, G, c, bns[0].eps)
     with torch.no_grad():
@@ -265,10 +280,16 @@ def _norm_linear(x, bns, linears):
             L = len(bns)
             with torch.cuda.device(x.device):
                 _C.check(_C.lib.scr_norm_running_stats(
-                    L, (C.c_int32 * L)(*widths), (C.c_int32 * L)(*cols), (C.c_float * L)(*[float(bn.momentum) for bn in bns]),
+                    L, d, (C.c_int32 * L)(*widths), (C.c_int32 * L)(*cols),
+                    None if col_at is None else (C.c_uint8 * d)(*[int(v) for v in col_at]),
+                    (C.c_float * L)(*[float(bn.momentum) for bn in bns]),
                     _ptr_table([bn.running_mean for bn in bns]), _ptr_table([bn.running_var for bn in bns]),
                     _ptr_table([bn.num_batches_tracked for bn in bns]), mean.data_ptr(), var.data_ptr(), n, _stream(x.device)))
             return y
+        if col_at is not None:                     # statistics back in the reference's column order
+            if at_idx is None:
+                at_idx = torch.as_tensor(list(col_at), dtype=torch.long, device=x.device)
+            mean, var = mean.index_select(0, at_idx), var.index_select(0, at_idx)
         off = 0
         for bn in bns:
             m, v = (mean, var) if shared else (mean[off:off + bn.num_features], var[off:off + bn.num_features])
@@ -432,6 +453,14 @@ class FeaturePlanes(nn.Module):               # scene/gaussian_model.py:97-169
             self.models.append(nn.Sequential(nn.BatchNorm1d(d), TallLinear(d, out_dim)))
             self.CTX_models.append(nn.Sequential(nn.BatchNorm1d(71), TallLinear(71, out_dim)))
 
+    def _stackable(self):
+        """Level 0's two grids (attention + plain) can be sampled as one: same plane sizes, same box, fused attention."""
+        from . import plane_attention
+        g0, g1 = self.k0s[0], self.k0s[1]
+        return (g0.TAflag and not g1.TAflag and g0.channels == g1.channels and g0.bounds_key() == g1.bounds_key()
+                and all(a.shape == b.shape for a, b in ((g0.xy_plane, g1.xy_plane), (g0.xz_plane, g1.xz_plane), (g0.yz_plane, g1.yz_plane)))
+                and 3 * (g0.channels // 3) <= 16 and plane_attention.fused_ok(g0.xy_plane, g0.xz_plane, g0.yz_plane, g0.TA))
+
     def inactive_parameters(self):
         """Parameters of the levels above activate_level: forward() does not touch them, so they never receive a gradient.
         The reference leaves their .grad None and torch.optim skips them; a training loop that pre-allocates gradients
@@ -444,31 +473,51 @@ class FeaturePlanes(nn.Module):               # scene/gaussian_model.py:97-169
         """parts=True: return the two 32-column halves (plane branch, attribute branch) instead of their
         concatenation, when they exist as separate matrices (the fused MLP heads read them as they are)."""
         L = self.activate_level + 1
+        col_at = None
         if FUSE_NORM_LINEAR and all(m[0].training for m in list(self.models[:L]) + list(self.CTX_models[:L])):
             # sum_i cat(Linear(BN(feat_i)), Linear(BN(g_fea))) is linear in the normalised inputs: two GEMMs
             if x.dim() == 2 and all(self.k0s[i].fused_ok(x) for i in range(L)):
                 # every active grid samples straight into its columns of one matrix (no torch.cat of the grids' outputs)
                 from .triplane import multi_triplane_sample
-                specs, col, shared = [], 0, {}
-                for i in range(L):
+                specs, col, shared, noise_cols = [], 0, {}, []
+                first = 0
+                if L > 1 and STACK_LEVEL0 and self._stackable():
+                    # The attention grid and the level-0 plain grid have the same size and the same box: every point
+                    # samples both at the same texels.  The plain grid's plane is stacked on the attention grid's pair planes
+                    # (plane | attended twin | level-0 plane: 3 r channels) and the two grids are sampled -- and their
+                    # gradients scattered -- as ONE: one gather / one record of 15 channels per projection instead of 10 + 5.
+                    # The samples of projection q land at columns 15 q .. 15 q + 15 where the reference's concatenation
+                    # (scene/gaussian_model.py:160-166) has grid 0's at 10 q .. and grid 1's at 30 + 5 q ..: col_at tells
+                    # the BatchNorm-Linear fold, which is free to keep its input columns in any order.
+                    g0, g1 = self.k0s[0], self.k0s[1]
+                    r = g1.channels // 3
+                    ind3, pairs, _ = g0.sample_spec(x, 0)
+                    shared.setdefault(g0.bounds_key(), ind3)
+                    stacked = tuple(torch.cat((pr, pl), dim=1) for pr, pl in zip(pairs, (g1.xy_plane, g1.xz_plane, g1.yz_plane)))
+                    specs.append((ind3, stacked, (0, 3 * r, 6 * r)))
+                    col_at = [(j // (2 * r)) * 3 * r + j % (2 * r) for j in range(6 * r)]
+                    col_at += [q * 3 * r + 2 * r + k for q in range(3) for k in range(r)]
+                    noise_cols = [(q * 3 * r + 2 * r, r) for q in range(3)]
+                    col, first = 9 * r, 2
+                for i in range(first, L):
                     # grids with the same box sample at the same normalised coordinates: ONE tensor, which also lets the
                     # backward of all grids run as one pass over the points
                     key = self.k0s[i].bounds_key()
                     spec = self.k0s[i].sample_spec(x, col, shared.get(key))
                     shared.setdefault(key, spec[0])
                     specs.append(spec)
+                    if not self.k0s[i].TAflag:
+                        noise_cols.append((col, self.k0s[i].get_dim()))
                     col += self.k0s[i].get_dim()
+                if col_at is not None:
+                    col_at += list(range(len(col_at), col))
                 feats = multi_triplane_sample(specs)
                 if Q != 0:                       # uniform noise on the plain grids' blocks only (scene/grids.py:159-181)
-                    col = 0
-                    for i in range(L):
-                        d = self.k0s[i].get_dim()
-                        if not self.k0s[i].TAflag:
-                            feats[:, col:col + d] += torch.empty(feats.shape[0], d, device=feats.device).uniform_(-0.5, 0.5) * Q
-                        col += d
+                    for c0, w in noise_cols:
+                        feats[:, c0:c0 + w] += torch.empty(feats.shape[0], w, device=feats.device).uniform_(-0.5, 0.5) * Q
             else:
                 feats = torch.cat([self.k0s[i](x, Q) for i in range(L)], dim=1) if L > 1 else self.k0s[0](x, Q)
-            a = _norm_linear(feats, [self.models[i][0] for i in range(L)], [self.models[i][1] for i in range(L)])
+            a = _norm_linear(feats, [self.models[i][0] for i in range(L)], [self.models[i][1] for i in range(L)], col_at=col_at)
             b = _norm_linear(g_fea, [self.CTX_models[i][0] for i in range(L)], [self.CTX_models[i][1] for i in range(L)])
             return (a, b) if parts else torch.cat((a, b), dim=1)
         res = []

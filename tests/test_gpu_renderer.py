@@ -942,3 +942,45 @@ def test_box_coords_and_inverse_index_equal_the_framework_ops():
         assert torch.equal(idx._scr_inverse, inv)
     empty = mask_indices(torch.zeros(100, dtype=torch.bool, device=dev))
     assert empty.numel() == 0 and torch.all(empty._scr_inverse == -1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, 2])
+def test_stacked_level0_grids_equal_separate_sampling(level):
+    """FeaturePlanes samples the attention grid and the same-size plain grid of level 0 as ONE stacked 15-channel grid
+    (scene_model.STACK_LEVEL0): features interleaved by projection, the BatchNorm-Linear fold told where each reference
+    column sits.  Against the separate-grid path: output, running statistics and every parameter gradient (the planes',
+    the attention module's, the BatchNorms', the Linears')."""
+    from splatco_amd import scene_model as sm
+    dev = torch.device("cuda:0")
+    res = {}
+    for stack in (False, True):
+        torch.manual_seed(5)
+        fp = sm.FeaturePlanes([96, 96, 96], torch.tensor([-2.0, -2.0, -2.0]), torch.tensor([2.0, 2.0, 2.0]), feat_dim=15).to(dev)
+        fp.activate_level = level
+        with torch.no_grad():
+            for p in fp.parameters():
+                p.add_(0.2 * torch.randn_like(p))
+        g = torch.Generator(device=dev).manual_seed(9)
+        x = torch.rand(300_007, 3, device=dev, generator=g) * 4.4 - 2.2
+        g_fea = torch.randn(300_007, 72, device=dev, generator=g)[:, :71]
+        w = torch.randn(300_007, 64, device=dev, generator=g)
+        sm.STACK_LEVEL0 = stack
+        try:
+            y = fp(x, g_fea, 0)
+        finally:
+            sm.STACK_LEVEL0 = False
+        (y * w).sum().backward()
+        res[stack] = (y.detach(), {n: p.grad.clone() for n, p in fp.named_parameters() if p.grad is not None},
+                      {n: b.clone() for n, b in fp.named_buffers()})
+    (y0, g0, b0), (y1, g1, b1) = res[False], res[True]
+    assert torch.allclose(y0, y1, rtol=1e-4, atol=1e-5), float((y0 - y1).abs().max())
+    assert set(g0) == set(g1) and len(g0) > 15
+    for n in g0:
+        num, den = float((g0[n] - g1[n]).norm()), max(float(g0[n].norm()), 1e-20)
+        assert num / den < 2e-4, (n, num / den)
+    for n in b0:
+        if b0[n].is_floating_point():
+            assert torch.allclose(b0[n], b1[n], rtol=1e-5, atol=1e-6), n
+        else:
+            assert torch.equal(b0[n], b1[n]), n
