@@ -195,9 +195,11 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
  * times their block of R gradient columns (grad_out0 / grad_out1: the column-offset pointers into the gradient matrix of
  * row stride ld); (cx, cy) are the columns of coords that hold (gx, gy).  Both grad_plane arrays are overwritten.
  * The points' coordinates and gradient pieces are first moved into per-tile runs of records (32x32-cell tiles), then
- * summed per node in registers; the order of the points inside a cell follows LDS / global atomics and the nodes on a
- * tile's border are flushed with global float atomics -- plane gradients are therefore reproducible only up to the
- * order of those adds, unlike every other output of this library.  R <= 16 (with planes = 2: two passes above R = 5); scratch from
+ * summed per node in registers; the nodes on a tile's border go through a per-tile halo block and are added across the
+ * (up to four) tiles that share them in a fixed order by a last small pass: no floating-point atomics anywhere, every element
+ * of the plane gradient is written exactly once.  What remains of run-to-run variation is the ORDER in which a cell's
+ * points are summed (their positions in the tile's run follow integer atomics): plane gradients are reproducible up to
+ * the rounding of that order (1e-7 relative), unlike every other output of this library, which is bit-reproducible.  R <= 16 (with planes = 2: two passes above R = 5); scratch from
  * scr_plane_sample_scratch_bytes(V, A, B, R * planes).  The sample positions get no gradient (the reference detaches
  * them, scene/gaussian_model.py:210).
  *

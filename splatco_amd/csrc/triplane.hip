@@ -16,8 +16,10 @@
 // scheme as the rasterizer's tile binning), for the three projections of a grid in ONE pass over the points that
 // moves each point's coordinates and gradient piece into the tile's run of 32 / 48-byte records
 // (tp_scatter_kernel); one workgroup per tile then sorts chunks of its run by cell in LDS and every thread sums,
-// in registers, the four corner contributions of the cell it owns (tp_cell_gather_kernel): no float atomics
-// inside a tile, global atomics only for the 128 border nodes a tile shares with its neighbours.
+// in registers, the four corner contributions of the cell it owns (tp_cell_gather_kernel); the 128 border nodes a tile
+// shares with its neighbours go to a per-tile halo block and are added across tiles in a fixed order by
+// tp_border_sum_kernel: no float atomics at all (round 2 flushed the border nodes with device atomics: 6.3 M per cfg2
+// step, 0.56 ms of the 2.3 ms the plane backward took).
 // Round 1 kept an index list per tile and gathered coordinates and gradients through it (0.43 ms per plane at
 // 4.6 M points, 5.2 ms per cfg2 step); records + one pass per grid + cell-centred sums: 3.2 ms per step.
 #include "common.h"
@@ -30,6 +32,11 @@ namespace scr {
 #endif
 constexpr int TP_TILE = SCR_TP_TILE;   // cells per tile edge; a tile owns (TP_TILE + 1)^2 nodes
 constexpr int TP_NODES = TP_TILE + 1;
+constexpr int TP_BORDER = 4 * TP_TILE;  // nodes on a tile's border (the outer ring of its TP_NODES x TP_NODES nodes)
+// position of border node (na, nb) in a tile's halo block: top row, bottom row, left column, right column
+__host__ __device__ inline int tp_border_index(int na, int nb) {
+    return na == 0 ? nb : (na == TP_TILE ? TP_NODES + nb : (nb == 0 ? 2 * TP_NODES + (na - 1) : 2 * TP_NODES + (TP_TILE - 1) + (na - 1)));
+}
 constexpr int TP_MAX_R = 16;           // channels per plane (R = num_channels / 3; a plain plane stacked on its attended twin: 2 R)
 constexpr int TP_THREADS = 1024;
 constexpr int TP_ROUNDS = 4;
@@ -89,6 +96,7 @@ struct TpProj {
     int col0, col1;                       // first gradient column of the plane (and of the second plane sampled with it)
     uint32_t *count, *start, *cursor;     // [tiles], [tiles + 1], [tiles]
     float* rec;                           // [V][tp_rec(R * NP)]
+    float* halo;                          // [tiles][TP_BORDER][R * NP]: every tile's sums for the nodes on its border
 };
 struct TpProjSet {
     TpProj p[3];
@@ -406,9 +414,9 @@ tp_scatter9_kernel(int64_t V, const float* __restrict__ coords, int cs, const fl
 // stay where they are), and every thread owns four of the tile's 32 x 32 cells: it walks the points of its cells
 // once and keeps the cell's four corner sums x RT channels in registers over all chunks.  At the end the corner sums
 // meet in an LDS image of the tile's 33 x 33 nodes, one corner per pass (within a pass every node receives from one
-// cell: plain read-modify-writes).  No float atomics inside the tile; the sums of a tile's border nodes (shared with
-// the neighbours) go out as global atomics, interior nodes as plain stores.  Points whose cell lies one step outside
-// the plane (grid coordinate just beyond -1: only their inner corners exist) are rare and go out as global atomics.
+// cell: plain read-modify-writes).  No float atomics: interior nodes go out as plain stores, the sums of a tile's border
+// nodes (shared with the neighbours) to the tile's halo block (pass 5 adds the tiles' shares).  Points whose cell lies
+// one step outside the plane (grid coordinate just beyond -1: only their inner corners exist) are folded into cell 0.
 #ifdef SCR_PHASE_TIMING
 __device__ unsigned long long tp_gather_ticks[16];
 #endif
@@ -434,7 +442,8 @@ constexpr size_t tpn_lds_bytes() {              // cnt, start, waves, order, rec
 template <int R, int NP>
 __global__ void __launch_bounds__(TPN_THREADS, (R * NP <= 5 ? 8 : 4))
 tp_cell_gather_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_start, const float* __restrict__ rec,
-                      float* __restrict__ grad_plane0 /*[R][A][B]*/, float* __restrict__ grad_plane1) {
+                      float* __restrict__ grad_plane0 /*[R][A][B]*/, float* __restrict__ grad_plane1,
+                      float* __restrict__ halo /*[tiles][TP_BORDER][R * NP]*/) {
     constexpr int RT = R * NP, REC = tp_rec(RT);
     constexpr int CHUNK = tpn_chunk<RT>();
     constexpr int PPT = (CHUNK + TPN_THREADS - 1) / TPN_THREADS;
@@ -487,26 +496,23 @@ tp_cell_gather_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_st
                 int a0, b0;
                 float fa, fb;
                 tp_cell(raw[q * REC], raw[q * REC + 1], A, B, a0, b0, fa, fb);
-                const int la = a0 - ta * TP_TILE, lb = b0 - tbb * TP_TILE;      // in [-1, 31]
-                if (la >= 0 && lb >= 0) {
-                    raw[q * REC] = fa;
-                    raw[q * REC + 1] = fb;
-                    cell[k] = la * TP_TILE + lb;
-                    rank[k] = atomicAdd(&cnt[cell[k]], 1u);
-                } else {
+                int la = a0 - ta * TP_TILE, lb = b0 - tbb * TP_TILE;      // in [-1, 31]
+                // A cell one step outside the plane (grid coordinate just below -1: only the corners on row / column 0
+                // exist) is folded into cell 0 of that axis: fraction 0 and the gradient scaled by the weight of the
+                // existing corner give exactly its contribution to row / column 0 and nothing to row / column 1 -- the
+                // point then takes the ordinary path (round 2 sent such points out as device atomics, which the plain
+                // stores of the border pass would now overwrite).
+                float scale = 1.0f;
+                if (la < 0) { scale *= fa; fa = 0.0f; la = 0; }
+                if (lb < 0) { scale *= fb; fb = 0.0f; lb = 0; }
+                if (scale != 1.0f) {
 #pragma unroll
-                    for (int corner = 0; corner < 4; ++corner) {
-                        const int da = corner >> 1, db = corner & 1;
-                        const int a = a0 + da, b = b0 + db;
-                        if (a < 0 || a >= A || b < 0 || b >= B) continue;
-                        const float w = (da ? fa : 1.0f - fa) * (db ? fb : 1.0f - fb);
-#pragma unroll
-                        for (int r = 0; r < RT; ++r) {
-                            float* dst = (r < R ? grad_plane0 + ((size_t)r * A + a) * B : grad_plane1 + ((size_t)(r - R) * A + a) * B) + b;
-                            unsafeAtomicAdd(dst, raw[q * REC + 2 + r] * w);
-                        }
-                    }
+                    for (int r = 0; r < RT; ++r) raw[q * REC + 2 + r] *= scale;
                 }
+                raw[q * REC] = fa;
+                raw[q * REC + 1] = fb;
+                cell[k] = la * TP_TILE + lb;
+                rank[k] = atomicAdd(&cnt[cell[k]], 1u);
             }
         }
         __syncthreads();
@@ -559,12 +565,15 @@ tp_cell_gather_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_st
         const int a = ta * TP_TILE + na, b = tbb * TP_TILE + nb;
         if (a >= A || b >= B) continue;
         const bool shared = na == 0 || na == TP_TILE || nb == 0 || nb == TP_TILE;
+        // a border node is shared with up to three neighbouring tiles: its sum goes to this tile's halo block and
+        // tp_border_sum_kernel adds the tiles' shares in a fixed order (round 2 added them with device float atomics:
+        // 6.3 M per cfg2 step, and the only gradient of the library that was not bit-reproducible)
+        float* hb = halo + ((size_t)t * TP_BORDER + (shared ? tp_border_index(na, nb) : 0)) * RT;
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            float* dst = (r < R ? grad_plane0 + ((size_t)r * A + a) * B : grad_plane1 + ((size_t)(r - R) * A + a) * B) + b;
             const float v = raw[nd * RT + r];
-            if (!shared) *dst = v;
-            else if (v != 0.0f) unsafeAtomicAdd(dst, v);
+            if (shared) hb[r] = v;
+            else *((r < R ? grad_plane0 + ((size_t)r * A + a) * B : grad_plane1 + ((size_t)(r - R) * A + a) * B) + b) = v;
         }
     }
 #ifdef SCR_PHASE_TIMING
@@ -574,6 +583,49 @@ tp_cell_gather_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_st
     SCR_PHASES_FLUSH(tp_gather_ticks, 6, threadIdx.x == 0);
 }
 
+
+// pass 5: the nodes on tile borders.  One thread per plane node that lies on a tile boundary line: the shares of the (up to
+// four) tiles that own it, added in the fixed order (upper-left, upper-right, lower-left, lower-right tile); a tile
+// without points has written nothing and counts as zero.  Plain stores: together with pass 4 every element of the plane
+// gradient is written exactly once by exactly one thread -- bit-reproducible.
+template <int R, int NP>
+__global__ void __launch_bounds__(256)
+tp_border_sum_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_start, const float* __restrict__ halo,
+                     float* __restrict__ grad_plane0, float* __restrict__ grad_plane1) {
+    constexpr int RT = R * NP;
+    const int b = blockIdx.x * 256 + threadIdx.x, a = blockIdx.y;
+    if (b >= B) return;
+    const bool on_a = a % TP_TILE == 0, on_b = b % TP_TILE == 0;
+    if (!on_a && !on_b) return;
+    const int ta_n = (A + TP_TILE - 1) / TP_TILE;
+    float acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = 0.0f;
+    // candidate tiles along each axis: the tile that starts at this line (local index 0) and the one that ends here (local TP_TILE)
+    const int ta_hi = a / TP_TILE, tb_hi = b / TP_TILE;
+#pragma unroll
+    for (int ia = 0; ia < 2; ++ia) {
+        const int ta = ia == 0 ? (on_a ? ta_hi - 1 : ta_hi) : ta_hi;     // ia == 0: the upper tile (or the only one when not on a row line)
+        if (ia == 1 && !on_a) continue;
+        if (ta < 0 || ta >= ta_n) continue;
+        const int na = a - ta * TP_TILE;
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            const int tbb = ib == 0 ? (on_b ? tb_hi - 1 : tb_hi) : tb_hi;
+            if (ib == 1 && !on_b) continue;
+            if (tbb < 0 || tbb >= tb) continue;
+            const int nb = b - tbb * TP_TILE;
+            const int t = ta * tb + tbb;
+            if (tile_start[t] == tile_start[t + 1]) continue;        // no points: the tile wrote nothing
+            const float* hb = halo + ((size_t)t * TP_BORDER + tp_border_index(na, nb)) * RT;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[r] += hb[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+        *((r < R ? grad_plane0 + ((size_t)r * A + a) * B : grad_plane1 + ((size_t)(r - R) * A + a) * B) + b) = acc[r];
+}
 
 // ---- forward: out[v, col_p + r] = bilinear sample of plane p (zeros padding), weights and
 // accumulation order as torch's grid_sampler_2d (nw, ne, sw, se)
@@ -752,7 +804,8 @@ int launch_triplane_forward(int64_t V, const float* coords, int cs, const float*
 
 static inline size_t tp_tiles(int A, int B) { return (size_t)((A + TP_TILE - 1) / TP_TILE) * ((B + TP_TILE - 1) / TP_TILE); }
 static inline size_t tp_proj_bytes(int64_t V, int A, int B, int channels) {
-    return align_up((3 * tp_tiles(A, B) + 2) * 4) + align_up((size_t)(V > 0 ? V : 1) * tp_rec(channels) * 4);
+    return align_up((3 * tp_tiles(A, B) + 2) * 4) + align_up((size_t)(V > 0 ? V : 1) * tp_rec(channels) * 4) +
+           align_up(tp_tiles(A, B) * TP_BORDER * channels * 4);
 }
 
 size_t triplane_scratch_bytes(int64_t V, int A, int B, int channels) { return tp_proj_bytes(V, A, B, channels); }
@@ -768,6 +821,7 @@ static char* tp_carve(TpProj& pj, int64_t V, int channels, char* scratch) {
     pj.start = pj.count + pj.tiles;
     pj.cursor = pj.start + pj.tiles + 1;
     pj.rec = (float*)(scratch + align_up((3 * (size_t)pj.tiles + 2) * 4));
+    pj.halo = (float*)((char*)pj.rec + align_up((size_t)(V > 0 ? V : 1) * tp_rec(channels) * 4));
     return scratch + tp_proj_bytes(V, pj.A, pj.B, channels);
 }
 
@@ -799,9 +853,12 @@ static void tp_backward_launch(int64_t V, const float* coords, int cs, const flo
         if (e == hipSuccess && dev >= 0 && dev < 64) big_lds[dev] = true;
         (void)hipGetLastError();      // a refused attribute shows up as a launch error
     }
-    for (int q = 0; q < ps.n; ++q)
+    for (int q = 0; q < ps.n; ++q) {
         tp_cell_gather_kernel<R, NP><<<ps.p[q].tiles, TPN_THREADS, tpn_lds_bytes<R * NP>(), st>>>(
-            ps.p[q].A, ps.p[q].B, ps.p[q].tb, ps.p[q].start, ps.p[q].rec, gp0[q], gp1[q]);
+            ps.p[q].A, ps.p[q].B, ps.p[q].tb, ps.p[q].start, ps.p[q].rec, gp0[q], gp1[q], ps.p[q].halo);
+        tp_border_sum_kernel<R, NP><<<dim3((unsigned)((ps.p[q].B + 255) / 256), (unsigned)ps.p[q].A), 256, 0, st>>>(
+            ps.p[q].A, ps.p[q].B, ps.p[q].tb, ps.p[q].start, ps.p[q].halo, gp0[q], gp1[q]);
+    }
 }
 
 // nproj projections (1, or the 3 of a grid) x `planes` (1 or 2) planes each; cols0/cols1: first gradient column of the
@@ -882,7 +939,8 @@ static void tp_gather_launch(const TpProj& pj, float* gp, hipStream_t st) {
         if (e == hipSuccess && dev >= 0 && dev < 64) big_lds[dev] = true;
         (void)hipGetLastError();
     }
-    tp_cell_gather_kernel<RR, NPX><<<pj.tiles, TPN_THREADS, tpn_lds_bytes<RR * NPX>(), st>>>(pj.A, pj.B, pj.tb, pj.start, pj.rec, gp, gp);
+    tp_cell_gather_kernel<RR, NPX><<<pj.tiles, TPN_THREADS, tpn_lds_bytes<RR * NPX>(), st>>>(pj.A, pj.B, pj.tb, pj.start, pj.rec, gp, gp, pj.halo);
+    tp_border_sum_kernel<RR, NPX><<<dim3((unsigned)((pj.B + 255) / 256), (unsigned)pj.A), 256, 0, st>>>(pj.A, pj.B, pj.tb, pj.start, pj.halo, gp, gp);
 }
 
 int launch_triplane_backward_multi(int64_t V, const float* coords, int cs, int ngrids, const int* R, const int* X, const int* Y,
