@@ -112,6 +112,20 @@ def test_bench_starts_its_own_ranks(config):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["allreduce"]["bytes"] > 0 and out["allreduce"]["ms"] > 0
     assert out["roofline"]["achieved"] >= 0 and config in out["config"]["workload"]
+    # what a first multi-GPU run is judged by: bus rate against one xGMI link and against all of them, the exchange the
+    # step could not hide (the same steps once more with the collectives switched off), who took part
+    ar, ex = out["allreduce"], out["exchange"]
+    assert ar["busbw_GBps"] > 0 and ar["frac_of_one_link"] > 0 and ar["frac_of_all_links"] > 0 and ar["xgmi_link_peak_GBps"] == 153.0
+    assert ex["ms_per_step_with_exchange"] > 0 and ex["ms_per_step_without_exchange"] > 0
+    assert abs(ex["exposed_ms"] - (ex["ms_per_step_with_exchange"] - ex["ms_per_step_without_exchange"])) < 1e-9
+    assert out["ranks"] == {"world_size": 2, "backend": "gloo", "rccl_version": None, "devices": out["ranks"]["devices"]}
+    assert "cfg2" not in out and "cpu_baseline" not in out          # N = 1 only
+    if config != "cfg1":
+        assert ar["units"] >= 2 and ar["anchor_ranges"] >= 1 and ar["issue_order_agreed"] is True
+    # the launcher's own timeout: ranks that do not finish are killed and the exit code says so (124), never a held node
+    slow = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", config, "--timeout", "0.5"]
+                          + (["--anchors", "200000"] if config != "cfg1" else []), capture_output=True, text=True, env=env, timeout=300)
+    assert slow.returncode == 124 and "did not finish" in slow.stderr
     # a launcher that started another number of ranks is an error, not a silent N = 1 run
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
