@@ -92,6 +92,16 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
 int scr_forward_run(int64_t P, int64_t num_rendered, int64_t max_tile_instances, const scr_settings* settings,
                     void* geom_buf, void* binning_buf, void* image_buf, float* out_color, void* stream);
 
+/* ---- forward, both phases in one call when the caller's guess of the binning size was good enough.
+ * Same as scr_forward_plan; then, if binning_buf is not NULL and binning_capacity_bytes >= scr_binning_bytes(I, max tile),
+ * scr_forward_run on it without returning to the caller in between (the GPU otherwise idles for the caller's allocation and
+ * second call: 20 us of a 1 ms step).  plan_host[3]: instances, largest tile, 1 if phase 2 ran (0: allocate and call
+ * scr_forward_run).  A training loop's instance count moves by a few per cent per step: last step's count plus slack. */
+int scr_forward_plan_run(int64_t P, int32_t M, const float* means3D, const float* scales, const float* rotations,
+                         const float* cov3D_precomp, const float* opacities, const float* shs, const float* colors_precomp,
+                         const scr_settings* settings, void* geom_buf, int32_t* radii_out, int64_t* plan_host,
+                         void* binning_buf, size_t binning_capacity_bytes, void* image_buf, float* out_color, void* stream);
+
 /* ---- backward.  dL_dcolor is [3,H,W].  Outputs (each may be NULL when its input was NULL):
  * dL_dmeans3D[P,3], dL_dmeans2D[P,3] (d/d NDC position, z = 0: the gradient SplatCo reads back
  * at scene/gaussian_model.py:779), dL_dcolors[P,3], dL_dsh[P,M,3], dL_dopacity[P], dL_dscales[P,3],
@@ -386,6 +396,9 @@ enum {
     SCR_PROF_COUNT = 19
 };
 int scr_profile_enable(int mask);
+/* Bracket only every `every`-th launch of a selected class (default 1 = every launch): a benchmark that times K steps
+ * takes its dominant kernel's average from K / every samples and leaves the other steps undisturbed. */
+int scr_profile_stride(int every);
 int scr_profile_read(double* total_ms, int64_t* launches);
 const char* scr_profile_kernel_name(int idx);
 

@@ -28,7 +28,8 @@ SYMBOLS = [
     "scr_statis_compute", "scr_statis_apply", "scr_copy_probe",
     "scr_knn", "scr_knn_curvature", "scr_anchor_gather", "scr_anchor_gather_backward", "scr_mlp_heads_hidden_bytes", "scr_mlp_heads_partial_bytes", "scr_mlp_heads_forward", "scr_mlp_heads_backward",
     "scr_norm_linear_scratch_bytes", "scr_norm_linear_forward", "scr_norm_linear_backward",
-    "scr_norm_fold", "scr_norm_fold_backward", "scr_norm_running_stats", "scr_box_coords",
+    "scr_norm_fold", "scr_norm_fold_backward", "scr_norm_running_stats", "scr_box_coords", "scr_forward_plan_run",
+    "scr_profile_stride",
 ]
 PROF_COUNT = 19
 ABI_VERSION = 18
@@ -77,6 +78,11 @@ def _load():
     lib.scr_mark_visible.argtypes = [i64, vp, vp, vp, vp]
     lib.scr_forward_plan.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, sp, vp, vp, C.POINTER(C.c_int64), vp]
     lib.scr_forward_run.argtypes = [i64, i64, i64, sp, vp, vp, vp, vp, vp]
+    lib.scr_forward_plan_run.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, sp, vp, vp, C.POINTER(C.c_int64), vp, C.c_size_t,
+                                         vp, vp, vp]
+    lib.scr_forward_plan_run.restype = C.c_int
+    lib.scr_profile_stride.argtypes = [C.c_int]
+    lib.scr_profile_stride.restype = C.c_int
     lib.scr_backward.argtypes = [i64, i32, i64, vp, vp, vp, vp, vp, sp, vp, vp, vp, vp, vp, vp,
                                  vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.scr_debug_get.argtypes = [C.c_int, i64, i64, i32, i32, vp, vp, vp, vp, vp]
@@ -165,8 +171,10 @@ def _load():
 lib = _load()
 
 
-def profile_enable(which):
-    """True / -1: time every kernel class; False / 0: off; a kernel name: only that class."""
+def profile_enable(which, every=1):
+    """True / -1: time every kernel class; False / 0: off; a kernel name: only that class.  every: bracket only every
+    `every`-th launch of a timed class (the event pair costs ~6 us of stream time around the launch it times)."""
+    check(lib.scr_profile_stride(max(int(every), 1)))
     if isinstance(which, str):
         names = [lib.scr_profile_kernel_name(i).decode() for i in range(PROF_COUNT)]
         mask = 1 << names.index(which)

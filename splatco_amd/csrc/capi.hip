@@ -46,6 +46,8 @@ static int fail(const char* fmt, ...) {
 namespace {
 struct ProfRec { int idx; hipEvent_t a, b; };
 unsigned g_prof_mask = 0;  // bit i set: kernel class i is timed
+unsigned g_prof_stride = 1;             // every g_prof_stride-th launch of a timed class is bracketed (scr_profile_stride)
+unsigned g_prof_seen[32] = {};          // launches of class i since the mask was set
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
 hipEvent_t prof_event() {
@@ -57,6 +59,7 @@ hipEvent_t prof_event() {
 struct ProfScope {
     bool on; hipStream_t st; ProfRec r;
     ProfScope(int idx, hipStream_t s) : on((g_prof_mask >> idx) & 1u), st(s) {
+        if (on && g_prof_stride > 1) on = (g_prof_seen[idx]++ % g_prof_stride) == 0;
         if (on) { r.idx = idx; r.a = prof_event(); r.b = prof_event(); (void)hipEventRecord(r.a, st); }
     }
     ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); g_prof_recs.push_back(r); } }
@@ -247,6 +250,22 @@ int scr_forward_run(int64_t P, int64_t I, int64_t max_tile, const scr_settings* 
     }
     { ProfScope ps_(SCR_PROF_BLEND_FORWARD, st); launch_blend_forward(ks, gv, bv, iv, out_color, 2 * max_tile * (int64_t)Grid(ks.H, ks.W).tiles > 3 * I, st); }
     CHECK_LAUNCH("blend_forward_kernel", settings->debug, st);
+    return 0;
+}
+
+int scr_forward_plan_run(int64_t P, int32_t M, const float* means3D, const float* scales, const float* rotations,
+                         const float* cov3D_precomp, const float* opacities, const float* shs, const float* colors_precomp,
+                         const scr_settings* settings, void* geom_buf, int32_t* radii_out, int64_t* plan_host,
+                         void* binning_buf, size_t binning_capacity_bytes, void* image_buf, float* out_color, void* stream) {
+    if (!plan_host) return fail("plan_host is NULL");
+    plan_host[2] = 0;
+    const int rc = scr_forward_plan(P, M, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, settings,
+                                    geom_buf, radii_out, plan_host, stream);
+    if (rc) return rc;
+    if (!binning_buf || scr_binning_bytes(plan_host[0], plan_host[1]) > binning_capacity_bytes) return 0;   // caller allocates, then scr_forward_run
+    const int rc2 = scr_forward_run(P, plan_host[0], plan_host[1], settings, geom_buf, binning_buf, image_buf, out_color, stream);
+    if (rc2) return rc2;
+    plan_host[2] = 1;
     return 0;
 }
 
@@ -843,6 +862,14 @@ int scr_copy_probe(const void* src, void* dst, size_t bytes, void* stream) {
 
 int scr_profile_enable(int mask) {
     g_prof_mask = mask < 0 ? 0xffffffffu : (unsigned)mask;
+    memset(g_prof_seen, 0, sizeof(g_prof_seen));
+    return 0;
+}
+
+int scr_profile_stride(int every) {
+    if (every < 1) return fail("scr_profile_stride: every >= 1");
+    g_prof_stride = (unsigned)every;
+    memset(g_prof_seen, 0, sizeof(g_prof_seen));
     return 0;
 }
 

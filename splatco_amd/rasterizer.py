@@ -104,6 +104,7 @@ class RasterState:
 
 
 last_plan = (0, 0, 0)      # (P, tile instances, largest tile) of the most recent forward: bench / profiling bookkeeping only
+_plan_guess = {}           # (device, H, W) -> (P, instances, largest tile) of the last forward at that resolution: sizes the speculative binning buffer
 
 
 def rasterize_forward(cs, means3D, opacities, scales, rotations, cov3D_precomp, shs, colors_precomp):
@@ -118,16 +119,32 @@ def rasterize_forward(cs, means3D, opacities, scales, rotations, cov3D_precomp, 
     st.image = _bytes(_C.lib.scr_image_bytes(cs.H, cs.W), dev)
     radii = torch.empty(P, dtype=torch.int32, device=dev)      # every entry is written by preprocess_kernel
     color = torch.empty(3, cs.H, cs.W, dtype=torch.float32, device=dev)
-    plan = (C.c_int64 * 2)(0, 0)      # (tile instances, largest per-tile instance count)
+    plan = (C.c_int64 * 3)(0, 0, 0)      # (tile instances, largest per-tile instance count, phase 2 already ran)
+    # The binning buffer's size is only known after the plan phase.  A guess from the previous call of this size (the
+    # instance count of a training loop moves by a few per cent per step) lets both phases go out in ONE call: the GPU
+    # does not wait for this thread's allocation and second call in the middle of every forward pass.
+    key = (dev.index, cs.H, cs.W)
+    guess = _plan_guess.get(key)      # (P, instances, largest tile) of the last forward at this resolution
+    spec = None
     with torch.cuda.device(dev):      # kernels launch on the CURRENT device: make it the tensors' device
-        _C.check(_C.lib.scr_forward_plan(P, M, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
-                                         _ptr(opacities), _ptr(shs), _ptr(colors_precomp), cs.ref(),
-                                         st.geom.data_ptr(), _ptr(radii), plan, _stream()))
+        if guess is not None and guess[0] > 0 and 0.5 <= P / guess[0] <= 2.0:
+            scale = 1.06 * P / guess[0]
+            cap = _C.lib.scr_binning_bytes(min(int(guess[1] * scale) + 4096, (1 << 32) - 2), max(int(guess[2] * 1.25), guess[2] + 64))
+            spec = _bytes(cap, dev)
+        _C.check(_C.lib.scr_forward_plan_run(P, M, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+                                             _ptr(opacities), _ptr(shs), _ptr(colors_precomp), cs.ref(),
+                                             st.geom.data_ptr(), _ptr(radii), plan, None if spec is None else spec.data_ptr(),
+                                             0 if spec is None else spec.numel(), st.image.data_ptr(), color.data_ptr(), _stream()))
         st.I, st.max_tile = int(plan[0]), int(plan[1])
         last_plan = (P, st.I, st.max_tile)
-        st.binning = _bytes(_C.lib.scr_binning_bytes(st.I, st.max_tile), dev)
-        _C.check(_C.lib.scr_forward_run(P, st.I, st.max_tile, cs.ref(), st.geom.data_ptr(), st.binning.data_ptr(),
-                                        st.image.data_ptr(), color.data_ptr(), _stream()))
+        _plan_guess[key] = (P, st.I, st.max_tile)
+        if plan[2]:
+            st.binning = spec
+        else:
+            del spec
+            st.binning = _bytes(_C.lib.scr_binning_bytes(st.I, st.max_tile), dev)
+            _C.check(_C.lib.scr_forward_run(P, st.I, st.max_tile, cs.ref(), st.geom.data_ptr(), st.binning.data_ptr(),
+                                            st.image.data_ptr(), color.data_ptr(), _stream()))
     st.radii = radii
     return color, radii, st
 
