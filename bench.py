@@ -590,8 +590,8 @@ def run_anchor_config(args, rank, world, dev):
     settle = 0
     if train and args.warmup:
         _C.profile_enable(False)
-        last = torch.cuda.memory_reserved()
-        while settle < 16:
+        last, quiet = torch.cuda.memory_reserved(), 0
+        while settle < 24:
             step()
             torch.cuda.synchronize()
             settle += 1
@@ -599,8 +599,9 @@ def run_anchor_config(args, rank, world, dev):
             last = torch.cuda.memory_reserved()
             if world > 1:
                 dist.all_reduce(grew, op=dist.ReduceOp.MAX)
-            if not grew.item():
-                break
+            quiet = 0 if grew.item() else quiet + 1
+            if quiet >= 3:       # three steps in a row without a new device allocation (one quiet step proved too few: a
+                break            # later step's sizes can still miss the pool, 180 ms of hipMalloc inside the timed region)
     # A fresh box also pays one-time costs that outlast a three-step warm-up (MIOpen compiles and caches the attention
     # grids' convolution kernels on first use; measured 34 instead of 27 ms per cfg2 step in the first process on a box):
     # untimed steps until a step takes no longer than 1.05 x the one before it (every rank the same count).

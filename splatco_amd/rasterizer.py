@@ -11,6 +11,8 @@ PyTorch is used for device memory and streams only.
 from typing import NamedTuple
 
 import ctypes as C
+import os
+
 import torch
 import torch.nn as nn
 
@@ -104,6 +106,7 @@ class RasterState:
 
 
 last_plan = (0, 0, 0)      # (P, tile instances, largest tile) of the most recent forward: bench / profiling bookkeeping only
+SPECULATE = os.environ.get("SPLATCO_SPECULATIVE_BINNING", "1") != "0"
 _plan_guess = {}           # (device, H, W) -> (P, instances, largest tile) of the last forward at that resolution: sizes the speculative binning buffer
 
 
@@ -127,7 +130,7 @@ def rasterize_forward(cs, means3D, opacities, scales, rotations, cov3D_precomp, 
     guess = _plan_guess.get(key)      # (P, instances, largest tile) of the last forward at this resolution
     spec = None
     with torch.cuda.device(dev):      # kernels launch on the CURRENT device: make it the tensors' device
-        if guess is not None and guess[0] > 0 and 0.5 <= P / guess[0] <= 2.0:
+        if SPECULATE and guess is not None and guess[0] > 0 and 0.5 <= P / guess[0] <= 2.0:
             scale = 1.06 * P / guess[0]
             cap = _C.lib.scr_binning_bytes(min(int(guess[1] * scale) + 4096, (1 << 32) - 2), max(int(guess[2] * 1.25), guess[2] + 64))
             spec = _bytes(cap, dev)
