@@ -130,6 +130,10 @@ enum {
     SCR_DBG_QMASK = 7,         /* uint8[I]  quadrant mask of every sorted list entry (bit q: the splat can reach quadrant q)  binning */
     SCR_DBG_GM_INDEX = 8       /* uint32[I] Gaussian-major index of every sorted list entry (where its gradient record goes)   binning */
 };
+/* Test hook: force (1) or forbid (0) the deep-tile-list variants of the forward's sort and of the backward (no gm_index
+ * array, per-Gaussian record flags), which the library otherwise selects when the lists average more than 8192 entries per
+ * tile (-1: automatic, the default).  Process-global; set it before a forward call and keep it for that call's backward. */
+int scr_debug_force_deep_lists(int mode);
 int scr_debug_get(int which, int64_t P, int64_t num_rendered, int32_t image_height, int32_t image_width,
                   const void* geom_buf, const void* binning_buf, const void* image_buf, void* out,
                   void* stream);

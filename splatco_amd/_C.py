@@ -29,7 +29,7 @@ SYMBOLS = [
     "scr_knn", "scr_knn_curvature", "scr_anchor_gather", "scr_anchor_gather_backward", "scr_mlp_heads_hidden_bytes", "scr_mlp_heads_partial_bytes", "scr_mlp_heads_forward", "scr_mlp_heads_backward",
     "scr_norm_linear_scratch_bytes", "scr_norm_linear_forward", "scr_norm_linear_backward",
     "scr_norm_fold", "scr_norm_fold_backward", "scr_norm_running_stats", "scr_box_coords", "scr_forward_plan_run",
-    "scr_profile_stride",
+    "scr_profile_stride", "scr_debug_force_deep_lists",
 ]
 PROF_COUNT = 19
 ABI_VERSION = 18
@@ -81,6 +81,8 @@ def _load():
     lib.scr_forward_plan_run.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, sp, vp, vp, C.POINTER(C.c_int64), vp, C.c_size_t,
                                          vp, vp, vp]
     lib.scr_forward_plan_run.restype = C.c_int
+    lib.scr_debug_force_deep_lists.argtypes = [C.c_int]
+    lib.scr_debug_force_deep_lists.restype = C.c_int
     lib.scr_profile_stride.argtypes = [C.c_int]
     lib.scr_profile_stride.restype = C.c_int
     lib.scr_backward.argtypes = [i64, i32, i64, vp, vp, vp, vp, vp, sp, vp, vp, vp, vp, vp, vp,

@@ -497,7 +497,8 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                       const uint8_t* __restrict__ qmask, const float4* __restrict__ rec,
                       const float* __restrict__ bg, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                      GradRec* __restrict__ grad_rec, unsigned long long* __restrict__ cut_key, unsigned long long stamp) {
+                      GradRec* __restrict__ grad_rec, unsigned long long* __restrict__ cut_key, unsigned long long stamp,
+                      uint8_t* __restrict__ has_rec) {
     // wave-private compacted records of the round: [wave][field group][3 pad + position]; group 0/1 =
     // the first 32 bytes of the splat record, group 2 = (blue, position in round, -, -).  A group of four
     // reads slots k .. k+3 of each field group: one address register and immediate offsets.  The three
@@ -596,7 +597,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     // ---- software pipeline over the live rounds, back to front:
     // (mask, id, slot) two rounds ahead, gathered records one round ahead
     uint32_t m_next = 0, id_next = 0, slot_next = 0;  // round ci-1
-    uint32_t m_cur = 0, slot_cur = 0;                 // round ci (records in r0/r1/r2x)
+    uint32_t m_cur = 0, slot_cur = 0, id_cur = 0;     // round ci (records in r0/r1/r2x)
     bool sel_cur = false;
     float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
     float r2x = 0.0f;
@@ -612,6 +613,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         sel_cur = ((m >> wave) & 1u) && i < wave_last;
         m_cur = m;
         slot_cur = slot;
+        id_cur = id;
         if (sel_cur) {
             r0 = rec[3 * (size_t)id];
             r1 = rec[3 * (size_t)id + 1];
@@ -636,7 +638,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             st[wave][1][pos + 3] = r1;
             st[wave][2][pos + 3] = make_float4(r2x, __uint_as_float((uint32_t)lane), 0.0f, 0.0f);
         }
-        const uint32_t m_this = m_cur, slot_this = slot_cur;
+        const uint32_t m_this = m_cur, slot_this = slot_cur, id_this = id_cur;
         gather(ci - 1, m_next, id_next, slot_next);
         load_meta(ci - 2, m_next, id_next, slot_next);
         // acc is double-buffered by round parity: this round's writes cannot collide with the
@@ -757,7 +759,10 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             GradRec& gr = grad_rec[slot_this];
             if (wave == 0) store16_dword_aligned(&gr.a, r);
             else if (wave == 1) store16_dword_aligned(&gr.b, r);
-            else gr.c = r.x;
+            else {
+                gr.c = r.x;
+                if (has_rec) has_rec[id_this] = 1;      // deep lists (kernel-uniform): this Gaussian has something to sum
+            }
         }
     }
 }
@@ -785,13 +790,15 @@ void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView
 }
 
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                           const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, bool gm_from_base,
+                           const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, bool deep,
                            hipStream_t st) {
     Grid g(ks.H, ks.W);
+    const bool gm_from_base = deep;
+    if (deep) (void)hipMemsetAsync(gv.has_rec, 0, (size_t)gv.P, st);
     blend_backward_kernel<<<(unsigned)blend_slots_per_xcd(g) * NUM_XCD, 256, 0, st>>>(
         ks.W, ks.H, g.gx, g.tiles, gv.tile_count, gv.total, gv.ranges, bv.point_list, gm_from_base ? nullptr : bv.gm_index, gv.gm_base,
         bv.qmask, gv.rec, ks.bg,
-        iv.final_T, iv.n_contrib, dL_dcolor, grad_rec, iv.cut_key, stamp);
+        iv.final_T, iv.n_contrib, dL_dcolor, grad_rec, iv.cut_key, stamp, deep ? gv.has_rec : nullptr);
 }
 
 }  // namespace scr

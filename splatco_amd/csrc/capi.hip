@@ -14,6 +14,7 @@
 using namespace scr;
 
 static thread_local char g_err[512] = "";
+namespace scr { int g_force_deep_lists = -1; }
 
 static int fail(const char* fmt, ...) {
     va_list ap;
@@ -298,10 +299,16 @@ int scr_backward(int64_t P, int32_t M, int64_t I, const float* means3D, const fl
     }
     { ProfScope ps_(SCR_PROF_PREPROCESS_BACKWARD, st);
       launch_preprocess_backward(P, M, means3D, scales, rotations, cov3D_precomp, shs, ks, radii, gv, bv,
-                                 (const GradRec*)scratch, iv.cut_key, stamp, dL_dmeans3D, dL_dmeans2D, shs ? nullptr : dL_dcolors,
+                                 (const GradRec*)scratch, iv.cut_key, stamp, deep_lists(I, Grid(ks.H, ks.W).tiles), dL_dmeans3D, dL_dmeans2D, shs ? nullptr : dL_dcolors,
                                  shs ? dL_dsh : nullptr, dL_dopacity, cov3D_precomp ? nullptr : dL_dscales,
                                  cov3D_precomp ? nullptr : dL_drotations, cov3D_precomp ? dL_dcov3D : nullptr, st); }
     CHECK_LAUNCH("preprocess_backward_kernel", settings->debug, st);
+    return 0;
+}
+
+int scr_debug_force_deep_lists(int mode) {
+    if (mode < -1 || mode > 1) return fail("scr_debug_force_deep_lists: -1 (automatic), 0 or 1");
+    scr::g_force_deep_lists = mode;
     return 0;
 }
 

@@ -59,10 +59,14 @@ struct GeomView {
     uint32_t* live_bits;      // [P] bit k: the k-th tile of the Gaussian's rect walk (row-major) can be reached by one of its
                               //     quadrants (quadrant mask != 0), k < 32; written by the scatter kernel.  An instance whose bit
                               //     is clear gets no gradient record (blend backward) and none is read (preprocess backward)
+    uint8_t* has_rec;         // [P] deep lists only: set by the blend backward for every Gaussian that got at least one gradient
+                              //     record, so that preprocess_backward skips the record loop of the others (at 20 M anchors most
+                              //     Gaussians sit behind every pixel's last contributor in all of their tiles)
     uint32_t* block_sums;     // [ceil(P/BIN_GPW)] -> exclusive prefix after scan
     uint32_t* tile_count;     // [tiles] instances per tile (preprocess -> plan scan); afterwards the blend launches' tile order
     uint32_t* ranges;         // [tiles][2] (start, end)
     uint32_t* cursor;         // [tiles]
+    int64_t P;                  // Gaussians (for the per-Gaussian arrays' sizes)
     unsigned long long* total;  // [16] number of instances, largest per-tile instance count, [2] 1 = tile_count holds the blend tile
                                 //      order, [4..12] first entry of every XCD's list in it
     size_t bytes;
@@ -81,12 +85,14 @@ inline __host__ GeomView geom_view(void* base, int64_t P, int H, int W) {
     v.clamped = (uint8_t*)take((size_t)P);
     v.gm_base = (uint2*)take((size_t)P * 8);
     v.live_bits = (uint32_t*)take((size_t)P * 4);
+    v.has_rec = (uint8_t*)take((size_t)P);
     v.block_sums = (uint32_t*)take((nblk + 1) * 4);
     v.tile_count = (uint32_t*)take((size_t)g.tiles * 4);
     v.ranges = (uint32_t*)take((size_t)g.tiles * 8);
     v.cursor = (uint32_t*)take((size_t)g.tiles * 4);
     v.total = (unsigned long long*)take(128);
     v.bytes = off;
+    v.P = P;
     return v;
 }
 
@@ -96,7 +102,10 @@ inline __host__ GeomView geom_view(void* base, int64_t P, int H, int W) {
 // from gm_base itself.  With every entry live (the benchmark density) the sort's coalesced gm_index is the cheaper way
 // round (measured both ways: tile sort 5.1 -> 4.0 ms at 20 M anchors; blend backward +4 % at cfg1 / cfg2).
 // Both passes derive the choice from the same two numbers.
-inline __host__ bool deep_lists(int64_t I, int tiles) { return I > (int64_t)8192 * tiles; }
+extern int g_force_deep_lists;      // capi.hip; scr_debug_force_deep_lists: -1 = by the rule below, 0 / 1 = forced (parity tests)
+inline __host__ bool deep_lists(int64_t I, int tiles) {
+    return g_force_deep_lists >= 0 ? g_force_deep_lists != 0 : I > (int64_t)8192 * tiles;
+}
 
 // ---- binning buffer: per (Gaussian, tile) instance lists ----
 struct BinView {
@@ -351,13 +360,13 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
 void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
                           float* out_color, bool longest_first, hipStream_t st);
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                           const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, bool gm_from_base,
+                           const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, bool deep,
                            hipStream_t st);
 void launch_preprocess_backward(int64_t P, int M, const float* means3D, const float* scales,
                                 const float* rotations, const float* cov3D, const float* shs,
                                 const KSettings& ks, const int32_t* radii, const GeomView& gv,
                                 const BinView& bv, const GradRec* grad_rec, const unsigned long long* cut_key,
-                                unsigned long long stamp, float* dL_dmeans3D,
+                                unsigned long long stamp, bool deep, float* dL_dmeans3D,
                                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh, float* dL_dopacity,
                                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, hipStream_t st);
 

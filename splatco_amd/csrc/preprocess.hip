@@ -319,7 +319,7 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
                            const float* __restrict__ cov3D, const float* __restrict__ shs, KSettings ks,
                            const int32_t* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
                            const uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ live_bits,
-                           const uint8_t* __restrict__ clamped,
+                           const uint8_t* __restrict__ has_rec, const uint8_t* __restrict__ clamped,
                            const float4* __restrict__ rec, const GradRec* __restrict__ grad_rec,
                            const unsigned long long* __restrict__ cut_key, unsigned long long stamp, int tiles,
                            float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
@@ -341,6 +341,9 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
         // ---- deterministic reduction of the per-(tile, Gaussian) records
         uint32_t n = tiles_touched[i];
         uint32_t off = point_offsets[i] - n;
+        // deep lists (kernel-uniform pointer): a Gaussian without a single record -- behind every pixel's last contributor
+        // in all of its tiles -- sums nothing; its slots are not even looked at (4.6 -> 3 ms at 20 M anchors)
+        if (has_rec && !has_rec[i]) n = 0;
         float sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0;  // moments of Y = opacity G dL/dalpha over the footprint
         // this Gaussian's records are contiguous, in tile order (the row-major walk of its tile rect); four at a time so
         // that twelve record loads are in flight per thread -- the loop is otherwise one memory latency per record --
@@ -662,13 +665,13 @@ void launch_preprocess_backward(int64_t P, int M, const float* means3D, const fl
                                 const float* rotations, const float* cov3D, const float* shs,
                                 const KSettings& ks, const int32_t* radii, const GeomView& gv,
                                 const BinView& bv, const GradRec* grad_rec, const unsigned long long* cut_key,
-                                unsigned long long stamp, float* dL_dmeans3D,
+                                unsigned long long stamp, bool deep, float* dL_dmeans3D,
                                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh, float* dL_dopacity,
                                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, hipStream_t st) {
     if (P <= 0) return;
     preprocess_backward_kernel<<<nblk(P, PRE_BLOCK), PRE_BLOCK, 0, st>>>(
         P, M, means3D, scales, rotations, cov3D, shs, ks, radii, gv.tiles_touched, gv.point_offsets, gv.live_bits,
-        gv.clamped, gv.rec, grad_rec, cut_key, stamp, Grid(ks.H, ks.W).tiles, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh, dL_dopacity,
+        deep ? gv.has_rec : nullptr, gv.clamped, gv.rec, grad_rec, cut_key, stamp, Grid(ks.H, ks.W).tiles, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh, dL_dopacity,
         dL_dscales, dL_drotations, dL_dcov3D);
 }
 

@@ -187,6 +187,54 @@ def test_forward_backward_colors_path(oracle, scene):
     assert np.array_equal(o["color"], o2["color"])
 
 
+@pytest.mark.parametrize("scene", ["cfg0_10k_400x400", "ragged_130x70", "opaque_pile", "merge_path_tile"])
+def test_deep_list_variants_forced_on_small_scenes(oracle, scene):
+    """The variants the library selects for deep tile lists (more than 8192 entries per tile on average: 20 M anchors) --
+    the tile sort without the gm_index array, the blend backward deriving a record's place from gm_base, per-Gaussian
+    record flags that let preprocess_backward skip Gaussians without any record -- forced on scenes the oracle can check
+    (scr_debug_force_deep_lists): same integers, same image, gradients to 1e-4, and bit-identical to the default variants
+    (the skipped terms are +0)."""
+    from splatco_amd import _C
+    rng = np.random.default_rng(3)
+    if scene == "cfg0_10k_400x400":
+        cam, g = synthetic_camera(400, 400), synthetic_gaussians(10_000, 400, 400, 0)
+    elif scene == "ragged_130x70":
+        cam, g = synthetic_camera(130, 70), synthetic_gaussians(1500, 130, 70, 4)
+    else:
+        # many opaque splats over a few tiles: the pixels finish after a few dozen entries of lists of thousands, so most
+        # rounds are cut and most Gaussians never get a record ("merge_path_tile": one tile beyond a sort chunk of 8192)
+        P = 6000 if scene == "opaque_pile" else 20000
+        cam, g = synthetic_camera(96, 64), synthetic_gaussians(P, 96, 64, seed=8)
+        tx, ty = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+        z = rng.uniform(2, 6, P).astype(np.float32)
+        span = 40 if scene == "opaque_pile" else 12
+        px, py = rng.uniform(30, 30 + span, P), rng.uniform(20, 20 + span * 0.6, P)
+        g["means3D"] = np.stack([((2 * px + 1) / 96 - 1) * tx * z, ((2 * py + 1) / 64 - 1) * ty * z, z], 1).astype(np.float32)
+        g["scales"] = (np.full((P, 3), 0.02, np.float32) * z[:, None]).astype(np.float32)
+        g["opacities"] = np.full((P, 1), 0.9, np.float32)
+    st = oracle_settings(oracle, cam, g["bg"])
+    f = oracle.forward(st, g["means3D"], g["opacities"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+    dL = rng.standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
+    base = _run_gpu(cam, g, dL=dL, ref=f)
+    _C.check(_C.lib.scr_debug_force_deep_lists(1))
+    try:
+        o = _run_gpu(cam, g, dL=dL, ref=f)
+    finally:
+        _C.check(_C.lib.scr_debug_force_deep_lists(-1))
+    _check_forward(f, o, st)
+    b = oracle.backward(st, f, o["dL_eff"], g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+    _check_grads(o["grads"], b, ["means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"])
+    assert np.array_equal(o["color"], base["color"]) and np.array_equal(o["point_list"], base["point_list"])
+    for k in o["grads"]:
+        assert np.array_equal(o["grads"][k], base["grads"][k]), k
+    if scene != "cfg0_10k_400x400" and scene != "ragged_130x70":
+        tile_n = f["ranges"][:, 1].astype(np.int64) - f["ranges"][:, 0]
+        assert tile_n.max() > (8192 if scene == "merge_path_tile" else 1024)
+        never = (o["grads"]["opacities"][:, 0] == 0) & (f["radii"] > 0)
+        print(f"[deep] {scene}: largest tile {tile_n.max()}, visible Gaussians without any gradient: {never.sum()} of {(f['radii'] > 0).sum()}")
+        assert never.sum() > 0.3 * (f["radii"] > 0).sum()            # the flags have something to skip
+
+
 def test_sh_and_cov_paths(oracle):
     cam, g = small_scene(P=300, W=96, H=64, spread=1.5, seed=8)
     rng = np.random.default_rng(5)
