@@ -202,7 +202,7 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
     KSettings ks = ksettings(settings);
     GeomView gv = geom_view(geom_buf, P, ks.H, ks.W);
     Grid g(ks.H, ks.W);
-    HIP_TRY(hipMemsetAsync(gv.tile_count, 0, (size_t)g.tiles * 4, st));
+    { ZeroList z; z.add(gv.tile_count, (size_t)g.tiles * 4); launch_zero(z, st); }
     { ProfScope ps_(SCR_PROF_PREPROCESS, st);
       launch_preprocess(P, M, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, ks, gv,
                         radii_out, st); }

@@ -335,6 +335,21 @@ __device__ inline uint32_t quadrant_mask(float4 r0, float4 r1, int tile_x0, int 
 #define SCR_PHASES_FLUSH(arr, n, leader)
 #endif
 
+// Several buffers cleared by ONE kernel launch (preprocess.hip).  hipMemsetAsync costs a 5 us fill kernel AND 8 - 11 us of
+// idle stream time in front of it per call (profiles/r03x_step_gaps.txt): one per forward pass at cfg1, eighteen per
+// tri-plane backward.  Pointers 4-byte aligned, sizes in bytes (multiples of 4).
+struct ZeroList {
+    static constexpr int MAX = 20;
+    void* p[MAX];
+    unsigned long long n[MAX];
+    int count = 0;
+    void add(void* ptr, size_t bytes) {
+        if (ptr && bytes && count < MAX) { p[count] = ptr; n[count] = bytes; ++count; }
+    }
+    bool full() const { return count >= MAX; }
+};
+void launch_zero(const ZeroList& z, hipStream_t st);
+
 // launchers (defined in the .hip files)
 void launch_box_coords(int64_t V, const float* xyz, const float* lo, const float* hi, float* out, hipStream_t st);
 int launch_nl_fold(int L, int d, const int* dd, const int* col, const unsigned char* col_at, const float* const* W,

@@ -675,4 +675,25 @@ void launch_preprocess_backward(int64_t P, int M, const float* means3D, const fl
         dL_dscales, dL_drotations, dL_dcov3D);
 }
 
+// ---- ZeroList: blockIdx.y = buffer, blockIdx.x = 16 KB piece of it
+__global__ void __launch_bounds__(256) zero_list_kernel(ZeroList z) {
+    const unsigned long long bytes = z.n[blockIdx.y];
+    char* base = (char*)z.p[blockIdx.y];
+    const unsigned long long lo = (unsigned long long)blockIdx.x * 16384ull;
+    if (lo >= bytes) return;
+    const unsigned long long hi = lo + 16384ull < bytes ? lo + 16384ull : bytes;
+    if (((uintptr_t)base & 15) == 0) {
+        for (unsigned long long o = lo + 16ull * threadIdx.x; o + 16 <= hi; o += 16ull * 256) *(float4*)(base + o) = make_float4(0, 0, 0, 0);
+        for (unsigned long long o = lo + ((hi - lo) & ~15ull) + 4ull * threadIdx.x; o < hi; o += 4ull * 256) *(uint32_t*)(base + o) = 0u;
+    } else {
+        for (unsigned long long o = lo + 4ull * threadIdx.x; o < hi; o += 4ull * 256) *(uint32_t*)(base + o) = 0u;
+    }
+}
+void launch_zero(const ZeroList& z, hipStream_t st) {
+    if (z.count <= 0) return;
+    unsigned long long mx = 0;
+    for (int i = 0; i < z.count; ++i) mx = z.n[i] > mx ? z.n[i] : mx;
+    zero_list_kernel<<<dim3((unsigned)((mx + 16383) / 16384), (unsigned)z.count), 256, 0, st>>>(z);
+}
+
 }  // namespace scr

@@ -876,6 +876,7 @@ static int tp_backward(int64_t V, const float* coords, int cs, int R, int planes
     ps.n = nproj;
     char* sc = (char*)scratch;
     int total = 0;
+    ZeroList zl;
     for (int q = 0; q < nproj; ++q) {
         TpProj& pj = ps.p[q];
         pj.cx = pairs[q][0];
@@ -887,10 +888,11 @@ static int tp_backward(int64_t V, const float* coords, int cs, int R, int planes
         sc = tp_carve(pj, V, R * planes, sc);
         if (pj.tiles > TP_HIST_MAX_TILES) return 2;
         total += pj.tiles;
-        (void)hipMemsetAsync(pj.count, 0, (size_t)pj.tiles * 4, st);
-        (void)hipMemsetAsync(gp0[q], 0, (size_t)R * pj.A * pj.B * 4, st);
-        if (planes == 2) (void)hipMemsetAsync(gp1[q], 0, (size_t)R * pj.A * pj.B * 4, st);
+        zl.add(pj.count, (size_t)pj.tiles * 4);
+        zl.add(gp0[q], (size_t)R * pj.A * pj.B * 4);
+        if (planes == 2) zl.add(gp1[q], (size_t)R * pj.A * pj.B * 4);
     }
+    launch_zero(zl, st);
     for (int q = nproj; q < 3; ++q) ps.p[q] = ps.p[0];
     if (V <= 0) return 0;
     if (total > TP_HIST_MAX_TILES) {     // the three histograms do not fit one workgroup's LDS: one projection per pass
@@ -956,6 +958,7 @@ int launch_triplane_backward_multi(int64_t V, const float* coords, int cs, int n
     const bool known = ((RA == 10 || RA == 5) && (RB == 0 || RB == 5) && (RC == 0 || RC == 5)) || (RA == 15 && (RB == 0 || RB == 5) && RC == 0);
     if (!known || (RC && !RB)) return 3;
     TpProjSet9 ps;
+    ZeroList zl;
     ps.n = 3 * ngrids;
     const int pairs[3][2] = {{1, 0}, {2, 0}, {2, 1}};
     char* sc = (char*)scratch;
@@ -971,10 +974,11 @@ int launch_triplane_backward_multi(int64_t V, const float* coords, int cs, int n
             pj.col0 = pj.col1 = col[g] + q * R[g];
             sc = tp_carve(pj, V, R[g], sc);
             total += pj.tiles;
-            (void)hipMemsetAsync(pj.count, 0, (size_t)pj.tiles * 4, st);
-            (void)hipMemsetAsync(grad_planes[3 * g + q], 0, (size_t)R[g] * pj.A * pj.B * 4, st);
+            zl.add(pj.count, (size_t)pj.tiles * 4);
+            zl.add(grad_planes[3 * g + q], (size_t)R[g] * pj.A * pj.B * 4);
         }
     }
+    launch_zero(zl, st);
     for (int q = ps.n; q < 9; ++q) ps.p[q] = ps.p[0];
     if (total > TP_HIST_MAX_TILES) return 3;
     if (V <= 0) return 0;
