@@ -801,8 +801,14 @@ def main():
         out = run_anchor_config(args, rank, world, dev)
     if out is not None:                                      # rank 0
         if world > 1:
-            out["ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
+            rccl = None
+            if dist.get_backend() == "nccl":
+                try:                                         # bookkeeping must never cost the line
+                    v = torch.cuda.nccl.version()
+                    rccl = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+                except Exception as e:
+                    rccl = f"unknown ({type(e).__name__})"
+            out["ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl,
                             "devices": torch.cuda.device_count()}
         print(json.dumps(out), flush=True)
     if world > 1:
