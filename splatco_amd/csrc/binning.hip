@@ -128,9 +128,14 @@ __global__ void __launch_bounds__(BIN_THREADS)
 scatter_kernel(int64_t P, int gx, int tiles, const float4* __restrict__ rec, uint2* __restrict__ gm_base,
                uint32_t* __restrict__ live_bits, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
                uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ ranges,
-               uint32_t* __restrict__ cursor, unsigned long long* __restrict__ keys) {
+               uint32_t* __restrict__ cursor, unsigned long long* __restrict__ keys,
+               const unsigned long long* __restrict__ total, unsigned long long cap_instances) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // [tiles] when LDS_HIST
     __shared__ uint32_t lds[BIN_THREADS / WAVE + 1];
+    // Launched ahead of the host's look at the instance count (scr_forward_plan_run: the count is still on its way
+    // through the mailbox) into a buffer sized from the previous forward: if this call's count does not fit, do nothing
+    // at all -- the host sees the same number, re-zeroes nothing (no cursor was touched) and takes the two-call path.
+    if (total[0] > cap_instances) return;
     if (LDS_HIST) {
         for (int t = threadIdx.x; t < tiles; t += BIN_THREADS) hist[t] = 0;
         __syncthreads();
@@ -666,7 +671,8 @@ void launch_plan_scans(int64_t P, const KSettings& ks, const GeomView& gv, unsig
                                          gv.ranges, gv.cursor, mailbox, seq);
 }
 
-void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const BinView& bv, hipStream_t st) {
+void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const BinView& bv, unsigned long long cap_instances,
+                    hipStream_t st) {
     if (P <= 0) return;
     Grid g(ks.H, ks.W);
     const unsigned nb = (unsigned)((P + BIN_GPW - 1) / BIN_GPW);
@@ -683,11 +689,11 @@ void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const Bi
     if (g.tiles <= LDS_HIST_MAX_TILES)
         scatter_kernel<true><<<nb, BIN_THREADS, (size_t)g.tiles * 4, st>>>(
             P, g.gx, g.tiles, gv.rec, gv.gm_base, gv.live_bits, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges,
-            gv.cursor, bv.keys);
+            gv.cursor, bv.keys, gv.total, cap_instances);
     else
         scatter_kernel<false><<<nb, BIN_THREADS, 0, st>>>(
             P, g.gx, g.tiles, gv.rec, gv.gm_base, gv.live_bits, gv.tiles_touched, gv.block_sums, gv.point_offsets, gv.ranges,
-            gv.cursor, bv.keys);
+            gv.cursor, bv.keys, gv.total, cap_instances);
 }
 
 void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, int64_t max_tile_instances,

@@ -179,10 +179,11 @@ int scr_mark_visible(int64_t P, const float* means3D, const float* viewmatrix, u
     return 0;
 }
 
-int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* scales,
-                     const float* rotations, const float* cov3D_precomp, const float* opacities,
-                     const float* shs, const float* colors_precomp, const scr_settings* settings,
-                     void* geom_buf, int32_t* radii_out, int64_t* plan_host, void* stream) {
+// phase 1, first half: argument checks, tile counts, projection, scans; the two counts are on their way to the mailbox
+static int plan_enqueue(int64_t P, int32_t M, const float* means3D, const float* scales, const float* rotations,
+                        const float* cov3D_precomp, const float* opacities, const float* shs, const float* colors_precomp,
+                        const scr_settings* settings, void* geom_buf, int32_t* radii_out, int64_t* plan_host, hipStream_t st,
+                        unsigned long long& seq_out) {
     if (check_settings(settings)) return 1;
     if (P < 0) return fail("P < 0");
     if (!plan_host) return fail("plan_host is NULL");
@@ -198,7 +199,6 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
     if (shs && (M < (settings->sh_degree + 1) * (settings->sh_degree + 1)))
         return fail("shs has %d coefficients, sh_degree %d needs %d", M, settings->sh_degree,
                     (settings->sh_degree + 1) * (settings->sh_degree + 1));
-    hipStream_t st = (hipStream_t)stream;
     KSettings ks = ksettings(settings);
     GeomView gv = geom_view(geom_buf, P, ks.H, ks.W);
     Grid g(ks.H, ks.W);
@@ -212,9 +212,18 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
     // hipStreamSynchronize + 16-byte copy costs a copy launch and, worse, a wake-up of the sleeping thread, which
     // on a busy host is anywhere between 10 and 200 us of idle GPU in the middle of every forward pass.
     Mailbox& mb = mailbox();
-    const unsigned long long seq = ++mb.seq;
-    { ProfScope ps_(SCR_PROF_PLAN_SCAN, st); launch_plan_scans(P, ks, gv, mb.dev, seq, st); }
+    seq_out = ++mb.seq;
+    { ProfScope ps_(SCR_PROF_PLAN_SCAN, st); launch_plan_scans(P, ks, gv, mb.dev, seq_out, st); }
     CHECK_LAUNCH("plan_scan_kernel", settings->debug, st);
+    return 0;
+}
+
+// phase 1, second half: wait for the two counts
+static int plan_wait(const scr_settings* settings, void* geom_buf, int64_t P, unsigned long long seq, int64_t* plan_host,
+                     hipStream_t st) {
+    KSettings ks = ksettings(settings);
+    GeomView gv = geom_view(geom_buf, P, ks.H, ks.W);
+    Mailbox& mb = mailbox();
     unsigned long long total[2] = {0, 0};
     const bool posted = mailbox_wait(mb, seq, true, st);
     if (posted) {
@@ -234,8 +243,26 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
     return 0;
 }
 
+int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* scales,
+                     const float* rotations, const float* cov3D_precomp, const float* opacities,
+                     const float* shs, const float* colors_precomp, const scr_settings* settings,
+                     void* geom_buf, int32_t* radii_out, int64_t* plan_host, void* stream) {
+    unsigned long long seq = 0;
+    const int rc = plan_enqueue(P, M, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, settings, geom_buf,
+                                radii_out, plan_host, (hipStream_t)stream, seq);
+    return rc ? rc : plan_wait(settings, geom_buf, P, seq, plan_host, (hipStream_t)stream);
+}
+
+static int forward_run_impl(int64_t P, int64_t I, int64_t max_tile, const scr_settings* settings, void* geom_buf,
+                            void* binning_buf, void* image_buf, float* out_color, void* stream, bool scatter_done);
+
 int scr_forward_run(int64_t P, int64_t I, int64_t max_tile, const scr_settings* settings, void* geom_buf,
                     void* binning_buf, void* image_buf, float* out_color, void* stream) {
+    return forward_run_impl(P, I, max_tile, settings, geom_buf, binning_buf, image_buf, out_color, stream, false);
+}
+
+static int forward_run_impl(int64_t P, int64_t I, int64_t max_tile, const scr_settings* settings, void* geom_buf,
+                            void* binning_buf, void* image_buf, float* out_color, void* stream, bool scatter_done) {
     if (check_settings(settings)) return 1;
     if (!geom_buf || !binning_buf || !image_buf || !out_color) return fail("NULL buffer");
     hipStream_t st = (hipStream_t)stream;
@@ -244,8 +271,10 @@ int scr_forward_run(int64_t P, int64_t I, int64_t max_tile, const scr_settings* 
     BinView bv = bin_view(binning_buf, I, max_tile);
     ImgView iv = img_view(image_buf, ks.H, ks.W);
     if (I > 0) {
-        { ProfScope ps_(SCR_PROF_SCATTER, st); launch_scatter(P, ks, gv, bv, st); }
-        CHECK_LAUNCH("scatter_kernel", settings->debug, st);
+        if (!scatter_done) {
+            { ProfScope ps_(SCR_PROF_SCATTER, st); launch_scatter(P, ks, gv, bv, ~0ull, st); }
+            CHECK_LAUNCH("scatter_kernel", settings->debug, st);
+        }
         { ProfScope ps_(SCR_PROF_TILE_SORT, st); launch_tile_sort(ks, gv, bv, max_tile, !deep_lists(I, Grid(ks.H, ks.W).tiles), st); }
         CHECK_LAUNCH("tile_sort_kernel", settings->debug, st);
     }
@@ -260,12 +289,41 @@ int scr_forward_plan_run(int64_t P, int32_t M, const float* means3D, const float
                          void* binning_buf, size_t binning_capacity_bytes, void* image_buf, float* out_color, void* stream) {
     if (!plan_host) return fail("plan_host is NULL");
     plan_host[2] = 0;
-    const int rc = scr_forward_plan(P, M, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, settings,
-                                    geom_buf, radii_out, plan_host, stream);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long seq = 0;
+    int rc = plan_enqueue(P, M, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, settings, geom_buf,
+                          radii_out, plan_host, st, seq);
     if (rc) return rc;
-    if (!binning_buf || scr_binning_bytes(plan_host[0], plan_host[1]) > binning_capacity_bytes) return 0;   // caller allocates, then scr_forward_run
-    const int rc2 = scr_forward_run(P, plan_host[0], plan_host[1], settings, geom_buf, binning_buf, image_buf, out_color, stream);
-    if (rc2) return rc2;
+    // The scatter kernel goes out BEFORE this thread has seen the instance count: it needs nothing the host knows (the
+    // keys are the first array of the binning buffer whatever the count), only room -- and checks on the device that the
+    // count fits (17 bytes per instance is the least a binning buffer of that many instances takes, so the keys fit).
+    // While it runs, the count arrives, the sort and the blend are queued behind it: the 12 - 20 us the GPU used to idle
+    // in the middle of every forward pass (profiles/r03x_step_gaps.txt) are gone.
+    const unsigned long long cap = binning_buf ? (unsigned long long)(binning_capacity_bytes / 17) : 0ull;
+    const bool early = binning_buf && P > 0 && cap > 0 && image_buf && out_color;
+    if (early) {
+        KSettings ks = ksettings(settings);
+        GeomView gv = geom_view(geom_buf, P, ks.H, ks.W);
+        BinView bv = bin_view(binning_buf, 0, 0);
+        { ProfScope ps_(SCR_PROF_SCATTER, st); launch_scatter(P, ks, gv, bv, cap, st); }
+        CHECK_LAUNCH("scatter_kernel", settings->debug, st);
+    }
+    rc = plan_wait(settings, geom_buf, P, seq, plan_host, st);
+    if (rc) return rc;
+    const bool fits = binning_buf && scr_binning_bytes(plan_host[0], plan_host[1]) <= binning_capacity_bytes;
+    const bool scattered = early && (unsigned long long)plan_host[0] <= cap;
+    if (!fits) {
+        if (scattered && plan_host[0] > 0) {      // the early scatter ran and used up the cursors: give scr_forward_run fresh ones
+            KSettings ks = ksettings(settings);
+            GeomView gv = geom_view(geom_buf, P, ks.H, ks.W);
+            ZeroList z;
+            z.add(gv.cursor, (size_t)Grid(ks.H, ks.W).tiles * 4);
+            launch_zero(z, st);
+        }
+        return 0;                                  // caller allocates, then scr_forward_run
+    }
+    rc = forward_run_impl(P, plan_host[0], plan_host[1], settings, geom_buf, binning_buf, image_buf, out_color, stream, scattered);
+    if (rc) return rc;
     plan_host[2] = 1;
     return 0;
 }

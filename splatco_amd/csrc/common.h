@@ -369,7 +369,8 @@ void launch_preprocess(int64_t P, int M, const float* means3D, const float* scal
                        const KSettings& ks, const GeomView& gv, int32_t* radii, hipStream_t st);
 void launch_plan_scans(int64_t P, const KSettings& ks, const GeomView& gv, unsigned long long* mailbox,
                        unsigned long long seq, hipStream_t st);
-void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const BinView& bv, hipStream_t st);
+void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const BinView& bv, unsigned long long cap_instances,
+                    hipStream_t st);
 void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, int64_t max_tile_instances,
                       bool with_gm_index, hipStream_t st);
 void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
