@@ -308,7 +308,13 @@ int scr_forward_plan_run(int64_t P, int32_t M, const float* means3D, const float
         { ProfScope ps_(SCR_PROF_SCATTER, st); launch_scatter(P, ks, gv, bv, cap, st); }
         CHECK_LAUNCH("scatter_kernel", settings->debug, st);
     }
+#ifdef SCR_HOST_TIMING
+    const auto th0 = std::chrono::steady_clock::now();
+#endif
     rc = plan_wait(settings, geom_buf, P, seq, plan_host, st);
+#ifdef SCR_HOST_TIMING
+    const auto th1 = std::chrono::steady_clock::now();
+#endif
     if (rc) return rc;
     const bool fits = binning_buf && scr_binning_bytes(plan_host[0], plan_host[1]) <= binning_capacity_bytes;
     const bool scattered = early && (unsigned long long)plan_host[0] <= cap;
@@ -323,6 +329,15 @@ int scr_forward_plan_run(int64_t P, int32_t M, const float* means3D, const float
         return 0;                                  // caller allocates, then scr_forward_run
     }
     rc = forward_run_impl(P, plan_host[0], plan_host[1], settings, geom_buf, binning_buf, image_buf, out_color, stream, scattered);
+#ifdef SCR_HOST_TIMING
+    {
+        const auto th2 = std::chrono::steady_clock::now();
+        static int n_ = 0;
+        if (++n_ % 8 == 0)
+            fprintf(stderr, "[host] mailbox wait %.1f us, sort + blend launches %.1f us\n",
+                    std::chrono::duration<double, std::micro>(th1 - th0).count(), std::chrono::duration<double, std::micro>(th2 - th1).count());
+    }
+#endif
     if (rc) return rc;
     plan_host[2] = 1;
     return 0;
