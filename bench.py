@@ -509,7 +509,7 @@ def run_cfg1(args, rank, world, dev):
         state.clear()
         torch.cuda.empty_cache()
         sub = argparse.Namespace(**vars(args))
-        sub.config, sub.steps, sub.warmup, sub.anchors = "cfg2", 5, 3, 0
+        sub.config, sub.steps, sub.warmup, sub.anchors = "cfg2", 10, 3, 0
         c2 = run_anchor_config(sub, rank, world, dev)
         out["cfg2"] = {k: c2[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "stages", "roofline",
                                           "kernel_ms_per_step", "peak_mem_GiB", "time_settle_steps")}
