@@ -32,7 +32,7 @@ SYMBOLS = [
     "scr_profile_stride", "scr_debug_force_deep_lists",
 ]
 PROF_COUNT = 19
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 (DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS, DBG_QMASK,
  DBG_GM_INDEX) = range(9)
