@@ -495,6 +495,9 @@ def run_cfg1(args, rank, world, dev):
                                     "blend kernels are FP32-VALU/exp-issue bound at this density (SURVEY.md 8d); "
                                     "the HBM fraction is reported as the contract asks"),
         "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])},
+        "kernel_ms_source": f"{dominant}: HIP events inside the timed region (every 4th step); the other classes: HIP events around "
+                            "every launch of the last three WARM-UP steps, each pair adding ~6 us of stream time on both sides of its "
+                            "launch -- their sum therefore exceeds ms_per_step, which is wall time over K undisturbed steps",
         "hbm_gbs_all_kernels": sum(algorithmic_bytes(k, P, I, npix) for k in kern) / (sum(kern.values()) * 1e-3) / 1e9,
     }
     if allreduce_info is not None:
