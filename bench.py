@@ -423,11 +423,21 @@ def run_cfg1(args, rank, world, dev):
         img, radii = rast(means2D=means2D, **params)
         img.backward(dL)
         if world > 1 and state.get("exchange", True):
-            allreduce_gradients(leaves, agree="once")         # SUM, in place on the operator's gradient arena (train.py:198,240);
+            allreduce_gradients(leaves, agree="once", shape=state.get("shape", "all_reduce"))         # SUM, in place on the operator's gradient arena (train.py:198,240);
                                                               # the ranks agree on the path once, not with a host read per step
         state["radii"], state["img"] = radii, img
         return radii
 
+    shapes_ms = None
+    if world > 1 and dist.get_backend() == "nccl" and args.warmup:
+        # which shape of the SUM exchange is faster on this machine's links is measured, not assumed: one all_reduce of the
+        # 56 MB arena against reduce_scatter + all_gather on the same memory, three repetitions each after one untimed
+        # step; the timings are MAX-reduced over the ranks, so every rank picks the same one (before the timed region)
+        step()
+        shapes_ms = {}
+        for shp in ("all_reduce", "rs_ag"):
+            shapes_ms[shp] = time_allreduce(lambda: allreduce_gradients(leaves, agree="once", shape=shp), dev, reps=3)
+        state["shape"] = min(shapes_ms, key=shapes_ms.get)
     # warm-up: the last warm-up steps are timed per kernel class (HIP events around every launch)
     # to find the dominant kernel; the timed region then brackets ONLY that class, because each
     # event pair costs a few microseconds of stream time.
@@ -465,10 +475,12 @@ def run_cfg1(args, rank, world, dev):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         # bookkeeping (outside the timed region): the gradient all-reduce on its own, SURVEY.md 8(e)
-        bucket = allreduce_gradients(leaves, agree="once")
-        ms = time_allreduce(lambda: allreduce_gradients(leaves, agree="once"), dev)
-        allreduce_info = allreduce_report(bucket.numel() * bucket.element_size(), ms, world,
-                                          what=f"{P}x14 fp32 per-Gaussian gradients, one in-place all-reduce of the operator's arena")
+        shp = state.get("shape", "all_reduce")
+        bucket = allreduce_gradients(leaves, agree="once", shape=shp)
+        ms = time_allreduce(lambda: allreduce_gradients(leaves, agree="once", shape=shp), dev)
+        allreduce_info = allreduce_report(bucket.numel() * bucket.element_size(), ms, world, shape=shp,
+                                          shapes_timed_in_warmup_ms=shapes_ms,
+                                          what=f"{P}x14 fp32 per-Gaussian gradients, exchanged in place on the operator's arena")
         exposed = exposed_exchange(step, state, args.steps, elapsed / args.steps * 1e3, ms, dev)
     if rank != 0:
         return None

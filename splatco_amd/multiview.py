@@ -78,7 +78,22 @@ class _Agreement:
         return len(self.refs) == len(params) and all(r() is p for r, p in zip(self.refs, params))
 
 
-def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = None, agree: str = "always") -> torch.Tensor:
+def _sum_over_ranks(flat: torch.Tensor, shape: str = "all_reduce"):
+    """SUM of a flat buffer over the ranks, in place.  shape "rs_ag": reduce_scatter_tensor + all_gather_into_tensor on the
+    same memory (every rank owns 1/world of the sum in between; on the point-to-point xGMI mesh both phases use all links)
+    when the length divides by the world size -- otherwise, and for "all_reduce", one all_reduce."""
+    world = dist.get_world_size()
+    if shape == "rs_ag" and flat.numel() % world == 0 and flat.numel() > 0:
+        n = flat.numel() // world
+        mine = flat[dist.get_rank() * n:(dist.get_rank() + 1) * n]
+        dist.reduce_scatter_tensor(mine, flat, op=dist.ReduceOp.SUM)
+        dist.all_gather_into_tensor(flat, mine)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+
+def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = None, agree: str = "always",
+                        shape: str = "all_reduce") -> torch.Tensor:
     """SUM-all-reduce the .grad of every tensor in `params` through one flat bucket, in place.
     Parameters without a gradient on this rank contribute zeros (a rank whose views do not see
     an anchor still takes part).  Returns the bucket (reusable).  Every rank must pass the same
@@ -86,7 +101,8 @@ def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = N
     agree: "always" -- the ranks agree on the in-place / packed path with a small MIN all-reduce and a host read on every
     call; "once" -- on the first call for these parameters only (a loop whose ranks run the same program: the host read
     would otherwise stand between every backward pass and its gradient exchange); a rank whose own situation changes
-    afterwards raises instead of exchanging misaligned data."""
+    afterwards raises instead of exchanging misaligned data.
+    shape: "all_reduce" | "rs_ag" (see _sum_over_ranks); every rank must pass the same."""
     params = [p for p in params if p is not None and p.requires_grad]
     if not params:
         return bucket
@@ -117,7 +133,7 @@ def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = N
         in_place = _agree(arena is not None, sig, dev)
     if in_place:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(arena, op=dist.ReduceOp.SUM)
+            _sum_over_ranks(arena, shape)
         return arena
     n = sum(p.numel() for p in params)
     if bucket is None or bucket.numel() != n or bucket.device != dev:
@@ -131,7 +147,7 @@ def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = N
             bucket[off:off + k].copy_(p.grad.reshape(-1))
         off += k
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+        _sum_over_ranks(bucket, shape)
     off = 0
     for p in params:
         k = p.numel()

@@ -124,6 +124,15 @@ ptr = a_.grad.data_ptr()
 out = allreduce_gradients([a_, b_, c_])
 assert out.data_ptr() == arena.data_ptr() and out.numel() == 12 and a_.grad.data_ptr() == ptr
 assert torch.equal(arena, torch.arange(12, dtype=torch.float64) * 3)
+# the same exchange as reduce_scatter + all_gather on the same memory (bench.py picks the faster shape on RCCL)
+arena = torch.arange(12, dtype=torch.float64) * (rank + 1)
+b_.grad, a_.grad, c_.grad = arena[0:3], arena[3:8], arena[8:12]
+out = allreduce_gradients([a_, b_, c_], shape="rs_ag")
+assert out.data_ptr() == arena.data_ptr() and torch.equal(arena, torch.arange(12, dtype=torch.float64) * 3)
+odd = torch.arange(7, dtype=torch.float64, requires_grad=True)            # a length the world size does not divide: one all_reduce
+odd.grad = torch.ones(7, dtype=torch.float64) * (rank + 1)
+allreduce_gradients([odd], shape="rs_ag")
+assert torch.equal(odd.grad, torch.full((7,), 3.0, dtype=torch.float64))
 c_.grad = torch.ones(4, dtype=torch.float64)                               # a stranger breaks the tiling: packed path
 allreduce_gradients([a_, b_, c_])
 assert torch.equal(c_.grad, torch.full((4,), 2.0, dtype=torch.float64)) and torch.equal(a_.grad, torch.arange(3, 8, dtype=torch.float64) * 6)
