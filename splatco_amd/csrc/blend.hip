@@ -790,15 +790,15 @@ void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView
 }
 
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                           const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, bool deep,
+                           const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, bool deep, bool flags,
                            hipStream_t st) {
     Grid g(ks.H, ks.W);
     const bool gm_from_base = deep;
-    if (deep) { ZeroList z; z.add(gv.has_rec, ((size_t)gv.P + 3) / 4 * 4); launch_zero(z, st); }   // (the array is padded to 256 bytes)
+    if (flags) { ZeroList z; z.add(gv.has_rec, ((size_t)gv.P + 3) / 4 * 4); launch_zero(z, st); }   // (the array is padded to 256 bytes)
     blend_backward_kernel<<<(unsigned)blend_slots_per_xcd(g) * NUM_XCD, 256, 0, st>>>(
         ks.W, ks.H, g.gx, g.tiles, gv.tile_count, gv.total, gv.ranges, bv.point_list, gm_from_base ? nullptr : bv.gm_index, gv.gm_base,
         bv.qmask, gv.rec, ks.bg,
-        iv.final_T, iv.n_contrib, dL_dcolor, grad_rec, iv.cut_key, stamp, deep ? gv.has_rec : nullptr);
+        iv.final_T, iv.n_contrib, dL_dcolor, grad_rec, iv.cut_key, stamp, flags ? gv.has_rec : nullptr);
 }
 
 }  // namespace scr

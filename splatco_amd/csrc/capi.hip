@@ -367,12 +367,13 @@ int scr_backward(int64_t P, int32_t M, int64_t I, const float* means3D, const fl
     const unsigned long long stamp = ++stamp_counter;
     if (I > 0) {
         { ProfScope ps_(SCR_PROF_BLEND_BACKWARD, st);
-          launch_blend_backward(ks, gv, bv, iv, dL_dcolor, (GradRec*)scratch, stamp, deep_lists(I, Grid(ks.H, ks.W).tiles), st); }
+          launch_blend_backward(ks, gv, bv, iv, dL_dcolor, (GradRec*)scratch, stamp, deep_lists(I, Grid(ks.H, ks.W).tiles),
+                                record_flags(I, Grid(ks.H, ks.W).tiles), st); }
         CHECK_LAUNCH("blend_backward_kernel", settings->debug, st);
     }
     { ProfScope ps_(SCR_PROF_PREPROCESS_BACKWARD, st);
       launch_preprocess_backward(P, M, means3D, scales, rotations, cov3D_precomp, shs, ks, radii, gv, bv,
-                                 (const GradRec*)scratch, iv.cut_key, stamp, deep_lists(I, Grid(ks.H, ks.W).tiles), dL_dmeans3D, dL_dmeans2D, shs ? nullptr : dL_dcolors,
+                                 (const GradRec*)scratch, iv.cut_key, stamp, record_flags(I, Grid(ks.H, ks.W).tiles), dL_dmeans3D, dL_dmeans2D, shs ? nullptr : dL_dcolors,
                                  shs ? dL_dsh : nullptr, dL_dopacity, cov3D_precomp ? nullptr : dL_dscales,
                                  cov3D_precomp ? nullptr : dL_drotations, cov3D_precomp ? dL_dcov3D : nullptr, st); }
     CHECK_LAUNCH("preprocess_backward_kernel", settings->debug, st);

@@ -107,6 +107,18 @@ inline __host__ bool deep_lists(int64_t I, int tiles) {
     return g_force_deep_lists >= 0 ? g_force_deep_lists != 0 : I > (int64_t)8192 * tiles;
 }
 
+// per-Gaussian record flags (has_rec): from which mean list length on the blend backward marks the Gaussians it wrote a
+// record for and preprocess_backward treats the others like invisible ones.  Measured (round 3): with 2048 entries per
+// tile on average and more the flags pay (preprocess_backward 0.88 -> 0.79 ms at cfg2, 0.97 -> 0.86 at cfg3, 4.6 -> 2.2 at
+// cfg4; the byte stores are lost in the blend backward); at the benchmark density (540 per tile, nearly every Gaussian has
+// a record) they cost the blend backward 1 - 2 %.  Forced together with the deep-list variants by the test hook.
+#ifndef SCR_FLAGS_MIN_MEAN
+#define SCR_FLAGS_MIN_MEAN 2048
+#endif
+inline __host__ bool record_flags(int64_t I, int tiles) {
+    return g_force_deep_lists >= 0 ? g_force_deep_lists != 0 : I > (int64_t)SCR_FLAGS_MIN_MEAN * tiles;
+}
+
 // ---- binning buffer: per (Gaussian, tile) instance lists ----
 struct BinView {
     unsigned long long* keys;  // [I] grouped by tile, unsorted: depth bits << 32 | gaussian id << 4 | quadrant mask
@@ -376,7 +388,7 @@ void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv
 void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
                           float* out_color, bool longest_first, hipStream_t st);
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                           const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, bool deep,
+                           const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, bool deep, bool flags,
                            hipStream_t st);
 void launch_preprocess_backward(int64_t P, int M, const float* means3D, const float* scales,
                                 const float* rotations, const float* cov3D, const float* shs,
