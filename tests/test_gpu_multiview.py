@@ -95,7 +95,7 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
 
 
-for mode, cw in (("all_reduce", 0.05), ("rs_ag", 0.0)):
+for mode, cw in (("all_reduce", 0.05), ("rs_ag", 0.0))[:int(sys.argv[2])]:
     pc_a, params_a, den_a = make()
     pc_b, params_b, den_b = make()
     assert all(torch.equal(a, b) for a, b in zip(params_a, params_b))
@@ -153,17 +153,21 @@ print("rank", rank, "ok")
 '''
 
 
-def test_sharded_step_equals_the_sequential_loop_on_the_hip_path(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_step_equals_the_sequential_loop_on_the_hip_path(tmp_path, world):
+    """world 2: two views per rank (the gather's backward overwrites for the first view and adds for the second);
+    world 4: one view per rank, every consistency pair crosses ranks."""
     script = tmp_path / "sharded_worker.py"
     script.write_text(SHARDED_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29641", str(script), ROOT],
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29639 + world), str(script), ROOT,
+                        "2" if world == 2 else "1"],               # world 4 runs the all_reduce + consistency case only
                        capture_output=True, text=True, env=env, timeout=1500)
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
-    assert r.stdout.count("ok") == 2
+    assert r.stdout.count("ok") == world
 
 
 def _train_setup(pc, seed, mode="all_reduce"):
