@@ -567,7 +567,11 @@ def run_anchor_config(args, rank, world, dev):
         idle = {id(p) for p in pc.feat_planes._feat.inactive_parameters()}     # plane levels above activate_level: grad None in the reference
         rest = [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad and id(p) not in idle]
         groups.append({"params": rest, "lr": 1e-3, "name": "mlp_and_feat_planes"})
-        opt = torch.optim.Adam(groups, eps=1e-15, fused=True)      # one pass over parameter / gradient / moments per tensor
+        if args.optimizer == "hip":         # csrc/adam.hip: the reference's Adam(l, lr=0.0, eps=1e-15) as one streaming pass per group
+            from splatco_amd.adam import FusedAdam
+            opt = FusedAdam(groups, eps=1e-15)
+        else:                               # torch's fused multi-tensor Adam, for comparison
+            opt = torch.optim.Adam(groups, eps=1e-15, fused=True)
         den = AnchorDensifier(pc, opt, seed=seed)
         arena = GradArena([p for grp in groups for p in grp["params"]], mode=args.exchange)
 
@@ -721,7 +725,9 @@ def run_anchor_config(args, rank, world, dev):
                    "visible_anchors_last_view": V, "gaussians_last_view": P1, "tile_instances_last_view": I,
                    "image": f"{W}x{H}",
                    "rendered_last_view": int((stats["rendered"] > 0).sum().item()),
-                   "parallelism": f"{mv} view(s), 1 per GPU" + (", RCCL gradient exchange in place" if world > 1 else "")},
+                   "parallelism": f"{mv} view(s), 1 per GPU" + (", RCCL gradient exchange in place" if world > 1 else ""),
+                   **({"optimizer": {"hip": "splatco_amd.adam.FusedAdam (csrc/adam.hip)",
+                                     "torch": "torch.optim.Adam(fused=True)"}[args.optimizer]} if train else {})},
         "iter_per_s": 1.0 / step_s,
         "stages": {
             "rasterizer_kernels_ms": {"forward": ras_f, "backward": ras_b},
@@ -776,6 +782,8 @@ def main():
                          "scene/gaussian_model.py:449) or as drawn (random in space: the stated worst case for every gather)")
     ap.add_argument("--exchange", choices=["all_reduce", "rs_ag"], default="all_reduce",
                     help="shape of the gradient exchange of cfg3/cfg4 (GradArena)")
+    ap.add_argument("--optimizer", choices=["hip", "torch"], default="hip",
+                    help="cfg3/cfg4: splatco_amd.adam.FusedAdam (csrc/adam.hip) or torch.optim.Adam(fused=True)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cfg2", action="store_true", help="cfg1 at N = 1: skip the cfg2 block that rides along on the line")
     ap.add_argument("--timeout", type=float, default=1500.0,

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 19
+#define SCR_ABI_VERSION 20
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -367,6 +367,26 @@ int scr_statis_compute(int64_t V, int32_t k, const float* neural_opacity, const 
 int scr_statis_apply(int64_t V, int32_t k, const int64_t* visible_index, const float* inc_opacity, const float* inc_grad,
                      float* opacity_accum, float* anchor_demon, float* offset_gradient_accum, float* offset_denom,
                      void* stream);
+
+/* ---- the optimizer step of the training step BASELINE.json configs[3] / configs[4] time: train.py:310-312
+ * `gaussians.optimizer.step()` with torch.optim.Adam(l, lr=0.0, eps=1e-15) (scene/gaussian_model.py:575; one group per
+ * per-anchor parameter, lr set per group by the schedulers), no weight decay, no amsgrad.  One streaming pass over
+ * parameter, gradient and the two moments of every tensor in the HOST table `tensors` (read during the call only):
+ *   exp_avg    += (1 - beta1) (grad - exp_avg)            exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) grad^2
+ *   param      -= (lr / bias_correction1) * exp_avg / (sqrt(exp_avg_sq) / bias_correction2_sqrt + eps)
+ * with bias_correction1 = 1 - beta1^step, bias_correction2_sqrt = sqrt(1 - beta2^step) of the tensor's own step count
+ * (computed by the caller, as torch does for non-capturable steps); beta1, beta2, eps are doubles because 1 - beta is
+ * formed in double and rounded once, as torch does (1 - 0.999f is 4.7e-5 off 0.001).  fp32, contiguous; any 4-byte alignment (16-byte
+ * aligned tensors take the vector path).  Elementwise: bit-reproducible. */
+typedef struct scr_adam_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+    float lr, bias_correction1, bias_correction2_sqrt, reserved;
+} scr_adam_tensor;
+int scr_adam_step(int32_t n_tensors, const scr_adam_tensor* tensors, double beta1, double beta2, double eps, void* stream);
 
 /* ---- k nearest neighbours for GaussianModel.compute_curvature (scene/gaussian_model.py:1092-1110: sklearn on the host +
  * a Python loop over the anchors there).  The caller buckets the N points into a uniform grid (grid_host[7] = x0, y0, z0,

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "adam.h"
 #include <chrono>
 #include <cstring>
 
@@ -911,6 +912,23 @@ int scr_statis_apply(int64_t V, int32_t k, const int64_t* visible_index, const f
     launch_statis_apply(V, k, visible_index, inc_opacity, inc_grad, opacity_accum, anchor_demon, offset_gradient_accum,
                         offset_denom, st);
     CHECK_LAUNCH("statis_apply_kernel", 0, st);
+    return 0;
+}
+
+// ---- optimizer step (adam.hip)
+int scr_adam_step(int32_t n_tensors, const scr_adam_tensor* tensors, double beta1, double beta2, double eps, void* stream) {
+    if (n_tensors < 0) return fail("scr_adam_step: n_tensors < 0");
+    if (n_tensors == 0) return 0;
+    if (!tensors) return fail("scr_adam_step: tensors is NULL");
+    if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0)) return fail("scr_adam_step: bad beta / eps");
+    for (int t = 0; t < n_tensors; ++t) {
+        const scr_adam_tensor& x = tensors[t];
+        if (x.numel < 0 || (x.numel > 0 && (!x.param || !x.grad || !x.exp_avg || !x.exp_avg_sq))) return fail("scr_adam_step: NULL tensor");
+        if (!(x.bias_correction1 > 0.0f) || !(x.bias_correction2_sqrt > 0.0f)) return fail("scr_adam_step: bias corrections must be > 0 (step >= 1)");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (launch_adam(n_tensors, tensors, beta1, beta2, eps, st)) return fail("scr_adam_step: more than 2^31 workgroups in one launch");
+    CHECK_LAUNCH("adam_kernel", 0, st);
     return 0;
 }
 
