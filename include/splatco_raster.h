@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 20
+#define SCR_ABI_VERSION 21
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -189,7 +189,12 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
                         const float* grid_scaling, const int32_t* out_index, const float* g_xyz,
                         const float* g_color, const float* g_opacity, const float* g_scaling,
                         const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
-                        float* d_offsets, float* d_grid_scaling, float* d_anchor, void* stream);
+                        float* d_offsets, float* d_grid_scaling, float* d_anchor, const float* g_reg, int64_t P,
+                        void* stream);
+/* g_reg (device scalar, may be NULL) + P (the number of selected candidates = rows of g_scaling): the upstream gradient
+ * of the view loss's regulariser mean(prod(scaling, 1)) (train.py:192-196).  When given, the kernel adds
+ * g_reg / P * (product of the candidate's other two scaling components) to g_scaling on the fly -- what autograd would
+ * otherwise materialise as a [P,3] tensor and add to the rasterizer's dL/dscales in a pass of its own. */
 
 /* ---- tri-plane bilinear feature sampling (scene/grids.py:146-182).  One plane sample is
  * out[v, r] = grid_sample(plane[1,R,A,B], (gx, gy) in [-1,1], bilinear, align_corners=True, zeros

@@ -32,7 +32,7 @@ SYMBOLS = [
     "scr_profile_stride", "scr_debug_force_deep_lists", "scr_adam_step",
 ]
 PROF_COUNT = 19
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 (DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS, DBG_QMASK,
  DBG_GM_INDEX) = range(9)
@@ -98,7 +98,7 @@ def _load():
     lib.scr_expand_scratch_bytes.argtypes = [C.c_int64]
     lib.scr_expand_plan.argtypes = [i64, vp, vp, C.POINTER(C.c_int64), vp]
     lib.scr_expand_run.argtypes = [i64, i32] + [vp] * 15
-    lib.scr_expand_backward.argtypes = [i64, i32] + [vp] * 16
+    lib.scr_expand_backward.argtypes = [i64, i32] + [vp] * 16 + [i64, vp]
     for f in ("scr_expand_plan", "scr_expand_run", "scr_expand_backward"):
         getattr(lib, f).restype = C.c_int
     lib.scr_plane_sample_scratch_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32]

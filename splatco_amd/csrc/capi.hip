@@ -509,8 +509,10 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
                         const float* grid_scaling, const int32_t* out_index, const float* g_xyz,
                         const float* g_color, const float* g_opacity, const float* g_scaling,
                         const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
-                        float* d_offsets, float* d_grid_scaling, float* d_anchor, void* stream) {
+                        float* d_offsets, float* d_grid_scaling, float* d_anchor, const float* g_reg, int64_t P,
+                        void* stream) {
     if (V < 0 || k <= 0) return fail("bad V / k");
+    if (g_reg && P <= 0) return fail("scr_expand_backward: g_reg needs P = the number of selected candidates");
     if (V == 0) return 0;
     if (!scale_rot || !offsets || !grid_scaling || !out_index || !d_neural_opacity || !d_color || !d_scale_rot ||
         !d_offsets || !d_grid_scaling || !d_anchor)
@@ -518,7 +520,7 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
     hipStream_t st = (hipStream_t)stream;
     { ProfScope ps_(SCR_PROF_EXPAND_BACKWARD, st);
       launch_expand_backward(V, k, scale_rot, offsets, grid_scaling, out_index, g_xyz, g_color, g_opacity, g_scaling,
-                             g_rot, d_neural_opacity, d_color, d_scale_rot, d_offsets, d_grid_scaling, d_anchor, st); }
+                             g_rot, d_neural_opacity, d_color, d_scale_rot, d_offsets, d_grid_scaling, d_anchor, g_reg, P, st); }
     CHECK_LAUNCH("expand_backward_kernel", 0, st);
     return 0;
 }

@@ -412,7 +412,8 @@ void launch_expand_backward(int64_t V, int k, const float* scale_rot, const floa
                             const float* grid_scaling, const int32_t* out_index, const float* g_xyz,
                             const float* g_color, const float* g_opacity, const float* g_scaling,
                             const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
-                            float* d_offsets, float* d_grid_scaling, float* d_anchor, hipStream_t st);
+                            float* d_offsets, float* d_grid_scaling, float* d_anchor, const float* g_reg, int64_t P,
+                            hipStream_t st);
 
 void launch_statis_compute(int64_t V, int k, const float* neural_opacity, const int32_t* out_index,
                            const uint8_t* update_filter, const float* grad, int gstride, float* inc_opacity,

@@ -199,7 +199,8 @@ expand_backward_kernel(int64_t V, int k, int apw, const float* __restrict__ scal
                        const float* __restrict__ g_opacity, const float* __restrict__ g_scaling,
                        const float* __restrict__ g_rot, float* __restrict__ d_neural_opacity,
                        float* __restrict__ d_color, float* __restrict__ d_scale_rot, float* __restrict__ d_offsets,
-                       float* __restrict__ d_grid_scaling, float* __restrict__ d_anchor) {
+                       float* __restrict__ d_grid_scaling, float* __restrict__ d_anchor,
+                       const float* __restrict__ g_reg, float inv_P) {
     extern __shared__ __attribute__((aligned(16))) float part[];  // [apw * k][9]
     const int64_t v0 = (int64_t)blockIdx.x * apw;
     const int nloc = (int)min((int64_t)apw, V - v0) * k;  // candidates of this workgroup
@@ -212,6 +213,19 @@ expand_backward_kernel(int64_t V, int k, int apw, const float* __restrict__ scal
         if (p >= 0) {
             const float* sr = scale_rot + 7 * i;
             dop = g_opacity[p];
+            float sg[3], gsc[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                sg[ch] = 1.0f / (1.0f + __expf(-sr[ch]));
+                gsc[ch] = g_scaling[3 * (size_t)p + ch];
+            }
+            if (g_reg) {   // + dL/dreg * d mean(prod(scaling)) / d scaling: the regulariser's gradient never exists as a tensor
+                const float a = gs[3] * sg[0], b = gs[4] * sg[1], c = gs[5] * sg[2];     // the forward's scaling, recomputed
+                const float w = g_reg[0] * inv_P;
+                gsc[0] = gsc[0] + w * (b * c);
+                gsc[1] = gsc[1] + w * (a * c);
+                gsc[2] = gsc[2] + w * (a * b);
+            }
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 dcol[ch] = g_color[3 * (size_t)p + ch];
@@ -219,10 +233,8 @@ expand_backward_kernel(int64_t V, int k, int apw, const float* __restrict__ scal
                 acc9[6 + ch] = gx;
                 dof[ch] = gx * gs[ch];
                 acc9[ch] = gx * offsets[3 * i + ch];
-                const float sg = 1.0f / (1.0f + __expf(-sr[ch]));
-                const float gsc = g_scaling[3 * (size_t)p + ch];
-                acc9[3 + ch] = gsc * sg;
-                dsr[ch] = gsc * gs[3 + ch] * sg * (1.0f - sg);
+                acc9[3 + ch] = gsc[ch] * sg[ch];
+                dsr[ch] = gsc[ch] * gs[3 + ch] * sg[ch] * (1.0f - sg[ch]);
             }
             const float q0 = sr[3], q1 = sr[4], q2 = sr[5], q3 = sr[6];
             const float nrm = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
@@ -296,12 +308,14 @@ void launch_expand_backward(int64_t V, int k, const float* scale_rot, const floa
                             const float* grid_scaling, const int32_t* out_index, const float* g_xyz,
                             const float* g_color, const float* g_opacity, const float* g_scaling,
                             const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
-                            float* d_offsets, float* d_grid_scaling, float* d_anchor, hipStream_t st) {
+                            float* d_offsets, float* d_grid_scaling, float* d_anchor, const float* g_reg, int64_t P,
+                            hipStream_t st) {
     const int apw = max(1, min(32, (48 * 1024) / (k * 9 * (int)sizeof(float))));
     const int threads = min(1024, ((apw * k + 63) / 64) * 64);
     expand_backward_kernel<<<(unsigned)((V + apw - 1) / apw), threads, (size_t)apw * k * 9 * sizeof(float), st>>>(
         V, k, apw, scale_rot, offsets, grid_scaling, out_index, g_xyz, g_color, g_opacity, g_scaling, g_rot,
-        d_neural_opacity, d_color, d_scale_rot, d_offsets, d_grid_scaling, d_anchor);
+        d_neural_opacity, d_color, d_scale_rot, d_offsets, d_grid_scaling, d_anchor, g_reg,
+        P > 0 ? (float)(1.0 / (double)P) : 0.0f);
 }
 
 }  // namespace scr

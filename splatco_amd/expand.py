@@ -39,16 +39,21 @@ class _ExpandCompact(torch.autograd.Function):
         ctx.save_for_backward(scale_rot, offsets, grid_scaling, out_index)
         ctx.dims = (V, k)
         ctx.mark_non_differentiable(mask, out_index)
-        return xyz, col, opa, sca, rot, mask, out_index
+        # `tap`: a one-element output whose only purpose is its gradient -- losses.scaling_reg hands dL/dreg of the view
+        # loss's regulariser mean(prod(scaling, 1)) to it, and the backward kernel adds the regulariser's gradient to
+        # dL/dscaling on the fly (no [P,3] tensor, no accumulation pass)
+        tap = torch.zeros(1, dtype=torch.float32, device=dev)
+        return xyz, col, opa, sca, rot, tap, mask, out_index
 
     @staticmethod
-    def backward(ctx, g_xyz, g_col, g_opa, g_sca, g_rot, _g_mask, _g_index):
+    def backward(ctx, g_xyz, g_col, g_opa, g_sca, g_rot, g_tap, _g_mask, _g_index):
         scale_rot, offsets, grid_scaling, out_index = ctx.saved_tensors
         V, k = ctx.dims
         dev, n = scale_rot.device, V * k
         z = lambda t, *s: (torch.zeros(*s, dtype=torch.float32, device=dev) if t is None else t.contiguous().float())
         P = int((out_index >= 0).sum().item()) if g_xyz is None else g_xyz.shape[0]
         g_xyz, g_col, g_opa, g_sca, g_rot = z(g_xyz, P, 3), z(g_col, P, 3), z(g_opa, P, 1), z(g_sca, P, 3), z(g_rot, P, 4)
+        g_tap = None if g_tap is None or P == 0 else g_tap.contiguous().float().reshape(1)
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         d_no, d_col, d_sr, d_off, d_gs, d_an = new(n, 1), new(n, 3), new(n, 7), new(V, k, 3), new(V, 6), new(V, 3)
         if n:
@@ -57,15 +62,17 @@ class _ExpandCompact(torch.autograd.Function):
                                                     out_index.data_ptr(), _ptr(g_xyz), _ptr(g_col), _ptr(g_opa),
                                                     _ptr(g_sca), _ptr(g_rot), d_no.data_ptr(), d_col.data_ptr(),
                                                     d_sr.data_ptr(), d_off.data_ptr(), d_gs.data_ptr(), d_an.data_ptr(),
-                                                    _stream(dev)))
+                                                    _ptr(g_tap), P, _stream(dev)))
         return d_no, d_col, d_sr, d_off, d_gs, d_an, None
 
 
 def expand_compact(neural_opacity, color, scale_rot, grid_offsets, grid_scaling, anchor, n_offsets):
     """neural_opacity [V*k,1], color [V*k,3], scale_rot [V*k,7], grid_offsets [V,k,3], grid_scaling [V,6],
     anchor [V,3]  ->  xyz, color, opacity, scaling, rot (compacted, order preserved), mask [V*k] bool."""
-    *out, mask, out_index = _ExpandCompact.apply(neural_opacity, color, scale_rot, grid_offsets, grid_scaling, anchor,
-                                                 int(n_offsets))
+    *out, tap, mask, out_index = _ExpandCompact.apply(neural_opacity, color, scale_rot, grid_offsets, grid_scaling, anchor,
+                                                      int(n_offsets))
+    if tap.requires_grad:
+        out[3]._scr_reg_tap = tap      # scaling: losses.scaling_reg routes the regulariser's gradient through the tap
     # the compaction index rides along with the mask: the densification statistics (stats.selection_index) need the
     # position of every selected candidate among the Gaussians and would otherwise recompute it with a prefix sum
     mask._scr_out_index = out_index

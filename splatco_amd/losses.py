@@ -3,6 +3,8 @@ utils/loss_utils.py:17-63 and utils/image_utils.py:14-19; pinned by tests/golden
 psnr() is the parity metric of BASELINE.json ("PSNR-match")."""
 from math import exp
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -117,9 +119,35 @@ class _ScalingReg(torch.autograd.Function):
         return d
 
 
+class _ScalingRegTap(torch.autograd.Function):
+    """The same value as _ScalingReg for the `scaling` output of expand.expand_compact, with the gradient sent to the
+    expansion's `tap` instead of to `scaling`: csrc/expand.hip's backward kernel adds dL/dreg * d reg / d scaling to the
+    rasterizer's dL/dscales while it reads them (at 88 M Gaussians the separate gradient tensor and autograd's
+    accumulation pass were 0.9 ms of the cfg4 step)."""
+
+    @staticmethod
+    def forward(ctx, tap, scaling):
+        from . import _C
+        from .rasterizer import _stream
+        s = scaling.detach().contiguous().float()
+        P = s.shape[0]
+        scratch = torch.empty(_C.lib.scr_scaling_reg_scratch_bytes(P), dtype=torch.uint8, device=s.device)
+        out = torch.empty(1, dtype=torch.float32, device=s.device)
+        with torch.cuda.device(s.device):
+            _C.check(_C.lib.scr_scaling_reg_forward(P, s.data_ptr(), scratch.data_ptr(), out.data_ptr(), _stream(s.device)))
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.reshape(1), None
+
+
 def scaling_reg(scaling):
     """mean(prod(scaling, dim=1)) (train.py:192-196)."""
     if scaling.is_cuda and scaling.dim() == 2 and scaling.shape[1] == 3 and scaling.shape[0] > 0:
+        tap = None if os.environ.get("SPLATCO_NO_REG_TAP") else getattr(scaling, "_scr_reg_tap", None)
+        if tap is not None and tap.requires_grad and scaling.dtype == torch.float32:
+            return _ScalingRegTap.apply(tap, scaling)
         return _ScalingReg.apply(scaling)
     return scaling.prod(dim=1).mean()
 

@@ -829,6 +829,43 @@ def test_scaling_regulariser_matches_torch_prod(P):
 
 
 @pytest.mark.gpu
+def test_scaling_regulariser_through_the_expansion_tap():
+    """losses.scaling_reg on the `scaling` output of expand_compact sends its gradient through the expansion's tap
+    (csrc/expand.hip adds it to dL/dscaling while reading it): every input gradient equals what the torch chain
+    `scaling.prod(1).mean()` + a second use of `scaling` gives; also twice (two taps' worth), alone (no other use of
+    scaling), and not at all (tap unused)."""
+    from splatco_amd.expand import expand_compact
+    from splatco_amd.losses import scaling_reg
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(11)
+    V, k = 20_011, 10
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    base = (r(V * k, 1), r(V * k, 3), r(V * k, 7), r(V, k, 3), torch.rand(V, 6, device=dev, generator=g) + 0.1, r(V, 3))
+    w_s = None
+    for uses, other in ((1, True), (2, True), (1, False), (0, True)):
+        grads = []
+        for tapped in (True, False):
+            ins = [t.clone().requires_grad_(True) for t in base]
+            xyz, color, opacity, scaling, rot, mask = expand_compact(*ins, k)
+            assert hasattr(scaling, "_scr_reg_tap")
+            if w_s is None:
+                w_s = r(*scaling.shape)
+            loss = (xyz * 0.3).sum() + (rot * 0.1).sum() + (opacity * 0.2).sum() + (color * 0.05).sum()
+            if other:
+                loss = loss + (scaling * w_s).sum()            # the rasterizer's dL/dscales stands in here
+            for _ in range(uses):
+                reg = scaling_reg(scaling) if tapped else scaling.prod(dim=1).mean()
+                loss = loss + 700.0 * reg
+            loss.backward()
+            grads.append([t.grad.clone() for t in ins])
+        for a, b, name in zip(*grads, ("neural_opacity", "color", "scale_rot", "offsets", "grid_scaling", "anchor")):
+            num, den = (a - b).norm().item(), max(b.norm().item(), 1e-20)
+            assert num / den < 2e-6, (uses, other, name, num / den)
+        if uses and not other:
+            assert grads[0][2][:, :3].abs().max() > 0          # the regulariser alone reaches the scale columns
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("training", [True, False])
 def test_appearance_embedding_path_on_the_gpu(training):
     """The reference's code default appearance_dim = 32 (arguments/__init__.py:76) on the device: fused anchor gather,
