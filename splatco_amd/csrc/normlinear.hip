@@ -21,6 +21,8 @@
 // features of one row: 16-byte stores.  A lane loads 16 bytes of a row (columns 16 q + 4 g .. + 3 for g = lane >> 4)
 // and feeds them to four MFMA steps; the contraction index is permuted accordingly on the weight side.
 #include "common.h"
+#include <mutex>
+#include <unordered_map>
 
 namespace scr {
 
@@ -29,7 +31,7 @@ __device__ __forceinline__ nlf4 nl_mfma(float a, float b, nlf4 c) { return __bui
 
 constexpr int NL_OUT = 32;              // output features of the Linear (FeaturePlanes: out_dim = 32)
 constexpr int NL_DP = 80;               // columns of x supported (padded width of every coefficient row)
-constexpr int NL_SLAB = 2048;           // rows per statistics workgroup
+constexpr int NL_SLAB = 2048;           // rows per statistics workgroup, at least (sizes the scratch; see nl_stat_slab)
 constexpr int NL_HSIZE = NL_OUT * NL_DP + NL_OUT;   // dy^T x (padded) + column sums of dy
 
 // coefficient block in scratch (floats)
@@ -55,12 +57,12 @@ size_t norm_linear_scratch_bytes(int64_t V) {
 // ---- column statistics, pass 1: per-workgroup sums of (x - shift) and (x - shift)^2, shift = the first row
 template <int CW>   // lanes per row: 64 (d <= 64) or 128
 __global__ void __launch_bounds__(256)
-nl_stats_partial_kernel(int64_t V, int d, const float* __restrict__ x, int ldx, float* __restrict__ partial) {
+nl_stats_partial_kernel(int64_t V, int d, int slab, const float* __restrict__ x, int ldx, float* __restrict__ partial) {
     constexpr int RG = 256 / CW;
     __shared__ float red[2][256];
     const int c = threadIdx.x % CW, rg = threadIdx.x / CW;
-    const int64_t r0 = (int64_t)blockIdx.x * NL_SLAB;
-    const int rows = (int)min((int64_t)NL_SLAB, V - r0);
+    const int64_t r0 = (int64_t)blockIdx.x * slab;
+    const int rows = (int)min((int64_t)slab, V - r0);
     float s = 0.0f, q = 0.0f;
     if (c < d) {
         const float shift = x[c];
@@ -375,9 +377,29 @@ nl_bwd_dx_kernel(int64_t V, int d, const float* __restrict__ x, int ldx, const f
     }
 }
 
-static inline unsigned nl_grid(int64_t V) {
+// Grid of a grid-stride kernel = the workgroups the chip holds at once (occupancy x CUs), never a fixed number: with 2048
+// workgroups the forward kernel (7 waves per SIMD for d = 60: 1792 resident) ran 1.14 rounds and the reduction (3
+// workgroups per CU for its 41 KB of LDS: 768 resident) 1.33 with 1024 -- the last round at a fraction of the machine
+// (reduction at cfg2: 0.92 -> 0.66 ms with 768).  Asked once per kernel, kept for the process (all GPUs of a node are alike).
+static int nl_resident_lookup(const void* kernel, int threads, int fallback) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, int> known;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = known.find(kernel);
+    if (it != known.end()) return it->second;
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1 || cus < 1)
+        return fallback;          // not remembered: asked again next time
+    return known[kernel] = per_cu * cus;
+}
+template <typename K>
+static int nl_resident_wgs(K kernel, int threads, int fallback) { return nl_resident_lookup((const void*)kernel, threads, fallback); }
+template <typename K>
+static inline unsigned nl_grid(int64_t V, K kernel) {
     const int64_t wgs = ((V + 15) / 16 + 3) / 4;
-    return (unsigned)(wgs < 2048 ? (wgs > 0 ? wgs : 1) : 2048);
+    const int64_t cap = nl_resident_wgs(kernel, 256, 1024);
+    return (unsigned)(wgs < cap ? (wgs > 0 ? wgs : 1) : cap);
 }
 
 int launch_norm_linear_forward(int64_t V, int d, const float* x, int ldx, const float* G, const float* c, float eps, float* y,
@@ -385,16 +407,21 @@ int launch_norm_linear_forward(int64_t V, int d, const float* x, int ldx, const 
     if (d < 1 || d > NL_DP) return 1;
     float* coef = (float*)scratch;
     float* spart = (float*)((char*)scratch + align_up((size_t)NLC_END * 4));
-    const int nwg = nl_stat_wgs(V);
-    if (d <= 64) nl_stats_partial_kernel<64><<<nwg, 256, 0, st>>>(V, d, x, ldx, spart);
-    else nl_stats_partial_kernel<128><<<nwg, 256, 0, st>>>(V, d, x, ldx, spart);
+    // slabs of 2048 rows until they are more than the chip holds at once (8 workgroups per CU), then one round of larger
+    // slabs: 2246 workgroups on 2048 places ran a second round at a tenth of the machine, and the single-workgroup finish
+    // kernel read 9 k partials at 18 M rows
+    const int resident = d <= 64 ? nl_resident_wgs(nl_stats_partial_kernel<64>, 256, 2048) : nl_resident_wgs(nl_stats_partial_kernel<128>, 256, 2048);
+    int64_t slab = NL_SLAB;
+    if ((V + slab - 1) / slab > resident) slab = ((V + resident - 1) / resident + 7) / 8 * 8;
+    const int nwg = (int)((V + slab - 1) / slab);          // <= nl_stat_wgs(V): the scratch holds it
+    if (d <= 64) nl_stats_partial_kernel<64><<<nwg, 256, 0, st>>>(V, d, (int)slab, x, ldx, spart);
+    else nl_stats_partial_kernel<128><<<nwg, 256, 0, st>>>(V, d, (int)slab, x, ldx, spart);
     nl_stats_finish_kernel<<<1, 1024, 0, st>>>(V, d, nwg, x, spart, G, c, eps, mean, var, inv, coef);
     const bool al = ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
-    const unsigned grid = nl_grid(V);
-#define SCR_NL_FWD(QQ)                                                                                  \
-    case QQ:                                                                                            \
-        if (al) nl_forward_kernel<QQ, true><<<grid, 256, 0, st>>>(V, d, x, ldx, coef, y);               \
-        else nl_forward_kernel<QQ, false><<<grid, 256, 0, st>>>(V, d, x, ldx, coef, y);                 \
+#define SCR_NL_FWD(QQ)                                                                                                              \
+    case QQ:                                                                                                                        \
+        if (al) nl_forward_kernel<QQ, true><<<nl_grid(V, nl_forward_kernel<QQ, true>), 256, 0, st>>>(V, d, x, ldx, coef, y);        \
+        else nl_forward_kernel<QQ, false><<<nl_grid(V, nl_forward_kernel<QQ, false>), 256, 0, st>>>(V, d, x, ldx, coef, y);         \
         break;
     switch ((d + 15) / 16) { SCR_NL_FWD(1) SCR_NL_FWD(2) SCR_NL_FWD(3) SCR_NL_FWD(4) SCR_NL_FWD(5) }
 #undef SCR_NL_FWD
@@ -408,19 +435,22 @@ int launch_norm_linear_backward(int64_t V, int d, const float* x, int ldx, const
     if (lddy % 4 != 0 || ((uintptr_t)dy & 15) != 0) return 2;
     float* coef = (float*)scratch;
     float* bpart = (float*)((char*)scratch + align_up((size_t)NLC_END * 4) + align_up((size_t)nl_stat_wgs(V) * 2 * NL_DP * 4));
-    const int nwg = nl_bwd_wgs(V);
-#define SCR_NL_RED(NN) case NN: nl_bwd_reduce_kernel<NN><<<nwg, 256, 0, st>>>(V, d, x, ldx, dy, lddy, bpart); break;
+    int nwg = nl_bwd_wgs(V);        // the scratch holds this many partials: an upper bound for the grid
+#define SCR_NL_RED(NN)                                                                              \
+    case NN:                                                                                        \
+        nwg = min(nwg, nl_resident_wgs(nl_bwd_reduce_kernel<NN>, 256, 768));                        \
+        nl_bwd_reduce_kernel<NN><<<nwg, 256, 0, st>>>(V, d, x, ldx, dy, lddy, bpart);               \
+        break;
     switch ((d + 15) / 16) { SCR_NL_RED(1) SCR_NL_RED(2) SCR_NL_RED(3) SCR_NL_RED(4) SCR_NL_RED(5) }
 #undef SCR_NL_RED
     nl_bwd_sum_kernel<<<(NL_HSIZE + 31) / 32, 256, 0, st>>>(nwg, bpart, coef);
     nl_bwd_finish_kernel<<<1, 128, 0, st>>>(V, d, G, mean, inv, coef, dG, dc);
     if (!dx) return 0;
     const bool al = ldx % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dx & 15) == 0;
-    const unsigned grid = nl_grid(V);
-#define SCR_NL_DX(NN)                                                                                          \
-    case NN:                                                                                                   \
-        if (al) nl_bwd_dx_kernel<NN, true><<<grid, 256, 0, st>>>(V, d, x, ldx, dy, lddy, coef, dx, lddx);      \
-        else nl_bwd_dx_kernel<NN, false><<<grid, 256, 0, st>>>(V, d, x, ldx, dy, lddy, coef, dx, lddx);        \
+#define SCR_NL_DX(NN)                                                                                                                          \
+    case NN:                                                                                                                                   \
+        if (al) nl_bwd_dx_kernel<NN, true><<<nl_grid(V, nl_bwd_dx_kernel<NN, true>), 256, 0, st>>>(V, d, x, ldx, dy, lddy, coef, dx, lddx);     \
+        else nl_bwd_dx_kernel<NN, false><<<nl_grid(V, nl_bwd_dx_kernel<NN, false>), 256, 0, st>>>(V, d, x, ldx, dy, lddy, coef, dx, lddx);      \
         break;
     switch ((d + 15) / 16) { SCR_NL_DX(1) SCR_NL_DX(2) SCR_NL_DX(3) SCR_NL_DX(4) SCR_NL_DX(5) }
 #undef SCR_NL_DX
