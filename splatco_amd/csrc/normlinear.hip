@@ -166,16 +166,19 @@ nl_stats_finish_kernel(int64_t V, int d, int nwg, const float* __restrict__ x, c
 // beyond d are zeroed with selects: a load under `if (k + 3 < d)` makes the compiler close every load with its own
 // s_waitcnt vmcnt(0) at the join, i.e. the Q loads of a row are served one memory round trip after the other.
 template <bool ALIGNED>
-__device__ __forceinline__ nlf4 nl_load4(const float* __restrict__ row, int k, int d, int ld) {
+__device__ __forceinline__ nlf4 nl_raw4(const float* __restrict__ row, int k, int d, int ld) {     // the loads alone
     nlf4 v;
     if (ALIGNED) {
-        v = *(const nlf4*)(row + min(k, ld - 4));      // k > ld - 4 means k >= ld >= d (both multiples of 4): all masked below
+        v = *(const nlf4*)(row + min(k, ld - 4));      // k > ld - 4 means k >= ld >= d (both multiples of 4): all masked by nl_mask4
     } else {
         v.x = row[min(k, d - 1)];
         v.y = row[min(k + 1, d - 1)];
         v.z = row[min(k + 2, d - 1)];
         v.w = row[min(k + 3, d - 1)];
     }
+    return v;
+}
+__device__ __forceinline__ nlf4 nl_mask4(nlf4 v, int k, int d) {      // columns past d read as zero
     v.x = k < d ? v.x : 0.0f;
     v.y = k + 1 < d ? v.y : 0.0f;
     v.z = k + 2 < d ? v.z : 0.0f;
@@ -218,7 +221,15 @@ nl_forward_kernel(int64_t V, int d, const float* __restrict__ x, int ldx, const 
         const float* xr = x + (size_t)(ok ? row : V - 1) * ldx;       // rows past the end recompute the last row, nothing is stored
         nlf4 xq[Q];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) xq[q] = nl_load4<ALIGNED>(xr, 16 * q + 4 * g, d, ldx);
+        for (int q = 0; q < Q; ++q) xq[q] = nl_raw4<ALIGNED>(xr, 16 * q + 4 * g, d, ldx);
+        // all loads of the step are issued before anything uses one: left alone, the scheduler sank three of the five
+        // behind the MFMAs that use the first two and closed each with s_waitcnt vmcnt(0) -- four memory round trips
+        // per step -- and with the column masks next to the loads it still waited for the first before issuing the third
+        // (forward at cfg2 1.30 -> 1.22 ms).  The dx kernel below keeps its branchy loads: there the same treatment
+        // (seven loads, one wait) was measured slower twice (rounds 2 and 3: 2.28 -> 2.40 ms per step at cfg2)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) xq[q] = nl_mask4(xq[q], 16 * q + 4 * g, d);
         nlf4 acc[2] = {cb[0], cb[1]};
 #pragma unroll
         for (int q = 0; q < Q; ++q)
