@@ -303,6 +303,34 @@ struct FinalLists {
             gm_index[i] = b.x + (uint32_t)ty * b.y + (uint32_t)tx;
         }
     }
+    // U entries per thread -- list positions e0, e0 + stride, ... below cnt, their sorted low words from getk(e) -- with all U
+    // gm_base gathers in flight before the first store.  As a loop of write() the stores of one entry and the gather of
+    // the next may alias as far as the compiler knows: it kept them in program order, one memory round trip per entry
+    // (tools/isa_waits.py: `S S L W0 S` sixteen times at the end of every wave-sorted tile).
+    template <int U, typename GetK>
+    __device__ __forceinline__ void write_batch(uint32_t lo, uint32_t e0, uint32_t stride, uint32_t cnt, GetK getk) const {
+        uint32_t k[U];
+        uint2 b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t e = e0 + (uint32_t)u * stride;
+            k[u] = e < cnt ? getk(e, u) : 0u;           // padding reads Gaussian 0's entry: a valid address, never stored
+        }
+        if (gm_index) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) b[u] = gm_base[k[u] >> 4];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t e = e0 + (uint32_t)u * stride;
+            if (e < cnt) {
+                point_list[lo + e] = k[u] >> 4;
+                qmask[lo + e] = (uint8_t)(k[u] & 15u);
+                if (gm_index) gm_index[lo + e] = b[u].x + (uint32_t)ty * b[u].y + (uint32_t)tx;
+            }
+        }
+    }
 };
 
 // Sorts the n (<= 64*E) keys at keys[0..n).  FINAL: write the tile's final lists; otherwise write the
@@ -344,12 +372,13 @@ __device__ __forceinline__ void wave_sort(uint32_t n, unsigned long long* __rest
     };
     transpose(klo);
     if (!FINAL) transpose(khi);
+    if (FINAL) {
+        fl.template write_batch<E>(lo, (uint32_t)lane, 64u, n, [&](uint32_t, int u) { return klo[u]; });   // sorted position u * 64 + lane
+    } else {
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const uint32_t i = (uint32_t)e * 64 + lane;  // sorted position
-        if (i < n) {
-            if (FINAL) fl.write(lo + i, klo[e]);
-            else keys[i] = ((unsigned long long)khi[e] << 32) | klo[e];
+        for (int e = 0; e < E; ++e) {
+            const uint32_t i = (uint32_t)e * 64 + lane;  // sorted position
+            if (i < n) keys[i] = ((unsigned long long)khi[e] << 32) | klo[e];
         }
     }
 }
@@ -411,11 +440,7 @@ __device__ __forceinline__ void wave_sort_split(uint32_t n, const unsigned long 
 #pragma unroll
     for (int k = 0; k < PER; ++k) tr[lane * (PER + 1) + k] = outk[k];
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < PER; ++e) {
-        const uint32_t i = (uint32_t)e * 64 + lane;  // sorted position
-        if (i < n) fl.write(lo + i, tr[i + i / PER]);
-    }
+    fl.template write_batch<PER>(lo, (uint32_t)lane, 64u, n, [&](uint32_t i, int) { return tr[i + i / PER]; });   // sorted position i
 }
 
 template <bool FINAL>
@@ -525,7 +550,8 @@ tile_sort_wg_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, unsi
     // ---- out: final lists (the whole tile was this chunk) or the sorted chunk back in place
     if (n <= (uint32_t)WG_SORT_MAX) {
         const FinalLists fl{gm_base, point_list, gm_index, qmask, t % gx, t / gx};
-        for (uint32_t e = threadIdx.x; e < cnt; e += WG_SORT_THREADS) fl.write(lo + e, (uint32_t)src[wg_slot((int)e)]);
+        for (uint32_t e = threadIdx.x; e < cnt; e += 4 * WG_SORT_THREADS)
+            fl.template write_batch<4>(lo, e, (uint32_t)WG_SORT_THREADS, cnt, [&](uint32_t i, int) { return (uint32_t)src[wg_slot((int)i)]; });
     } else {
         for (uint32_t e = threadIdx.x; e < cnt; e += WG_SORT_THREADS) chunk[e] = src[wg_slot((int)e)];
     }
@@ -655,7 +681,8 @@ tile_merge_path_kernel(int tiles, int gx, uint32_t pass, const uint32_t* __restr
     __syncthreads();
     if (pass + 1 == merge_passes_needed(n)) {  // the tile's last pass writes the final lists directly
         const FinalLists fl{gm_base, point_list, gm_index, qmask, t % gx, t / gx};
-        for (uint32_t e = threadIdx.x; e < tot; e += 256) fl.write(lo + pairbase + s0 + e, (uint32_t)buf[wg_slot((int)e)]);
+        for (uint32_t e = threadIdx.x; e < tot; e += 4 * 256)
+            fl.template write_batch<4>(lo + pairbase + s0, e, 256u, tot, [&](uint32_t i, int) { return (uint32_t)buf[wg_slot((int)i)]; });
     } else {
         unsigned long long* out = dst + lo + pairbase + s0;
         for (uint32_t e = threadIdx.x; e < tot; e += 256) out[e] = buf[wg_slot((int)e)];
