@@ -31,10 +31,16 @@ __global__ void __launch_bounds__(EXP_THREADS)
 expand_count_kernel(int64_t n, const float* __restrict__ neural_opacity, uint32_t* __restrict__ wg_count) {
     __shared__ uint32_t wsum[EXP_THREADS / WAVE];
     uint32_t c = 0;
+    float no[EXP_ITEMS];      // all loads first, from clamped indices: `i < n && load` put a branch around every load and
+#pragma unroll                // the ballot behind it -- four memory round trips one after the other per workgroup
+    for (int r = 0; r < EXP_ITEMS; ++r) {
+        const int64_t i = (int64_t)blockIdx.x * EXP_PER_WG + r * EXP_THREADS + threadIdx.x;
+        no[r] = neural_opacity[min(i, n - 1)];
+    }
 #pragma unroll
     for (int r = 0; r < EXP_ITEMS; ++r) {
         const int64_t i = (int64_t)blockIdx.x * EXP_PER_WG + r * EXP_THREADS + threadIdx.x;
-        const bool keep = i < n && neural_opacity[i] > 0.0f;
+        const bool keep = i < n && no[r] > 0.0f;
         c += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(keep));
     }
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;  // every lane of a wave holds the wave's count
@@ -139,10 +145,16 @@ expand_run_kernel(int64_t n, int k, const float* __restrict__ neural_opacity, co
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     bool keep[EXP_ITEMS];
     uint32_t below[EXP_ITEMS];
+    float no[EXP_ITEMS];      // (all loads first, as in the count kernel)
 #pragma unroll
     for (int r = 0; r < EXP_ITEMS; ++r) {
         const int64_t i = (int64_t)blockIdx.x * EXP_PER_WG + r * EXP_THREADS + threadIdx.x;
-        keep[r] = i < n && neural_opacity[i] > 0.0f;
+        no[r] = neural_opacity[min(i, n - 1)];
+    }
+#pragma unroll
+    for (int r = 0; r < EXP_ITEMS; ++r) {
+        const int64_t i = (int64_t)blockIdx.x * EXP_PER_WG + r * EXP_THREADS + threadIdx.x;
+        keep[r] = i < n && no[r] > 0.0f;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep[r]);
         below[r] = lanes_below64(bal);
         if (lane == 0) wcnt[r][w] = (uint32_t)__builtin_popcountll(bal);
@@ -170,7 +182,7 @@ expand_run_kernel(int64_t n, int k, const float* __restrict__ neural_opacity, co
         const int64_t v = i / k;
         const float* sr = scale_rot + 7 * i;
         const float* gs = grid_scaling + 6 * v;
-        opacity[p] = neural_opacity[i];
+        opacity[p] = no[r];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             color_out[3 * p + c] = color[3 * i + c];
