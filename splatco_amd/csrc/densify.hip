@@ -84,16 +84,15 @@ statis_compute2_kernel(int64_t V, int k, int per, const float* __restrict__ neur
         const float2 no = *(const float2*)(neural_opacity + c);
         o0 = fmaxf(no.x, 0.0f);
         o1 = fmaxf(no.y, 0.0f);
-        const bool r0 = p.x >= 0 && update_filter[p.x], r1 = p.y >= 0 && update_filter[p.y];
+        // filter byte and gradient of both candidates asked for together, from clamped indices (an unselected candidate
+        // reads Gaussian 0's): as `p >= 0 && filter[p]` then `if (...) grad[p]` they were two more dependent round trips
+        const size_t q0 = (size_t)max(p.x, 0), q1 = (size_t)max(p.y, 0);
+        const uint8_t f0 = update_filter[q0], f1 = update_filter[q1];
+        const float gx0 = grad[q0 * gstride], gy0 = grad[q0 * gstride + 1];
+        const float gx1 = grad[q1 * gstride], gy1 = grad[q1 * gstride + 1];
         float2 g = make_float2(-1.0f, -1.0f);
-        if (r0) {
-            const float gx = grad[(size_t)p.x * gstride], gy = grad[(size_t)p.x * gstride + 1];
-            g.x = sqrtf(gx * gx + gy * gy);
-        }
-        if (r1) {
-            const float gx = grad[(size_t)p.y * gstride], gy = grad[(size_t)p.y * gstride + 1];
-            g.y = sqrtf(gx * gx + gy * gy);
-        }
+        if (p.x >= 0 && f0) g.x = sqrtf(gx0 * gx0 + gy0 * gy0);
+        if (p.y >= 0 && f1) g.y = sqrtf(gx1 * gx1 + gy1 * gy1);
         *(float2*)(inc_grad + c) = g;
     }
     op[2 * threadIdx.x] = o0;
@@ -141,7 +140,8 @@ void launch_statis_compute(int64_t V, int k, const float* neural_opacity, const 
                            float* inc_grad, hipStream_t st) {
     const int64_t n = V * k;
     if (n <= 0) return;
-    if (statis_pairs_ok(k, neural_opacity, out_index, inc_grad, inc_grad)) {
+    // (the pair kernel reads entry 0 of update_filter / grad for unselected candidates: both must exist)
+    if (statis_pairs_ok(k, neural_opacity, out_index, inc_grad, inc_grad) && update_filter && grad) {
         const int per2 = (512 / k) * k;
         statis_compute2_kernel<<<(unsigned)((n + per2 - 1) / per2), 256, 0, st>>>(V, k, per2, neural_opacity, out_index, update_filter,
                                                                                  grad, gstride, inc_opacity, inc_grad);
