@@ -16,6 +16,9 @@ from .rasterizer import _ptr, _stream
 class _ExpandCompact(torch.autograd.Function):
     @staticmethod
     def forward(ctx, neural_opacity, color, scale_rot, offsets, grid_scaling, anchor, k):
+        # no zero "gradients" for mask / out_index (bool and int32 [V*k]: two fills of 184 M elements per backward at
+        # configs[4]) nor for outputs the loss did not use: backward() takes None as zero
+        ctx.set_materialize_grads(False)
         f = lambda t: t.contiguous().float()
         neural_opacity, color, scale_rot = f(neural_opacity).reshape(-1), f(color), f(scale_rot)
         offsets, grid_scaling, anchor = f(offsets).reshape(-1, 3), f(grid_scaling), f(anchor)
@@ -51,7 +54,8 @@ class _ExpandCompact(torch.autograd.Function):
         V, k = ctx.dims
         dev, n = scale_rot.device, V * k
         z = lambda t, *s: (torch.zeros(*s, dtype=torch.float32, device=dev) if t is None else t.contiguous().float())
-        P = int((out_index >= 0).sum().item()) if g_xyz is None else g_xyz.shape[0]
+        given = next((t for t in (g_xyz, g_col, g_opa, g_sca, g_rot) if t is not None), None)
+        P = int((out_index >= 0).sum().item()) if given is None else given.shape[0]
         g_xyz, g_col, g_opa, g_sca, g_rot = z(g_xyz, P, 3), z(g_col, P, 3), z(g_opa, P, 1), z(g_sca, P, 3), z(g_rot, P, 4)
         g_tap = None if g_tap is None or P == 0 else g_tap.contiguous().float().reshape(1)
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)

@@ -171,6 +171,9 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings):
         cs = _CSettings(raster_settings)
+        # no zero tensors for outputs that received no gradient: autograd filled an int32 [P] "gradient" of radii with
+        # zeros before every backward (88 M elements at configs[4]); backward() treats a missing dL/dcolor as zero
+        ctx.set_materialize_grads(False)
         means3D = _dev_f32(means3D, "means3D")
         none_if_empty = lambda t, n: None if t is None or t.numel() == 0 else _dev_f32(t, n)
         sh, colors_precomp = none_if_empty(sh, "shs"), none_if_empty(colors_precomp, "colors_precomp")
@@ -206,6 +209,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         st = ctx.state
         if st is None:
             return tuple(None if t is None else torch.zeros_like(t) for t in ctx.shapes) + (None,)
+        if grad_out_color is None:      # the image took no part in the loss: every gradient is zero
+            return (None,) * 9
         means3D, scales, rotations, cov3D, sh, colors, opacities = ctx.saved_tensors
         dev, P, cs = means3D.device, st.P, st.cs
         g = _dev_f32(grad_out_color, "grad_out_color")
