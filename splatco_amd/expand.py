@@ -84,9 +84,16 @@ def expand_compact(neural_opacity, color, scale_rot, grid_offsets, grid_scaling,
 
 
 def visible_indices(mask):
-    """mask.nonzero().squeeze(1) for a 1-D mask: the HIP op on the GPU, torch elsewhere."""
+    """mask.nonzero().squeeze(1) for a 1-D mask: the HIP op on the GPU, torch elsewhere.  The list is remembered on the
+    mask tensor (with the version it was built from): a training step asks for it twice -- the gather of render() and the
+    densification statistics -- and each build is two kernels and a host read of the count."""
     if mask.is_cuda and mask.dim() == 1 and mask.dtype in (torch.bool, torch.uint8):
-        return mask_indices(mask)
+        cached = getattr(mask, "_scr_index", None)
+        if cached is not None and cached[0] == mask._version:
+            return cached[1]
+        idx = mask_indices(mask)
+        mask._scr_index = (mask._version, idx)
+        return idx
     return mask.nonzero(as_tuple=False).squeeze(1)
 
 
