@@ -74,8 +74,9 @@ __device__ __forceinline__ void mh_store16(float* p, float a, float b, float c, 
     const f4 q = {a, b, c, d};
     asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(q) : "memory");
 }
-__device__ __forceinline__ float mh_sigmoid(float z) { return __frcp_rn(1.0f + __expf(-z)); }
-__device__ __forceinline__ float mh_tanh(float z) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * z)); }
+// (__frcp_rn is the correctly rounded reciprocal: a dozen instructions of division sequence each; the instruction itself)
+__device__ __forceinline__ float mh_sigmoid(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+__device__ __forceinline__ float mh_tanh(float z) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * z)); }
 
 // ---------------------------------------------------------------- forward
 __global__ void __launch_bounds__(64 * MH_WAVES, 2)
