@@ -531,7 +531,8 @@ def test_fused_anchor_gather_matches_the_torch_ops():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("V,d,ld", [(2, 60, 60), (15, 71, 71), (1000, 60, 64), (4099, 71, 71), (100003, 60, 60), (100003, 71, 71),
-                                    (65536, 30, 30), (20000, 80, 80), (20000, 16, 99), (33333, 7, 7)])
+                                    (65536, 30, 30), (20000, 80, 80), (20000, 16, 99), (33333, 7, 7),
+                                    (4_400_003, 60, 60)])      # more statistics slabs than the chip holds: the slabs grow
 def test_fused_norm_linear_matches_batchnorm_linear_chain(V, d, ld):
     """csrc/normlinear.hip (column statistics, folded GEMM, the three backward passes) against BatchNorm1d (training
     mode) -> Linear evaluated by torch autograd in float64, and against the torch ops the CPU path uses.  Columns
