@@ -156,3 +156,21 @@ def test_fused_adam_refuses_what_the_reference_does_not_use():
     p.grad = torch.ones(4)
     with pytest.raises(ValueError, match="no CPU path"):
         opt.step()
+
+
+def test_scr_adam_step_rejects_bad_arguments_without_a_gpu():
+    """The C-ABI entry validates its host-side arguments before anything is launched."""
+    import ctypes as C
+    from splatco_amd import _C
+    lib = _C.lib
+    err = lambda: lib.scr_last_error().decode()
+    assert lib.scr_adam_step(-1, None, 0.9, 0.999, 1e-15, None) != 0 and "n_tensors" in err()
+    assert lib.scr_adam_step(0, None, 0.9, 0.999, 1e-15, None) == 0              # nothing to do
+    assert lib.scr_adam_step(1, None, 0.9, 0.999, 1e-15, None) != 0 and "NULL" in err()
+    t = (_C.AdamTensor * 1)()
+    t[0].numel, t[0].lr, t[0].bias_correction1, t[0].bias_correction2_sqrt = 4, 1e-3, 0.1, 0.03
+    assert lib.scr_adam_step(1, t, 0.9, 0.999, 1e-15, None) != 0 and "NULL tensor" in err()
+    t[0].param = t[0].grad = t[0].exp_avg = t[0].exp_avg_sq = 16                  # non-null: the checks below come first
+    assert lib.scr_adam_step(1, t, 1.0, 0.999, 1e-15, None) != 0 and "beta" in err()
+    t[0].bias_correction1 = 0.0                                                   # step 0: no bias correction exists
+    assert lib.scr_adam_step(1, t, 0.9, 0.999, 1e-15, None) != 0 and "bias" in err()
