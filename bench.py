@@ -536,7 +536,27 @@ def run_cfg1(args, rank, world, dev):
 
 
 # ------------------------------------------------------------------ cfg2..4: the anchor scenes
+LAST_PLAN = [0, 0, 0]      # (P, tile instances, largest tile) of the most recent rasterizer forward of THIS bench process
+
+
+def record_plans():
+    """Bench bookkeeping, kept out of the product: wrap splatco_amd.rasterizer.rasterize_forward so that the instance count
+    of the last forward (part of the per-call RasterState) is visible to the byte model."""
+    from splatco_amd import rasterizer as R
+    if getattr(R.rasterize_forward, "_recording", False):
+        return
+    inner = R.rasterize_forward
+
+    def rasterize_forward(*a, **k):
+        color, radii, st = inner(*a, **k)
+        LAST_PLAN[:] = (st.P, st.I, st.max_tile)
+        return color, radii, st
+    rasterize_forward._recording = True
+    R.rasterize_forward = rasterize_forward
+
+
 def run_anchor_config(args, rank, world, dev):
+    record_plans()
     import torch.distributed as dist
     from splatco_amd import _C
     from splatco_amd.densify import AnchorDensifier
@@ -575,9 +595,14 @@ def run_anchor_config(args, rank, world, dev):
         den = AnchorDensifier(pc, opt, seed=seed)
         arena = GradArena([p for grp in groups for p in grp["params"]], mode=args.exchange)
 
+        from splatco_amd.tv import TV_EVERY, TV_WEIGHT_A
+
         def step():
             arena.world = world if stats.get("exchange", True) else 1      # 1: reduce() and the hooks issue no collective
-            loss, out, _ = collaborative_step(pc, views, gts, pipe, bg, optimizer=opt, densifier=den, arena=arena)
+            stats["iteration"] = stats.get("iteration", 0) + 1             # train.py:147: iterations count from 1
+            # the tri-plane total-variation term rides on every 4th iteration (train.py:242-243, opt.tv_weight_a = 4e-7)
+            loss, out, _ = collaborative_step(pc, views, gts, pipe, bg, optimizer=opt, densifier=den, arena=arena,
+                                              iteration=stats["iteration"], tv_weight=TV_WEIGHT_A)
             stats["P"], stats["V"] = out["radii"].shape[0], int(out["selection_mask"].numel() // pc.n_offsets)
             stats["rendered"] = out["radii"]
     else:
@@ -702,8 +727,7 @@ def run_anchor_config(args, rank, world, dev):
     lvl0 = pc.feat_planes._feat.k0s[0]
     extra = {"N": N, "V": V, "n": V * pc.n_offsets, "C": lvl0.channels,
              "HW": lvl0.xy_plane.shape[2] * lvl0.xy_plane.shape[3]}
-    from splatco_amd import rasterizer as R
-    I = R.last_plan[1]                                       # (Gaussian, tile) instances of the last rasterised view
+    I = LAST_PLAN[1]                                         # (Gaussian, tile) instances of the last rasterised view
     launches = {k: n / nwarm for k, (ms, n) in warm_prof.items() if n}
     ab = algorithmic_bytes(dominant, P1, I, W * H, extra) / max(launches.get(dominant, 1.0), 1.0)     # per launch
     out = {
@@ -762,6 +786,26 @@ def run_anchor_config(args, rank, world, dev):
         if k == "blend_forward_kernel" and v["frac_of_measured_peak"] > 1.0:
             v["note"] = ("the byte model counts every entry of every tile list; the forward stops reading a tile's list once "
                          "all of its pixels are opaque (T < 1e-4), which at this density is long before the end")
+    if train:
+        # the total-variation pass on its own (it runs on every 4th timed step): HBM-bound, 12 algorithmic bytes per plane
+        # element (read plane, read + write gradient) over the planes of the active grids
+        feat = pc.feat_planes._feat
+        elems = sum(p.numel() for lvl in range(feat.activate_level + 1)
+                    for p in (feat.k0s[lvl].xy_plane, feat.k0s[lvl].xz_plane, feat.k0s[lvl].yz_plane))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pc.feat_planes.tv_loss(TV_WEIGHT_A)
+        e0.record()
+        for _ in range(10):
+            pc.feat_planes.tv_loss(TV_WEIGHT_A)
+        e1.record()
+        torch.cuda.synchronize()
+        tv_ms = e0.elapsed_time(e1) / 10
+        out["config"]["tv"] = f"every {TV_EVERY}th step (train.py:242-243), weight {TV_WEIGHT_A}, after the gradient exchange, once"
+        out["tv_pass"] = {"kernel": "tv_add_grad_kernel", "ms": round(tv_ms, 4), "plane_elements": elems,
+                          "algorithmic_MB": round(12 * elems / 1e6, 1), "GBps": round(12 * elems / (tv_ms * 1e-3) / 1e9, 1),
+                          "frac_of_measured_peak": round(12 * elems / (tv_ms * 1e-3) / 1e9 / peak, 3),
+                          "timed_steps_with_the_term": sum(1 for i in range(stats["iteration"] - args.steps + 1, stats["iteration"] + 1)
+                                                           if i % TV_EVERY == 0)}
     if allreduce_info is not None:
         out["allreduce"] = allreduce_info
     if exposed is not None:

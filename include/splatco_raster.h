@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 21
+#define SCR_ABI_VERSION 22
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -392,6 +392,25 @@ typedef struct scr_adam_tensor {
     float lr, bias_correction1, bias_correction2_sqrt, reserved;
 } scr_adam_tensor;
 int scr_adam_step(int32_t n_tensors, const scr_adam_tensor* tensors, double beta1, double beta2, double eps, void* stream);
+
+/* ---- the tri-plane total-variation term of the training step: train.py:242-243 (`iteration % 4 == 0`, after
+ * backward(), before optimizer.step()) -> scene/gaussian_model.py:217-220 (grid `level` of the active levels gets the
+ * weight w * 0.5^(2 - level)) -> scene/grids.py:240-250 PlaneGrid.total_variation_add_grad(w): smooth-L1 (beta 1, 'sum')
+ * of the neighbour differences along both axes of each of the grid's three planes, the six sums times w, / 6,
+ * .backward().  Here: the closed-form derivative ADDED into `grad` in place, one streaming pass, no temporaries:
+ *   grad[r,a,b] += h(p[a,b] - p[a-1,b]) - h(p[a+1,b] - p[a,b]) + h(p[a,b] - p[a,b-1]) - h(p[a,b+1] - p[a,b])
+ * with h(d) = coef * clamp(d, -1, 1), terms with a neighbour outside the plane dropped.  coef = fp32(1/6) * fp32(w_level)
+ * (the caller forms it; that is the product autograd forms).  `planes` is a HOST table read during the call only;
+ * plane / grad: [channels, rows, cols] fp32 contiguous device buffers (the reference's [1, R, X, Y] parameters), distinct.
+ * In a sharded step the term depends on the parameters only: add it ONCE, after the gradient SUM, on every rank.
+ * Elementwise: bit-reproducible. */
+typedef struct scr_tv_plane {
+    const float* plane;
+    float* grad;
+    int32_t channels, rows, cols;
+    float coef;
+} scr_tv_plane;
+int scr_tv_add_grad(int32_t n_planes, const scr_tv_plane* planes, void* stream);
 
 /* ---- k nearest neighbours for GaussianModel.compute_curvature (scene/gaussian_model.py:1092-1110: sklearn on the host +
  * a Python loop over the anchors there).  The caller buckets the N points into a uniform grid (grid_host[7] = x0, y0, z0,

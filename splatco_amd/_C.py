@@ -29,10 +29,10 @@ SYMBOLS = [
     "scr_knn", "scr_knn_curvature", "scr_anchor_gather", "scr_anchor_gather_backward", "scr_mlp_heads_hidden_bytes", "scr_mlp_heads_partial_bytes", "scr_mlp_heads_forward", "scr_mlp_heads_backward",
     "scr_norm_linear_scratch_bytes", "scr_norm_linear_forward", "scr_norm_linear_backward",
     "scr_norm_fold", "scr_norm_fold_backward", "scr_norm_running_stats", "scr_box_coords", "scr_forward_plan_run",
-    "scr_profile_stride", "scr_debug_force_deep_lists", "scr_adam_step",
+    "scr_profile_stride", "scr_debug_force_deep_lists", "scr_adam_step", "scr_tv_add_grad",
 ]
 PROF_COUNT = 19
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 (DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS, DBG_QMASK,
  DBG_GM_INDEX) = range(9)
@@ -43,6 +43,12 @@ class AdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("numel", C.c_int64), ("lr", C.c_float), ("bias_correction1", C.c_float),
                 ("bias_correction2_sqrt", C.c_float), ("reserved", C.c_float)]
+
+
+class TvPlane(C.Structure):
+    """scr_tv_plane (include/splatco_raster.h)."""
+    _fields_ = [("plane", C.c_void_p), ("grad", C.c_void_p), ("channels", C.c_int32), ("rows", C.c_int32),
+                ("cols", C.c_int32), ("coef", C.c_float)]
 
 
 class Settings(C.Structure):
@@ -167,6 +173,8 @@ def _load():
     lib.scr_knn.restype = lib.scr_knn_curvature.restype = C.c_int
     lib.scr_adam_step.argtypes = [i32, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, vp]
     lib.scr_adam_step.restype = C.c_int
+    lib.scr_tv_add_grad.argtypes = [i32, C.POINTER(TvPlane), vp]
+    lib.scr_tv_add_grad.restype = C.c_int
     lib.scr_copy_probe.argtypes = [vp, vp, C.c_size_t, vp]
     lib.scr_copy_probe.restype = C.c_int
     lib.scr_profile_enable.argtypes = [C.c_int]

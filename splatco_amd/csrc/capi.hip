@@ -9,6 +9,7 @@
 
 #include "common.h"
 #include "adam.h"
+#include "tv.h"
 #include <chrono>
 #include <cstring>
 
@@ -931,6 +932,23 @@ int scr_adam_step(int32_t n_tensors, const scr_adam_tensor* tensors, double beta
     hipStream_t st = (hipStream_t)stream;
     if (launch_adam(n_tensors, tensors, beta1, beta2, eps, st)) return fail("scr_adam_step: more than 2^31 workgroups in one launch");
     CHECK_LAUNCH("adam_kernel", 0, st);
+    return 0;
+}
+
+// ---- tri-plane total-variation term (tv.hip)
+int scr_tv_add_grad(int32_t n_planes, const scr_tv_plane* planes, void* stream) {
+    if (n_planes < 0) return fail("scr_tv_add_grad: n_planes < 0");
+    if (n_planes == 0) return 0;
+    if (!planes) return fail("scr_tv_add_grad: planes is NULL");
+    for (int t = 0; t < n_planes; ++t) {
+        const scr_tv_plane& x = planes[t];
+        if (x.channels < 0 || x.rows < 0 || x.cols < 0) return fail("scr_tv_add_grad: negative plane size");
+        if ((int64_t)x.channels * x.rows * x.cols > 0 && (!x.plane || !x.grad)) return fail("scr_tv_add_grad: NULL plane / grad");
+        if (x.plane == x.grad && x.plane) return fail("scr_tv_add_grad: plane and grad must be distinct buffers");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (launch_tv_add_grad(n_planes, planes, st)) return fail("scr_tv_add_grad: more than 2^31 wave units in one launch");
+    CHECK_LAUNCH("tv_add_grad_kernel", 0, st);
     return 0;
 }
 

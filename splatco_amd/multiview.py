@@ -438,14 +438,15 @@ def consistency_loss(local: Sequence, weight: float = 0.05, device=None):
                              "buffers on the communicator's device)")
         mine = [(int(i), g.detach(), r.detach()) for i, g, r in local]
         everyone = [None] * world
-        dist.all_gather_object(everyone, [(i, tuple(g.shape)) for i, g, _ in mine])
+        # (shape and dtype travel with the index: a rank without local views has no image to copy them from)
+        dist.all_gather_object(everyone, [(i, tuple(g.shape), g.dtype) for i, g, _ in mine])
         for src in range(world):
-            for i, shape in everyone[src]:
+            for i, shape, dtype in everyone[src]:
                 if src == rank:
                     g, r = next((g, r) for j, g, r in mine if j == i)
                     pair = torch.stack([g, r]).contiguous()
                 else:
-                    pair = torch.empty((2,) + shape, dtype=local[0][1].dtype if local else torch.float32, device=device)
+                    pair = torch.empty((2,) + shape, dtype=dtype, device=device)
                 dist.broadcast(pair, src=src)
                 if src != rank:
                     items.append((i, pair[0], pair[1], False))
@@ -468,13 +469,16 @@ def consistency_loss(local: Sequence, weight: float = 0.05, device=None):
 
 def multiview_step(views: Sequence, params: Sequence[torch.Tensor],
                    render_loss: Callable[[object], torch.Tensor], bucket: torch.Tensor = None,
-                   consistency_weight: float = 0.0):
+                   consistency_weight: float = 0.0, after_reduce: Callable[[], None] = None):
     """One collaborative step: this rank renders its shard of `views`, sums the per-view losses,
     runs ONE backward (as train.py:240 does) and all-reduces the gradients.  After the call every
     rank holds d(sum over ALL views of loss)/d(params) -- identical to the sequential mv loop.
     With consistency_weight > 0 (train.py: 0.05 for update_from < iteration < update_until)
     `render_loss(view)` must return (loss, rendered image, gt image) and the pairwise cross-view term is
-    added (see consistency_loss).  Returns (local loss sum, bucket)."""
+    added (see consistency_loss).
+    after_reduce: called once the summed gradients are in place -- where terms that depend on the parameters only belong
+    (the tri-plane total-variation term of train.py:242-243: added before the exchange it would count once per rank).
+    Returns (local loss sum, bucket)."""
     for p in params:
         p.grad = None
     total = None
@@ -487,10 +491,12 @@ def multiview_step(views: Sequence, params: Sequence[torch.Tensor],
             rendered.append((rank + k * world, img, gt))
         total = loss if total is None else total + loss
     if consistency_weight:
-        term, _ = consistency_loss(rendered, consistency_weight)
+        term, _ = consistency_loss(rendered, consistency_weight, device=params[0].device)
         if term is not None:
             total = term if total is None else total + term
     if total is not None:
         total.backward()
     bucket = allreduce_gradients(params, bucket)
-    return (total.detach() if total is not None else torch.zeros((), device=params[0].device)), bucket
+    if after_reduce is not None:
+        after_reduce()
+    return (total.detach() if total is not None else torch.zeros((), dtype=params[0].dtype, device=params[0].device)), bucket

@@ -105,14 +105,12 @@ class RasterState:
         return out
 
 
-last_plan = (0, 0, 0)      # (P, tile instances, largest tile) of the most recent forward: bench / profiling bookkeeping only
 SPECULATE = os.environ.get("SPLATCO_SPECULATIVE_BINNING", "1") != "0"
 _plan_guess = {}           # (device, H, W) -> (P, instances, largest tile) of the last forward at that resolution: sizes the speculative binning buffer
 
 
 def rasterize_forward(cs, means3D, opacities, scales, rotations, cov3D_precomp, shs, colors_precomp):
     """plan + run through the C-ABI.  Returns (color, radii, RasterState)."""
-    global last_plan
     dev = means3D.device
     P = means3D.shape[0]
     M = 0 if shs is None else shs.shape[1]
@@ -139,7 +137,6 @@ def rasterize_forward(cs, means3D, opacities, scales, rotations, cov3D_precomp, 
                                              st.geom.data_ptr(), _ptr(radii), plan, None if spec is None else spec.data_ptr(),
                                              0 if spec is None else spec.numel(), st.image.data_ptr(), color.data_ptr(), _stream()))
         st.I, st.max_tile = int(plan[0]), int(plan[1])
-        last_plan = (P, st.I, st.max_tile)
         _plan_guess[key] = (P, st.I, st.max_tile)
         if plan[2]:
             st.binning = spec

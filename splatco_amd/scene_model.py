@@ -360,6 +360,12 @@ class PlaneGrid(nn.Module):                   # scene/grids.py:102-201
     def get_dim(self):
         return self.channels * 2 if self.TAflag else self.channels
 
+    def total_variation_add_grad(self, w):
+        """scene/grids.py:240-250: adds the gradient of the smooth-L1 total variation of the three planes (weight w, / 6)
+        into their .grad, in place (csrc/tv.hip; the attention module takes no part, as there)."""
+        from .tv import grid_planes, tv_add_grad
+        tv_add_grad([(p, w) for p in grid_planes(self)])
+
     def fused_ok(self, xyz):
         return self.xy_plane.is_cuda and self.channels // 3 <= 8 and not xyz.requires_grad    # csrc/triplane.hip (2 R <= 16)
 
@@ -536,6 +542,11 @@ class GaussianLearner(nn.Module):             # scene/gaussian_model.py:184-220
 
     def activate_plane_level(self):
         self._feat.activate_level += 1
+
+    def tv_loss(self, w):
+        """scene/gaussian_model.py:217-220: grid `level` of the active levels gets w * 0.5^(2 - level); one launch."""
+        from .tv import feature_planes_tv
+        feature_planes_tv(self._feat, w)
 
     def inference(self, xyz, g_fea, Q0, parts=False):
         # the reference ignores the Q0 argument and uses self.Q0 (:209-215); xyz is detached

@@ -3,7 +3,8 @@ for the multi-view configurations of BASELINE.json (configs[3], configs[4]): ren
 shard of the mv views, per-view loss 0.8 L1 + 0.2 (1 - SSIM) + 0.01 mean(prod scaling) summed over
 views (train.py:192-198), optionally the pairwise cross-view consistency term (train.py:201-239, weight
 0.05 for update_from < iteration < update_until), ONE backward (train.py:240), SUM all-reduce of the
-gradients, the densification statistics of the LAST view of the mv loop (train.py:264-266) on every rank,
+gradients, every 4th iteration the tri-plane total-variation term added into the summed plane gradients
+(train.py:242-243; tv.py), the densification statistics of the LAST view of the mv loop (train.py:264-266) on every rank,
 and the optimizer step (train.py:310-312).  Learning-rate schedules, the key-point pruning of
 train.py:219-236, logging and checkpoints are out of scope."""
 import torch
@@ -12,6 +13,7 @@ import torch.distributed as dist
 from .losses import view_loss
 from .multiview import GradArena, allreduce_gradients, consistency_loss, shard_views, world_info
 from .renderer import prefilter_voxel, render
+from .tv import tv_due
 
 
 def sync_densification_stats(densifier, n_views, out, vis, device):
@@ -52,13 +54,18 @@ def sync_densification_stats(densifier, n_views, out, vis, device):
 
 
 def collaborative_step(pc, views, gt_images, pipe, bg_color, optimizer=None, bucket=None,
-                       consistency_weight=0.0, densifier=None, arena=None):
+                       consistency_weight=0.0, densifier=None, arena=None, iteration=None, tv_weight=0.0):
     """views / gt_images: the identically ordered mv view list every rank holds; gt_images[i] is the
     [3,H,W] target of views[i] (host or device).  densifier: a splatco_amd.densify.AnchorDensifier; its
     accumulators receive the statistics of the LAST view of the list on every rank (sync_densification_stats).
     arena: a multiview.GradArena over the trainable parameters (gradients live in one persistent buffer that is
     all-reduced in place, piecewise, overlapping the tail of the backward pass); without it the gradients are
-    packed into `bucket`.  Returns (local loss sum, last render dict, bucket or arena buffer)."""
+    packed into `bucket`.
+    iteration / tv_weight: the tri-plane total-variation term of train.py:242-243 -- with tv_weight > 0 (the reference's
+    opt.tv_weight_a = 4e-7) and `iteration % 4 == 0` its gradient is added into the plane gradients AFTER the exchange,
+    identically on every rank: the term is a function of the parameters alone, so adding it before the SUM would count it
+    once per rank.  (The reference also waits for gaussians.enable_net, which is True from iteration 1 on.)
+    Returns (local loss sum, last render dict, bucket or arena buffer)."""
     params = arena.params if arena is not None else [p for p in pc.parameters() if p.requires_grad]
     if arena is not None:
         # the per-anchor gradients (99 % of the arena) are written in place by the gather's backward kernel; the sink is
@@ -101,6 +108,8 @@ def collaborative_step(pc, views, gt_images, pipe, bg_color, optimizer=None, buc
         bucket = arena.reduce()
     else:
         bucket = allreduce_gradients(params, bucket)
+    if tv_weight and iteration is not None and tv_due(iteration):
+        pc.feat_planes.tv_loss(tv_weight)
     if densifier is not None:
         sync_densification_stats(densifier, len(views), out, vis, device)
     if optimizer is not None:

@@ -1,8 +1,8 @@
 """GPU tests of the multi-view branch at the sizes BASELINE.json names for it, on the ONE GPU of the test box:
 
   * sharded == sequential ON THE HIP PATH: two ranks on one device over gloo run train_step.collaborative_step with a
-    GradArena (gradient sink, hook-issued pieces, per-anchor exchange in anchor ranges), the cross-view consistency term
-    and a densifier; every rank then replays the reference's sequential mv loop (train.py:171-240: all views, summed
+    GradArena (gradient sink, hook-issued pieces, per-anchor exchange in anchor ranges), the cross-view consistency term,
+    the tri-plane total-variation term (added once, after the exchange) and a densifier; every rank then replays the reference's sequential mv loop (train.py:171-240: all views, summed
     losses + pairwise term, ONE backward; training_statis of the last view, train.py:264-266) with the same kernels.
   * configs[3] per-GPU reality: 5 M anchors, mv = 4 views rendered one after another on one GPU -- four live rasterizer
     graphs, one backward -- which is exactly how the reference executes --mv 4.
@@ -43,6 +43,7 @@ torch.cuda.set_device(dev)
 pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
 bg = torch.ones(3, device=dev)
 W, H, N, MV = 640, 360, 200_000, 4
+TVW = 1e-3          # the reference's 4e-7 would vanish next to this scene's plane gradients: the test wants the term visible
 views = [v.to(dev) for v in synthetic_views(MV, W, H)]
 g = torch.Generator(device=dev).manual_seed(5)
 base = torch.rand(3, H, W, device=dev, generator=g)
@@ -83,6 +84,12 @@ def sequential(pc, params, den, cw):
                 else:
                     cross = cross + cw * t.detach()
     total.backward()
+    # the tri-plane total-variation term (train.py:242-243): once, whatever the number of ranks
+    plane = pc.feat_planes._feat.k0s[0].xy_plane
+    before = plane.grad.clone()
+    pc.feat_planes.tv_loss(TVW)
+    share = float((plane.grad - before).norm() / plane.grad.norm())
+    assert share > 1e-2, share            # large enough that adding it once per rank would fail the 1e-6 comparison below
     out, vis = outs[-1]
     with torch.no_grad():
         inc_op, inc_g = stats.statis_increments(den.n_offsets, out["viewspace_points"].grad, out["neural_opacity"],
@@ -101,7 +108,8 @@ for mode, cw in (("all_reduce", 0.05), ("rs_ag", 0.0))[:int(sys.argv[2])]:
     assert all(torch.equal(a, b) for a, b in zip(params_a, params_b))
     arena = GradArena(params_a, chunk_bytes=4 << 20, mode=mode, anchor_ranges=4)       # several pieces per large parameter
     for it in range(2):         # step 0 goes out from reduce() and agrees on the order; step 1 issues from the hooks / ranges
-        loss_a, out_a, _ = collaborative_step(pc_a, views, gts, pipe, bg, consistency_weight=cw, densifier=den_a, arena=arena)
+        loss_a, out_a, _ = collaborative_step(pc_a, views, gts, pipe, bg, consistency_weight=cw, densifier=den_a, arena=arena,
+                                                  iteration=4 * (it + 1), tv_weight=TVW)
         loss_b, own, cross = sequential(pc_b, params_b, den_b, cw)
     assert arena._order is not None and arena._sink is not None and len(arena.sink_ranges) == 4
     assert arena._cursor == len(arena.units)
@@ -273,11 +281,21 @@ def test_cfg4_20M_anchors_one_view_per_rank(oracle):
     gt = torch.rand(3, 1080, 1920, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + seed))
     before = pc._anchor_feat.detach().clone()
     torch.cuda.reset_peak_memory_stats()
-    loss, out, _ = collaborative_step(pc, [cam.to(dev)], [gt], pipe, bg, densifier=den, arena=arena)
+    plans, inner = [], R.rasterize_forward         # test bookkeeping: the instance count lives in the per-call RasterState
+
+    def recording(*a, **k):
+        res = inner(*a, **k)
+        plans.append((res[2].P, res[2].I, res[2].max_tile))
+        return res
+    R.rasterize_forward = recording
+    try:
+        loss, out, _ = collaborative_step(pc, [cam.to(dev)], [gt], pipe, bg, densifier=den, arena=arena)
+    finally:
+        R.rasterize_forward = inner
     torch.cuda.synchronize()
-    P, I = out["radii"].shape[0], R.last_plan[1]
+    P, I = out["radii"].shape[0], plans[-1][1]
     print(f"[cfg4] 20 M anchors, one view: {P} Gaussians, {I} tile instances ({I / 2**32:.3f} of the 2^32 index space), "
-          f"largest tile {R.last_plan[2]}, loss {float(loss):.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+          f"largest tile {plans[-1][2]}, loss {float(loss):.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     assert P > 50_000_000 and 100_000_000 < I < 2 ** 32
     assert torch.isfinite(loss) and torch.isfinite(out["render"]).all()
     _check_param_grads(pc)

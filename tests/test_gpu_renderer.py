@@ -1022,3 +1022,87 @@ def test_stacked_level0_grids_equal_separate_sampling(level):
             assert torch.allclose(b0[n], b1[n], rtol=1e-5, atol=1e-6), n
         else:
             assert torch.equal(b0[n], b1[n]), n
+
+
+@pytest.mark.gpu
+def test_tv_term_on_the_gpu_matches_the_reference_fixture():
+    """csrc/tv.hip against what the reference's PlaneGrid.total_variation_add_grad / GaussianLearner.tv_loss left in the
+    planes' .grad (tests/golden/tv.npz; scene/grids.py:240-250, scene/gaussian_model.py:217-220): rel-L2 <= 1e-6 per
+    plane, into empty and into existing gradients, scalar (odd row length) and float4 path, bit-reproducible."""
+    from util import rel_l2
+    from splatco_amd.scene_model import GaussianLearner, PlaneGrid
+    dev = torch.device("cuda:0")
+    G = np.load(os.path.join(GOLD, "tv.npz"))
+    names = ("xy_plane", "xz_plane", "yz_plane")
+    for tag, ws, ta in (("cube_plain", [24, 24, 24], False), ("cube_ta", [24, 24, 24], True),
+                        ("odd_plain", [37, 19, 30], False), ("odd_ta", [37, 19, 30], True)):
+        w = float(G[f"{tag}.w"])
+        pg = PlaneGrid(15, ws, [-2.0] * 3, [2.0] * 3, TAflag=ta).to(dev)
+        with torch.no_grad():
+            for n in names:
+                getattr(pg, n).copy_(torch.tensor(G[f"{tag}.{n}"]))
+        pg.total_variation_add_grad(w)
+        first = {n: getattr(pg, n).grad.clone() for n in names}
+        for n in names:
+            assert rel_l2(first[n].cpu().numpy(), G[f"{tag}.{n}.grad"]) <= 1e-6, (tag, n)
+        if ta:
+            assert all(p.grad is None for p in pg.TA.parameters())      # the attention module takes no part
+        for n in names:
+            getattr(pg, n).grad = torch.tensor(G[f"{tag}.{n}.prior"], device=dev)
+        pg.total_variation_add_grad(w)
+        for n in names:
+            assert rel_l2(getattr(pg, n).grad.cpu().numpy(), G[f"{tag}.{n}.grad_acc"]) <= 1e-6, (tag, n, "accumulate")
+        for n in names:
+            getattr(pg, n).grad = None
+        pg.total_variation_add_grad(w)
+        assert all(torch.equal(getattr(pg, n).grad, first[n]) for n in names)
+    for level in (0, 2):
+        gl = GaussianLearner(40, 15).to(dev)
+        gl._feat.activate_level = level
+        with torch.no_grad():
+            for gi, grid in enumerate(gl._feat.k0s):
+                for n in names:
+                    getattr(grid, n).copy_(torch.tensor(G[f"learner.k0s.{gi}.{n}"]))
+        gl.tv_loss(4e-7)
+        for gi, grid in enumerate(gl._feat.k0s):
+            for n in names:
+                want, got = G[f"learner.level{level}.k0s.{gi}.{n}.grad"], getattr(grid, n).grad
+                if want.size == 0:
+                    assert got is None, (level, gi, n)
+                else:
+                    assert rel_l2(got.cpu().numpy(), want) <= 1e-6, (level, gi, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,A,B", [(5, 700, 700), (5, 1400, 1400), (3, 33, 2051), (1, 1, 9), (2, 7, 1), (4, 65, 260)])
+def test_tv_term_at_plane_sizes_equals_autograd(R, A, B):
+    """The reference's formulation (six smooth-L1 sums -> autograd) run by torch on the GPU against csrc/tv.hip at the plane
+    sizes of plane_size = 2800 (700^2 and 1400^2 are the grids tv_loss touches), at strip / tile remainders and at
+    degenerate planes; the gradient must also be the exact negative under p -> -p (odd symmetry of the closed form)."""
+    import torch.nn.functional as F
+    from splatco_amd.tv import tv_add_grad
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(R * 1000 + A + B)
+    p = torch.nn.Parameter((torch.randn(1, R, A, B, generator=g) * 0.8).to(dev))
+    w = 4e-7
+    loss = 0
+    if A > 1:
+        loss = loss + w * F.smooth_l1_loss(p[:, :, 1:], p[:, :, :-1], reduction="sum")
+    if B > 1:
+        loss = loss + w * F.smooth_l1_loss(p[:, :, :, 1:], p[:, :, :, :-1], reduction="sum")
+    want = torch.autograd.grad(loss / 6, p)[0] if (A > 1 or B > 1) else torch.zeros_like(p)
+    prior = (torch.randn(1, R, A, B, generator=g) * 1e-8).to(dev)
+    p.grad = prior.clone()
+    tv_add_grad([(p, w)])
+    got = p.grad - prior
+    err = (got - want).norm() / want.norm().clamp_min(1e-30)
+    assert float(err) <= 1e-6 if float(want.norm()) > 0 else float(got.abs().max()) == 0.0, float(err)
+    q = torch.nn.Parameter(-p.detach())
+    tv_add_grad([(q, w)])
+    p.grad = None
+    tv_add_grad([(p, w)])
+    assert torch.equal(q.grad, -p.grad)
+    # argument validation: same buffer for plane and gradient, non-contiguous planes
+    q.grad = q.data
+    with pytest.raises(RuntimeError, match="distinct"):
+        tv_add_grad([(q, w)])

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from torch_restatements import expand_torch_chain, training_statis_torch
+from util import rel_l2
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -267,3 +268,58 @@ def test_host_fallbacks_of_the_small_ops():
     assert s.grad is not None and s.grad.shape == s.shape
     m = torch.rand(1000) < 0.3
     assert torch.equal(visible_indices(m), m.nonzero(as_tuple=False).squeeze(1))
+
+
+def test_tv_closed_form_matches_the_reference_autograd():
+    """tests/golden/tv.npz holds what the reference's PlaneGrid.total_variation_add_grad / GaussianLearner.tv_loss left
+    in the planes' .grad (scene/grids.py:240-250, scene/gaussian_model.py:217-220).  The closed form csrc/tv.hip
+    implements -- restated in torch as the CPU checker -- must reproduce it, into empty and into existing gradients; and
+    the host logic of splatco_amd.tv (which grids, which level weights, when) is checked with that stand-in."""
+    import splatco_amd.tv as tv
+    from torch_restatements import tv_add_grad_torch
+    G = np.load(os.path.join(GOLD, "tv.npz"))
+    names = ("xy_plane", "xz_plane", "yz_plane")
+    for tag in ("cube_plain", "cube_ta", "odd_plain", "odd_ta"):
+        w = float(G[f"{tag}.w"])
+        planes = [torch.nn.Parameter(torch.tensor(G[f"{tag}.{n}"])) for n in names]
+        tv_add_grad_torch([(p, w) for p in planes])
+        for p, n in zip(planes, names):
+            want = G[f"{tag}.{n}.grad"]
+            assert np.abs(want).max() > 0
+            assert rel_l2(p.grad.numpy(), want) <= 1e-6, (tag, n)
+        for p, n in zip(planes, names):
+            p.grad = torch.tensor(G[f"{tag}.{n}.prior"])
+        tv_add_grad_torch([(p, w) for p in planes])
+        for p, n in zip(planes, names):
+            assert rel_l2(p.grad.numpy(), G[f"{tag}.{n}.grad_acc"]) <= 1e-6, (tag, n, "accumulate")
+    # the clamp region of smooth-L1 is exercised by the fixture (neighbour differences beyond the knee at 1)
+    p = G["odd_plain.xy_plane"]
+    assert (np.abs(np.diff(p, axis=2)) > 1).mean() > 0.05 and (np.abs(np.diff(p, axis=2)) < 1).mean() > 0.05
+    # GaussianLearner.tv_loss: grids k0s[0 .. activate_level], weights w * 0.5^(2 - level)
+    from splatco_amd.scene_model import GaussianLearner
+    real = tv.tv_add_grad
+    tv.tv_add_grad = tv_add_grad_torch
+    try:
+        for level in (0, 2):
+            gl = GaussianLearner(40, 15)
+            gl._feat.activate_level = level
+            with torch.no_grad():
+                for gi, grid in enumerate(gl._feat.k0s):
+                    for n in names:
+                        getattr(grid, n).copy_(torch.tensor(G[f"learner.k0s.{gi}.{n}"]))
+            gl.tv_loss(4e-7)
+            for gi, grid in enumerate(gl._feat.k0s):
+                for n in names:
+                    want = G[f"learner.level{level}.k0s.{gi}.{n}.grad"]
+                    got = getattr(grid, n).grad
+                    if want.size == 0:
+                        assert got is None, (level, gi, n)
+                    else:
+                        assert rel_l2(got.numpy(), want) <= 1e-6, (level, gi, n)
+    finally:
+        tv.tv_add_grad = real
+    assert [tv.tv_due(i) for i in range(1, 9)] == [False, False, False, True, False, False, False, True]   # train.py:242
+    assert not tv.tv_due(4, enable_net=False) and not tv.tv_due(4, no_regularization=True)
+    # no CPU path in the product: the real entry refuses host tensors
+    with pytest.raises(RuntimeError, match="GPU"):
+        tv.tv_add_grad([(torch.nn.Parameter(torch.zeros(1, 5, 4, 4)), 1e-3)])

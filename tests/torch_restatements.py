@@ -4,6 +4,7 @@ from the reference's own Python): nothing under splatco_amd/ imports this file.
 
   expand_torch_chain     gaussian_renderer/__init__.py:68-111   -> checker of csrc/expand.hip
   training_statis_torch  scene/gaussian_model.py:761-782        -> checker of csrc/densify.hip
+  tv_add_grad_torch      scene/grids.py:240-250 (closed form)   -> checker of csrc/tv.hip, CPU stand-in in the gloo tests
 """
 import torch
 import torch.nn.functional as F
@@ -60,3 +61,21 @@ def statis_apply_torch(opacity_accum, anchor_demon, offset_gradient_accum, offse
     hit = inc_grad >= 0
     offset_gradient_accum[rows[hit], 0] += inc_grad[hit]
     offset_denom[rows[hit], 0] += 1
+
+
+def tv_add_grad_torch(entries):
+    """CPU stand-in of splatco_amd.tv.tv_add_grad (csrc/tv.hip): the closed-form derivative of the smooth-L1 total
+    variation, coef * clamp(neighbour difference, -1, 1), added into plane.grad.  Pinned by tests/golden/tv.npz."""
+    from splatco_amd.tv import tv_coef
+    with torch.no_grad():
+        for p, w in entries:
+            c = torch.tensor(tv_coef(w), dtype=p.dtype)
+            g = torch.zeros_like(p)
+            for dim in (2, 3):
+                n = p.shape[dim]
+                if n < 2:
+                    continue
+                h = (p.narrow(dim, 1, n - 1) - p.narrow(dim, 0, n - 1)).clamp(-1, 1) * c
+                g.narrow(dim, 1, n - 1).add_(h)
+                g.narrow(dim, 0, n - 1).sub_(h)
+            p.grad = g if p.grad is None else p.grad.add_(g)

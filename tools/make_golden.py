@@ -25,6 +25,10 @@ Fixtures (all float32 / int, a few hundred KB in total):
                  neural_gaussians.npz: the structured array's field names, its bytes and the element name, recorded by
                  a stand-in for PlyElement.describe / PlyData.write (plyfile is not installed here); and what the
                  reference's load_ply_sparse_gaussian (:675-712) makes of that element
+  tv.npz         PlaneGrid.total_variation_add_grad (scene/grids.py:240-250) with and without TriPlaneAttention, a
+                 cubic 24^3 grid and a 37 x 19 x 30 one (odd row lengths), plane values scaled so that neighbour
+                 differences fall on both sides of the smooth-L1 knee, into empty and into existing .grad; and
+                 GaussianLearner.tv_loss (scene/gaussian_model.py:217-220) at activate_level 0 and 2
   densify.npz    GaussianModel.adjust_anchor (anchor_growing + prune_anchor, optimizer state surgery) and
                  compute_curvature on small seeded models (scene/gaussian_model.py:784-997,1092-1110)
 """
@@ -152,6 +156,51 @@ def make_planegrid():
         with torch.no_grad():
             out[f"{name}.out_q003"] = f32(pg(xyz, 0.03))
     np.savez_compressed(os.path.join(OUT, "planegrid.npz"), **out)
+
+
+def make_tv():
+    """The total-variation term of train.py:242-243 as the reference computes it (autograd through six smooth-L1 sums)."""
+    grids = _load("scene/grids.py", "ref_grids")
+    out = {}
+    names = ("xy_plane", "xz_plane", "yz_plane")
+    for tag, ws, ta, scale, w in (("cube_plain", [24, 24, 24], False, 1.0, 4e-7), ("cube_ta", [24, 24, 24], True, 6.0, 1e-7),
+                                  ("odd_plain", [37, 19, 30], False, 8.0, 4e-7), ("odd_ta", [37, 19, 30], True, 1.0, 2.5e-3)):
+        torch.manual_seed(5)
+        pg = grids.PlaneGrid(15, ws, [-2.0, -2.0, -2.0], [2.0, 2.0, 2.0], config={"factor": 1}, TAflag=ta)
+        g = torch.Generator().manual_seed(6)
+        with torch.no_grad():
+            for n in names:
+                getattr(pg, n).mul_(scale)
+        out[f"{tag}.w"] = np.float64(w)
+        for n in names:
+            out[f"{tag}.{n}"] = f32(getattr(pg, n))
+        pg.total_variation_add_grad(w)                       # into empty .grad
+        for n in names:
+            out[f"{tag}.{n}.grad"] = f32(getattr(pg, n).grad)
+        assert all(p.grad is None for p in pg.parameters() if all(p is not getattr(pg, n) for n in names))
+        for n in names:                                      # into an existing .grad (what backward() left there)
+            prior = torch.randn(getattr(pg, n).shape, generator=g) * 1e-6
+            out[f"{tag}.{n}.prior"] = f32(prior)
+            getattr(pg, n).grad = prior.clone()
+        pg.total_variation_add_grad(w)
+        for n in names:
+            out[f"{tag}.{n}.grad_acc"] = f32(getattr(pg, n).grad)
+    # GaussianLearner.tv_loss: which grids, which weights (plane_size 40 -> grids of 10, 10, 20, 40)
+    for level in (0, 2):
+        pc, _, _ = _ref_model([], 8, seed=21)
+        pc.feat_planes._feat.activate_level = level
+        with torch.no_grad():
+            for gi, grid in enumerate(pc.feat_planes._feat.k0s):
+                for n in names:
+                    getattr(grid, n).mul_(3.0 + gi)
+        pc.feat_planes.tv_loss(4e-7)
+        for gi, grid in enumerate(pc.feat_planes._feat.k0s):
+            for n in names:
+                p = getattr(grid, n)
+                if level == 0:
+                    out[f"learner.k0s.{gi}.{n}"] = f32(p)
+                out[f"learner.level{level}.k0s.{gi}.{n}.grad"] = f32(p.grad) if p.grad is not None else np.zeros(0, np.float32)
+    np.savez_compressed(os.path.join(OUT, "tv.npz"), **out)
 
 
 def make_neural_gaussians():
@@ -453,7 +502,7 @@ if __name__ == "__main__":
     install_stubs()
     makers = {"cameras": make_cameras, "losses": make_losses, "planegrid": make_planegrid,
               "neural_gaussians": make_neural_gaussians, "neural_gaussians_app": make_neural_gaussians_appearance,
-              "ply_layout": make_ply_layout, "densify": make_densify}
+              "ply_layout": make_ply_layout, "tv": make_tv, "densify": make_densify}
     for name in (sys.argv[1:] or list(makers)):          # densify patches torch.zeros / torch.ones: keep it last
         makers[name]()
     for f in sorted(os.listdir(OUT)):
