@@ -521,6 +521,117 @@ void orc_blend_backward(int H, int W, const uint32_t* ranges, const uint32_t* id
     }
 }
 
+/* The same sums in the FORMULATION of the device's blend backward (splatco_amd/csrc/blend.hip, "moments about the
+   quadrant's origin -> about the splat's centre"): per 8x8 pixel quadrant of a tile the raw moments
+   M0 = sum Y, Mx = sum Y x, My, Mxx, Mxy, Myy of Y = (o G) dL/dalpha in the pixel's integer coordinates inside the quadrant,
+   shifted once per (quadrant, splat) to the splat's centre with a = mean.x - x0, b = mean.y - y0:
+     sum Y dx = a M0 - Mx          sum Y dx^2  = a (sum Y dx - Mx) + Mxx          sum Y dx dy = (a sum Y dy - b Mx) + Mxy
+   summed over quadrants and tiles per Gaussian, then factored into dL/dmean2D, dL/dconic, dL/dopacity.  A STUDY leg
+   (tools/exp/shift_study.py): run in binary32 next to orc_blend_backward it isolates what the raw-moment shift costs
+   against sums taken directly about the centre, everything else (per-pixel values, visit order) being equal. */
+void orc_blend_backward_raw_moments(int H, int W, const uint32_t* ranges, const uint32_t* ids_sorted,
+                                    const real* xy, const real* conic_opacity, const real* rgb, const float* bg,
+                                    const real* final_T, const uint32_t* n_contrib, const real* dL_dpix /*[3][H][W]*/,
+                                    int P, real* dL_dmean2D, real* dL_dconic, real* dL_dopacity, real* dL_dcolor,
+                                    int centred /* 1: the per-quadrant sums are taken of dx, dy directly (no shift): the
+                                                   re-association alone, as a control */) {
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    memset(dL_dcolor, 0, sizeof(real) * 3 * (size_t)P);
+    real* S = (real*)calloc((size_t)P * 6 + 1, sizeof(real));      /* per Gaussian: sum Y dx, Y dy, Y dx^2, Y dx dy, Y dy^2, Y */
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        const int ty = tile / gx, tx = tile % gx;
+        const uint32_t lo = ranges[2 * tile], hi = ranges[2 * tile + 1];
+        if (hi <= lo) continue;
+        const size_t n = hi - lo;
+        real* mom = (real*)calloc(n * 4 * 6, sizeof(real));        /* [entry][quadrant][M0, Mx, My, Mxx, Mxy, Myy] */
+        for (int ly = 0; ly < TILE; ++ly)
+            for (int lx = 0; lx < TILE; ++lx) {
+                int px = tx * TILE + lx, py = ty * TILE + ly;
+                if (px >= W || py >= H) continue;
+                size_t pix = (size_t)py * W + px;
+                real pxf = (real)px, pyf = (real)py;
+                const int q = (ly >> 3) * 2 + (lx >> 3);
+                const real xq = (real)(lx & 7), yq = (real)(ly & 7);
+                real T_final = final_T[pix];
+                real T = T_final;
+                uint32_t last = n_contrib[pix];
+                real dLp[3];
+                for (int ch = 0; ch < 3; ++ch) dLp[ch] = dL_dpix[(size_t)ch * H * W + pix];
+                real bg_dot = ((real)bg[0] * dLp[0] + (real)bg[1] * dLp[1]) + (real)bg[2] * dLp[2];
+                real accum[3] = {0, 0, 0}, last_alpha = 0, last_col[3] = {0, 0, 0};
+                for (uint32_t kk = last; kk-- > 0;) {
+                    uint32_t g = ids_sorted[lo + kk];
+                    real dx = xy[2 * g] - pxf, dy = xy[2 * g + 1] - pyf;
+                    real Qxx = conic_opacity[4 * g], Qxy = conic_opacity[4 * g + 1],
+                         Qyy = conic_opacity[4 * g + 2], o = conic_opacity[4 * g + 3];
+                    real A = R(-0.5) * Qxx, B = -Qxy, Cc = R(-0.5) * Qyy;
+                    real power = r_fma(dx, r_fma(A, dx, B * dy), (Cc * dy) * dy);
+                    if (power > 0) continue;
+                    real G = r_exp(power);
+                    real alpha = r_fmin(R(0.99), o * G);
+                    if (alpha < R(1.0) / R(255.0)) continue;
+                    T = T / (R(1.0) - alpha);
+                    real dchan = alpha * T;
+                    real dL_dalpha = 0;
+                    for (int ch = 0; ch < 3; ++ch) {
+                        real c = rgb[3 * g + ch];
+                        accum[ch] = last_alpha * last_col[ch] + (R(1.0) - last_alpha) * accum[ch];
+                        last_col[ch] = c;
+                        dL_dalpha += (c - accum[ch]) * dLp[ch];
+                        dL_dcolor[3 * g + ch] += dchan * dLp[ch];
+                    }
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / (R(1.0) - alpha)) * bg_dot;
+                    const real Y = (o * G) * dL_dalpha;
+                    real* m = mom + ((size_t)kk * 4 + q) * 6;
+                    const real ux = centred ? dx : xq, uy = centred ? dy : yq;
+                    const real Yx = Y * ux, Yy = Y * uy;
+                    m[0] += Y;
+                    m[1] += Yx;
+                    m[2] += Yy;
+                    m[3] += Yx * ux;
+                    m[4] += Yx * uy;
+                    m[5] += Yy * uy;
+                }
+            }
+        for (size_t kk = 0; kk < n; ++kk) {
+            const uint32_t g = ids_sorted[lo + kk];
+            real part[6] = {0, 0, 0, 0, 0, 0};
+            for (int q = 0; q < 4; ++q) {
+                const real* m = mom + (kk * 4 + q) * 6;
+                const real a = xy[2 * g] - (real)(tx * TILE + (q & 1) * 8), b = xy[2 * g + 1] - (real)(ty * TILE + (q >> 1) * 8);
+                const real M0 = m[0], Mx = m[1], My = m[2], Mxx = m[3], Mxy = m[4], Myy = m[5];
+                if (centred) {
+                    for (int v = 0; v < 5; ++v) part[v] += m[v + 1];
+                    part[5] += M0;
+                    continue;
+                }
+                const real t1 = a * M0 - Mx, t2 = b * M0 - My;
+                part[0] += t1;
+                part[1] += t2;
+                part[2] += a * (t1 - Mx) + Mxx;
+                part[3] += (a * t2 - b * Mx) + Mxy;
+                part[4] += b * (t2 - My) + Myy;
+                part[5] += M0;
+            }
+            for (int v = 0; v < 6; ++v) S[(size_t)g * 6 + v] += part[v];
+        }
+        free(mom);
+    }
+    for (int g = 0; g < P; ++g) {
+        const real* s = S + (size_t)g * 6;
+        const real Qxx = conic_opacity[4 * g], Qxy = conic_opacity[4 * g + 1], Qyy = conic_opacity[4 * g + 2], o = conic_opacity[4 * g + 3];
+        dL_dmean2D[2 * g] = -(Qxx * s[0]) - Qxy * s[1];
+        dL_dmean2D[2 * g + 1] = -(Qyy * s[1]) - Qxy * s[0];
+        dL_dconic[3 * g] = R(-0.5) * s[2];
+        dL_dconic[3 * g + 1] = -s[3];
+        dL_dconic[3 * g + 2] = R(-0.5) * s[4];
+        dL_dopacity[g] = s[5] != 0 ? s[5] / o : 0;
+    }
+    free(S);
+}
+
 /* ---------------------------------------------------------------- A.5 preprocess backward */
 /* Chain from (dL_dmean2D [pixel units], dL_dconic, dL_dopacity passthrough, dL_dcolor) to the
    operator inputs.  Recomputes the forward projection.  dL_dmeans2D_out is the extra output

@@ -206,9 +206,11 @@ def forward(st, means3D, opacities, scales=None, rotations=None, cov3D_precomp=N
     return out
 
 
-def blend_backward(st, fwd, dL_dcolor_img, f64=False):
+def blend_backward(st, fwd, dL_dcolor_img, f64=False, raw_moments=False):
     """Screen-space gradient sums of the blend: (dL/dmean2D [P,2] in pixel units, dL/dconic [P,3], dL/dopacity [P],
-    dL/dcolour [P,3])."""
+    dL/dcolour [P,3]).  raw_moments: the same sums in the device kernel's formulation (raw moments per 8x8 quadrant, shifted
+    to the splat's centre; orc_blend_backward_raw_moments; "reassociated": that function's control, per-quadrant partial
+    sums of the centred terms without any shift) -- a study leg, see tools/exp/shift_study.py."""
     lib, rt = _lib(f64), (np.float64 if f64 else np.float32)
     H, W = st.image_height, st.image_width
     P = fwd["radii"].shape[0]
@@ -219,12 +221,14 @@ def blend_backward(st, fwd, dL_dcolor_img, f64=False):
     g_col = np.zeros((P, 3), rt)
     ids = np.ascontiguousarray(fwd["point_list"] if fwd["num_rendered"] else np.zeros(1, np.uint32))
     bg = _f32(st.bg)
-    lib.orc_blend_backward(C.c_int(H), C.c_int(W), _p(fwd["ranges"]), _p(ids),
-                           _p(np.ascontiguousarray(fwd["xy"], rt)),
-                           _p(np.ascontiguousarray(fwd["conic_opacity"], rt)),
-                           _p(np.ascontiguousarray(fwd["rgb"], rt)), _p(bg),
-                           _p(np.ascontiguousarray(fwd["final_T"], rt)), _p(fwd["n_contrib"]),
-                           _p(dpix), C.c_int(P), _p(g_m2), _p(g_conic), _p(g_op), _p(g_col))
+    args = (C.c_int(H), C.c_int(W), _p(fwd["ranges"]), _p(ids), _p(np.ascontiguousarray(fwd["xy"], rt)),
+            _p(np.ascontiguousarray(fwd["conic_opacity"], rt)), _p(np.ascontiguousarray(fwd["rgb"], rt)), _p(bg),
+            _p(np.ascontiguousarray(fwd["final_T"], rt)), _p(fwd["n_contrib"]), _p(dpix), C.c_int(P), _p(g_m2), _p(g_conic),
+            _p(g_op), _p(g_col))
+    if raw_moments:      # "reassociated": per-quadrant partial sums of the CENTRED terms, no shift (the control)
+        lib.orc_blend_backward_raw_moments(*args, C.c_int(1 if raw_moments == "reassociated" else 0))
+    else:
+        lib.orc_blend_backward(*args)
     return g_m2, g_conic, g_op, g_col
 
 

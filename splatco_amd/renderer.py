@@ -134,16 +134,35 @@ def _settings(viewpoint_camera, bg_color, scaling_modifier, debug):
         prefiltered=False, debug=debug)
 
 
+class _ZeroCarrier(torch.autograd.Function):
+    """zeros_like(like) as a non-leaf of the autograd graph: what `torch.zeros_like(xyz, requires_grad=True) + 0`
+    (gaussian_renderer/__init__.py:133) produces, in one fill instead of a fill and an add.  `anchor` is an empty leaf that
+    only ties the result into the graph; nothing flows back into it."""
+
+    @staticmethod
+    def forward(ctx, anchor, like, dtype):
+        ctx.set_materialize_grads(False)
+        return torch.zeros_like(like, dtype=dtype)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return None, None, None
+
+
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, visible_mask=None, retain_grad=False):
     """gaussian_renderer/__init__.py:118-188.  Background tensor must be on the GPU."""
     is_training = pc.get_color_mlp.training
     out = generate_neural_gaussians(viewpoint_camera, pc, visible_mask, is_training=is_training)
     xyz, color, opacity, scaling, rot = out[:5]
-    # zero tensor whose .grad receives the screen-space mean gradient (:133-138).  The reference makes it a non-leaf
-    # (`zeros_like(..., requires_grad=True) + 0` + retain_grad()); a leaf carries the same .grad after backward() without
-    # the extra pass over [P, 3] forward and the accumulate-into-retained-copy backward (retain_grad=True is accepted
-    # and means nothing more)
-    screenspace_points = torch.zeros_like(xyz, dtype=pc.get_anchor.dtype, requires_grad=True)
+    # zero tensor that carries the screen-space mean gradient back to the caller (:133-138): a NON-LEAF that requires grad
+    # (the reference's `zeros_like(..., requires_grad=True) + 0`), whose .grad is populated only with retain_grad (:134-138,
+    # train.py:185-186) -- same contract, without the extra pass over [P, 3] that the `+ 0` costs (_ZeroCarrier)
+    screenspace_points = _ZeroCarrier.apply(torch.empty(0, device=xyz.device, requires_grad=True), xyz, pc.get_anchor.dtype)
+    if retain_grad:
+        try:
+            screenspace_points.retain_grad()
+        except RuntimeError:          # under no_grad the tensor does not require grad (as the reference's does not)
+            pass
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, bg_color, scaling_modifier, pipe.debug))
     rendered_image, radii = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=color,
                                        opacities=opacity, scales=scaling, rotations=rot, cov3D_precomp=None)

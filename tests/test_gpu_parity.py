@@ -417,6 +417,9 @@ def _fp64_on_fp32_records(oracle, st, f):
 
 
 CERTIFY = 1e-5         # a gradient row is "pinned by binary32" when the fp32 oracle's own row is this close to fp64
+# On the rows binary32 does not pin: (device's distance from fp64) / max(fp32 oracle's distance, 2-ulp noise floor), L2 over the
+# set.  MEASURED over the 27 branch-(b) scenes of seeds 0-4 (profiles/r04_stress.txt, one line per scene and tensor).
+UNPINNED_RATIO_MAX = 10.0
 
 
 def stress_case(oracle, rng, verbose=False, info=None):
@@ -482,12 +485,14 @@ def stress_case(oracle, rng, verbose=False, info=None):
                      f"{d_o32 / max(np.linalg.norm(ref[loose]), 1e-300):.1e}, 2-ulp noise floor "
                      f"{d_noise / max(np.linalg.norm(ref[loose]), 1e-300):.1e} from fp64 there), pinned rows {e_pinned:.1e};")
             if e32[k] > GRAD_TOL:
+                ratio = d_dev / max(d_o32, d_noise, 1e-300)
                 if info is not None:
                     info.setdefault("branch_b", {})[k] = {"all_rows": e32[k], "unpinned_rows": int(loose.sum()),
-                                                           "visible_rows": int(vis.sum()), "pinned_rel_l2": e_pinned}
+                                                           "visible_rows": int(vis.sum()), "pinned_rel_l2": e_pinned,
+                                                           "ratio": ratio, "ratio_vs_oracle": d_dev / max(d_o32, 1e-300)}
                 assert e_pinned <= GRAD_TOL, (k, "rows pinned by fp32", e_pinned)
-                assert d_dev <= 10.0 * max(d_o32, d_noise), (k, "ill-conditioned rows vs fp64: device", d_dev, "fp32 oracle", d_o32,
-                                                             "noise floor", d_noise)
+                assert ratio <= UNPINNED_RATIO_MAX, (k, "ill-conditioned rows vs fp64: device", d_dev, "fp32 oracle", d_o32,
+                                                     "noise floor", d_noise, "ratio", ratio)
     ranges = f["ranges"]
     if info is not None:
         info.update({"P": int(g["means3D"].shape[0]), "visible": int((f["radii"] > 0).sum()), "worst": float(worst),
@@ -511,10 +516,10 @@ B_SCENES_MAX = 7               # of the ten scenes of a seed
 def test_randomised_stress_scenes(oracle, seed):
     """50 seeded scenes of the randomised stress set (tools/stress_parity.py runs more of the same).  Every scene's
     outcome -- worst rel-L2 over all rows, which tensors needed branch (b), how many rows fp32 does not pin -- goes to
-    the report file named by SPLATCO_STRESS_REPORT (committed as profiles/r03_stress.txt), and the use of branch (b) is
+    the report file named by SPLATCO_STRESS_REPORT (committed as profiles/r04_stress.txt), and the use of branch (b) is
     bounded by asserts."""
     rng = np.random.default_rng(seed)
-    lines, b_scenes, over = [], 0, []
+    lines, b_scenes, over, worst_ratio = [], 0, [], 0.0
     for it in range(10):
         info = {}
         print(f"[stress {seed}/{it}] " + stress_case(oracle, rng, info=info))
@@ -524,9 +529,11 @@ def test_randomised_stress_scenes(oracle, seed):
         lines.append(f"seed {seed} scene {it}: P={info['P']} {info['image']} I={info['I']} visible={info['visible']} worst rel-L2 over all rows "
                      f"{info['worst']:.2e} -> " + ("branch (a): 1e-4 over all rows" if not bb else
                      "branch (b) for " + ", ".join(f"{k} (all rows {v['all_rows']:.1e}, pinned rows {v['pinned_rel_l2']:.1e}, "
-                                                   f"{v['unpinned_rows']} of {v['visible_rows']} rows unpinned)" for k, v in bb.items())))
+                                                   f"{v['unpinned_rows']} of {v['visible_rows']} rows unpinned, there device / max(oracle, noise) "
+                                                   f"= {v['ratio']:.2f}, device / oracle = {v['ratio_vs_oracle']:.2f})" for k, v in bb.items())))
+        worst_ratio = max([worst_ratio] + [v["ratio"] for v in bb.values()])
         over.append((it, frac)) if frac > (UNPINNED_MAX if info["visible"] >= 1000 else UNPINNED_MAX_SMALL) else None
-    lines.append(f"seed {seed}: {b_scenes} of 10 scenes used branch (b)")
+    lines.append(f"seed {seed}: {b_scenes} of 10 scenes used branch (b); worst device / max(oracle, noise) ratio on unpinned rows {worst_ratio:.2f}")
     path = os.environ.get("SPLATCO_STRESS_REPORT")
     if path:
         with open(path, "a") as fh:

@@ -44,6 +44,10 @@ def test_prefilter_and_render_contract(oracle):
     assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii", "selection_mask",
                         "neural_opacity", "scaling"}
     P = out["viewspace_points"].shape[0]
+    # the gradient carrier is what the reference builds at :133-138: a non-leaf of zeros that requires grad
+    vp = out["viewspace_points"]
+    assert vp.requires_grad and not vp.is_leaf and vp.grad_fn is not None and vp.dtype == pc.get_anchor.dtype
+    assert float(vp.detach().abs().max()) == 0.0
     assert out["render"].shape == (3, 120, 200) and out["render"].dtype == torch.float32
     assert out["radii"].dtype == torch.int32 and out["radii"].shape == (P,)
     assert out["visibility_filter"].dtype == torch.bool
@@ -76,11 +80,19 @@ def test_prefilter_and_render_contract(oracle):
     same = f["margin"] > 1e-5
     assert np.abs(out["render"].detach().cpu().numpy() - f["color"])[:, same].max() <= 1e-4
     assert np.array_equal(out["radii"].cpu().numpy(), f["radii"])
+    # without retain_grad the non-leaf carrier keeps no .grad (train.py:185-186 switches it off after update_until)
+    import warnings
+    out3 = render(cam, pc, pipe, bg, visible_mask=vis)
+    (out3["render"] - target).abs().mean().backward()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert not out3["viewspace_points"].is_leaf and out3["viewspace_points"].grad is None
     # eval mode: 4 keys
     pc.eval()
     with torch.no_grad():
-        out2 = render(cam, pc, pipe, bg, visible_mask=vis)
+        out2 = render(cam, pc, pipe, bg, visible_mask=vis, retain_grad=True)     # retain_grad under no_grad: swallowed, as there
     assert set(out2) == {"render", "viewspace_points", "visibility_filter", "radii"}
+    assert not out2["viewspace_points"].requires_grad
 
 
 def test_fused_expand_compact_matches_torch_chain():
