@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 22
+#define SCR_ABI_VERSION 23
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -78,10 +78,16 @@ int scr_mark_visible(int64_t P, const float* means3D, const float* viewmatrix, u
 /* ---- forward, phase 1: projection / culling / tile counting / offsets.
  * Exactly one of (shs, colors_precomp) and one of ((scales, rotations), cov3D_precomp) non-NULL.
  * M = SH coefficients per Gaussian (shs is [P, M, 3]); opacities is [P] (or [P,1]).
- * Writes radii_out[P] and geom_buf; returns through plan_host[2] (host pointer; the call waits for
- * the two numbers -- the scan kernel posts them to a pinned mailbox this thread polls, with a stream
- * synchronisation as fallback) the number of (Gaussian, tile) instances and the largest
- * per-tile instance count (it sizes the sort's grid); both go to scr_binning_bytes / scr_forward_run. */
+ * Writes radii_out[P] and geom_buf; returns through plan_host[4] (host pointer; the call waits for
+ * the numbers -- the scan kernel posts them to a pinned mailbox this thread polls, with a stream
+ * synchronisation as fallback): [0] the number of (Gaussian, tile) instances, [1] the largest per-tile instance
+ * count (it sizes the sort's grid) -- both go to scr_binning_bytes / scr_forward_run --, [2] unused here (see
+ * scr_forward_plan_run), [3] the plan flags: an opaque word the caller hands back to scr_forward_run and scr_backward.
+ * Today one bit, SCR_PLAN_NONFINITE_COLOUR: a visible Gaussian carries a colour that is NaN or +-Inf.  The reference
+ * SKIPS a splat at every pixel it does not contribute to, so such a colour reaches only the pixels the splat does
+ * contribute to; the fast blend kernels carry non-contributing splats with alpha 0 (0 * NaN would spread), so calls
+ * with this bit run the kernels' select-based instantiations and give the reference's result, NaN for NaN. */
+enum { SCR_PLAN_NONFINITE_COLOUR = 1 };
 int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* scales,
                      const float* rotations, const float* cov3D_precomp, const float* opacities,
                      const float* shs, const float* colors_precomp, const scr_settings* settings,
@@ -89,14 +95,15 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
 
 /* ---- forward, phase 2: per-tile bucketing, depth sort, front-to-back blend.
  * out_color is [3, H, W] fp32.  geom_buf / binning_buf / image_buf must be kept for scr_backward. */
-int scr_forward_run(int64_t P, int64_t num_rendered, int64_t max_tile_instances, const scr_settings* settings,
-                    void* geom_buf, void* binning_buf, void* image_buf, float* out_color, void* stream);
+int scr_forward_run(int64_t P, int64_t num_rendered, int64_t max_tile_instances, int64_t plan_flags,
+                    const scr_settings* settings, void* geom_buf, void* binning_buf, void* image_buf, float* out_color,
+                    void* stream);
 
 /* ---- forward, both phases in one call when the caller's guess of the binning size was good enough.
  * Same as scr_forward_plan; then, if binning_buf is not NULL and binning_capacity_bytes >= scr_binning_bytes(I, max tile),
  * scr_forward_run on it without returning to the caller in between (the GPU otherwise idles for the caller's allocation and
- * second call: 20 us of a 1 ms step).  plan_host[3]: instances, largest tile, 1 if phase 2 ran (0: allocate and call
- * scr_forward_run).  A training loop's instance count moves by a few per cent per step: last step's count plus slack. */
+ * second call: 20 us of a 1 ms step).  plan_host[4]: instances, largest tile, 1 if phase 2 ran (0: allocate and call
+ * scr_forward_run), plan flags.  A training loop's instance count moves by a few per cent per step: last step's count plus slack. */
 int scr_forward_plan_run(int64_t P, int32_t M, const float* means3D, const float* scales, const float* rotations,
                          const float* cov3D_precomp, const float* opacities, const float* shs, const float* colors_precomp,
                          const scr_settings* settings, void* geom_buf, int32_t* radii_out, int64_t* plan_host,
@@ -109,7 +116,7 @@ int scr_forward_plan_run(int64_t P, int32_t M, const float* means3D, const float
  * Deterministic: bit-identical results run to run (no floating-point atomics).  scratch: scr_backward_scratch_bytes
  * (one 36-byte gradient record per (Gaussian, tile) instance; the entries of a tile's list behind every pixel's last
  * contributor get none -- the tile's cut key in the image buffer, written by the backward, tells which). */
-int scr_backward(int64_t P, int32_t M, int64_t num_rendered, const float* means3D, const float* scales,
+int scr_backward(int64_t P, int32_t M, int64_t num_rendered, int64_t plan_flags, const float* means3D, const float* scales,
                  const float* rotations, const float* cov3D_precomp, const float* shs,
                  const scr_settings* settings, const int32_t* radii, const void* geom_buf,
                  const void* binning_buf, const void* image_buf, const float* dL_dcolor, void* scratch,

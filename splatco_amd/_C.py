@@ -31,8 +31,9 @@ SYMBOLS = [
     "scr_norm_fold", "scr_norm_fold_backward", "scr_norm_running_stats", "scr_box_coords", "scr_forward_plan_run",
     "scr_profile_stride", "scr_debug_force_deep_lists", "scr_adam_step", "scr_tv_add_grad",
 ]
+PLAN_NONFINITE_COLOUR = 1      # SCR_PLAN_NONFINITE_COLOUR
 PROF_COUNT = 19
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 (DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS, DBG_QMASK,
  DBG_GM_INDEX) = range(9)
@@ -90,7 +91,7 @@ def _load():
     lib.scr_visible_filter.argtypes = [i64, vp, vp, vp, vp, sp, vp, vp]
     lib.scr_mark_visible.argtypes = [i64, vp, vp, vp, vp]
     lib.scr_forward_plan.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, sp, vp, vp, C.POINTER(C.c_int64), vp]
-    lib.scr_forward_run.argtypes = [i64, i64, i64, sp, vp, vp, vp, vp, vp]
+    lib.scr_forward_run.argtypes = [i64, i64, i64, i64, sp, vp, vp, vp, vp, vp]
     lib.scr_forward_plan_run.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, sp, vp, vp, C.POINTER(C.c_int64), vp, C.c_size_t,
                                          vp, vp, vp]
     lib.scr_forward_plan_run.restype = C.c_int
@@ -98,7 +99,7 @@ def _load():
     lib.scr_debug_force_deep_lists.restype = C.c_int
     lib.scr_profile_stride.argtypes = [C.c_int]
     lib.scr_profile_stride.restype = C.c_int
-    lib.scr_backward.argtypes = [i64, i32, i64, vp, vp, vp, vp, vp, sp, vp, vp, vp, vp, vp, vp,
+    lib.scr_backward.argtypes = [i64, i32, i64, i64, vp, vp, vp, vp, vp, sp, vp, vp, vp, vp, vp, vp,
                                  vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.scr_debug_get.argtypes = [C.c_int, i64, i64, i32, i32, vp, vp, vp, vp, vp]
     lib.scr_expand_scratch_bytes.argtypes = [C.c_int64]

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(uint32_t nblk, uint32_t
                                                          uint32_t* __restrict__ cursor,
                                                          volatile unsigned long long* mailbox,
                                                          unsigned long long seq) {
-    // mailbox (optional): four words of pinned host memory the GPU can write -- (I, seq, max tile count, seq).
+    // mailbox (optional): four words of pinned host memory the GPU can write -- (I, seq, max tile count | plan flags << 32, seq).
     // The host spins on the two stamps instead of sleeping in a stream synchronisation.
     __shared__ uint32_t lds[1024 / WAVE + 1];
     __shared__ unsigned long long wide[1024 / WAVE];
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(1024) plan_scan_kernel(uint32_t nblk, uint32_t
             total[1] = m;
             total[2] = 0;      // no tile order yet (tile_order_kernel sets it)
             if (mailbox) {
-                mailbox[2] = m;
+                mailbox[2] = (unsigned long long)m | (total[3] << 32);      // total[3]: the plan flags preprocess_kernel raised
                 __threadfence_system();
                 mailbox[3] = seq;
             }
@@ -461,10 +461,7 @@ __device__ __forceinline__ void wave_sort_any(uint32_t n, unsigned long long* ke
 }
 
 // Tiles with <= 1024 instances: one wave sorts the tile and writes its final lists.
-#ifndef SCR_SORT_MIN_WAVES
-#define SCR_SORT_MIN_WAVES 1
-#endif
-__global__ void __launch_bounds__(64, SCR_SORT_MIN_WAVES)
+__global__ void __launch_bounds__(64, 1)
 tile_sort_wave_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, unsigned long long* __restrict__ keys,
                       const uint2* __restrict__ gm_base, uint32_t* __restrict__ point_list,
                       uint32_t* __restrict__ gm_index, uint8_t* __restrict__ qmask) {
@@ -482,7 +479,6 @@ tile_sort_wave_kernel(int tiles, int gx, const uint32_t* __restrict__ ranges, un
 // consecutive outputs: one bisection along its diagonal, 16 compare-and-advance steps) make one run of them.  A tile
 // of up to 8192 instances is finished here (final lists written); a larger tile gets its 8192-chunks
 // sorted in place and goes on to the global merge passes.
-constexpr int WG_SORT_MAX = SCR_WG_SORT_MAX;   // keys a workgroup sorts on chip: one wave per 1024
 constexpr int WG_SORT_THREADS = WG_SORT_MAX / 16;   // 16 keys per lane
 __device__ __forceinline__ int wg_slot(int p) { return p + (p >> 4); }  // 16 keys of a lane start 17 slots apart
 __global__ void __launch_bounds__(WG_SORT_THREADS)

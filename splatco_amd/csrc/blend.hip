@@ -131,6 +131,11 @@ __device__ __forceinline__ int blend_tile(int slot, int tiles, const uint32_t* _
 // ------------------------------------------------------------------ forward
 constexpr int FCHUNK = 64;  // list entries examined per round (one per lane)
 
+// SAFE: some visible Gaussian of this call carries a colour that is not finite (NaN / Inf input; preprocess_kernel raised
+// SCR_PLAN_NONFINITE_COLOUR and the host picked this instantiation).  Such a colour must reach only the pixels its splat
+// contributes to, as it does where non-contributing splats are SKIPPED; blended with alpha 0 it would turn 0 * colour into
+// NaN for every pixel of every quadrant that stages the record.  The SAFE instantiation selects the colour sums instead.
+template <bool SAFE>
 __global__ void __launch_bounds__(64)
 blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const unsigned long long* __restrict__ total,
                      const uint32_t* __restrict__ ranges,
@@ -250,29 +255,22 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
                 // The stop test runs on the unselected alpha and is masked afterwards; T never drops below 1e-4 (the
                 // update that would do so is the stop).
                 const unsigned long long hm = hit[u] & ~done;
-#ifdef SCR_FWD_OLD_SELECTS
-                const float a = sel(hm, alpha[u], 0.0f);
-                const float test_T = T * (1.0f - a);
-                const unsigned long long stop = lanes(test_T < 0.0001f);
-                done |= stop;
-                const float w = sel(stop, 0.0f, a * T);
-                C0 = __builtin_fmaf(cr, w, C0);
-                C1 = __builtin_fmaf(cg, w, C1);
-                C2 = __builtin_fmaf(cb, w, C2);
-                T = sel(stop, T, test_T);
-                last = sel(hm & ~stop, __float_as_uint(cj), last);
-#else
                 const unsigned long long stop = lanes(T * (1.0f - alpha[u]) < 0.0001f) & hm;
                 done |= stop;
                 const unsigned long long live = hm & ~stop;
                 const float a = sel(live, alpha[u], 0.0f);
                 const float w = a * T;
-                C0 = __builtin_fmaf(cr, w, C0);
-                C1 = __builtin_fmaf(cg, w, C1);
-                C2 = __builtin_fmaf(cb, w, C2);
+                if (SAFE) {     // 0 * colour is not 0 for a colour that is not finite
+                    C0 = sel(live, __builtin_fmaf(cr, w, C0), C0);
+                    C1 = sel(live, __builtin_fmaf(cg, w, C1), C1);
+                    C2 = sel(live, __builtin_fmaf(cb, w, C2), C2);
+                } else {
+                    C0 = __builtin_fmaf(cr, w, C0);
+                    C1 = __builtin_fmaf(cg, w, C1);
+                    C2 = __builtin_fmaf(cb, w, C2);
+                }
                 T = T * (1.0f - a);
                 last = sel(live, __float_as_uint(cj), last);
-#endif
             }
         };
         int k = 0;
@@ -427,13 +425,18 @@ struct PixState {
     float T, dLp0, dLp1, dLp2;
     float behind, last_alpha, d_last;
 };
+// SAFE (a colour that is not finite is among the call's Gaussians, see blend_forward_kernel): the colour term of a splat
+// that does not contribute to this pixel (`hit` clear; G = alpha = 0) is dropped by a select -- 0 * NaN is not 0, and the
+// reference skips such a splat altogether.
+template <bool SAFE>
 __device__ __forceinline__ void splat_pixel_grad(PixState& s, float T, float4 b, float cb, float G, float alpha,
-                                                 float& g_0, float& g_c0, float& g_c1, float& g_c2) {
+                                                 unsigned long long hit, float& g_0, float& g_c0, float& g_c1, float& g_c2) {
 #pragma clang fp contract(fast)
     // T = transmittance in front of this splat (group_transmittance)
     const float w = alpha * T;
     s.behind = s.last_alpha * (s.d_last - s.behind) + s.behind;
-    const float d = b.z * s.dLp0 + b.w * s.dLp1 + cb * s.dLp2;
+    float d = b.z * s.dLp0 + b.w * s.dLp1 + cb * s.dLp2;
+    if (SAFE) d = sel(hit, d, 0.0f);
     g_c0 = w * s.dLp0; g_c1 = w * s.dLp1; g_c2 = w * s.dLp2;
     const float Y = G * (T * (d - s.behind));  // G = opacity * exp(power) here: the unclamped alpha times dL/dalpha (straight-through min(0.99, .))
     s.last_alpha = alpha;
@@ -472,24 +475,13 @@ __device__ __forceinline__ void store16_dword_aligned(void* p, float4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(q) : "memory");
 }
 
-// Developer builds with -DSCR_TILE_TIMING (tools/tile_times.py): every backward workgroup leaves the wall-clock
-// ticks (100 MHz constant counter) at which it started and finished, to see the distribution of per-tile durations
-// and how much of the kernel is the tail of the last tiles.  Not in the product build.
-#ifdef SCR_TILE_TIMING
-__device__ unsigned long long scr_tile_ticks[2 * 65536];
-#endif
-
 // ------------------------------------------------------------------ backward
 constexpr int BCH = 64;  // list entries per round: one per lane of each wave
-#ifndef SCR_BWD_ACC_BUFS
-#define SCR_BWD_ACC_BUFS 2
-#endif
-#ifndef SCR_BWD_MIN_WAVES
-#define SCR_BWD_MIN_WAVES 5   // 96 VGPRs: five workgroups per CU (the LDS allows five); no spills
-#endif
-constexpr int ACC_BUFS = SCR_BWD_ACC_BUFS;  // 2: per-round sums double-buffered (one barrier per round)
+constexpr int BWD_MIN_WAVES = 5;   // 96 VGPRs: five workgroups per CU (the LDS allows five); no spills
+constexpr int ACC_BUFS = 2;        // per-round sums double-buffered by round parity (one barrier per round)
 
-__global__ void __launch_bounds__(256, SCR_BWD_MIN_WAVES)
+template <bool SAFE>       // see blend_forward_kernel / splat_pixel_grad
+__global__ void __launch_bounds__(256, BWD_MIN_WAVES)
 blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const unsigned long long* __restrict__ total,
                       const uint32_t* __restrict__ ranges,
                       const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ gm_index,
@@ -511,13 +503,6 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     __shared__ uint32_t wave_max[4];
     const int t = blend_tile((int)blockIdx.x, tiles, order, total);
     if (t < 0) return;
-#ifdef SCR_TILE_TIMING
-    struct Stamp {
-        int t;
-        __device__ Stamp(int t_) : t(t_) { if (threadIdx.x == 0 && t < 65536) scr_tile_ticks[2 * t] = wall_clock64(); }
-        __device__ ~Stamp() { __syncthreads(); if (threadIdx.x == 0 && t < 65536) scr_tile_ticks[2 * t + 1] = wall_clock64(); }
-    } stamp(t);
-#endif
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
     if (n == 0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;  // wave == quadrant
@@ -644,14 +629,14 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         // acc is double-buffered by round parity: this round's writes cannot collide with the
         // previous round's combine, so ONE barrier per round suffices (a wave reaches the writes of
         // round r+2 only after barrier B of round r+1, which every wave passes after its combine of r)
-        const int par = ACC_BUFS == 2 ? (ci & 1) : 0;
-        if (ACC_BUFS == 1) __syncthreads();  // A: the previous round's combine has read acc
+        const int par = ci & 1;
         // back to front, four splats per reduction.  A round's first group (the last one walked) is partial in three
         // rounds of four: its missing splats are skipped with wave-uniform branches (TAIL) instead of being blended
         // with alpha 0 -- about 1.5 of the ~22 entries a wave holds per round; the full groups stay branch-free.
         auto group = [&](const int k, auto tail) {
             constexpr bool TAIL = decltype(tail)::value;
             float g[4][4];      // Y and the three colour terms of each splat
+            unsigned long long hits[4] = {0ull, 0ull, 0ull, 0ull};
             uint32_t jj[4];
             unsigned long long any = 0ull;
             // all four records first (one LDS round trip per group instead of four)
@@ -688,6 +673,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 al[u] = vmin(c099, Gs[u]);
                 om[u] = 1.0f - al[u];
                 any |= hit;
+                if (SAFE) hits[u] = hit;
                 jj[u] = j;
             }
             group_transmittance(ps.T, om, Tu);
@@ -698,7 +684,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                     for (int v = 0; v < 4; ++v) g[u][v] = 0.0f;
                     continue;
                 }
-                splat_pixel_grad(ps, Tu[u], rb[u], rc[u].x, Gs[u], al[u], g[u][0], g[u][1], g[u][2], g[u][3]);
+                splat_pixel_grad<SAFE>(ps, Tu[u], rb[u], rc[u].x, Gs[u], al[u], hits[u], g[u][0], g[u][1], g[u][2], g[u][3]);
             }
             float r[6], myy;
             if (any) {
@@ -778,24 +764,26 @@ static int blend_slots_per_xcd(const Grid& g) {
 }
 
 void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                          float* out_color, bool longest_first, hipStream_t st) {
+                          float* out_color, bool longest_first, bool safe, hipStream_t st) {
     Grid g(ks.H, ks.W);
     // gv.tile_count has been consumed by the plan scan: with longest_first it holds from here on every XCD's tiles,
     // longest list first, and total[2] says so to this launch and to the backward one
     if (longest_first)
         tile_order_kernel<<<NUM_XCD, 1024, 0, st>>>(g.tiles, g.gx, gv.ranges, gv.tile_count, gv.total + 2, gv.total + 4);
-    blend_forward_kernel<<<(unsigned)blend_slots_per_xcd(g) * NUM_XCD * 4, 64, 0, st>>>(
+    auto kernel = safe ? blend_forward_kernel<true> : blend_forward_kernel<false>;
+    kernel<<<(unsigned)blend_slots_per_xcd(g) * NUM_XCD * 4, 64, 0, st>>>(
         ks.W, ks.H, g.gx, g.tiles, gv.tile_count, gv.total, gv.ranges, bv.point_list, bv.qmask, gv.rec, ks.bg, out_color, iv.final_T,
         iv.n_contrib);
 }
 
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
                            const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, bool deep, bool flags,
-                           hipStream_t st) {
+                           bool safe, hipStream_t st) {
     Grid g(ks.H, ks.W);
     const bool gm_from_base = deep;
     if (flags) { ZeroList z; z.add(gv.has_rec, ((size_t)gv.P + 3) / 4 * 4); launch_zero(z, st); }   // (the array is padded to 256 bytes)
-    blend_backward_kernel<<<(unsigned)blend_slots_per_xcd(g) * NUM_XCD, 256, 0, st>>>(
+    auto kernel = safe ? blend_backward_kernel<true> : blend_backward_kernel<false>;
+    kernel<<<(unsigned)blend_slots_per_xcd(g) * NUM_XCD, 256, 0, st>>>(
         ks.W, ks.H, g.gx, g.tiles, gv.tile_count, gv.total, gv.ranges, bv.point_list, gm_from_base ? nullptr : bv.gm_index, gv.gm_base,
         bv.qmask, gv.rec, ks.bg,
         iv.final_T, iv.n_contrib, dL_dcolor, grad_rec, iv.cut_key, stamp, flags ? gv.has_rec : nullptr);
@@ -803,8 +791,3 @@ void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinVie
 
 }  // namespace scr
 
-#ifdef SCR_TILE_TIMING
-extern "C" int scr_debug_tile_ticks(unsigned long long* out_host, int tiles) {
-    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(scr::scr_tile_ticks), (size_t)tiles * 16, 0, hipMemcpyDeviceToHost);
-}
-#endif

@@ -189,7 +189,7 @@ static int plan_enqueue(int64_t P, int32_t M, const float* means3D, const float*
     if (check_settings(settings)) return 1;
     if (P < 0) return fail("P < 0");
     if (!plan_host) return fail("plan_host is NULL");
-    plan_host[0] = plan_host[1] = 0;
+    plan_host[0] = plan_host[1] = plan_host[3] = 0;
     if (!geom_buf) return fail("geom_buf is NULL");
     if ((shs != nullptr) == (colors_precomp != nullptr))
         return fail("pass either shs or colors_precomp (one of them, not both, not neither)");
@@ -204,7 +204,7 @@ static int plan_enqueue(int64_t P, int32_t M, const float* means3D, const float*
     KSettings ks = ksettings(settings);
     GeomView gv = geom_view(geom_buf, P, ks.H, ks.W);
     Grid g(ks.H, ks.W);
-    { ZeroList z; z.add(gv.tile_count, (size_t)g.tiles * 4); launch_zero(z, st); }
+    { ZeroList z; z.add(gv.tile_count, (size_t)g.tiles * 4); z.add(gv.total + 3, 8); launch_zero(z, st); }
     { ProfScope ps_(SCR_PROF_PREPROCESS, st);
       launch_preprocess(P, M, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, ks, gv,
                         radii_out, st); }
@@ -226,14 +226,15 @@ static int plan_wait(const scr_settings* settings, void* geom_buf, int64_t P, un
     KSettings ks = ksettings(settings);
     GeomView gv = geom_view(geom_buf, P, ks.H, ks.W);
     Mailbox& mb = mailbox();
-    unsigned long long total[2] = {0, 0};
+    unsigned long long total[4] = {0, 0, 0, 0};      // instances, largest tile, -, plan flags
     const bool posted = mailbox_wait(mb, seq, true, st);
     if (posted) {
         total[0] = mb.host[0];
-        total[1] = mb.host[2];
+        total[1] = mb.host[2] & 0xffffffffull;
+        total[3] = mb.host[2] >> 32;
     }
     if (!posted) {  // no mailbox, or its writes are not visible on this system: the classic read-back
-        HIP_TRY(hipMemcpyAsync(total, gv.total, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(total, gv.total, 32, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     // per-workgroup sums saturate at 2^32 - 1 (preprocess_kernel) and the scan adds them in 64 bits: any total at or above
@@ -242,6 +243,7 @@ static int plan_wait(const scr_settings* settings, void* geom_buf, int64_t P, un
         return fail("num_rendered >= 2^32 - 1 (counted %llu): the (Gaussian, tile) instances do not fit 32-bit indices", total[0]);
     plan_host[0] = (int64_t)total[0];
     plan_host[1] = (int64_t)total[1];
+    plan_host[3] = (int64_t)total[3];
     return 0;
 }
 
@@ -255,17 +257,18 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
     return rc ? rc : plan_wait(settings, geom_buf, P, seq, plan_host, (hipStream_t)stream);
 }
 
-static int forward_run_impl(int64_t P, int64_t I, int64_t max_tile, const scr_settings* settings, void* geom_buf,
+static int forward_run_impl(int64_t P, int64_t I, int64_t max_tile, int64_t plan_flags, const scr_settings* settings, void* geom_buf,
                             void* binning_buf, void* image_buf, float* out_color, void* stream, bool scatter_done);
 
-int scr_forward_run(int64_t P, int64_t I, int64_t max_tile, const scr_settings* settings, void* geom_buf,
+int scr_forward_run(int64_t P, int64_t I, int64_t max_tile, int64_t plan_flags, const scr_settings* settings, void* geom_buf,
                     void* binning_buf, void* image_buf, float* out_color, void* stream) {
-    return forward_run_impl(P, I, max_tile, settings, geom_buf, binning_buf, image_buf, out_color, stream, false);
+    return forward_run_impl(P, I, max_tile, plan_flags, settings, geom_buf, binning_buf, image_buf, out_color, stream, false);
 }
 
-static int forward_run_impl(int64_t P, int64_t I, int64_t max_tile, const scr_settings* settings, void* geom_buf,
+static int forward_run_impl(int64_t P, int64_t I, int64_t max_tile, int64_t plan_flags, const scr_settings* settings, void* geom_buf,
                             void* binning_buf, void* image_buf, float* out_color, void* stream, bool scatter_done) {
     if (check_settings(settings)) return 1;
+    if (plan_flags & ~(int64_t)SCR_PLAN_NONFINITE_COLOUR) return fail("plan_flags %lld: not a value scr_forward_plan returned", (long long)plan_flags);
     if (!geom_buf || !binning_buf || !image_buf || !out_color) return fail("NULL buffer");
     hipStream_t st = (hipStream_t)stream;
     KSettings ks = ksettings(settings);
@@ -280,7 +283,8 @@ static int forward_run_impl(int64_t P, int64_t I, int64_t max_tile, const scr_se
         { ProfScope ps_(SCR_PROF_TILE_SORT, st); launch_tile_sort(ks, gv, bv, max_tile, !deep_lists(I, Grid(ks.H, ks.W).tiles), st); }
         CHECK_LAUNCH("tile_sort_kernel", settings->debug, st);
     }
-    { ProfScope ps_(SCR_PROF_BLEND_FORWARD, st); launch_blend_forward(ks, gv, bv, iv, out_color, 2 * max_tile * (int64_t)Grid(ks.H, ks.W).tiles > 3 * I, st); }
+    { ProfScope ps_(SCR_PROF_BLEND_FORWARD, st); launch_blend_forward(ks, gv, bv, iv, out_color, 2 * max_tile * (int64_t)Grid(ks.H, ks.W).tiles > 3 * I,
+                                                                      (plan_flags & SCR_PLAN_NONFINITE_COLOUR) != 0, st); }
     CHECK_LAUNCH("blend_forward_kernel", settings->debug, st);
     return 0;
 }
@@ -310,13 +314,7 @@ int scr_forward_plan_run(int64_t P, int32_t M, const float* means3D, const float
         { ProfScope ps_(SCR_PROF_SCATTER, st); launch_scatter(P, ks, gv, bv, cap, st); }
         CHECK_LAUNCH("scatter_kernel", settings->debug, st);
     }
-#ifdef SCR_HOST_TIMING
-    const auto th0 = std::chrono::steady_clock::now();
-#endif
     rc = plan_wait(settings, geom_buf, P, seq, plan_host, st);
-#ifdef SCR_HOST_TIMING
-    const auto th1 = std::chrono::steady_clock::now();
-#endif
     if (rc) return rc;
     const bool fits = binning_buf && scr_binning_bytes(plan_host[0], plan_host[1]) <= binning_capacity_bytes;
     const bool scattered = early && (unsigned long long)plan_host[0] <= cap;
@@ -330,22 +328,13 @@ int scr_forward_plan_run(int64_t P, int32_t M, const float* means3D, const float
         }
         return 0;                                  // caller allocates, then scr_forward_run
     }
-    rc = forward_run_impl(P, plan_host[0], plan_host[1], settings, geom_buf, binning_buf, image_buf, out_color, stream, scattered);
-#ifdef SCR_HOST_TIMING
-    {
-        const auto th2 = std::chrono::steady_clock::now();
-        static int n_ = 0;
-        if (++n_ % 8 == 0)
-            fprintf(stderr, "[host] mailbox wait %.1f us, sort + blend launches %.1f us\n",
-                    std::chrono::duration<double, std::micro>(th1 - th0).count(), std::chrono::duration<double, std::micro>(th2 - th1).count());
-    }
-#endif
+    rc = forward_run_impl(P, plan_host[0], plan_host[1], plan_host[3], settings, geom_buf, binning_buf, image_buf, out_color, stream, scattered);
     if (rc) return rc;
     plan_host[2] = 1;
     return 0;
 }
 
-int scr_backward(int64_t P, int32_t M, int64_t I, const float* means3D, const float* scales,
+int scr_backward(int64_t P, int32_t M, int64_t I, int64_t plan_flags, const float* means3D, const float* scales,
                  const float* rotations, const float* cov3D_precomp, const float* shs,
                  const scr_settings* settings, const int32_t* radii, const void* geom_buf,
                  const void* binning_buf, const void* image_buf, const float* dL_dcolor, void* scratch,
@@ -354,6 +343,7 @@ int scr_backward(int64_t P, int32_t M, int64_t I, const float* means3D, const fl
                  void* stream) {
     if (check_settings(settings)) return 1;
     if (P == 0) return 0;
+    if (plan_flags & ~(int64_t)SCR_PLAN_NONFINITE_COLOUR) return fail("plan_flags %lld: not a value scr_forward_plan returned", (long long)plan_flags);
     if (!geom_buf || !binning_buf || !image_buf || !dL_dcolor || !scratch) return fail("NULL buffer");
     if (!means3D || !radii || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity) return fail("NULL argument");
     if (shs ? !dL_dsh : !dL_dcolors) return fail("colour gradient output missing");
@@ -370,7 +360,7 @@ int scr_backward(int64_t P, int32_t M, int64_t I, const float* means3D, const fl
     if (I > 0) {
         { ProfScope ps_(SCR_PROF_BLEND_BACKWARD, st);
           launch_blend_backward(ks, gv, bv, iv, dL_dcolor, (GradRec*)scratch, stamp, deep_lists(I, Grid(ks.H, ks.W).tiles),
-                                record_flags(I, Grid(ks.H, ks.W).tiles), st); }
+                                record_flags(I, Grid(ks.H, ks.W).tiles), (plan_flags & SCR_PLAN_NONFINITE_COLOUR) != 0, st); }
         CHECK_LAUNCH("blend_backward_kernel", settings->debug, st);
     }
     { ProfScope ps_(SCR_PROF_PREPROCESS_BACKWARD, st);
@@ -840,13 +830,6 @@ int scr_norm_linear_backward(int64_t V, int32_t d, const float* x, int32_t ldx, 
     return 0;
 }
 
-#ifdef SCR_PHASE_TIMING
-extern "C++" { namespace scr { int mh_debug_ticks(int fwd, unsigned long long* out); int tp_debug_ticks(unsigned long long* out); } }
-// developer builds only (see common.h): per-phase wall-clock ticks of an instrumented kernel, read and cleared
-int scr_debug_phase_ticks(int32_t which, unsigned long long* out16) {
-    return which == 2 ? scr::tp_debug_ticks(out16) : scr::mh_debug_ticks(which == 1, out16);
-}
-#endif
 
 // ---- MLP heads (mlp_heads.hip)
 size_t scr_mlp_heads_hidden_bytes(int64_t V) { return mlp_heads_hidden_bytes(V > 0 ? V : 1); }

@@ -20,23 +20,12 @@ constexpr int TILE_PIX = TILE * TILE;   // 256
 constexpr int WAVE = 64;                // CDNA wavefront
 constexpr int NUM_XCD = 8;
 constexpr int PRE_BLOCK = 256;          // Gaussians per preprocess-backward workgroup
-#ifndef SCR_BIN_THREADS
-#define SCR_BIN_THREADS 1024
-#endif
-#ifndef SCR_BIN_ROUNDS
-#define SCR_BIN_ROUNDS 4
-#endif
-constexpr int BIN_THREADS = SCR_BIN_THREADS;  // threads of a preprocess / scatter workgroup
-constexpr int BIN_ROUNDS = SCR_BIN_ROUNDS;    // Gaussians per thread
+constexpr int BIN_THREADS = 1024;       // threads of a preprocess / scatter workgroup
+constexpr int BIN_ROUNDS = 4;           // Gaussians per thread
 constexpr int BIN_GPW = BIN_THREADS * BIN_ROUNDS;  // Gaussians per preprocess / scatter workgroup
-#ifndef SCR_LDS_HIST_MAX_TILES
-#define SCR_LDS_HIST_MAX_TILES 40000
-#endif
-constexpr int LDS_HIST_MAX_TILES = SCR_LDS_HIST_MAX_TILES;  // per-tile LDS histogram (4 B / tile) in the CU's 160 KB of LDS (4K images: 32400 tiles)
+constexpr int LDS_HIST_MAX_TILES = 40000;  // per-tile LDS histogram (4 B / tile) in the CU's 160 KB of LDS (4K images: 32400 tiles)
 constexpr int ID_BITS = 28;             // sort key = depth:32 | id:28 | quadrant mask:4  ->  P < 2^28
-#ifndef SCR_WG_SORT_MAX
-#define SCR_WG_SORT_MAX 8192              // keys an on-chip workgroup sort takes (binning.hip tile_sort_wg_kernel)
-#endif
+constexpr int WG_SORT_MAX = 8192;       // keys an on-chip workgroup sort takes (binning.hip tile_sort_wg_kernel): one wave per 1024
 constexpr int REC_F = 12;               // floats per splat record (48 B, three float4)
 constexpr int GRAD_F = 9;               // floats per per-instance gradient record (GradRec)
 
@@ -68,7 +57,8 @@ struct GeomView {
     uint32_t* cursor;         // [tiles]
     int64_t P;                  // Gaussians (for the per-Gaussian arrays' sizes)
     unsigned long long* total;  // [16] number of instances, largest per-tile instance count, [2] 1 = tile_count holds the blend tile
-                                //      order, [4..12] first entry of every XCD's list in it
+                                //      order, [3] plan flags (SCR_PLAN_*, raised by preprocess_kernel), [4..12] first entry of
+                                //      every XCD's list in the tile order
     size_t bytes;
 };
 
@@ -112,11 +102,9 @@ inline __host__ bool deep_lists(int64_t I, int tiles) {
 // tile on average and more the flags pay (preprocess_backward 0.88 -> 0.79 ms at cfg2, 0.97 -> 0.86 at cfg3, 4.6 -> 2.2 at
 // cfg4; the byte stores are lost in the blend backward); at the benchmark density (540 per tile, nearly every Gaussian has
 // a record) they cost the blend backward 1 - 2 %.  Forced together with the deep-list variants by the test hook.
-#ifndef SCR_FLAGS_MIN_MEAN
-#define SCR_FLAGS_MIN_MEAN 2048
-#endif
+constexpr int FLAGS_MIN_MEAN = 2048;
 inline __host__ bool record_flags(int64_t I, int tiles) {
-    return g_force_deep_lists >= 0 ? g_force_deep_lists != 0 : I > (int64_t)SCR_FLAGS_MIN_MEAN * tiles;
+    return g_force_deep_lists >= 0 ? g_force_deep_lists != 0 : I > (int64_t)FLAGS_MIN_MEAN * tiles;
 }
 
 // ---- binning buffer: per (Gaussian, tile) instance lists ----
@@ -139,7 +127,7 @@ inline __host__ BinView bin_view(void* base, int64_t I, int64_t max_tile_instanc
     v.point_list = (uint32_t*)take(n * 4);
     v.gm_index = (uint32_t*)take(n * 4);
     v.qmask = (uint8_t*)take(n);
-    const bool merge = max_tile_instances > SCR_WG_SORT_MAX;  // tiles above one workgroup sort chunk (binning.hip) take global merge passes
+    const bool merge = max_tile_instances > WG_SORT_MAX;  // tiles above one workgroup sort chunk (binning.hip) take global merge passes
     v.keys2 = merge ? (unsigned long long*)take(n * 8) : nullptr;
     v.bytes = off;
     return v;
@@ -224,6 +212,11 @@ __device__ __forceinline__ float vmin(float a, float b) {
     return r;
 }
 __device__ __forceinline__ unsigned long long lanes(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// any of three values NaN or +-Inf (v_cmp_class_f32: signalling NaN, quiet NaN, -Inf, +Inf)
+__device__ __forceinline__ bool nonfinite3(float a, float b, float c) {
+    constexpr int NAN_OR_INF = 0x1 | 0x2 | 0x4 | 0x200;
+    return __builtin_amdgcn_classf(a, NAN_OR_INF) || __builtin_amdgcn_classf(b, NAN_OR_INF) || __builtin_amdgcn_classf(c, NAN_OR_INF);
+}
 
 // XCD-aware block -> tile map: consecutive tiles (which share splats) run on one XCD so their
 // record gathers hit that XCD's L2.  Blocks are observed to be dealt round-robin to the 8 XCDs;
@@ -281,9 +274,6 @@ __device__ inline SplatForm splat_form(float4 r0, float4 r1) {
 // case distinction is left.  Everything that depends on one axis only is shared by the two quadrants of a row / column.
 // The splat is kept when either candidate stays within the threshold plus the rounding margin of its own terms.
 __device__ inline uint32_t quadrant_mask(float4 r0, float4 r1, int tile_x0, int tile_y0) {
-#ifdef SCR_QMASK_ALL   // developer timing: no culling (still correct: the masks are conservative)
-    return 0xfu;
-#endif
     const SplatForm f = splat_form(r0, r1);
     if (!f.ok) return 0xfu;
     const float x0 = (float)tile_x0, y0 = (float)tile_y0;
@@ -324,28 +314,9 @@ __device__ inline uint32_t quadrant_mask(float4 r0, float4 r1, int tile_x0, int 
 // the leader thread of every workgroup / wave adds the per-phase ticks into a device array that
 // scr_debug_phase_ticks(which, out[16]) reads and clears (which: 0 = mlp_heads backward, 1 = mlp_heads forward,
 // 2 = plane-gradient cell gather).  tools/exp/phase_probe.py prints the shares.  The stamps are fenced with sched_barrier(0); the product build contains none of this.
-#ifdef SCR_PHASE_TIMING
-#define SCR_PHASES(n) unsigned long long ph_last_ = wall_clock64(), ph_[n] = {}
-#define SCR_PHASE(k)                                        \
-    do {                                                    \
-        __builtin_amdgcn_sched_barrier(0);                  \
-        const unsigned long long ph_now_ = wall_clock64();  \
-        ph_[k] += ph_now_ - ph_last_;                       \
-        ph_last_ = ph_now_;                                 \
-        __builtin_amdgcn_sched_barrier(0);                  \
-    } while (0)
-#define SCR_PHASES_FLUSH(arr, n, leader)                                   \
-    do {                                                                   \
-        if (leader) {                                                      \
-            for (int k_ = 0; k_ < (n); ++k_) atomicAdd(&(arr)[k_], ph_[k_]); \
-            atomicAdd(&(arr)[15], 1ull);                                   \
-        }                                                                  \
-    } while (0)
-#else
 #define SCR_PHASES(n)
 #define SCR_PHASE(k)
 #define SCR_PHASES_FLUSH(arr, n, leader)
-#endif
 
 // Several buffers cleared by ONE kernel launch (preprocess.hip).  hipMemsetAsync costs a 5 us fill kernel AND 8 - 11 us of
 // idle stream time in front of it per call (profiles/r03x_step_gaps.txt): one per forward pass at cfg1, eighteen per
@@ -386,10 +357,10 @@ void launch_scatter(int64_t P, const KSettings& ks, const GeomView& gv, const Bi
 void launch_tile_sort(const KSettings& ks, const GeomView& gv, const BinView& bv, int64_t max_tile_instances,
                       bool with_gm_index, hipStream_t st);
 void launch_blend_forward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
-                          float* out_color, bool longest_first, hipStream_t st);
+                          float* out_color, bool longest_first, bool safe, hipStream_t st);
 void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinView& bv, const ImgView& iv,
                            const float* dL_dcolor, GradRec* grad_rec, unsigned long long stamp, bool deep, bool flags,
-                           hipStream_t st);
+                           bool safe, hipStream_t st);
 void launch_preprocess_backward(int64_t P, int M, const float* means3D, const float* scales,
                                 const float* rotations, const float* cov3D, const float* shs,
                                 const KSettings& ks, const int32_t* radii, const GeomView& gv,

@@ -29,9 +29,6 @@
 #include "common.h"
 
 namespace scr {
-#ifdef SCR_PHASE_TIMING
-__device__ unsigned long long mh_bwd_ticks[16], mh_fwd_ticks[16];
-#endif
 
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -119,7 +116,6 @@ mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, const float*
     const float cx = campos[0], cy = campos[1], cz = campos[2];
     const int n = lane & 15, g = lane >> 4;
     const int64_t tiles = (V + 15) / 16;
-    SCR_PHASES(5);     // 0 loads + ob_view, 1 layer-1 MFMAs, 2 relu + hidden store, 3 layer-2 MFMAs, 4 activations + stores
     for (int64_t tile = (int64_t)blockIdx.x * MH_WAVES + wave; tile < tiles; tile += (int64_t)gridDim.x * MH_WAVES) {
         const int64_t v = tile * 16 + n;
         const bool valid = v < V;
@@ -135,7 +131,6 @@ mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, const float*
             const float inv = 1.0f / sqrtf((ox * ox + oy * oy) + oz * oz);
             xb[6] = g == 0 ? f4{ox * inv, oy * inv, oz * inv, 1.0f} : f4{0.0f, 0.0f, 0.0f, 0.0f};
         }
-        SCR_PHASE(0);
         f4 h[MH_MT];
 #pragma unroll
         for (int mt = 0; mt < MH_MT; ++mt) h[mt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -157,14 +152,12 @@ mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, const float*
                 for (int mt = 0; mt < MH_MT; ++mt) h[mt] = mfma4(a1[blk & 1][mt][t], xb[blk][t], h[mt]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        SCR_PHASE(1);
 #pragma unroll
         for (int mt = 0; mt < MH_MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[mt][r] = fmaxf(h[mt][r], 0.0f);
             hidden_save[(tile * MH_MT + mt) * 64 + lane] = h[mt];     // register layout, coalesced 1 KB
         }
-        SCR_PHASE(2);
         f4 o[MH_OT];
 #pragma unroll
         for (int ot = 0; ot < MH_OT; ++ot) o[ot] = f4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -182,7 +175,6 @@ mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, const float*
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
-        SCR_PHASE(3);
         if (valid) {
 #pragma unroll
             for (int ot = 0; ot < MH_OT; ++ot) {
@@ -203,9 +195,7 @@ mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, const float*
                 else if (col0 + 1 < nout) *(float2*)dst = make_float2(z[0], z[1]);
             }
         }
-        SCR_PHASE(4);
     }
-    SCR_PHASES_FLUSH(mh_fwd_ticks, 5, (threadIdx.x & 63) == 0);
 }
 
 // ---------------------------------------------------------------- backward
@@ -320,12 +310,10 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
     // The phases of a tile are fenced with sched_barrier(0): left alone, the scheduler (one wave per SIMD, 500 registers)
     // moves pieces of one phase into another and ends up 12 % slower than the fenced order (found with a phase-stamped
     // build, tools/exp/phase_probe.py: the stamps' fences alone made the kernel faster).
-    SCR_PHASES(8);     // 0 stage dZ / H, 1 dH MFMAs + relu, 2 dW2 MFMAs + db2, 3 issue loads, 4 dX MFMAs, 5 1/|o| + stores, 6 restage + dW1, 7 loop top
     for (int64_t tile = tile0; tile < tiles; tile += tstep) {
         const int64_t v = tile * 16 + n;
         const bool valid = v < V;
         const int64_t vc = valid ? v : V - 1;
-        SCR_PHASE(7);
         finish_tile();
         // ---- stage dZ^T [output][anchor] and H^T [hidden][anchor] for the dW2 contraction over the anchors
 #pragma unroll
@@ -336,7 +324,6 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
         for (int mt = 0; mt < MH_MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sb[(16 * mt + 4 * g + r) * MH_AS + n] = h[mt][r];
-        SCR_PHASE(0);
         __builtin_amdgcn_sched_barrier(0);
         // ---- dH^T = W2^T dZ^T per head; dPre = dH where the hidden unit was active
         f4 dpre[MH_MT];
@@ -356,7 +343,6 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
         for (int mt = 0; mt < MH_MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) dpre[mt][r] = h[mt][r] > 0.0f ? dpre[mt][r] : 0.0f;
-        SCR_PHASE(1);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's staging writes have landed (wave-private buffers)
         // ---- dW2[out][hidden] += dZ^T H ; db2[out] += sum over the anchors
@@ -380,7 +366,6 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
             for (int c = 0; c < 16; c += 4) { const f4 x = *(const f4*)&row[c]; sum += (x[0] + x[1]) + (x[2] + x[3]); }
             db2[half] += sum;
         }
-        SCR_PHASE(2);
         __builtin_amdgcn_sched_barrier(0);
         if (tile + tstep < tiles) load_tile(tile + tstep);      // dz and h are dead from here on: next tile's loads
         // ---- dX^T = W1^T dPre^T -> d feat, d geo_fea, d ob_view
@@ -391,7 +376,6 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
         for (int blk = 0; blk < 4; ++blk)
             xb[2 + blk] = *(const f4*)((blk < 2 ? geo_a : geo_b) + vc * (MH_GEO / 2) + 16 * (blk & 1) + 4 * g);
         const float ax = anchor[3 * vc], ay = anchor[3 * vc + 1], az = anchor[3 * vc + 2];   // used after the dX MFMAs
-        SCR_PHASE(3);
         __builtin_amdgcn_sched_barrier(0);
         f4 dx[MH_KB];
 #pragma unroll
@@ -406,7 +390,6 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
 #pragma unroll
                 for (int ft = 0; ft < MH_KB; ++ft) dx[ft] = mfma4(a[ft][r], dpre[mt][r], dx[ft]);
         }
-        SCR_PHASE(4);
         // Nothing that needs one of the loads above may be scheduled before the 168 MFMAs above: vmcnt retires in order,
         // so the first use waits for ALL of them (the compiler had hoisted this 1 / |o| arithmetic over the MFMAs: one
         // exposed memory round trip per tile).
@@ -427,7 +410,6 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
                 d_anchor[3 * v + 2] = (dx[6][2] - uz * dot) * inv;
             }
         }
-        SCR_PHASE(5);
         __builtin_amdgcn_sched_barrier(0);
         // ---- dW1[hidden][k] += dPre^T X : restage (the dW2 reads above are done: same wave, program order)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -453,9 +435,7 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads finished before the next tile's staging writes
         __builtin_amdgcn_sched_barrier(0);
-        SCR_PHASE(6);
     }
-    SCR_PHASES_FLUSH(mh_bwd_ticks, 8, lane == 0);
     // ---- this wave's partial sums: accumulator (lane (j, gi), register r) = row 4 gi + r, column j of its 16x16 tile
     float* p = partial + ((size_t)blockIdx.x * MH_WAVES + wave) * MH_PART;
 #pragma unroll
@@ -561,15 +541,5 @@ void launch_mlp_heads_backward(int64_t V, const float* feat, const float* anchor
                                                                   d_b2o, d_w2c, d_b2c, d_w2v, d_b2v);
 }
 
-#ifdef SCR_PHASE_TIMING
-int mh_debug_ticks(int fwd, unsigned long long* out) {
-    unsigned long long z[16] = {};
-    int rc = (int)(fwd ? hipMemcpyFromSymbol(out, HIP_SYMBOL(mh_fwd_ticks), 128, 0, hipMemcpyDeviceToHost)
-                       : hipMemcpyFromSymbol(out, HIP_SYMBOL(mh_bwd_ticks), 128, 0, hipMemcpyDeviceToHost));
-    rc |= (int)(fwd ? hipMemcpyToSymbol(HIP_SYMBOL(mh_fwd_ticks), z, 128, 0, hipMemcpyHostToDevice)
-                    : hipMemcpyToSymbol(HIP_SYMBOL(mh_bwd_ticks), z, 128, 0, hipMemcpyHostToDevice));
-    return rc;
-}
-#endif
 
 }  // namespace scr

@@ -13,9 +13,6 @@
 // is written in the evaluation order of DESIGN.md "Normative arithmetic" (no FMA, IEEE sqrt/div).
 #include "common.h"
 
-#ifndef SCR_PREBWD_MIN_BLOCKS
-#define SCR_PREBWD_MIN_BLOCKS 1
-#endif
 namespace scr {
 
 // ------------------------------------------------------------------ shared projection maths
@@ -237,7 +234,7 @@ preprocess_kernel(int64_t P, int M, const float* __restrict__ means3D, const flo
                   const float* __restrict__ colors, KSettings ks, int tiles, float4* __restrict__ rec,
                   uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped,
                   uint32_t* __restrict__ block_sums, uint32_t* __restrict__ tile_count,
-                  int32_t* __restrict__ radii) {
+                  int32_t* __restrict__ radii, unsigned long long* __restrict__ plan_flags) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // [tiles] when LDS_HIST
     __shared__ uint32_t wave_sum[BIN_THREADS / WAVE];
     if (LDS_HIST) {
@@ -269,6 +266,9 @@ preprocess_kernel(int64_t P, int M, const float* __restrict__ means3D, const flo
                 sh_to_rgb(ks.sh_degree, shs + (size_t)i * M * 3, dx / n, dy / n, dz / n, rgb, cb);
             }
             if (clamped) clamped[i] = cb;
+            // a colour that is not finite (NaN / Inf input): the blend kernels must keep it away from the pixels its splat
+            // does not contribute to -- the host launches their SAFE instantiations for this call (blend.hip)
+            if (nonfinite3(rgb[0], rgb[1], rgb[2])) atomicOr(plan_flags, (unsigned long long)SCR_PLAN_NONFINITE_COLOUR);
             tt = (uint32_t)((ft.rmaxx - ft.rminx) * (ft.rmaxy - ft.rminy));
             uint32_t rlo = (uint32_t)ft.rminx | ((uint32_t)ft.rminy << 16);
             uint32_t rhi = (uint32_t)ft.rmaxx | ((uint32_t)ft.rmaxy << 16);
@@ -313,7 +313,7 @@ preprocess_kernel(int64_t P, int M, const float* __restrict__ means3D, const flo
 // ------------------------------------------------------------------ backward: reduce + chain
 // One thread per Gaussian.  Sums its per-instance gradient records in tile order (fixed order ->
 // bit-reproducible), then differentiates the projection (recomputed from the inputs).
-__global__ void __launch_bounds__(PRE_BLOCK, SCR_PREBWD_MIN_BLOCKS)
+__global__ void __launch_bounds__(PRE_BLOCK, 1)
 preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
                            const float* __restrict__ scales, const float* __restrict__ rotations,
                            const float* __restrict__ cov3D, const float* __restrict__ shs, KSettings ks,
@@ -655,11 +655,11 @@ void launch_preprocess(int64_t P, int M, const float* means3D, const float* scal
     if (g.tiles <= LDS_HIST_MAX_TILES)
         preprocess_kernel<true><<<nblk(P, BIN_GPW), BIN_THREADS, (size_t)g.tiles * 4, st>>>(
             P, M, means3D, scales, rotations, cov3D, opacities, shs, colors, ks, g.tiles, gv.rec, gv.tiles_touched,
-            shs ? gv.clamped : nullptr, gv.block_sums, gv.tile_count, radii);
+            shs ? gv.clamped : nullptr, gv.block_sums, gv.tile_count, radii, gv.total + 3);
     else
         preprocess_kernel<false><<<nblk(P, BIN_GPW), BIN_THREADS, 0, st>>>(
             P, M, means3D, scales, rotations, cov3D, opacities, shs, colors, ks, g.tiles, gv.rec, gv.tiles_touched,
-            shs ? gv.clamped : nullptr, gv.block_sums, gv.tile_count, radii);
+            shs ? gv.clamped : nullptr, gv.block_sums, gv.tile_count, radii, gv.total + 3);
 }
 
 void launch_preprocess_backward(int64_t P, int M, const float* means3D, const float* scales,

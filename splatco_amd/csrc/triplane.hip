@@ -417,9 +417,6 @@ tp_scatter9_kernel(int64_t V, const float* __restrict__ coords, int cs, const fl
 // cell: plain read-modify-writes).  No float atomics: interior nodes go out as plain stores, the sums of a tile's border
 // nodes (shared with the neighbours) to the tile's halo block (pass 5 adds the tiles' shares).  Points whose cell lies
 // one step outside the plane (grid coordinate just beyond -1: only their inner corners exist) are folded into cell 0.
-#ifdef SCR_PHASE_TIMING
-__device__ unsigned long long tp_gather_ticks[16];
-#endif
 constexpr int TPN_NODES = TP_NODES * TP_NODES;
 constexpr int TPN_CELLS = TP_TILE * TP_TILE;
 constexpr int TPN_THREADS = 1024;               // one cell per thread
@@ -463,7 +460,6 @@ tp_cell_gather_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_st
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int r = 0; r < RT; ++r) acc[k][r] = 0.0f;
-    SCR_PHASES(6);     // 0 copy, 1 cells + ranks, 2 scan, 3 index list, 4 cell loop, 5 corner exchange + output
     for (uint32_t c0 = lo; c0 < hi; c0 += CHUNK) {
         const uint32_t n = min((uint32_t)CHUNK, hi - c0);
         cnt[c] = 0;
@@ -484,7 +480,6 @@ tp_cell_gather_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_st
             }
         }
         __syncthreads();
-        SCR_PHASE(0);
         // ---- this thread's points: cell and rank inside the cell; the coordinates become the bilinear fractions
         int cell[PPT];
         uint32_t rank[PPT];
@@ -516,7 +511,6 @@ tp_cell_gather_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_st
             }
         }
         __syncthreads();
-        SCR_PHASE(1);
         // ---- exclusive scan of the cell counts
         {
             const uint32_t v = cnt[c];
@@ -526,13 +520,11 @@ tp_cell_gather_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_st
             if (threadIdx.x == 0) start[TPN_CELLS] = tot;
         }
         __syncthreads();
-        SCR_PHASE(2);
         // ---- index list in cell order
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
             if (cell[k] >= 0) order[start[cell[k]] + rank[k]] = (uint16_t)(threadIdx.x + TPN_THREADS * k);
         __syncthreads();
-        SCR_PHASE(3);
         // ---- the cell's points: weights as torch, (da ? fa : 1 - fa) * (db ? fb : 1 - fb) for corner (da, db)
         for (uint32_t sidx = start[c], e = start[c + 1]; sidx < e; ++sidx) {
             const float* pr = raw + (uint32_t)order[sidx] * REC;
@@ -546,7 +538,6 @@ tp_cell_gather_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_st
             }
         }
         __syncthreads();
-        SCR_PHASE(4);
     }
     // ---- corner sums -> nodes (LDS image of the 33 x 33 nodes, RT channels)
     for (int i = threadIdx.x; i < TPN_NODES * RT; i += TPN_THREADS) raw[i] = 0.0f;
@@ -576,11 +567,6 @@ tp_cell_gather_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_st
             else *((r < R ? grad_plane0 + ((size_t)r * A + a) * B : grad_plane1 + ((size_t)(r - R) * A + a) * B) + b) = v;
         }
     }
-#ifdef SCR_PHASE_TIMING
-    __syncthreads();
-#endif
-    SCR_PHASE(5);
-    SCR_PHASES_FLUSH(tp_gather_ticks, 6, threadIdx.x == 0);
 }
 
 
@@ -1025,14 +1011,6 @@ int launch_triplane_backward(int64_t V, const float* coords, int cs, int R, int 
     return tp_backward(V, coords, cs, R, planes, 3, pairs, sizes, grad_out, ld, cols, cols1, grad_planes, gp1, scratch, st);
 }
 
-#ifdef SCR_PHASE_TIMING
-int tp_debug_ticks(unsigned long long* out) {
-    unsigned long long z[16] = {};
-    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tp_gather_ticks), 128, 0, hipMemcpyDeviceToHost);
-    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(tp_gather_ticks), z, 128, 0, hipMemcpyHostToDevice);
-    return rc;
-}
-#endif
 
 // ---- normalised sample coordinates: ind = (xyz - lo) / (hi - lo) * 2 - 1 (scene/grids.py:146), the framework's four
 // elementwise passes over [V, 3] as one; the same IEEE operations in the same order, so the same bits

@@ -82,7 +82,7 @@ def _bytes(n, device):
 
 class RasterState:
     """Per-call saved buffers (opaque to Python) + what the debug getters need."""
-    __slots__ = ("P", "M", "I", "max_tile", "cs", "geom", "binning", "image", "radii")
+    __slots__ = ("P", "M", "I", "max_tile", "flags", "cs", "geom", "binning", "image", "radii")
 
     def debug(self, which):
         """Integer / float intermediates for the parity tests (SCR_DBG_* selectors)."""
@@ -120,7 +120,7 @@ def rasterize_forward(cs, means3D, opacities, scales, rotations, cov3D_precomp, 
     st.image = _bytes(_C.lib.scr_image_bytes(cs.H, cs.W), dev)
     radii = torch.empty(P, dtype=torch.int32, device=dev)      # every entry is written by preprocess_kernel
     color = torch.empty(3, cs.H, cs.W, dtype=torch.float32, device=dev)
-    plan = (C.c_int64 * 3)(0, 0, 0)      # (tile instances, largest per-tile instance count, phase 2 already ran)
+    plan = (C.c_int64 * 4)(0, 0, 0, 0)   # (tile instances, largest per-tile instance count, phase 2 already ran, plan flags)
     # The binning buffer's size is only known after the plan phase.  A guess from the previous call of this size (the
     # instance count of a training loop moves by a few per cent per step) lets both phases go out in ONE call: the GPU
     # does not wait for this thread's allocation and second call in the middle of every forward pass.
@@ -136,14 +136,14 @@ def rasterize_forward(cs, means3D, opacities, scales, rotations, cov3D_precomp, 
                                              _ptr(opacities), _ptr(shs), _ptr(colors_precomp), cs.ref(),
                                              st.geom.data_ptr(), _ptr(radii), plan, None if spec is None else spec.data_ptr(),
                                              0 if spec is None else spec.numel(), st.image.data_ptr(), color.data_ptr(), _stream()))
-        st.I, st.max_tile = int(plan[0]), int(plan[1])
+        st.I, st.max_tile, st.flags = int(plan[0]), int(plan[1]), int(plan[3])
         _plan_guess[key] = (P, st.I, st.max_tile)
         if plan[2]:
             st.binning = spec
         else:
             del spec
             st.binning = _bytes(_C.lib.scr_binning_bytes(st.I, st.max_tile), dev)
-            _C.check(_C.lib.scr_forward_run(P, st.I, st.max_tile, cs.ref(), st.geom.data_ptr(), st.binning.data_ptr(),
+            _C.check(_C.lib.scr_forward_run(P, st.I, st.max_tile, st.flags, cs.ref(), st.geom.data_ptr(), st.binning.data_ptr(),
                                             st.image.data_ptr(), color.data_ptr(), _stream()))
     st.radii = radii
     return color, radii, st
@@ -228,7 +228,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         scratch = _bytes(_C.lib.scr_backward_scratch_bytes(st.I), dev)
         try:
           with torch.cuda.device(dev):
-            _C.check(_C.lib.scr_backward(P, st.M, st.I, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D),
+            _C.check(_C.lib.scr_backward(P, st.M, st.I, st.flags, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D),
                                          _ptr(sh), cs.ref(), st.radii.data_ptr(), st.geom.data_ptr(),
                                          st.binning.data_ptr(), st.image.data_ptr(), g.data_ptr(), scratch.data_ptr(),
                                          g_means3D.data_ptr(), g_means2D.data_ptr(), _ptr(g_col), _ptr(g_sh),

@@ -540,3 +540,84 @@ def test_randomised_stress_scenes(oracle, seed):
             fh.write("\n".join(lines) + "\n")
     assert not over, (seed, "scenes whose fraction of visible rows not pinned by binary32 exceeds the bar", over)
     assert b_scenes <= B_SCENES_MAX, (seed, b_scenes)
+
+
+def _same_with_nonfinite(a, b, tol, what):
+    """a == b where NaN must sit where NaN sits and +-Inf where the same Inf sits; the finite rest within tol (max-abs
+    relative to the largest finite magnitude)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert np.array_equal(np.isnan(a), np.isnan(b)), (what, "NaN positions", int(np.isnan(a).sum()), int(np.isnan(b).sum()))
+    inf = np.isinf(b)
+    assert np.array_equal(np.isinf(a), inf) and np.array_equal(a[inf], b[inf]), (what, "Inf positions")
+    fin = np.isfinite(b)
+    if fin.any():
+        scale = max(np.abs(b[fin]).max(), 1e-30)
+        assert np.abs(a[fin] - b[fin]).max() <= tol * scale, (what, float(np.abs(a[fin] - b[fin]).max() / scale))
+
+
+@pytest.mark.parametrize("case", ["nan_colour_hidden", "nan_colour_partly_visible", "inf_colour", "inf_opacity", "nan_opacity",
+                                  "nan_mean_scale_rotation"])
+def test_non_finite_inputs_follow_the_reference_skip_semantics(oracle, case):
+    """The reference SKIPS a splat at every pixel it does not contribute to (alpha < 1/255, power > 0, pixel already
+    opaque), so a colour that is NaN / Inf reaches only the pixels its splat contributes to.  The fast blend kernels carry
+    non-contributing splats with alpha 0; calls whose plan reports SCR_PLAN_NONFINITE_COLOUR run the select-based
+    instantiations instead.  Device == oracle, NaN for NaN and Inf for Inf, forward and every gradient; Gaussians with a
+    NaN mean / scale / rotation are culled on both sides."""
+    from splatco_amd import _C, rasterizer as R
+    cam, g = small_scene(P=400, W=160, H=96, seed=11)
+    g = {k: np.array(v, copy=True) for k, v in g.items()}
+    rng = np.random.default_rng(5)
+    f0 = oracle.forward(oracle_settings(oracle, cam, g["bg"]), g["means3D"], g["opacities"], g["scales"], g["rotations"],
+                        colors_precomp=g["colors"])
+    vis = np.nonzero(f0["radii"] > 0)[0]
+    order = vis[np.argsort(f0["depth"][vis])]
+    front, back = order[: len(order) // 8], order[-len(order) // 3:]
+    expect_flag = False
+    if case == "nan_colour_hidden":
+        # an opaque wall in front of everything, NaN colours far behind it: no pixel of the wall's footprint reaches them
+        wall = front[0]
+        g["means3D"][wall] = [0.1, 0.05, -2.0]
+        g["scales"][wall] = [3.0, 3.0, 0.01]
+        g["rotations"][wall] = [1, 0, 0, 0]
+        g["opacities"][wall] = 1.0
+        g["colors"][back[:20], 1] = np.nan
+        expect_flag = True
+    elif case == "nan_colour_partly_visible":
+        g["colors"][order[::7], rng.integers(0, 3, len(order[::7]))] = np.nan
+        expect_flag = True
+    elif case == "inf_colour":
+        g["colors"][order[3::9], 0] = np.inf
+        g["colors"][order[5::11], 2] = -np.inf
+        expect_flag = True
+    elif case == "inf_opacity":
+        g["opacities"][order[4::10]] = np.inf
+    elif case == "nan_opacity":
+        g["opacities"][order[2::10]] = np.nan
+    else:
+        g["means3D"][order[0], 1] = np.nan
+        g["scales"][order[1], 2] = np.nan
+        g["rotations"][order[2], 0] = np.nan
+        g["scales"][order[3], 0] = np.inf
+    st = oracle_settings(oracle, cam, g["bg"])
+    f = oracle.forward(st, g["means3D"], g["opacities"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+    dL = rng.standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
+    o = _run_gpu(cam, g, dL=dL, ref=f)
+    assert np.array_equal(o["radii"], f["radii"]) and np.array_equal(o["tiles_touched"], f["tiles_touched"])
+    assert o["num_rendered"] == f["num_rendered"] and np.array_equal(o["point_list"], f["point_list"])
+    if case == "nan_mean_scale_rotation":
+        assert (o["radii"][order[:3]] == 0).all(), "NaN mean / scale / rotation: culled"
+    same_n = o["n_contrib"] == f["n_contrib"]
+    assert same_n.mean() >= 0.999
+    _same_with_nonfinite(o["color"][:, same_n], f["color"][:, same_n], 1e-4, "image")
+    if case == "nan_colour_hidden":
+        wall_px = f["n_contrib"] <= (np.nonzero(f["point_list"] == wall)[0].size and f["n_contrib"])    # all: documentation
+        assert np.isfinite(f["color"]).mean() > 0.5, "the wall hides the NaN colours from most pixels in the reference semantics"
+    b = oracle.backward(st, f, o["dL_eff"], g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
+    for k in STRESS_NAMES:
+        _same_with_nonfinite(o["grads"][k], b[k], 2e-3, k)        # max-abs over the tensor (rows mix 1e-6 .. 1 magnitudes)
+    # the plan flag is what selected the kernels
+    rs = _settings(cam, g["bg"])
+    t = lambda a: torch.tensor(a, device=_dev())
+    _, _, stt = R.rasterize_forward(R._CSettings(rs), t(g["means3D"]), t(g["opacities"]), t(g["scales"]), t(g["rotations"]), None,
+                                    None, t(g["colors"]))
+    assert bool(stt.flags & _C.PLAN_NONFINITE_COLOUR) == expect_flag

@@ -33,7 +33,7 @@ print("excused pixels", bad.sum())
 P, I = stt.P, stt.I
 scratch = torch.zeros(_C.lib.scr_backward_scratch_bytes(I), dtype=torch.uint8, device=dev)
 outs = [torch.empty(P, w, device=dev) for w in (3, 3, 3, 1, 3, 4)]
-_C.check(_C.lib.scr_backward(P, 0, I, m.data_ptr(), s.data_ptr(), r.data_ptr(), None, None, cs.ref(), stt.radii.data_ptr(),
+_C.check(_C.lib.scr_backward(P, 0, I, stt.flags, m.data_ptr(), s.data_ptr(), r.data_ptr(), None, None, cs.ref(), stt.radii.data_ptr(),
                              stt.geom.data_ptr(), stt.binning.data_ptr(), stt.image.data_ptr(), t(dL).data_ptr(), scratch.data_ptr(),
                              outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), None, outs[3].data_ptr(), outs[4].data_ptr(),
                              outs[5].data_ptr(), None, R._stream()))

@@ -40,7 +40,7 @@ def stats(name, rs, means3D, opacities, colors, scales, rotations):
     g = torch.randn(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
     scratch = torch.full((_C.lib.scr_backward_scratch_bytes(I),), 0x7f, dtype=torch.uint8, device=dev)
     outs = [torch.empty(P, w, device=dev) for w in (3, 3, 3, 1, 3, 4)]
-    _C.check(_C.lib.scr_backward(P, 0, I, means3D.data_ptr(), scales.data_ptr(), rotations.data_ptr(), None, None, cs.ref(),
+    _C.check(_C.lib.scr_backward(P, 0, I, st.flags, means3D.data_ptr(), scales.data_ptr(), rotations.data_ptr(), None, None, cs.ref(),
                                  st.radii.data_ptr(), st.geom.data_ptr(), st.binning.data_ptr(), st.image.data_ptr(), g.data_ptr(),
                                  scratch.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), None,
                                  outs[3].data_ptr(), outs[4].data_ptr(), outs[5].data_ptr(), None, R._stream(dev)))
