@@ -434,11 +434,14 @@ __device__ __forceinline__ void splat_pixel_grad(PixState& s, float T, float4 b,
 #pragma clang fp contract(fast)
     // T = transmittance in front of this splat (group_transmittance)
     const float w = alpha * T;
-    s.behind = s.last_alpha * (s.d_last - s.behind) + s.behind;
+    // (SAFE: the reference's form of the same interpolation -- it keeps an infinite accumulator infinite where a (d - b) + b
+    // makes Inf - Inf of it)
+    s.behind = SAFE ? s.last_alpha * s.d_last + (1.0f - s.last_alpha) * s.behind : s.last_alpha * (s.d_last - s.behind) + s.behind;
     float d = b.z * s.dLp0 + b.w * s.dLp1 + cb * s.dLp2;
     if (SAFE) d = sel(hit, d, 0.0f);
     g_c0 = w * s.dLp0; g_c1 = w * s.dLp1; g_c2 = w * s.dLp2;
-    const float Y = G * (T * (d - s.behind));  // G = opacity * exp(power) here: the unclamped alpha times dL/dalpha (straight-through min(0.99, .))
+    float Y = G * (T * (d - s.behind));  // G = opacity * exp(power) here: the unclamped alpha times dL/dalpha (straight-through min(0.99, .))
+    if (SAFE) Y = sel(hit, Y, 0.0f);     // `behind` is NaN once a NaN colour contributed to this pixel; a skipped splat takes nothing from it
     s.last_alpha = alpha;
     s.d_last = d;
     // the moments of Y about the quadrant's origin are made INSIDE the reduction: the x-dependent ones from the halves
