@@ -81,10 +81,22 @@ def algorithmic_bytes(kernel, P, I, npix, extra=None):
     return float(table.get(kernel, 0))
 
 
+MLP_HEADS_MAC = 3 * 99 * 32 + 32 * (10 + 70 + 30)      # 13 024 multiply-adds per anchor: three 99 -> 32 layers, 32 -> {10, 70, 30}
+
+
 def algorithmic_flops(kernel, V):
-    """fp32-MFMA work of the kernels that are bound by it: MFMA instructions per 16-anchor tile x 2048 flop
-    (v_mfma_f32_16x16x4_f32), counted in the kernels' ISA (profiles/r02_isa_mix.txt): forward 28 k-steps x 6 hidden tiles
-    + 8 k-steps x 8 output tiles = 232; backward dH 64 + dW2 64 + dX 168 + dW1 168 = 464."""
+    """ALGORITHMIC fp32 flops of the kernels bound by the matrix pipe (what roofline.frac is computed from): the MLP heads
+    99 -> 32 -> {10, 70, 30} (scene/gaussian_model.py:315-337) are 13 024 MAC = 26 048 flop per anchor forward; the backward
+    forms an input gradient and a weight gradient per layer: twice that."""
+    per_anchor = {"mlp_heads_kernel": 2.0 * MLP_HEADS_MAC, "mlp_heads_backward_kernel": 4.0 * MLP_HEADS_MAC}.get(kernel)
+    return None if per_anchor is None else per_anchor * V
+
+
+def issued_mfma_flops(kernel, V):
+    """What the kernels ISSUE to the matrix pipe: MFMA instructions per 16-anchor tile x 2048 flop (v_mfma_f32_16x16x4_f32),
+    counted in the kernels' ISA (profiles/r02_isa_mix.txt): forward 28 k-steps x 6 hidden tiles + 8 k-steps x 8 output tiles
+    = 232; backward dH 64 + dW2 64 + dX 168 + dW1 168 = 464.  More than the algorithmic count by the K padding 99 -> 112,
+    the output padding 110 -> 128 and the hidden-layer recompute of the backward."""
     per_tile = {"mlp_heads_kernel": 232, "mlp_heads_backward_kernel": 464}.get(kernel)
     return None if per_tile is None else per_tile * 2048.0 * ((V + 15) // 16)
 
@@ -318,7 +330,7 @@ def profile_value(fname, kernel):
                                "command": prov.get("command"), "sources": {n: then[n] for n in need}}
 
 
-def roofline_object(dom, avg_ms, ab, peak_measured, note, flops=None, traffic_file="hbm_traffic.json", launches=1.0):
+def roofline_object(dom, avg_ms, ab, peak_measured, note, flops=None, traffic_file="hbm_traffic.json", launches=1.0, issued=None):
     achieved = ab / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
     # PMC-derived bytes per launch (cfg1) / per step (cfg2): only if collected on THIS kernel code
     traffic, traffic_src = profile_value(traffic_file, dom)
@@ -334,6 +346,11 @@ def roofline_object(dom, avg_ms, ab, peak_measured, note, flops=None, traffic_fi
         tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms else 0.0
         out.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": tf / MFMA_F32_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops,
+                    "frac_is": "ALGORITHMIC flops (2 flop per multiply-add of the layers, x2 for the backward) / time / dense fp32-MFMA peak",
+                    **({"mfma_issue_frac": issued / (avg_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if avg_ms else 0.0,
+                        "issued_mfma_flops_per_launch": issued,
+                        "mfma_issue_frac_is": "flops of the MFMA instructions the kernel issues (K 99 -> 112 and output 110 -> 128 "
+                                              "padding, hidden-layer recompute) / time / peak"} if issued else {}),
                     "hbm_view": {"achieved_GBps": achieved, "frac": achieved / HBM_PEAK_GBS,
                                  "frac_of_measured": (achieved / peak_measured) if peak_measured else None}})
         out.pop("frac_of_measured", None)
@@ -403,7 +420,7 @@ def run_cfg1(args, rank, world, dev):
     from splatco_amd.synthetic import synthetic_gaussians
 
     P, W, H = P_CFG1, W_CFG1, H_CFG1
-    g = synthetic_gaussians(P, W, H, seed=0)
+    g = synthetic_gaussians(P, W, H, seed=0, sigma_scale=args.sigma_scale)
     cam = make_view(rank, W, H)
     rast = GaussianRasterizer(settings_for(cam, g["bg"], dev))
     t = lambda a: torch.tensor(a, device=dev, requires_grad=True)
@@ -511,13 +528,23 @@ def run_cfg1(args, rank, world, dev):
                             "every launch of the last three WARM-UP steps, each pair adding ~6 us of stream time on both sides of its "
                             "launch -- their sum therefore exceeds ms_per_step, which is wall time over K undisturbed steps",
         "hbm_gbs_all_kernels": sum(algorithmic_bytes(k, P, I, npix) for k in kern) / (sum(kern.values()) * 1e-3) / 1e9,
+        # every kernel class against ITS byte model, from the per-launch times above
+        "kernel_rooflines": {k: {"ms": round(ms, 4), "algorithmic_MB": round(algorithmic_bytes(k, P, I, npix) / 1e6, 1),
+                                 "GBps": round(algorithmic_bytes(k, P, I, npix) / (ms * 1e-3) / 1e9, 1),
+                                 "frac_of_8TBps": round(algorithmic_bytes(k, P, I, npix) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                                 "frac_of_measured_peak": round(algorithmic_bytes(k, P, I, npix) / (ms * 1e-3) / 1e9 / peak, 3)}
+                             for k, ms in sorted(kern.items(), key=lambda kv: -kv[1]) if ms > 0},
     }
+    if args.sigma_scale != 1.0:
+        out["config"]["workload"] += f" -- DEVELOPER SWEEP POINT: every screen-space sigma x {args.sigma_scale} (sparser tile lists)"
+        out["config"]["sigma_scale"] = args.sigma_scale
+        out["config"]["mean_list_entries_per_tile"] = round(I / (((W + 15) // 16) * ((H + 15) // 16)), 1)
     if allreduce_info is not None:
         out["allreduce"] = allreduce_info
     if exposed is not None:
         out["exchange"] = exposed
     hip_image = state["img"].detach().cpu().numpy()
-    if world == 1 and not args.no_cfg2:
+    if world == 1 and not args.no_cfg2 and args.sigma_scale == 1.0:
         # the largest single-GPU configuration (BASELINE.json configs[2]) measured by the same process, after the headline:
         # cfg1 stays the line's metric / value, cfg2 rides along so that it is timed under the driver's clock too
         del params, leaves, means2D, dL, st
@@ -530,7 +557,7 @@ def run_cfg1(args, rank, world, dev):
                                           "kernel_ms_per_step", "peak_mem_GiB", "time_settle_steps")}
         out["cfg2"]["kernel_rooflines"] = {k: {kk: v[kk] for kk in ("ms_per_step", "GBps", "frac_of_measured_peak") if kk in v}
                                            for k, v in c2["kernel_rooflines"].items()}
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.sigma_scale == 1.0:
         out["cpu_baseline"], out["psnr_match_db"] = cpu_baseline(g, cam, dev, hip_image)
     return out
 
@@ -762,7 +789,7 @@ def run_anchor_config(args, rank, world, dev):
         "roofline": roofline_object(dominant, kern.get(dominant, 0.0), ab, peak,
                                     "dominant among this library's kernel classes by time per step",
                                     flops=algorithmic_flops(dominant, V), traffic_file=f"hbm_traffic_{args.config}.json",
-                                    launches=max(launches.get(dominant, 1.0), 1.0)),
+                                    launches=max(launches.get(dominant, 1.0), 1.0), issued=issued_mfma_flops(dominant, V)),
         "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(warm_step_ms.items(), key=lambda kv: -kv[1])},
         # every kernel class of this library against ITS byte model (per step, all launches of the class)
         "kernel_rooflines": {k: {"ms_per_step": round(ms, 4),
@@ -770,7 +797,8 @@ def run_anchor_config(args, rank, world, dev):
                                  "GBps": round(algorithmic_bytes(k, P1, I, W * H, extra) / (ms * 1e-3) / 1e9, 1),
                                  "frac_of_measured_peak": round(algorithmic_bytes(k, P1, I, W * H, extra) / (ms * 1e-3) / 1e9 / peak, 3),
                                  **({"mfma_TFLOPs": round(algorithmic_flops(k, V) / (ms * 1e-3) / 1e12, 1),
-                                     "frac_of_f32_mfma_peak": round(algorithmic_flops(k, V) / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 3)}
+                                     "frac_of_f32_mfma_peak": round(algorithmic_flops(k, V) / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 3),
+                                     "mfma_issue_frac": round(issued_mfma_flops(k, V) / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 3)}
                                     if algorithmic_flops(k, V) else {})}
                              for k, ms in sorted(warm_step_ms.items(), key=lambda kv: -kv[1]) if ms > 0},
         "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
@@ -828,6 +856,8 @@ def main():
                     help="shape of the gradient exchange of cfg3/cfg4 (GradArena)")
     ap.add_argument("--optimizer", choices=["hip", "torch"], default="hip",
                     help="cfg3/cfg4: splatco_amd.adam.FusedAdam (csrc/adam.hip) or torch.optim.Adam(fused=True)")
+    ap.add_argument("--sigma-scale", type=float, default=1.0,
+                    help="cfg1 developer sweep: multiply every screen-space sigma (sparser tile lists; the headline is 1.0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cfg2", action="store_true", help="cfg1 at N = 1: skip the cfg2 block that rides along on the line")
     ap.add_argument("--timeout", type=float, default=1500.0,

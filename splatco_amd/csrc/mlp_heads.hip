@@ -437,23 +437,28 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
         __builtin_amdgcn_sched_barrier(0);
     }
     // ---- this wave's partial sums: accumulator (lane (j, gi), register r) = row 4 gi + r, column j of its 16x16 tile
-    float* p = partial + ((size_t)blockIdx.x * MH_WAVES + wave) * MH_PART;
+    // (the lane's coordinates are re-derived behind an opaque copy: computed from the loop's own n / g the compiler forms the
+    // store addresses BEFORE the anchor loop and, all 512 registers being taken inside it, spills them to scratch)
+    int le = threadIdx.x;
+    asm volatile("" : "+v"(le));
+    const int ne = le & 15, ge = (le >> 4) & 3, we = le >> 6, lane_e = le & 63;
+    float* p = partial + ((size_t)blockIdx.x * MH_WAVES + we) * MH_PART;
 #pragma unroll
     for (int mt = 0; mt < MH_MT; ++mt)
 #pragma unroll
         for (int ft = 0; ft < MH_KB; ++ft)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * g + r) * (MH_KB * 16) + 16 * ft + n] = aW1[mt][ft][r];
+            for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * ge + r) * (MH_KB * 16) + 16 * ft + ne] = aW1[mt][ft][r];
     float* p2 = p + MH_MT * 16 * MH_KB * 16;
 #pragma unroll
     for (int ot = 0; ot < MH_OT; ++ot)
 #pragma unroll
         for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p2[(16 * ot + 4 * g + r) * MH_HID + 16 * ml + n] = aW2[ot][ml][r];
+            for (int r = 0; r < 4; ++r) p2[(16 * ot + 4 * ge + r) * MH_HID + 16 * ml + ne] = aW2[ot][ml][r];
     float* p3 = p2 + MH_OT * 16 * MH_HID;
-    p3[lane] = db2[0];
-    p3[lane + 64] = db2[1];
+    p3[lane_e] = db2[0];
+    p3[lane_e + 64] = db2[1];
 }
 
 // sums the per-wave partials in wave order and un-permutes them into the parameter layouts

@@ -25,9 +25,10 @@ def synthetic_camera(width, height, fovx_deg=60.0):
     return make_camera(np.eye(3), np.zeros(3), FoVx, FoVy, width, height)
 
 
-def synthetic_gaussians(P, width, height, seed=0, fovx_deg=60.0):
+def synthetic_gaussians(P, width, height, seed=0, fovx_deg=60.0, sigma_scale=1.0):
     """Returns float32 numpy arrays: means3D[P,3], scales[P,3], rotations[P,4], opacities[P,1],
-    colors[P,3] and bg[3]."""
+    colors[P,3] and bg[3].  sigma_scale: multiplies every screen-space sigma (1 = the benchmark scene of SURVEY.md 8d;
+    smaller = the same Gaussians, same positions, sparser tile lists -- bench.py's --sigma-scale sweep)."""
     rng = np.random.default_rng(seed)
     tanfovx = math.tan(math.radians(fovx_deg) / 2)
     tanfovy = tanfovx * height / width
@@ -35,7 +36,7 @@ def synthetic_gaussians(P, width, height, seed=0, fovx_deg=60.0):
     px = rng.uniform(0.0, width, P)
     py = rng.uniform(0.0, height, P)
     z = rng.uniform(2.0, 20.0, P)
-    sig = np.exp(rng.uniform(math.log(0.5), math.log(5.0), (P, 3)))
+    sig = np.exp(rng.uniform(math.log(0.5), math.log(5.0), (P, 3))) * float(sigma_scale)
     q = rng.standard_normal((P, 4))
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     opac = rng.uniform(0.05, 0.95, (P, 1))

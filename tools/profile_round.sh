@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp
-B="$REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cfg2"
+B="$REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cfg2 $BENCH_ARGS"      # BENCH_ARGS: e.g. "--sigma-scale 0.1"
 # every pass under its own timeout: a failed counter request leaves rocprofv3 hanging in its signal handler;
 # FETCH_SIZE and WRITE_SIZE do not fit in one pass ("exceeds the capabilities of the hardware to collect")
 T="timeout -k 5 240"
