@@ -77,6 +77,9 @@ def build(force=False):
 
 _LIBS = {}
 _THREADED = False
+# "_asan": the AddressSanitizer + UBSan build of the same source (oracle/Makefile target `asan`; the interpreter must be
+# started with libasan / libubsan preloaded).  Parity results are the same; the run is the memory-safety check of the checker.
+_VARIANT = os.environ.get("SPLATCO_ORACLE_VARIANT", "")
 
 
 def use_threads(on):
@@ -91,10 +94,12 @@ def threads():
 
 
 def _lib(f64=False):
-    key = "f64" if f64 else ("f32_omp" if _THREADED else "f32")
+    key = "f64" if f64 else ("f32_omp" if _THREADED and not _VARIANT else "f32")
     if key not in _LIBS:
         build()
-        lib = C.CDLL(os.path.join(_HERE, f"libraster_oracle_{key}.so"))
+        if _VARIANT:
+            subprocess.run(["make", "-C", _HERE, _VARIANT.lstrip("_")], check=True, stdout=subprocess.DEVNULL)
+        lib = C.CDLL(os.path.join(_HERE, f"libraster_oracle_{key}{_VARIANT}.so"))
         lib.orc_scan.restype = C.c_int64
         assert lib.orc_real_size() == (8 if f64 else 4)
         _LIBS[key] = lib

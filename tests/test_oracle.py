@@ -235,3 +235,32 @@ def test_oracle_finite_differences(oracle):
             assert abs(fd - an) <= 1e-4 * max(abs(an), abs(fd), 1e-3), (key, i, j, fd, an)
             checked += 1
     assert checked >= 20
+
+
+def test_non_finite_inputs_skip_semantics_of_the_oracle(oracle):
+    """The normative behaviour for NaN / Inf inputs (the device is checked against it in tests/test_gpu_parity.py):
+    a Gaussian whose mean, scale or rotation is not finite is culled; a colour that is not finite reaches exactly the
+    pixels its splat contributes to -- a splat is SKIPPED wherever alpha < 1/255, power > 0 or the pixel is already
+    opaque -- and nothing else; no gradient of another Gaussian is touched unless such a pixel feeds it."""
+    cam = _cam()
+    # three opaque splats in front (alpha is capped at 0.99: T = 1e-2, 1e-4 -> the third one stops the pixel), a NaN-coloured
+    # splat behind them and one beside them
+    fronts = [_unproject(cam, 16, 32, z) for z in (3.0, 3.1, 3.2)]
+    hidden = _unproject(cam, 16, 32, 6.0)
+    beside = _unproject(cam, 48, 32, 6.0)
+    means = np.array(fronts + [hidden, beside, _unproject(cam, 48, 10, 4.0), [np.nan, 0, 5], _unproject(cam, 30, 30, 5.0)], np.float32)
+    scales = np.array([[1.5] * 3] * 3 + [[0.1] * 3] * 4 + [[np.nan, 0.1, 0.1]], np.float32)
+    op = np.array([1.0, 1.0, 1.0, 0.9, 0.9, 0.9, 0.9, 0.9], np.float32)
+    col = np.array([[1, 0, 0]] * 3 + [[np.nan, 0.5, 0.5], [np.nan, 0.5, 0.5], [0.2, 0.3, 0.4], [0.5] * 3, [0.5] * 3], np.float32)
+    st, f = _one(oracle, cam, means, scales, op, col, bg=(0.1, 0.2, 0.3))
+    assert f["radii"][6] == 0 and f["radii"][7] == 0 and (f["radii"][:6] > 0).all()      # NaN mean / NaN scale: culled
+    assert f["n_contrib"][32, 16] < 3          # stopped inside the opaque stack (0.01 * 0.01 rounds below 1e-4)
+    img = f["color"]
+    assert np.isfinite(img[:, 32, 16]).all(), "the hidden NaN colour sits behind an opaque pixel: never reached"
+    assert np.isnan(img[0, 32, 48]) and np.isfinite(img[1:, 32, 48]).all(), "the visible one poisons its own channel there"
+    assert np.isfinite(img[:, 10, 48]).all() and np.isfinite(img[:, 0, 63]).all()
+    dL = np.ones((3, 64, 64), np.float32)
+    b = oracle.backward(st, f, dL, means, scales, np.tile(np.array([1, 0, 0, 0], np.float32), (8, 1)), colors_precomp=col)
+    assert np.isfinite(b["means3D"][5]).all() and np.isfinite(b["opacities"][5]).all()     # an unrelated Gaussian: untouched
+    assert np.isnan(b["opacities"][4]).all()                                               # the visible NaN colour: its own alpha gradient
+    assert (b["means3D"][6] == 0).all() and (b["scales"][7] == 0).all()                    # culled: zero gradients, not NaN
