@@ -83,11 +83,13 @@ int scr_mark_visible(int64_t P, const float* means3D, const float* viewmatrix, u
  * synchronisation as fallback): [0] the number of (Gaussian, tile) instances, [1] the largest per-tile instance
  * count (it sizes the sort's grid) -- both go to scr_binning_bytes / scr_forward_run --, [2] unused here (see
  * scr_forward_plan_run), [3] the plan flags: an opaque word the caller hands back to scr_forward_run and scr_backward.
- * Today one bit, SCR_PLAN_NONFINITE_COLOUR: a visible Gaussian carries a colour that is NaN or +-Inf.  The reference
+ * SCR_PLAN_NONFINITE_COLOUR: a visible Gaussian carries a colour that is NaN or +-Inf.  The reference
  * SKIPS a splat at every pixel it does not contribute to, so such a colour reaches only the pixels the splat does
  * contribute to; the fast blend kernels carry non-contributing splats with alpha 0 (0 * NaN would spread), so calls
  * with this bit run the kernels' select-based instantiations and give the reference's result, NaN for NaN. */
-enum { SCR_PLAN_NONFINITE_COLOUR = 1 };
+enum { SCR_PLAN_NONFINITE_COLOUR = 1,
+       SCR_PLAN_LARGE_RECTS = 2 };  /* some Gaussian's tile rect has more than 32 tiles: scr_backward clears the gradient
+                                     * records of its further tiles before the blend backward fills in the ones it writes */
 int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* scales,
                      const float* rotations, const float* cov3D_precomp, const float* opacities,
                      const float* shs, const float* colors_precomp, const scr_settings* settings,
@@ -115,11 +117,13 @@ int scr_forward_plan_run(int64_t P, int32_t M, const float* means3D, const float
  * dL_drotations[P,4], dL_dcov3D[P,6].  Every output element is written (zeros for culled Gaussians).
  * Deterministic: bit-identical results run to run (no floating-point atomics).  scratch: scr_backward_scratch_bytes
  * (one 36-byte gradient record per (Gaussian, tile) instance; the entries of a tile's list behind every pixel's last
- * contributor get none -- the tile's cut key in the image buffer, written by the backward, tells which). */
+ * contributor get none -- the tile's cut key in the image buffer, written by the backward, tells which).
+ * geom_buf and image_buf are WRITTEN (per-Gaussian record flags, per-tile cut keys): one backward at a time per forward
+ * state; the forward's results in them are left intact, so the backward can be repeated.  plan_flags: plan_host[3]. */
 int scr_backward(int64_t P, int32_t M, int64_t num_rendered, int64_t plan_flags, const float* means3D, const float* scales,
                  const float* rotations, const float* cov3D_precomp, const float* shs,
-                 const scr_settings* settings, const int32_t* radii, const void* geom_buf,
-                 const void* binning_buf, const void* image_buf, const float* dL_dcolor, void* scratch,
+                 const scr_settings* settings, const int32_t* radii, void* geom_buf,
+                 const void* binning_buf, void* image_buf, const float* dL_dcolor, void* scratch,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
                  float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                  void* stream);
@@ -385,9 +389,10 @@ int scr_statis_apply(int64_t V, int32_t k, const int64_t* visible_index, const f
  * per-anchor parameter, lr set per group by the schedulers), no weight decay, no amsgrad.  One streaming pass over
  * parameter, gradient and the two moments of every tensor in the HOST table `tensors` (read during the call only):
  *   exp_avg    += (1 - beta1) (grad - exp_avg)            exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) grad^2
- *   param      -= (lr / bias_correction1) * exp_avg / (sqrt(exp_avg_sq) / bias_correction2_sqrt + eps)
- * with bias_correction1 = 1 - beta1^step, bias_correction2_sqrt = sqrt(1 - beta2^step) of the tensor's own step count
- * (computed by the caller, as torch does for non-capturable steps); beta1, beta2, eps are doubles because 1 - beta is
+ *   param      -= step_size * exp_avg / (sqrt(exp_avg_sq) / bias_correction2_sqrt + eps)
+ * with step_size = lr / (1 - beta1^step) and bias_correction2_sqrt = sqrt(1 - beta2^step) of the tensor's own step count,
+ * both formed by the caller in DOUBLE (as torch does for non-capturable steps: Python floats) and rounded to binary32 once,
+ * here, where torch's kernels round their scalar arguments; beta1, beta2, eps are doubles because 1 - beta is
  * formed in double and rounded once, as torch does (1 - 0.999f is 4.7e-5 off 0.001).  fp32, contiguous; any 4-byte alignment (16-byte
  * aligned tensors take the vector path).  Elementwise: bit-reproducible. */
 typedef struct scr_adam_tensor {
@@ -396,7 +401,7 @@ typedef struct scr_adam_tensor {
     float* exp_avg;
     float* exp_avg_sq;
     int64_t numel;
-    float lr, bias_correction1, bias_correction2_sqrt, reserved;
+    double step_size, bias_correction2_sqrt;
 } scr_adam_tensor;
 int scr_adam_step(int32_t n_tensors, const scr_adam_tensor* tensors, double beta1, double beta2, double eps, void* stream);
 

@@ -31,7 +31,7 @@ SYMBOLS = [
     "scr_norm_fold", "scr_norm_fold_backward", "scr_norm_running_stats", "scr_box_coords", "scr_forward_plan_run",
     "scr_profile_stride", "scr_debug_force_deep_lists", "scr_adam_step", "scr_tv_add_grad",
 ]
-PLAN_NONFINITE_COLOUR = 1      # SCR_PLAN_NONFINITE_COLOUR
+PLAN_NONFINITE_COLOUR, PLAN_LARGE_RECTS = 1, 2      # SCR_PLAN_*
 PROF_COUNT = 19
 ABI_VERSION = 23
 
@@ -42,8 +42,7 @@ ABI_VERSION = 23
 class AdamTensor(C.Structure):
     """scr_adam_tensor (include/splatco_raster.h)."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
-                ("numel", C.c_int64), ("lr", C.c_float), ("bias_correction1", C.c_float),
-                ("bias_correction2_sqrt", C.c_float), ("reserved", C.c_float)]
+                ("numel", C.c_int64), ("step_size", C.c_double), ("bias_correction2_sqrt", C.c_double)]
 
 
 class TvPlane(C.Structure):

@@ -65,11 +65,11 @@ class FusedAdam(torch.optim.Optimizer):
                     raise ValueError(f"FusedAdam: shapes differ: param {tuple(p.shape)}, grad {tuple(g.shape)}, moments {tuple(m.shape)}")
                 t = float(st["step"]) + 1.0
                 e.param, e.grad, e.exp_avg, e.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
-                e.numel, e.lr = p.numel(), lr
-                e.bias_correction1 = 1.0 - b1 ** t
+                e.numel = p.numel()
+                e.step_size = lr / (1.0 - b1 ** t)                     # doubles, as torch's Python forms them
                 e.bias_correction2_sqrt = math.sqrt(1.0 - b2 ** t)
-            for p in ps:                        # every tensor of the group passed the checks: the step counts move together
-                self.state[p]["step"] += 1
             with torch.cuda.device(dev):
                 _C.check(_C.lib.scr_adam_step(len(ps), table, b1, b2, float(group["eps"]), torch.cuda.current_stream(dev).cuda_stream))
+            for p in ps:                        # the update is queued for every tensor of the group: the step counts move together
+                self.state[p]["step"] += 1
         return loss

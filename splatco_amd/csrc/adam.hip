@@ -11,7 +11,8 @@
 //
 // Arithmetic = torch's (fused_adam_utils.cuh; the single-tensor path gives the same numbers):
 //   m  = m + (1 - beta1) (g - m)                      v = beta2 v + ((1 - beta2) g) g          (1 - beta in double, then fp32)
-//   p -= (lr / bias1) * m / (sqrt(v) / sqrt(bias2) + eps)          bias_i = 1 - beta_i^step
+//   p -= (lr / bias1) * m / (sqrt(v) / sqrt(bias2) + eps)          bias_i = 1 - beta_i^step  (the two scalars formed in double by
+//   the caller, as torch's Python does, and rounded to fp32 once)
 #include "adam.h"
 
 namespace scr {
@@ -27,7 +28,7 @@ struct AdamArgs {
     float* m[ADAM_MAX];
     float* v[ADAM_MAX];
     int64_t numel[ADAM_MAX];
-    float step_size[ADAM_MAX];              // lr / bias1
+    float step_size[ADAM_MAX];              // lr / bias1 (the caller's double quotient, rounded once)
     float bias2_sqrt[ADAM_MAX];             // torch divides by it (no reciprocal)
     uint8_t aligned[ADAM_MAX];              // all four pointers on 16 bytes
 };
@@ -96,8 +97,8 @@ int launch_adam(int n, const scr_adam_tensor* ts, double beta1, double beta2, do
             a.m[t] = x.exp_avg;
             a.v[t] = x.exp_avg_sq;
             a.numel[t] = x.numel;
-            a.step_size[t] = x.lr / x.bias_correction1;
-            a.bias2_sqrt[t] = x.bias_correction2_sqrt;
+            a.step_size[t] = (float)x.step_size;
+            a.bias2_sqrt[t] = (float)x.bias_correction2_sqrt;
             a.aligned[t] = ((((uintptr_t)x.param | (uintptr_t)x.grad | (uintptr_t)x.exp_avg | (uintptr_t)x.exp_avg_sq) & 15u) == 0);
         }
         a.first_block[a.n] = (uint32_t)blocks;

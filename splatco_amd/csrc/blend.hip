@@ -784,7 +784,7 @@ void launch_blend_backward(const KSettings& ks, const GeomView& gv, const BinVie
                            bool safe, hipStream_t st) {
     Grid g(ks.H, ks.W);
     const bool gm_from_base = deep;
-    if (flags) { ZeroList z; z.add(gv.has_rec, ((size_t)gv.P + 3) / 4 * 4); launch_zero(z, st); }   // (the array is padded to 256 bytes)
+    if (flags) { ZeroList z; z.add(gv.has_rec, ((size_t)gv.P + 3) / 4 * 4, st); launch_zero(z, st); }   // (the array is padded to 256 bytes)
     auto kernel = safe ? blend_backward_kernel<true> : blend_backward_kernel<false>;
     kernel<<<(unsigned)blend_slots_per_xcd(g) * NUM_XCD, 256, 0, st>>>(
         ks.W, ks.H, g.gx, g.tiles, gv.tile_count, gv.total, gv.ranges, bv.point_list, gm_from_base ? nullptr : bv.gm_index, gv.gm_base,

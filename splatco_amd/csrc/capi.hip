@@ -204,7 +204,7 @@ static int plan_enqueue(int64_t P, int32_t M, const float* means3D, const float*
     KSettings ks = ksettings(settings);
     GeomView gv = geom_view(geom_buf, P, ks.H, ks.W);
     Grid g(ks.H, ks.W);
-    { ZeroList z; z.add(gv.tile_count, (size_t)g.tiles * 4); z.add(gv.total + 3, 8); launch_zero(z, st); }
+    { ZeroList z; z.add(gv.tile_count, (size_t)g.tiles * 4, st); z.add(gv.total + 3, 8, st); launch_zero(z, st); }
     { ProfScope ps_(SCR_PROF_PREPROCESS, st);
       launch_preprocess(P, M, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, ks, gv,
                         radii_out, st); }
@@ -268,7 +268,7 @@ int scr_forward_run(int64_t P, int64_t I, int64_t max_tile, int64_t plan_flags, 
 static int forward_run_impl(int64_t P, int64_t I, int64_t max_tile, int64_t plan_flags, const scr_settings* settings, void* geom_buf,
                             void* binning_buf, void* image_buf, float* out_color, void* stream, bool scatter_done) {
     if (check_settings(settings)) return 1;
-    if (plan_flags & ~(int64_t)SCR_PLAN_NONFINITE_COLOUR) return fail("plan_flags %lld: not a value scr_forward_plan returned", (long long)plan_flags);
+    if (plan_flags & ~(int64_t)(SCR_PLAN_NONFINITE_COLOUR | SCR_PLAN_LARGE_RECTS)) return fail("plan_flags %lld: not a value scr_forward_plan returned", (long long)plan_flags);
     if (!geom_buf || !binning_buf || !image_buf || !out_color) return fail("NULL buffer");
     hipStream_t st = (hipStream_t)stream;
     KSettings ks = ksettings(settings);
@@ -323,7 +323,7 @@ int scr_forward_plan_run(int64_t P, int32_t M, const float* means3D, const float
             KSettings ks = ksettings(settings);
             GeomView gv = geom_view(geom_buf, P, ks.H, ks.W);
             ZeroList z;
-            z.add(gv.cursor, (size_t)Grid(ks.H, ks.W).tiles * 4);
+            z.add(gv.cursor, (size_t)Grid(ks.H, ks.W).tiles * 4, st);
             launch_zero(z, st);
         }
         return 0;                                  // caller allocates, then scr_forward_run
@@ -336,14 +336,14 @@ int scr_forward_plan_run(int64_t P, int32_t M, const float* means3D, const float
 
 int scr_backward(int64_t P, int32_t M, int64_t I, int64_t plan_flags, const float* means3D, const float* scales,
                  const float* rotations, const float* cov3D_precomp, const float* shs,
-                 const scr_settings* settings, const int32_t* radii, const void* geom_buf,
-                 const void* binning_buf, const void* image_buf, const float* dL_dcolor, void* scratch,
+                 const scr_settings* settings, const int32_t* radii, void* geom_buf,
+                 const void* binning_buf, void* image_buf, const float* dL_dcolor, void* scratch,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
                  float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                  void* stream) {
     if (check_settings(settings)) return 1;
     if (P == 0) return 0;
-    if (plan_flags & ~(int64_t)SCR_PLAN_NONFINITE_COLOUR) return fail("plan_flags %lld: not a value scr_forward_plan returned", (long long)plan_flags);
+    if (plan_flags & ~(int64_t)(SCR_PLAN_NONFINITE_COLOUR | SCR_PLAN_LARGE_RECTS)) return fail("plan_flags %lld: not a value scr_forward_plan returned", (long long)plan_flags);
     if (!geom_buf || !binning_buf || !image_buf || !dL_dcolor || !scratch) return fail("NULL buffer");
     if (!means3D || !radii || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity) return fail("NULL argument");
     if (shs ? !dL_dsh : !dL_dcolors) return fail("colour gradient output missing");
@@ -351,13 +351,17 @@ int scr_backward(int64_t P, int32_t M, int64_t I, int64_t plan_flags, const floa
         return fail("covariance gradient output missing");
     hipStream_t st = (hipStream_t)stream;
     KSettings ks = ksettings(settings);
-    GeomView gv = geom_view((void*)geom_buf, P, ks.H, ks.W);
+    GeomView gv = geom_view(geom_buf, P, ks.H, ks.W);
     BinView bv = bin_view((void*)binning_buf, I, 0);  // the lists read here come first in the layout
-    ImgView iv = img_view((void*)image_buf, ks.H, ks.W);
+    ImgView iv = img_view(image_buf, ks.H, ks.W);
     // a value no earlier call of this process used (and that uninitialised memory is unlikely to hold): see blend.hip
     static std::atomic<unsigned long long> stamp_counter{0x5ca1ab1e00000000ull};
     const unsigned long long stamp = ++stamp_counter;
     if (I > 0) {
+        if (plan_flags & SCR_PLAN_LARGE_RECTS) {
+            launch_zero_far_records(P, gv, (GradRec*)scratch, st);
+            CHECK_LAUNCH("zero_far_records_kernel", settings->debug, st);
+        }
         { ProfScope ps_(SCR_PROF_BLEND_BACKWARD, st);
           launch_blend_backward(ks, gv, bv, iv, dL_dcolor, (GradRec*)scratch, stamp, deep_lists(I, Grid(ks.H, ks.W).tiles),
                                 record_flags(I, Grid(ks.H, ks.W).tiles), (plan_flags & SCR_PLAN_NONFINITE_COLOUR) != 0, st); }
@@ -910,7 +914,8 @@ int scr_adam_step(int32_t n_tensors, const scr_adam_tensor* tensors, double beta
     for (int t = 0; t < n_tensors; ++t) {
         const scr_adam_tensor& x = tensors[t];
         if (x.numel < 0 || (x.numel > 0 && (!x.param || !x.grad || !x.exp_avg || !x.exp_avg_sq))) return fail("scr_adam_step: NULL tensor");
-        if (!(x.bias_correction1 > 0.0f) || !(x.bias_correction2_sqrt > 0.0f)) return fail("scr_adam_step: bias corrections must be > 0 (step >= 1)");
+        if (!(x.step_size >= 0.0) || !(x.step_size < 1e30) || !(x.bias_correction2_sqrt > 0.0))
+            return fail("scr_adam_step: step_size must be finite and >= 0, bias_correction2_sqrt > 0 (step >= 1)");
     }
     hipStream_t st = (hipStream_t)stream;
     if (launch_adam(n_tensors, tensors, beta1, beta2, eps, st)) return fail("scr_adam_step: more than 2^31 workgroups in one launch");

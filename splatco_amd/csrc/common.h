@@ -326,12 +326,19 @@ struct ZeroList {
     void* p[MAX];
     unsigned long long n[MAX];
     int count = 0;
-    void add(void* ptr, size_t bytes) {
-        if (ptr && bytes && count < MAX) { p[count] = ptr; n[count] = bytes; ++count; }
-    }
     bool full() const { return count >= MAX; }
+    // queue one buffer; a full list is launched first (on `st`) and restarted, so that no buffer is ever dropped
+    void add(void* ptr, size_t bytes, hipStream_t st);
 };
-void launch_zero(const ZeroList& z, hipStream_t st);
+void launch_zero(const ZeroList& z, hipStream_t st);      // launches nothing for an empty list
+void launch_zero_far_records(int64_t P, const GeomView& gv, GradRec* grad_rec, hipStream_t st);
+inline void ZeroList::add(void* ptr, size_t bytes, hipStream_t st) {
+    if (!ptr || !bytes) return;
+    if (full()) { launch_zero(*this, st); count = 0; }
+    p[count] = ptr;
+    n[count] = bytes;
+    ++count;
+}
 
 // launchers (defined in the .hip files)
 void launch_box_coords(int64_t V, const float* xyz, const float* lo, const float* hi, float* out, hipStream_t st);

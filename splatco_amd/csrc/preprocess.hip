@@ -266,10 +266,15 @@ preprocess_kernel(int64_t P, int M, const float* __restrict__ means3D, const flo
                 sh_to_rgb(ks.sh_degree, shs + (size_t)i * M * 3, dx / n, dy / n, dz / n, rgb, cb);
             }
             if (clamped) clamped[i] = cb;
-            // a colour that is not finite (NaN / Inf input): the blend kernels must keep it away from the pixels its splat
-            // does not contribute to -- the host launches their SAFE instantiations for this call (blend.hip)
-            if (nonfinite3(rgb[0], rgb[1], rgb[2])) atomicOr(plan_flags, (unsigned long long)SCR_PLAN_NONFINITE_COLOUR);
             tt = (uint32_t)((ft.rmaxx - ft.rminx) * (ft.rmaxy - ft.rminy));
+            // plan flags (rare; one atomic per wave that has something to report):
+            //  * a colour that is not finite (NaN / Inf input): the blend kernels must keep it away from the pixels its splat
+            //    does not contribute to -- the host launches their SAFE instantiations for this call (blend.hip)
+            //  * a rect of more than 32 tiles: the per-tile record verdicts of its tiles 32.. do not fit live_bits; the
+            //    backward zeroes those records first and sums them unconditionally (zero_far_records_kernel)
+            const unsigned long long w_nf = lanes(nonfinite3(rgb[0], rgb[1], rgb[2])), w_big = lanes(tt > 32u);
+            if ((w_nf | w_big) != 0ull && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
+                atomicOr(plan_flags, (unsigned long long)((w_nf ? SCR_PLAN_NONFINITE_COLOUR : 0) | (w_big ? SCR_PLAN_LARGE_RECTS : 0)));
             uint32_t rlo = (uint32_t)ft.rminx | ((uint32_t)ft.rminy << 16);
             uint32_t rhi = (uint32_t)ft.rmaxx | ((uint32_t)ft.rmaxy << 16);
             // blend-ready conic: A = -Qxx/2, B = -Qxy, C = -Qyy/2 (exact scalings of Q)
@@ -360,22 +365,14 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
         int tcx = rx0, tcy = (int)(rlo >> 16);      // tile of record k
         // An instance no quadrant of its tile can reach (quadrant mask 0: the splat's rect covers the tile, its ellipse at
         // the alpha >= 1/255 level does not -- a third of the instances at the benchmark density) has NO record: the blend
-        // backward skipped it.  The scatter kernel left the verdicts of the first 32 tiles of the walk in live_bits; for
-        // the rare larger rects the same test on the same record is repeated here (same function, same inputs, same
-        // compiler flags: bit for bit the same decision).
+        // backward skipped it.  The scatter kernel left the verdicts of the first 32 tiles of the walk in live_bits (the
+        // records of a larger rect's further tiles: see below).
         const uint32_t lbits = live_bits[i];
-        const float4 qa = rec[3 * i], qb = rec[3 * i + 1];
         uint32_t kwalk = 0;
         auto next_tile = [&](bool& live) {      // the first 32 tiles of the walk: a bit test, nothing that branches
             const int t = tcy * gxt + tcx;
             live = ((lbits >> (kwalk & 31u)) & 1u) != 0u;
             ++kwalk;
-            if (++tcx == rx1) { tcx = rx0; ++tcy; }
-            return t;
-        };
-        auto next_tile_far = [&](bool& live) {  // beyond them (rects of more than 32 tiles: rare): the test itself
-            const int t = tcy * gxt + tcx;
-            live = quadrant_mask(qa, qb, tcx * TILE, tcy * TILE) != 0u;
             if (++tcx == rx1) { tcx = rx0; ++tcy; }
             return t;
         };
@@ -425,12 +422,10 @@ preprocess_backward_kernel(int64_t P, int M, const float* __restrict__ means3D,
                 add(*SCR_PB_SRC(live, gr + k), live);
             }
         }
-        for (; k < n; ++k) {                // tiles 32.. of a large rect
-            bool live;
-            const int t = next_tile_far(live);
-            const unsigned long long ck = any_cut ? cut_key[t] : ~0ull;
-            if (live) add(gr[k], mykey < ck);
-        }
+        // tiles 32.. of a large rect: their records were zeroed before the blend backward ran (zero_far_records_kernel; the
+        // plan flag SCR_PLAN_LARGE_RECTS told the host) and are summed as they are -- no second evaluation of the blend
+        // backward's "does this instance get a record" decision that would have to agree with it bit for bit
+        for (; k < n; ++k) add(gr[k], true);
         // the per-splat constants the blend kernel left out.  The moments are of Y = opacity * G * dL/dalpha, i.e.
         // dL/dG already: dG/dmean = -G Q d with Q = (-2A, -B, -2C), dG/dQ = -G/2 d d^T (Qxy counted once: factor 1);
         // dL/dopacity = sum G dL/dalpha = (sum Y) / opacity -- a non-zero sum means some pixel passed
@@ -674,6 +669,29 @@ void launch_preprocess_backward(int64_t P, int M, const float* means3D, const fl
         P, M, means3D, scales, rotations, cov3D, shs, ks, radii, gv.tiles_touched, gv.point_offsets, gv.live_bits,
         deep ? gv.has_rec : nullptr, gv.clamped, gv.rec, grad_rec, cut_key, stamp, Grid(ks.H, ks.W).tiles, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh, dL_dopacity,
         dL_dscales, dL_drotations, dL_dcov3D);
+}
+
+// ---- gradient records 32.. of every Gaussian whose rect has more than 32 tiles: cleared before the blend backward writes
+// the ones it has something for.  One wave per 64 Gaussians; the (rare) large ones are cleared by the whole wave, 256 bytes
+// per store instruction.  Launched only when the plan reported SCR_PLAN_LARGE_RECTS.
+__global__ void __launch_bounds__(256) zero_far_records_kernel(int64_t P, const uint32_t* __restrict__ tiles_touched,
+                                                               const uint32_t* __restrict__ point_offsets, uint32_t* __restrict__ rec_words) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = i < P ? tiles_touched[i] : 0u;
+    const uint32_t end = (i < P && n > 32u) ? point_offsets[i] : 0u;      // inclusive scan: one past the Gaussian's last record
+    unsigned long long big = lanes(n > 32u);
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const uint32_t n_s = (uint32_t)__shfl((int)n, src, WAVE), end_s = (uint32_t)__shfl((int)end, src, WAVE);
+        const size_t w0 = (size_t)(end_s - n_s + 32u) * GRAD_F, w1 = (size_t)end_s * GRAD_F;      // dwords
+        for (size_t w = w0 + lane; w < w1; w += WAVE) rec_words[w] = 0u;
+    }
+}
+void launch_zero_far_records(int64_t P, const GeomView& gv, GradRec* grad_rec, hipStream_t st) {
+    if (P <= 0) return;
+    zero_far_records_kernel<<<nblk(P, 256), 256, 0, st>>>(P, gv.tiles_touched, gv.point_offsets, (uint32_t*)grad_rec);
 }
 
 // ---- ZeroList: blockIdx.y = buffer, blockIdx.x = 16 KB piece of it

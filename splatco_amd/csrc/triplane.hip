@@ -874,9 +874,9 @@ static int tp_backward(int64_t V, const float* coords, int cs, int R, int planes
         sc = tp_carve(pj, V, R * planes, sc);
         if (pj.tiles > TP_HIST_MAX_TILES) return 2;
         total += pj.tiles;
-        zl.add(pj.count, (size_t)pj.tiles * 4);
-        zl.add(gp0[q], (size_t)R * pj.A * pj.B * 4);
-        if (planes == 2) zl.add(gp1[q], (size_t)R * pj.A * pj.B * 4);
+        zl.add(pj.count, (size_t)pj.tiles * 4, st);
+        zl.add(gp0[q], (size_t)R * pj.A * pj.B * 4, st);
+        if (planes == 2) zl.add(gp1[q], (size_t)R * pj.A * pj.B * 4, st);
     }
     launch_zero(zl, st);
     for (int q = nproj; q < 3; ++q) ps.p[q] = ps.p[0];
@@ -960,8 +960,8 @@ int launch_triplane_backward_multi(int64_t V, const float* coords, int cs, int n
             pj.col0 = pj.col1 = col[g] + q * R[g];
             sc = tp_carve(pj, V, R[g], sc);
             total += pj.tiles;
-            zl.add(pj.count, (size_t)pj.tiles * 4);
-            zl.add(grad_planes[3 * g + q], (size_t)R[g] * pj.A * pj.B * 4);
+            zl.add(pj.count, (size_t)pj.tiles * 4, st);
+            zl.add(grad_planes[3 * g + q], (size_t)R[g] * pj.A * pj.B * 4, st);
         }
     }
     launch_zero(zl, st);

@@ -86,15 +86,28 @@ def expand_compact(neural_opacity, color, scale_rot, grid_offsets, grid_scaling,
 def visible_indices(mask):
     """mask.nonzero().squeeze(1) for a 1-D mask: the HIP op on the GPU, torch elsewhere.  The list is remembered on the
     mask tensor (with the version it was built from): a training step asks for it twice -- the gather of render() and the
-    densification statistics -- and each build is two kernels and a host read of the count."""
+    densification statistics -- and each build is two kernels and a host read of the count.
+    CONTRACT: the cache is keyed on the tensor's autograd version counter and storage address, so it follows every
+    in-place torch operation on the mask -- but NOT writes that bypass the counter: a kernel writing through data_ptr()
+    (e.g. scr_mark_visible into a reused buffer) or `mask.data[...] = ...`.  Masks handed to render() / training_statis
+    must therefore be fresh tensors (prefilter_voxel returns one per call) or be modified through torch operations only;
+    call `forget_indices(mask)` after rewriting one behind autograd's back."""
     if mask.is_cuda and mask.dim() == 1 and mask.dtype in (torch.bool, torch.uint8):
+        key = (mask._version, mask.data_ptr(), mask.shape[0])
         cached = getattr(mask, "_scr_index", None)
-        if cached is not None and cached[0] == mask._version:
+        if cached is not None and cached[0] == key:
             return cached[1]
         idx = mask_indices(mask)
-        mask._scr_index = (mask._version, idx)
+        mask._scr_index = (key, idx)
         return idx
     return mask.nonzero(as_tuple=False).squeeze(1)
+
+
+def forget_indices(mask):
+    """Drop the index list visible_indices() remembered on `mask` (after the mask's memory was rewritten without a torch
+    in-place operation)."""
+    if hasattr(mask, "_scr_index"):
+        del mask._scr_index
 
 
 def mask_indices(mask, inverse=True):

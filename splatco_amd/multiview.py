@@ -168,7 +168,8 @@ class GradArena:
     into a bucket and unpacking after the collective would copy that twice per step.  Here every p.grad is a view
     of the arena from the start: autograd accumulates into it in place (AccumulateGrad adds into an existing
     .grad), the collective runs on slices of the same memory, and the optimiser reads the reduced values where
-    they are.  Per step: zero() -> backward -> reduce() -> optimizer.step().
+    they are.  Per step: zero() -> ONE backward() -> reduce() -> optimizer.step().  (A gradient that arrives for a unit whose
+    exchange is already on the wire -- a second backward() in the same step -- raises instead of being silently left out.)
 
     The exchange is issued in UNITS: one per parameter (split into `chunk_bytes` pieces, every piece an independent
     collective that RCCL can spread over the xGMI links); the four per-anchor parameters written through the gradient
@@ -341,6 +342,11 @@ class GradArena:
                 self.views[i].copy_(param.grad)           # autograd replaced the tensor (never seen; kept correct)
                 param.grad = self.views[i]
             k = self._unit_of_param.get(i)
+            if k is not None and self._issued[k]:
+                # the unit's exchange is already on the wire: this accumulation would never reach the other ranks
+                raise RuntimeError("GradArena: a gradient arrived for a parameter whose exchange was already issued in this step -- "
+                                   "the arena expects ONE backward() per step (zero() -> backward -> reduce()); sum the views' losses "
+                                   "and call backward once, or build the arena with overlap=False")
             if k is not None and not self._ready[k]:
                 self._ready[k] = True
                 self._fire_log.append(k)
@@ -351,6 +357,9 @@ class GradArena:
         """anchor_gather's last backward of the step finished anchor range r (its kernel is queued on the current
         stream; the collective waits for it there)."""
         k = self._unit_of_range.get(r)
+        if k is not None and self._issued[k]:
+            raise RuntimeError("GradArena: an anchor range was reported final twice in one step (a second backward() after its "
+                               "exchange was issued): the arena expects ONE backward() per step")
         if k is not None and not self._ready[k]:
             self._ready[k] = True
             self._flush()

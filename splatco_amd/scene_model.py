@@ -678,7 +678,9 @@ class AnchorGaussianModel(nn.Module):
     def get_rotation(self):
         # normalize(_rotation), scene/gaussian_model.py:405-407.  The anchors' rotation never receives a gradient
         # (requires_grad False in the reference): the normalised copy is kept until the parameter is written or replaced
-        # instead of two passes over [N, 4] in every prefilter_voxel call
+        # instead of two passes over [N, 4] in every prefilter_voxel call.  "Written" = an in-place torch operation (the
+        # version counter moves) or a new tensor / storage; a write through `_rotation.data[...]` or a raw kernel is NOT
+        # seen -- assign `pc._rot_key = None` after one
         r = self._rotation
         key = (id(r), r._version, r.data_ptr(), tuple(r.shape))
         if getattr(self, "_rot_key", None) != key or r.requires_grad:

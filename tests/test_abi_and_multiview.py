@@ -214,6 +214,22 @@ for mode in ("all_reduce", "rs_ag"):
             assert torch.equal(eq[j].grad, torch.full((64,), w, dtype=torch.float64)), (mode, it, rank, j, eq[j].grad[:2])
     assert arena._order is not None
     arena.close()
+# ---- ONE backward per step: a second one whose gradients arrive after their unit's exchange went out must raise (it
+# used to be left out of the exchange silently)
+arena = GradArena(eq, chunk_bytes=256, mode="all_reduce", overlap=True)
+for it in range(3):
+    arena.zero()
+    sum(e.sum() for e in eq).backward()
+    if it == 2:                                              # the order is agreed: the hooks have issued every unit
+        assert arena._cursor == 3
+        try:
+            sum(e.sum() for e in eq).backward()
+            raised = False
+        except RuntimeError as e:
+            raised = "ONE backward" in str(e)
+        assert raised
+    arena.reduce()
+arena.close()
 for p in eq: p.grad = None
 # ---- the per-anchor exchange in anchor RANGES (the sink's units) equals the unchunked exchange bit for bit, whether the
 # ranges are reported during the step (rank 0) or only declared final by reduce() (rank 1), and in both collective shapes

@@ -168,9 +168,9 @@ def test_scr_adam_step_rejects_bad_arguments_without_a_gpu():
     assert lib.scr_adam_step(0, None, 0.9, 0.999, 1e-15, None) == 0              # nothing to do
     assert lib.scr_adam_step(1, None, 0.9, 0.999, 1e-15, None) != 0 and "NULL" in err()
     t = (_C.AdamTensor * 1)()
-    t[0].numel, t[0].lr, t[0].bias_correction1, t[0].bias_correction2_sqrt = 4, 1e-3, 0.1, 0.03
+    t[0].numel, t[0].step_size, t[0].bias_correction2_sqrt = 4, 1e-2, 0.03
     assert lib.scr_adam_step(1, t, 0.9, 0.999, 1e-15, None) != 0 and "NULL tensor" in err()
     t[0].param = t[0].grad = t[0].exp_avg = t[0].exp_avg_sq = 16                  # non-null: the checks below come first
     assert lib.scr_adam_step(1, t, 1.0, 0.999, 1e-15, None) != 0 and "beta" in err()
-    t[0].bias_correction1 = 0.0                                                   # step 0: no bias correction exists
+    t[0].step_size = float("inf")                                                 # step 0: lr / (1 - beta1^0) does not exist
     assert lib.scr_adam_step(1, t, 0.9, 0.999, 1e-15, None) != 0 and "bias" in err()

@@ -188,7 +188,7 @@ def test_forward_backward_colors_path(oracle, scene):
     assert np.array_equal(o["color"], o2["color"])
 
 
-@pytest.mark.parametrize("scene", ["cfg0_10k_400x400", "ragged_130x70", "opaque_pile", "merge_path_tile"])
+@pytest.mark.parametrize("scene", ["cfg0_10k_400x400", "ragged_130x70", "opaque_pile", "merge_path_tile", "large_rects"])
 def test_deep_list_variants_forced_on_small_scenes(oracle, scene):
     """The variants the library selects for deep tile lists (more than 8192 entries per tile on average: 20 M anchors) --
     the tile sort without the gm_index array, the blend backward deriving a record's place from gm_base, per-Gaussian
@@ -201,6 +201,14 @@ def test_deep_list_variants_forced_on_small_scenes(oracle, scene):
         cam, g = synthetic_camera(400, 400), synthetic_gaussians(10_000, 400, 400, 0)
     elif scene == "ragged_130x70":
         cam, g = synthetic_camera(130, 70), synthetic_gaussians(1500, 130, 70, 4)
+    elif scene == "large_rects":
+        # needles and discs whose tile rects hold hundreds of tiles (260 in the image), most of them out of reach of the
+        # alpha >= 1/255 ellipse: the per-tile record verdicts beyond a rect's first 32 tiles do not fit live_bits -- the
+        # plan reports SCR_PLAN_LARGE_RECTS, scr_backward clears those records and preprocess_backward sums them all
+        cam, g = synthetic_camera(320, 200), synthetic_gaussians(1200, 320, 200, 6)
+        big = rng.choice(1200, 300, replace=False)
+        g["scales"][big] *= rng.uniform(8, 40, (300, 1)).astype(np.float32) * np.array([[1.0, 0.08, 0.3]], np.float32)
+        g["opacities"][big] = rng.uniform(0.02, 0.6, (300, 1)).astype(np.float32)
     else:
         # many opaque splats over a few tiles: the pixels finish after a few dozen entries of lists of thousands, so most
         # rounds are cut and most Gaussians never get a record ("merge_path_tile": one tile beyond a sort chunk of 8192)
@@ -228,7 +236,17 @@ def test_deep_list_variants_forced_on_small_scenes(oracle, scene):
     assert np.array_equal(o["color"], base["color"]) and np.array_equal(o["point_list"], base["point_list"])
     for k in o["grads"]:
         assert np.array_equal(o["grads"][k], base["grads"][k]), k
-    if scene != "cfg0_10k_400x400" and scene != "ragged_130x70":
+    if scene == "large_rects":
+        from splatco_amd import rasterizer as R
+        t = lambda a: torch.tensor(a, device=_dev())
+        _, _, stt = R.rasterize_forward(R._CSettings(_settings(cam, g["bg"])), t(g["means3D"]), t(g["opacities"]), t(g["scales"]),
+                                        t(g["rotations"]), None, None, t(g["colors"]))
+        assert stt.flags & _C.PLAN_LARGE_RECTS
+        qm = stt.debug(_C.DBG_QMASK).cpu().numpy()
+        print(f"[deep] large_rects: {(f['tiles_touched'] > 32).sum()} Gaussians with more than 32 tiles (largest {f['tiles_touched'].max()}), "
+              f"{(qm == 0).mean():.0%} of the instances out of reach of every quadrant")
+        assert (f["tiles_touched"] > 32).sum() >= 100 and (qm == 0).mean() > 0.3
+    elif scene != "cfg0_10k_400x400" and scene != "ragged_130x70":
         tile_n = f["ranges"][:, 1].astype(np.int64) - f["ranges"][:, 0]
         assert tile_n.max() > (8192 if scene == "merge_path_tile" else 1024)
         never = (o["grads"]["opacities"][:, 0] == 0) & (f["radii"] > 0)
