@@ -202,13 +202,13 @@ def test_deep_list_variants_forced_on_small_scenes(oracle, scene):
     elif scene == "ragged_130x70":
         cam, g = synthetic_camera(130, 70), synthetic_gaussians(1500, 130, 70, 4)
     elif scene == "large_rects":
-        # needles and discs whose tile rects hold hundreds of tiles (260 in the image), most of them out of reach of the
+        # faint discs whose tile rects hold hundreds of tiles (260 in the image), most of them out of reach of the
         # alpha >= 1/255 ellipse: the per-tile record verdicts beyond a rect's first 32 tiles do not fit live_bits -- the
         # plan reports SCR_PLAN_LARGE_RECTS, scr_backward clears those records and preprocess_backward sums them all
         cam, g = synthetic_camera(320, 200), synthetic_gaussians(1200, 320, 200, 6)
         big = rng.choice(1200, 300, replace=False)
-        g["scales"][big] *= rng.uniform(8, 40, (300, 1)).astype(np.float32) * np.array([[1.0, 0.08, 0.3]], np.float32)
-        g["opacities"][big] = rng.uniform(0.02, 0.6, (300, 1)).astype(np.float32)
+        g["scales"][big] *= rng.uniform(8, 40, (300, 1)).astype(np.float32) * np.array([[1.0, 0.5, 0.7]], np.float32)
+        g["opacities"][big] = rng.uniform(0.01, 0.3, (300, 1)).astype(np.float32)     # faint: the reachable ellipse is a fraction of the 3-sigma rect
     else:
         # many opaque splats over a few tiles: the pixels finish after a few dozen entries of lists of thousands, so most
         # rounds are cut and most Gaussians never get a record ("merge_path_tile": one tile beyond a sort chunk of 8192)
