@@ -114,6 +114,8 @@ def launch_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if args.dry_run_ranks:      # every rank on device 0, gloo in RCCL's place: the call sequence is what is looked at
+        env.update(SPLATCO_BENCH_ONE_DEVICE="1", SPLATCO_BENCH_BACKEND="gloo")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     # the ranks get their own session = their own process group, so that a hang (a rank that died inside a collective
@@ -130,6 +132,70 @@ def launch_ranks(args):
             pass
         proc.wait()
         sys.exit(124)
+
+
+class CollectiveLog:
+    """--dry-run-ranks: every torch.distributed collective the step issues, in issue order, with its payload.  Installed by
+    replacing the module-level functions (the product calls them as dist.<name>), so what is logged is exactly what an RCCL
+    run would issue; the ranks of a dry run execute them over gloo on one device."""
+    NAMES = ("all_reduce", "reduce_scatter_tensor", "all_gather_into_tensor", "broadcast", "all_gather", "all_gather_object", "barrier")
+
+    def __init__(self):
+        self.log, self.on = [], False
+
+    def install(self):
+        import torch.distributed as dist
+        for name in self.NAMES:
+            inner = getattr(dist, name)
+
+            def wrapper(*a, __inner=inner, __name=name, **k):
+                if self.on:
+                    tens = [x for x in a if isinstance(x, torch.Tensor)] + [x for x in k.values() if isinstance(x, torch.Tensor)]
+                    big = max(tens, key=lambda t: t.numel()) if tens else None
+                    self.log.append({"collective": __name, "bytes": int(big.numel() * big.element_size()) if big is not None else 0,
+                                     "dtype": str(big.dtype).replace("torch.", "") if big is not None else None,
+                                     "async": bool(k.get("async_op", False)),
+                                     **({"src": k["src"]} if "src" in k else {})})
+                return __inner(*a, **k)
+            setattr(dist, name, wrapper)
+
+    def capture(self, fn):
+        self.log, self.on = [], True
+        try:
+            fn()
+        finally:
+            self.on = False
+        return list(self.log)
+
+
+DRY = None      # a CollectiveLog in --dry-run-ranks runs
+
+
+def dry_run_report(args, step, rank, world, dev, what):
+    """One step under the collective log; every rank's sequence must be the same (collectives are matched by issue order);
+    rank 0 prints it."""
+    import torch.distributed as dist
+    DRY.on = False
+    seq = DRY.capture(step)
+    torch.cuda.synchronize()
+    everyone = [None] * world
+    dist.all_gather_object(everyone, seq)
+    if rank != 0:
+        return
+    same = all(e == everyone[0] for e in everyone)
+    groups, out = [], []
+    for e in seq:                                            # run-length encode identical consecutive calls
+        if groups and {k: v for k, v in groups[-1].items() if k != "count"} == e:
+            groups[-1]["count"] += 1
+        else:
+            groups.append(dict(e, count=1))
+    print(json.dumps({
+        "dry_run_ranks": world, "status": "UNMEASURED ON HARDWARE: call sequence only (gloo on one device executes what RCCL would be handed)",
+        "what": what, "exchange": args.exchange, "optimizer": getattr(args, "optimizer", None),
+        "identical_on_all_ranks": same, "collectives_per_step": len(seq), "bytes_per_step": sum(e["bytes"] for e in seq),
+        "sequence": groups}), flush=True)
+    if not same:
+        raise SystemExit("bench.py --dry-run-ranks: the ranks issued DIFFERENT collective sequences")
 
 
 def make_view(rank, W, H):
@@ -445,6 +511,10 @@ def run_cfg1(args, rank, world, dev):
         state["radii"], state["img"] = radii, img
         return radii
 
+    if DRY is not None:
+        step()
+        dry_run_report(args, step, rank, world, dev, f"cfg1: {P} Gaussians, one view per rank, forward + backward + gradient exchange")
+        return None
     shapes_ms = None
     if world > 1 and dist.get_backend() == "nccl" and args.warmup:
         # which shape of the SUM exchange is faster on this machine's links is measured, not assumed: one all_reduce of the
@@ -614,13 +684,17 @@ def run_anchor_config(args, rank, world, dev):
         idle = {id(p) for p in pc.feat_planes._feat.inactive_parameters()}     # plane levels above activate_level: grad None in the reference
         rest = [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad and id(p) not in idle]
         groups.append({"params": rest, "lr": 1e-3, "name": "mlp_and_feat_planes"})
+        arena = GradArena([p for grp in groups for p in grp["params"]], mode=args.exchange)
         if args.optimizer == "hip":         # csrc/adam.hip: the reference's Adam(l, lr=0.0, eps=1e-15) as one streaming pass per group
             from splatco_amd.adam import FusedAdam
             opt = FusedAdam(groups, eps=1e-15)
+        elif args.optimizer == "sharded":   # the same update on this rank's 1/world of the parameters; the parameters are gathered
+            from splatco_amd.adam import ShardedFusedAdam
+            opt = ShardedFusedAdam(groups, arena, eps=1e-15)
         else:                               # torch's fused multi-tensor Adam, for comparison
             opt = torch.optim.Adam(groups, eps=1e-15, fused=True)
-        den = AnchorDensifier(pc, opt, seed=seed)
-        arena = GradArena([p for grp in groups for p in grp["params"]], mode=args.exchange)
+        # (the densifier only accumulates statistics here; its optimizer surgery is not exercised by the bench)
+        den = AnchorDensifier(pc, opt if args.optimizer != "sharded" else torch.optim.Adam(groups[:1], eps=1e-15), seed=seed)
 
         from splatco_amd.tv import TV_EVERY, TV_WEIGHT_A
 
@@ -645,6 +719,14 @@ def run_anchor_config(args, rank, world, dev):
             stats["P"], stats["V"] = out["radii"].shape[0], int(out["selection_mask"].numel() // pc.n_offsets)
             stats["rendered"] = out["radii"]
 
+    if DRY is not None:
+        step(); step()                                       # the first exchange agrees on the issue order; the second uses it
+        dry_run_report(args, step, rank, world, dev,
+                       f"{args.config}: {N} anchors, mv = {mv} views, one per rank: one full training step "
+                       f"(iteration {stats.get('iteration', 0) + 1}: {'with' if (stats.get('iteration', 0) + 1) % 4 == 0 else 'without'} the total-variation term)")
+        step(); step()
+        dry_run_report(args, step, rank, world, dev, f"{args.config}: the step of iteration {stats.get('iteration', 0) + 1}")
+        return None
     for w in range(args.warmup):
         if w == max(args.warmup - 2, 0):
             torch.cuda.synchronize()
@@ -738,8 +820,9 @@ def run_anchor_config(args, rank, world, dev):
                 mode=args.exchange, ms_all_reduce_pieces=ms_ar, ms_reduce_scatter_all_gather=ms_rs,
                 units=len(arena.units), anchor_ranges=len(arena.sink_ranges),
                 issue_order_agreed=arena._order is not None)
-            exposed = exposed_exchange(step, stats, args.steps, elapsed / args.steps * 1e3,
-                                       ms_ar if args.exchange == "all_reduce" else ms_rs, dev)
+            if args.optimizer != "sharded":      # (the sharded optimizer's parameter all-gather IS half of the exchange: it cannot be switched off)
+                exposed = exposed_exchange(step, stats, args.steps, elapsed / args.steps * 1e3,
+                                           ms_ar if args.exchange == "all_reduce" else ms_rs, dev)
     if rank != 0:
         return None
     step_s = elapsed / args.steps
@@ -778,7 +861,9 @@ def run_anchor_config(args, rank, world, dev):
                    "rendered_last_view": int((stats["rendered"] > 0).sum().item()),
                    "parallelism": f"{mv} view(s), 1 per GPU" + (", RCCL gradient exchange in place" if world > 1 else ""),
                    **({"optimizer": {"hip": "splatco_amd.adam.FusedAdam (csrc/adam.hip)",
-                                     "torch": "torch.optim.Adam(fused=True)"}[args.optimizer]} if train else {})},
+                                     "torch": "torch.optim.Adam(fused=True)",
+                                     "sharded": "splatco_amd.adam.ShardedFusedAdam (Adam and its moments / ranks; parameters all-gathered)"}[args.optimizer]}
+                      if train else {})},
         "iter_per_s": 1.0 / step_s,
         "stages": {
             "rasterizer_kernels_ms": {"forward": ras_f, "backward": ras_b},
@@ -854,8 +939,14 @@ def main():
                          "scene/gaussian_model.py:449) or as drawn (random in space: the stated worst case for every gather)")
     ap.add_argument("--exchange", choices=["all_reduce", "rs_ag"], default="all_reduce",
                     help="shape of the gradient exchange of cfg3/cfg4 (GradArena)")
-    ap.add_argument("--optimizer", choices=["hip", "torch"], default="hip",
-                    help="cfg3/cfg4: splatco_amd.adam.FusedAdam (csrc/adam.hip) or torch.optim.Adam(fused=True)")
+    ap.add_argument("--optimizer", choices=["hip", "torch", "sharded"], default="hip",
+                    help="cfg3/cfg4: splatco_amd.adam.FusedAdam (csrc/adam.hip), torch.optim.Adam(fused=True), or "
+                         "splatco_amd.adam.ShardedFusedAdam (needs --exchange rs_ag: reduce-scatter, Adam on 1/N of the parameters, "
+                         "all-gather of the parameters)")
+    ap.add_argument("--dry-run-ranks", action="store_true",
+                    help="with --gpus N: run the N ranks on ONE device over gloo, log every collective of one step (name, bytes, "
+                         "order), check that all ranks issue the same sequence and print it -- the sequence the first RCCL run "
+                         "can be diffed against.  No timing is reported.")
     ap.add_argument("--sigma-scale", type=float, default=1.0,
                     help="cfg1 developer sweep: multiply every screen-space sigma (sparser tile lists; the headline is 1.0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -868,6 +959,15 @@ def main():
     if args.warmup is None:
         args.warmup = 5 if args.config == "cfg1" else 3
 
+    if args.optimizer == "sharded" and args.exchange != "rs_ag":
+        raise SystemExit("bench.py: --optimizer sharded needs --exchange rs_ag")
+    if args.dry_run_ranks:
+        if args.gpus < 2:
+            raise SystemExit("bench.py: --dry-run-ranks needs --gpus N with N > 1")
+        if args.config != "cfg1" and not args.anchors:
+            args.anchors = 200_000                           # N ranks share one device
+            sys.argv += ["--anchors", "200000"]
+        args.steps, args.warmup = 1, 1
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)                                   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -892,6 +992,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        if args.dry_run_ranks:
+            global DRY
+            DRY = CollectiveLog()
+            DRY.install()
     if args.config == "cfg1":
         out = run_cfg1(args, rank, world, dev)
     else:

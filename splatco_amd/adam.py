@@ -73,3 +73,131 @@ class FusedAdam(torch.optim.Optimizer):
             for p in ps:                        # the update is queued for every tensor of the group: the step counts move together
                 self.state[p]["step"] += 1
         return loss
+
+
+def _adam_apply(entries, beta1, beta2, eps, device):
+    """entries: [(param slice, grad slice, exp_avg slice, exp_avg_sq slice, step_size, bias_correction2_sqrt)], flat fp32
+    device tensors of equal length -> ONE scr_adam_step call (the library launches in chunks of its table size)."""
+    table = (_C.AdamTensor * len(entries))()
+    for e, (p, g, m, v, step_size, bc2) in zip(table, entries):
+        if not (p.is_cuda and g.is_cuda and m.is_cuda and v.is_cuda):
+            raise ValueError("ShardedFusedAdam: parameters, gradients and moments must live on the GPU (no CPU path)")
+        e.param, e.grad, e.exp_avg, e.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+        e.numel, e.step_size, e.bias_correction2_sqrt = p.numel(), step_size, bc2
+    with torch.cuda.device(device):
+        _C.check(_C.lib.scr_adam_step(len(entries), table, beta1, beta2, eps, torch.cuda.current_stream(device).cuda_stream))
+
+
+class ShardedFusedAdam:
+    """The reference's Adam (torch.optim.Adam(l, lr=0.0, eps=1e-15), scene/gaussian_model.py:575) with its WORK and its
+    MOMENTS divided by the number of ranks, for the sharded multi-view step (BASELINE.json configs[3] / configs[4]).
+
+    The replicated step sums the gradients over the ranks (reduce-scatter + all-gather on the xGMI mesh) and then runs the
+    same Adam over all parameters on every rank: at 20 M anchors 40 GB of optimizer traffic and 11.4 GB of moments per GPU,
+    eight times over.  Here the exchange stops after the reduce-scatter (multiview.GradArena.reduce(gather=False)): every
+    rank holds the summed gradient of its owned slices -- 1/world of every exchange piece --, runs scr_adam_step on exactly
+    those slices of the PARAMETERS (which live in one flat buffer with the arena's layout), and the all-gather that would
+    have completed the gradients distributes the updated parameters instead.  Same bytes on the wire, Adam / world,
+    moments / world.  Adam is elementwise, so the result is the replicated step's, bit for bit.
+
+    Parameter groups as torch's: [{"params": [...], "lr": ...}, ...]; lr may be changed between steps through
+    .param_groups (the reference's schedulers do).  The parameters must be exactly the arena's.  Not a torch.optim.Optimizer:
+    the moments are flat per-rank shards; full_state() / load_full_state() convert to and from per-parameter tensors in
+    torch.optim.Adam's layout (all-gather), which is how densification's optimizer surgery and checkpoints reach them."""
+
+    def __init__(self, param_groups, arena, betas=(0.9, 0.999), eps=1e-15):
+        import torch.distributed as dist
+        if arena.mode != "rs_ag":
+            raise ValueError("ShardedFusedAdam needs a GradArena in mode 'rs_ag' (the exchange it splits)")
+        self.arena, self.betas, self.eps = arena, (float(betas[0]), float(betas[1])), float(eps)
+        self.param_groups = [dict(g) for g in param_groups]
+        ids = {id(p): i for i, p in enumerate(arena.params)}
+        self._group_of = {}
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                if id(p) not in ids:
+                    raise ValueError("ShardedFusedAdam: a parameter of the groups is not in the arena")
+                self._group_of[ids[id(p)]] = gi
+        if len(self._group_of) != len(arena.params):
+            raise ValueError("ShardedFusedAdam: the groups must cover exactly the arena's parameters")
+        self.world = arena.world
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        # parameters move into ONE flat buffer with the arena's layout (p.data becomes a view of it)
+        self.pflat = torch.zeros_like(arena.flat)
+        for p, o in zip(arena.params, arena.offsets):
+            view = self.pflat[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+        self.slices = arena.owned_slices()
+        self._state_off, total = [], 0
+        for _, a, b in self.slices:
+            self._state_off.append(total)
+            total += b - a
+        self.exp_avg = torch.zeros(total, dtype=self.pflat.dtype, device=self.pflat.device)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+        self.steps = [0] * len(arena.params)
+
+    def nbytes_state(self):
+        return 2 * self.exp_avg.numel() * self.exp_avg.element_size()
+
+    @torch.no_grad()
+    def step(self):
+        """After arena.reduce(gather=False): update this rank's slices, then all-gather the parameters."""
+        import torch.distributed as dist
+        b1, b2 = self.betas
+        flat, entries = self.arena.flat, []
+        for (i, a, b), so in zip(self.slices, self._state_off):
+            if b <= a:
+                continue
+            t = self.steps[i] + 1
+            lr = float(self.param_groups[self._group_of[i]]["lr"])
+            entries.append((self.pflat[a:b], flat[a:b], self.exp_avg[so:so + b - a], self.exp_avg_sq[so:so + b - a],
+                            lr / (1.0 - b1 ** t), math.sqrt(1.0 - b2 ** t)))
+        if entries:
+            _adam_apply(entries, b1, b2, self.eps, self.pflat.device)
+        for i in range(len(self.steps)):
+            self.steps[i] += 1
+        if self.world > 1:
+            work = []
+            for pieces in self.arena.unit_pieces:
+                for a, b in pieces:
+                    n = (b - a) // self.world
+                    work.append(dist.all_gather_into_tensor(self.pflat[a:b], self.pflat[a + self.rank * n:a + (self.rank + 1) * n],
+                                                            async_op=True))
+            for w in work:
+                w.wait()
+
+    def zero_grad(self, set_to_none=True):
+        """The arena owns the gradients (GradArena.zero() starts a step)."""
+
+    # ---- conversion to / from torch.optim.Adam's per-parameter state (densification surgery, checkpoints)
+    @torch.no_grad()
+    def full_state(self):
+        """{parameter index: {"step", "exp_avg", "exp_avg_sq"}} with full-size moments, identical on every rank."""
+        import torch.distributed as dist
+        full_m, full_v = torch.zeros_like(self.pflat), torch.zeros_like(self.pflat)
+        for (i, a, b), so in zip(self.slices, self._state_off):
+            full_m[a:b] = self.exp_avg[so:so + b - a]
+            full_v[a:b] = self.exp_avg_sq[so:so + b - a]
+        if self.world > 1:
+            dist.all_reduce(full_m)          # the ranks' slices are disjoint: the sum assembles them
+            dist.all_reduce(full_v)
+        out = {}
+        for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+            out[i] = {"step": torch.tensor(float(self.steps[i])), "exp_avg": full_m[o:o + p.numel()].view_as(p).clone(),
+                      "exp_avg_sq": full_v[o:o + p.numel()].view_as(p).clone()}
+        return out
+
+    @torch.no_grad()
+    def load_full_state(self, state):
+        """Inverse of full_state(): keep this rank's slices of full-size moments."""
+        for i, st in state.items():
+            self.steps[i] = int(float(st["step"]))
+        for (i, a, b), so in zip(self.slices, self._state_off):
+            if i in state and b > a:
+                o = self.arena.offsets[i]
+                n = self.arena.params[i].numel()
+                lo, hi = max(a, o), min(b, o + n)          # the slice may reach into the parameter's padding
+                if hi > lo:
+                    self.exp_avg[so + lo - a:so + hi - a] = state[i]["exp_avg"].reshape(-1)[lo - o:hi - o]
+                    self.exp_avg_sq[so + lo - a:so + hi - a] = state[i]["exp_avg_sq"].reshape(-1)[lo - o:hi - o]

@@ -225,11 +225,12 @@ class GradArena:
         range of the sink.  Every quantity here depends on shapes only, so all ranks build the same table."""
         align = self.align
         padded = lambda p: (p.numel() + align - 1) // align * align
-        self.units, self.unit_pieces, self.sink_ranges = [], [], []
+        self.units, self.unit_pieces, self.unit_piece_param, self.sink_ranges = [], [], [], []
         for i, (o, p) in enumerate(zip(self.offsets, self.params)):
             if i not in self._sink_ids:
                 self.units.append(("p", i))
                 self.unit_pieces.append(self._split(o, o + padded(p)))
+                self.unit_piece_param.append([i] * len(self.unit_pieces[-1]))
         if self._sink_ids:
             N = self.params[self._sink_ids[0]].shape[0]
             step = -(-N // self.anchor_ranges)
@@ -239,14 +240,17 @@ class GradArena:
                 self.sink_ranges.append((n0, min(N, n0 + step)))
                 n0 += step
             for r, (n0, n1) in enumerate(self.sink_ranges):
-                pieces = []
+                pieces, owners = [], []
                 for i in self._sink_ids:
                     p, o = self.params[i], self.offsets[i]
                     w = p.numel() // max(N, 1)
                     end = o + padded(p) if n1 == N else o + n1 * w     # the last range takes the parameter's padding
-                    pieces += self._split(o + n0 * w, end)
+                    part = self._split(o + n0 * w, end)
+                    pieces += part
+                    owners += [i] * len(part)
                 self.units.append(("s", r))
                 self.unit_pieces.append(pieces)
+                self.unit_piece_param.append(owners)
         self._unit_of_param = {u[1]: k for k, u in enumerate(self.units) if u[0] == "p"}
         self._unit_of_range = {u[1]: k for k, u in enumerate(self.units) if u[0] == "s"}
         self._order = None                                   # agreed issue order (unit numbers); None until agreed
@@ -261,6 +265,18 @@ class GradArena:
     def pieces(self):
         """Per unit: [(start, stop)] of its collectives in the flat buffer."""
         return self.unit_pieces
+
+    def owned_slices(self):
+        """[(parameter index, start, stop)] of the flat buffer this rank OWNS in mode "rs_ag": its 1/world of every piece, i.e.
+        where reduce(gather=False) leaves the summed gradient (the whole piece when there is one rank).  A function of the
+        shapes, the world size and the rank only -- the layout adam.ShardedFusedAdam keeps its moments in."""
+        rank = dist.get_rank() if self.world > 1 else 0
+        out = []
+        for pieces, owners in zip(self.unit_pieces, self.unit_piece_param):
+            for (a, b), i in zip(pieces, owners):
+                n = (b - a) // self.world
+                out.append((i, a + rank * n, a + (rank + 1) * n))
+        return out
 
     def bind(self):
         for p, v in zip(self.params, self.views):
@@ -383,10 +399,15 @@ class GradArena:
         silent = [k for k in range(n) if not flags[k] and pos[k] >= n]
         self._order = fired + [k for k in range(n) if flags[k]] + silent
 
-    def reduce(self):
+    def reduce(self, gather=True):
         """SUM over ranks of everything in the arena; returns when the reduced gradients are usable on the current
         stream.  Units that were not issued during the backward pass (no gradient on this rank: zeros; or behind one
-        that was not ready) are exchanged now, in the agreed order."""
+        that was not ready) are exchanged now, in the agreed order.
+        gather=False (mode "rs_ag" only): stop after the reduce-scatter phase -- every rank then holds the summed gradient
+        of its owned_slices() and nothing usable elsewhere; the optimizer updates those slices of the PARAMETERS and
+        all-gathers the parameters instead of the gradients (adam.ShardedFusedAdam: Adam's work and moments / world)."""
+        if not gather and self.mode != "rs_ag":
+            raise ValueError("GradArena.reduce(gather=False) needs mode='rs_ag'")
         self._settle_sink()
         if self.world > 1:
             order = self._order if self._order is not None else list(range(len(self.units)))
@@ -396,7 +417,7 @@ class GradArena:
             self._cursor = len(order)
             for w in self._work:
                 w.wait()
-            self._work = [dist.all_gather_into_tensor(piece, mine, async_op=True) for piece, mine in self._pending]
+            self._work = [dist.all_gather_into_tensor(piece, mine, async_op=True) for piece, mine in self._pending] if gather else []
             for w in self._work:
                 w.wait()
             self._work, self._pending = [], []

@@ -65,6 +65,10 @@ def collaborative_step(pc, views, gt_images, pipe, bg_color, optimizer=None, buc
     opt.tv_weight_a = 4e-7) and `iteration % 4 == 0` its gradient is added into the plane gradients AFTER the exchange,
     identically on every rank: the term is a function of the parameters alone, so adding it before the SUM would count it
     once per rank.  (The reference also waits for gaussians.enable_net, which is True from iteration 1 on.)
+    optimizer: anything with .step() -- torch.optim.Adam, adam.FusedAdam, or adam.ShardedFusedAdam (Adam's work and moments
+    divided by the number of ranks; needs the arena in mode "rs_ag").  With the sharded optimizer the gradients in the arena
+    are complete on the owning rank only; the total-variation term is added over whole planes on every rank, which gives
+    every owned slice its term exactly once.
     Returns (local loss sum, last render dict, bucket or arena buffer)."""
     params = arena.params if arena is not None else [p for p in pc.parameters() if p.requires_grad]
     if arena is not None:
@@ -104,8 +108,14 @@ def collaborative_step(pc, views, gt_images, pipe, bg_color, optimizer=None, buc
             total.backward()
     finally:
         pc._grad_sink = None
+    from .adam import ShardedFusedAdam
+    sharded = isinstance(optimizer, ShardedFusedAdam)
+    if sharded and optimizer.arena is not arena:
+        raise ValueError("collaborative_step: the ShardedFusedAdam was built on another GradArena")
     if arena is not None:
-        bucket = arena.reduce()
+        # sharded optimizer: the exchange stops after the reduce-scatter; only this rank's slices of the arena hold the
+        # summed gradient (the optimizer's all-gather distributes the updated PARAMETERS instead)
+        bucket = arena.reduce(gather=not sharded)
     else:
         bucket = allreduce_gradients(params, bucket)
     if tv_weight and iteration is not None and tv_due(iteration):

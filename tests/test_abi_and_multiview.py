@@ -231,6 +231,59 @@ for it in range(3):
     arena.reduce()
 arena.close()
 for p in eq: p.grad = None
+# ---- optimiser-state sharding: reduce-scatter -> Adam on this rank's 1/world of every piece of a PARAMETER arena ->
+# all-gather of the parameters.  Same parameters as the replicated step (all-reduce, Adam over everything on every rank)
+# after three iterations: bit for bit with two ranks (a + b in either order); beyond two the collective's own summation
+# order may differ between the two exchanges
+import math as _math
+import splatco_amd.adam as adam_mod
+from torch_restatements import adam_apply_torch
+adam_mod._adam_apply = adam_apply_torch                       # CPU stand-in of csrc/adam.hip (the product has no CPU path)
+def fresh():
+    gen = torch.Generator().manual_seed(123)
+    shapes = ((257, 3), (64, 32), (5,), (1000, 6), (33,))     # lengths the world size does not divide: padding inside pieces
+    return [torch.randn(*sh, generator=gen, dtype=torch.float32).requires_grad_(True) for sh in shapes]
+def loss_of(ps, view):
+    return sum(((p * (1.0 + 0.1 * view.uid)) ** 2).sum() * (j + 1) * 1e-2 + (p * (view.uid + 1)).sum() * 1e-3 for j, p in enumerate(ps))
+pa, pb = fresh(), fresh()
+lrs = (1e-2, 3e-3, 1e-1, 2e-3, 5e-2)
+arena_a = GradArena(pa, chunk_bytes=1024, mode="rs_ag", overlap=True)
+opt_a = adam_mod.ShardedFusedAdam([{"params": [p], "lr": lr} for p, lr in zip(pa, lrs)], arena_a, eps=1e-15)
+assert all(p.data_ptr() == opt_a.pflat[o:].data_ptr() for p, o in zip(pa, arena_a.offsets))      # the parameters moved into the flat buffer
+assert opt_a.exp_avg.numel() * world == arena_a.flat.numel()                                     # moments / world
+arena_b = GradArena(pb, chunk_bytes=1024, mode="all_reduce", overlap=True)
+m_b, v_b = [torch.zeros_like(p) for p in pb], [torch.zeros_like(p) for p in pb]
+for it in range(1, 4):
+    # (one arena per backward pass: collectives are matched by issue order, and a rank without views issues everything
+    # from reduce() -- two arenas fed by ONE backward would interleave differently on the ranks that do render)
+    for arena_x, ps in ((arena_a, pa), (arena_b, pb)):
+        arena_x.zero()
+        lx = None
+        for v in shard_views(views):
+            l = loss_of(ps, v)
+            lx = l if lx is None else lx + l
+        if lx is not None:
+            lx.backward()
+        if arena_x is arena_a:
+            arena_a.reduce(gather=False)
+            opt_a.step()
+        else:
+            arena_b.reduce()
+    adam_apply_torch([(p.data, p.grad, m, v_, lr / (1.0 - 0.9 ** it), _math.sqrt(1.0 - 0.999 ** it))
+                      for p, m, v_, lr in zip(pb, m_b, v_b, lrs)], 0.9, 0.999, 1e-15)
+    if it == 2:
+        opt_a.param_groups[0]["lr"] = lrs[0] * 0.5            # a scheduler moves a group's learning rate
+        lrs = (lrs[0] * 0.5,) + lrs[1:]
+full = opt_a.full_state()
+for i, (m, v_) in enumerate(zip(m_b, v_b)):
+    ok = (torch.equal if world == 2 else (lambda x, y: torch.allclose(x, y, rtol=1e-5, atol=1e-8)))
+    assert ok(pa[i].data, pb[i].data), ("parameters", i, world, (pa[i].data - pb[i].data).abs().max())
+    assert ok(full[i]["exp_avg"], m) and ok(full[i]["exp_avg_sq"], v_) and float(full[i]["step"]) == 3.0, ("moments", i)
+# round trip of the sharded moments through torch.optim.Adam's per-parameter layout
+opt_a2 = adam_mod.ShardedFusedAdam([{"params": [p], "lr": lr} for p, lr in zip(pa, lrs)], arena_a, eps=1e-15)
+opt_a2.load_full_state(full)
+assert torch.equal(opt_a2.exp_avg, opt_a.exp_avg) and torch.equal(opt_a2.exp_avg_sq, opt_a.exp_avg_sq) and opt_a2.steps == opt_a.steps
+arena_a.close(); arena_b.close()
 # ---- the per-anchor exchange in anchor RANGES (the sink's units) equals the unchunked exchange bit for bit, whether the
 # ranges are reported during the step (rank 0) or only declared final by reduce() (rank 1), and in both collective shapes
 Na = 1000

@@ -42,7 +42,7 @@ dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
 bg = torch.ones(3, device=dev)
-W, H, N, MV = 640, 360, 200_000, 4
+W, H, N, MV = 640, 360, 200_000, int(sys.argv[3])
 TVW = 1e-3          # the reference's 4e-7 would vanish next to this scene's plane gradients: the test wants the term visible
 views = [v.to(dev) for v in synthetic_views(MV, W, H)]
 g = torch.Generator(device=dev).manual_seed(5)
@@ -58,7 +58,7 @@ def make():
     groups.append({"params": rest, "lr": 1e-3, "name": "mlp_and_feat_planes"})
     opt = torch.optim.Adam(groups, eps=1e-15)
     den = AnchorDensifier(pc, opt, voxel_size=0.01, seed=77)
-    return pc, [p for grp in groups for p in grp["params"]], den
+    return pc, [p for grp in groups for p in grp["params"]], den, groups
 
 
 def sequential(pc, params, den, cw):
@@ -103,8 +103,8 @@ def rel(a, b):
 
 
 for mode, cw in (("all_reduce", 0.05), ("rs_ag", 0.0))[:int(sys.argv[2])]:
-    pc_a, params_a, den_a = make()
-    pc_b, params_b, den_b = make()
+    pc_a, params_a, den_a, _ = make()
+    pc_b, params_b, den_b, _ = make()
     assert all(torch.equal(a, b) for a, b in zip(params_a, params_b))
     arena = GradArena(params_a, chunk_bytes=4 << 20, mode=mode, anchor_ranges=4)       # several pieces per large parameter
     for it in range(2):         # step 0 goes out from reduce() and agrees on the order; step 1 issues from the hooks / ranges
@@ -156,22 +156,53 @@ for mode, cw in (("all_reduce", 0.05), ("rs_ag", 0.0))[:int(sys.argv[2])]:
         assert pc_b._anchor.shape[0] == n_new and torch.equal(pc_a._anchor, pc_b._anchor) and torch.equal(pc_a._offset, pc_b._offset)
     print(f"[rank {rank}] {mode} consistency {cw}: worst gradient rel-L2 {worst:.2e}, anchors {N} -> {n_new}", flush=True)
     arena.close()
+if int(sys.argv[2]) >= 2:
+    # ---- optimiser-state sharding (adam.ShardedFusedAdam: reduce-scatter -> scr_adam_step on this rank's 1/world of every
+    # piece of the parameter arena -> all-gather of the parameters) against the replicated step (all-reduce, FusedAdam over
+    # everything on every rank): the same parameters after three full training steps with the total-variation term
+    from splatco_amd.adam import FusedAdam, ShardedFusedAdam
+    pc_c, params_c, _, groups_c = make()
+    pc_d, params_d, _, groups_d = make()
+    arena_c = GradArena(params_c, chunk_bytes=4 << 20, mode="rs_ag", anchor_ranges=4)
+    opt_c = ShardedFusedAdam(groups_c, arena_c, eps=1e-15)
+    arena_d = GradArena(params_d, chunk_bytes=4 << 20, mode="all_reduce", anchor_ranges=4)
+    opt_d = FusedAdam(groups_d, eps=1e-15)
+    assert opt_c.nbytes_state() * world == 2 * arena_c.nbytes()
+    for it in range(3):
+        for pc_x, opt_x, arena_x in ((pc_c, opt_c, arena_c), (pc_d, opt_d, arena_d)):
+            collaborative_step(pc_x, views, gts, pipe, bg, optimizer=opt_x, arena=arena_x, iteration=4 * (it + 1), tv_weight=TVW)
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(params_c, params_d)):
+        assert a.data_ptr() != b.data_ptr()
+        if world == 2:
+            assert torch.equal(a, b), ("sharded optimizer vs replicated", i, tuple(a.shape), rel(a, b))      # a + b either way
+        else:
+            worst = max(worst, rel(a, b))
+            assert rel(a, b) <= 1e-6, (i, rel(a, b))
+    full = opt_c.full_state()
+    st_d = opt_d.state[params_d[0]]
+    assert torch.equal(full[0]["exp_avg"], st_d["exp_avg"]) or world != 2
+    print(f"[rank {rank}] sharded optimizer: parameters equal the replicated step's after 3 steps (moments {opt_c.nbytes_state() >> 20} MiB per rank "
+          f"instead of {2 * arena_c.nbytes() >> 20})", flush=True)
+    arena_c.close(); arena_d.close()
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_step_equals_the_sequential_loop_on_the_hip_path(tmp_path, world):
-    """world 2: two views per rank (the gather's backward overwrites for the first view and adds for the second);
-    world 4: one view per rank, every consistency pair crosses ranks."""
+    """world 2: two views per rank (the gather's backward overwrites for the first view and adds for the second), both
+    exchange shapes, then the sharded optimizer against the replicated one; world 4: one view per rank, every consistency
+    pair crosses ranks; world 8 (the node of configs[4]): eight views, one per rank, eight processes on the one device."""
     script = tmp_path / "sharded_worker.py"
     script.write_text(SHARDED_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                         "--master-addr", "127.0.0.1", "--master-port", str(29639 + world), str(script), ROOT,
-                        "2" if world == 2 else "1"],               # world 4 runs the all_reduce + consistency case only
+                        "2" if world == 2 else "1",                # world 4 / 8 run the all_reduce + consistency case only
+                        "8" if world == 8 else "4"],
                        capture_output=True, text=True, env=env, timeout=1500)
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]

@@ -5,6 +5,7 @@ from the reference's own Python): nothing under splatco_amd/ imports this file.
   expand_torch_chain     gaussian_renderer/__init__.py:68-111   -> checker of csrc/expand.hip
   training_statis_torch  scene/gaussian_model.py:761-782        -> checker of csrc/densify.hip
   tv_add_grad_torch      scene/grids.py:240-250 (closed form)   -> checker of csrc/tv.hip, CPU stand-in in the gloo tests
+  adam_apply_torch       torch.optim.Adam's update (no decay)   -> CPU stand-in of csrc/adam.hip in the gloo tests
 """
 import torch
 import torch.nn.functional as F
@@ -79,3 +80,13 @@ def tv_add_grad_torch(entries):
                 g.narrow(dim, 1, n - 1).add_(h)
                 g.narrow(dim, 0, n - 1).sub_(h)
             p.grad = g if p.grad is None else p.grad.add_(g)
+
+
+def adam_apply_torch(entries, beta1, beta2, eps, device=None):
+    """CPU stand-in of splatco_amd.adam._adam_apply (csrc/adam.hip): the same elementwise update on every
+    (param, grad, exp_avg, exp_avg_sq, step_size, bias_correction2_sqrt) entry, in the tensors' own dtype."""
+    with torch.no_grad():
+        for p, g, m, v, step_size, bc2 in entries:
+            m.add_((g - m) * (1.0 - beta1))
+            v.mul_(beta2).add_(((1.0 - beta2) * g) * g)
+            p.sub_(step_size * (m / (v.sqrt() / bc2 + eps)))
