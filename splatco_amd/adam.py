@@ -128,14 +128,26 @@ class ShardedFusedAdam:
             view = self.pflat[o:o + p.numel()].view_as(p)
             view.copy_(p.data)
             p.data = view
+        self.steps = [0] * len(arena.params)
+        self._shard()
+
+    def _shard(self):
+        """(Re)build this rank's slice table and moment shards for the arena's CURRENT unit table.  The table changes when a
+        gradient sink is attached or detached (GradArena.attach_sink: per-anchor parameters are then exchanged in anchor
+        ranges); moments that already hold history are carried over through the per-parameter layout (a collective: every rank
+        gets here at the same point of the same program)."""
+        carried = self.full_state() if getattr(self, "slices", None) is not None and any(self.steps) else None
+        arena = self.arena
         self.slices = arena.owned_slices()
+        self._layout_seen = arena.layout_version
         self._state_off, total = [], 0
         for _, a, b in self.slices:
             self._state_off.append(total)
             total += b - a
         self.exp_avg = torch.zeros(total, dtype=self.pflat.dtype, device=self.pflat.device)
         self.exp_avg_sq = torch.zeros_like(self.exp_avg)
-        self.steps = [0] * len(arena.params)
+        if carried is not None:
+            self.load_full_state(carried)
 
     def nbytes_state(self):
         return 2 * self.exp_avg.numel() * self.exp_avg.element_size()
@@ -144,6 +156,8 @@ class ShardedFusedAdam:
     def step(self):
         """After arena.reduce(gather=False): update this rank's slices, then all-gather the parameters."""
         import torch.distributed as dist
+        if self._layout_seen != self.arena.layout_version:
+            self._shard()
         b1, b2 = self.betas
         flat, entries = self.arena.flat, []
         for (i, a, b), so in zip(self.slices, self._state_off):

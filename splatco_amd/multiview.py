@@ -251,6 +251,7 @@ class GradArena:
                 self.units.append(("s", r))
                 self.unit_pieces.append(pieces)
                 self.unit_piece_param.append(owners)
+        self.layout_version = getattr(self, "layout_version", 0) + 1      # owned_slices() changed (adam.ShardedFusedAdam follows it)
         self._unit_of_param = {u[1]: k for k, u in enumerate(self.units) if u[0] == "p"}
         self._unit_of_range = {u[1]: k for k, u in enumerate(self.units) if u[0] == "s"}
         self._order = None                                   # agreed issue order (unit numbers); None until agreed

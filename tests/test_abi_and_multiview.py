@@ -241,12 +241,13 @@ from torch_restatements import adam_apply_torch
 adam_mod._adam_apply = adam_apply_torch                       # CPU stand-in of csrc/adam.hip (the product has no CPU path)
 def fresh():
     gen = torch.Generator().manual_seed(123)
-    shapes = ((257, 3), (64, 32), (5,), (1000, 6), (33,))     # lengths the world size does not divide: padding inside pieces
+    shapes = ((300, 32), (300, 3), (300, 30), (300, 6), (64, 32), (5,), (33,))     # four per-anchor tensors; lengths the world size does not divide
     return [torch.randn(*sh, generator=gen, dtype=torch.float32).requires_grad_(True) for sh in shapes]
 def loss_of(ps, view):
     return sum(((p * (1.0 + 0.1 * view.uid)) ** 2).sum() * (j + 1) * 1e-2 + (p * (view.uid + 1)).sum() * 1e-3 for j, p in enumerate(ps))
 pa, pb = fresh(), fresh()
-lrs = (1e-2, 3e-3, 1e-1, 2e-3, 5e-2)
+lrs = (1e-2, 3e-3, 1e-1, 2e-3, 5e-2, 7e-3, 2e-2)
+sink_a = None
 arena_a = GradArena(pa, chunk_bytes=1024, mode="rs_ag", overlap=True)
 opt_a = adam_mod.ShardedFusedAdam([{"params": [p], "lr": lr} for p, lr in zip(pa, lrs)], arena_a, eps=1e-15)
 assert all(p.data_ptr() == opt_a.pflat[o:].data_ptr() for p, o in zip(pa, arena_a.offsets))      # the parameters moved into the flat buffer
@@ -258,6 +259,10 @@ for it in range(1, 4):
     # from reduce() -- two arenas fed by ONE backward would interleave differently on the ranks that do render)
     for arena_x, ps in ((arena_a, pa), (arena_b, pb)):
         arena_x.zero()
+        if arena_x is arena_a and sink_a is not None:        # what the gather's backward kernel does for the sink's tensors:
+            for t_ in sink_a.tensors:                        # the first write of a step overwrites (here: clear, autograd adds)
+                t_.zero_()
+            sink_a.fresh = False
         lx = None
         for v in shard_views(views):
             l = loss_of(ps, v)
@@ -271,6 +276,11 @@ for it in range(1, 4):
             arena_b.reduce()
     adam_apply_torch([(p.data, p.grad, m, v_, lr / (1.0 - 0.9 ** it), _math.sqrt(1.0 - 0.999 ** it))
                       for p, m, v_, lr in zip(pb, m_b, v_b, lrs)], 0.9, 0.999, 1e-15)
+    if it == 1:
+        # the arena's unit table changes under the optimizer (a gradient sink makes the [N, .] parameters travel in anchor
+        # ranges): the moment shards follow, history included
+        sink_a = arena_a.attach_sink(pa[:4])
+        assert sink_a is not None and opt_a._layout_seen != arena_a.layout_version
     if it == 2:
         opt_a.param_groups[0]["lr"] = lrs[0] * 0.5            # a scheduler moves a group's learning rate
         lrs = (lrs[0] * 0.5,) + lrs[1:]
