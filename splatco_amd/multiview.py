@@ -172,7 +172,7 @@ class GradArena:
     exchange is already on the wire -- a second backward() in the same step -- raises instead of being silently left out.)
 
     The exchange is issued in UNITS: one per parameter (split into `chunk_bytes` pieces, every piece an independent
-    collective that RCCL can spread over the xGMI links); the four per-anchor parameters written through the gradient
+    collective that RCCL can spread over the xGMI links), consecutive small parameters sharing one; the four per-anchor parameters written through the gradient
     sink (see sink()) form `anchor_ranges` units instead, one per range of anchors, each holding that range's slice of
     all four.  A unit becomes READY when its gradient is final on this rank -- a parameter's post-accumulate hook, or
     the sink's per-range callback from the last anchor-gather backward of the step -- and reduce() declares the rest
@@ -187,8 +187,10 @@ class GradArena:
     of the sum and all 7 links carry traffic in both phases).
     Every rank must build the arena from the same parameters in the same order (the layout is that order)."""
 
+    SMALL = 1 << 16      # elements: parameters up to this size are merged with their small neighbours into one exchange unit
+
     def __init__(self, params: Sequence[torch.Tensor], chunk_bytes: int = 256 << 20, mode: str = "all_reduce",
-                 overlap: bool = True, anchor_ranges: int = 8):
+                 overlap: bool = True, anchor_ranges: int = 8, merge_small: bool = True):
         self.params = [p for p in params if p is not None and p.requires_grad]
         assert self.params, "no trainable parameters"
         assert mode in ("all_reduce", "rs_ag")
@@ -197,6 +199,7 @@ class GradArena:
         assert all(p.dtype == dt and p.device == dev for p in self.params)
         self.itemsize = self.params[0].element_size()
         self.mode, self.overlap = mode, overlap
+        self.small = self.SMALL if merge_small else 0
         rank, world = world_info()
         self.world = world
         self.align = align = 64 * max(world, 1)          # elements: every parameter starts on a 256-byte, world-divisible boundary
@@ -225,12 +228,25 @@ class GradArena:
         range of the sink.  Every quantity here depends on shapes only, so all ranks build the same table."""
         align = self.align
         padded = lambda p: (p.numel() + align - 1) // align * align
-        self.units, self.unit_pieces, self.unit_piece_param, self.sink_ranges = [], [], [], []
-        for i, (o, p) in enumerate(zip(self.offsets, self.params)):
-            if i not in self._sink_ids:
-                self.units.append(("p", i))
-                self.unit_pieces.append(self._split(o, o + padded(p)))
-                self.unit_piece_param.append([i] * len(self.unit_pieces[-1]))
+        self.units, self.unit_pieces, self.sink_ranges = [], [], []
+        # consecutive SMALL parameters (the MLP / BatchNorm / attention tensors: four dozen of a few hundred floats each) share
+        # one unit: every collective costs a launch and a rendezvous whatever its size, and a unit per tensor put 48 of them
+        # on the wire per step for 64 KB of payload.  A merged unit is ready when the last of its members is.
+        i, n_par = 0, len(self.params)
+        while i < n_par:
+            if i in self._sink_ids:
+                i += 1
+                continue
+            members, span = [i], padded(self.params[i])
+            if span <= self.small:
+                j = i + 1
+                while j < n_par and j not in self._sink_ids and padded(self.params[j]) <= self.small and span + padded(self.params[j]) <= 8 * self.small:
+                    span += padded(self.params[j])
+                    members.append(j)
+                    j += 1
+            self.units.append(("p", i) if len(members) == 1 else ("g", tuple(members)))
+            self.unit_pieces.append(self._split(self.offsets[i], self.offsets[i] + span))
+            i = members[-1] + 1
         if self._sink_ids:
             N = self.params[self._sink_ids[0]].shape[0]
             step = -(-N // self.anchor_ranges)
@@ -240,24 +256,26 @@ class GradArena:
                 self.sink_ranges.append((n0, min(N, n0 + step)))
                 n0 += step
             for r, (n0, n1) in enumerate(self.sink_ranges):
-                pieces, owners = [], []
+                pieces = []
                 for i in self._sink_ids:
                     p, o = self.params[i], self.offsets[i]
                     w = p.numel() // max(N, 1)
                     end = o + padded(p) if n1 == N else o + n1 * w     # the last range takes the parameter's padding
-                    part = self._split(o + n0 * w, end)
-                    pieces += part
-                    owners += [i] * len(part)
+                    pieces += self._split(o + n0 * w, end)
                 self.units.append(("s", r))
                 self.unit_pieces.append(pieces)
-                self.unit_piece_param.append(owners)
         self.layout_version = getattr(self, "layout_version", 0) + 1      # owned_slices() changed (adam.ShardedFusedAdam follows it)
-        self._unit_of_param = {u[1]: k for k, u in enumerate(self.units) if u[0] == "p"}
+        self._unit_of_param = {}
+        for k, u in enumerate(self.units):
+            for i in ((u[1],) if u[0] == "p" else u[1] if u[0] == "g" else ()):
+                self._unit_of_param[i] = k
         self._unit_of_range = {u[1]: k for k, u in enumerate(self.units) if u[0] == "s"}
         self._order = None                                   # agreed issue order (unit numbers); None until agreed
         self._begin_step()
 
     def _begin_step(self):
+        self._fired = set()                                  # parameters whose hook has fired in this step
+        self._left = [len(u[1]) if u[0] == "g" else 1 for u in self.units]      # members of a unit still to report
         self._ready = [False] * len(self.units)
         self._issued = [False] * len(self.units)
         self._cursor, self._fire_log = 0, []
@@ -271,12 +289,18 @@ class GradArena:
         """[(parameter index, start, stop)] of the flat buffer this rank OWNS in mode "rs_ag": its 1/world of every piece, i.e.
         where reduce(gather=False) leaves the summed gradient (the whole piece when there is one rank).  A function of the
         shapes, the world size and the rank only -- the layout adam.ShardedFusedAdam keeps its moments in."""
+        import bisect
         rank = dist.get_rank() if self.world > 1 else 0
         out = []
-        for pieces, owners in zip(self.unit_pieces, self.unit_piece_param):
-            for (a, b), i in zip(pieces, owners):
+        for pieces in self.unit_pieces:
+            for a, b in pieces:
                 n = (b - a) // self.world
-                out.append((i, a + rank * n, a + (rank + 1) * n))
+                lo, hi = a + rank * n, a + (rank + 1) * n
+                i = bisect.bisect_right(self.offsets, lo) - 1         # a piece of a merged unit spans several parameters:
+                while lo < hi:                                        # one entry per parameter (each has its own learning rate)
+                    end = min(hi, self.offsets[i + 1] if i + 1 < len(self.offsets) else self.flat.numel())
+                    out.append((i, lo, end))
+                    lo, i = end, i + 1
         return out
 
     def bind(self):
@@ -364,10 +388,13 @@ class GradArena:
                 raise RuntimeError("GradArena: a gradient arrived for a parameter whose exchange was already issued in this step -- "
                                    "the arena expects ONE backward() per step (zero() -> backward -> reduce()); sum the views' losses "
                                    "and call backward once, or build the arena with overlap=False")
-            if k is not None and not self._ready[k]:
-                self._ready[k] = True
-                self._fire_log.append(k)
-                self._flush()
+            if k is not None and i not in self._fired:
+                self._fired.add(i)
+                self._left[k] -= 1
+                if self._left[k] == 0 and not self._ready[k]:
+                    self._ready[k] = True
+                    self._fire_log.append(k)
+                    self._flush()
         return hook
 
     def _range_done(self, r):

@@ -199,7 +199,7 @@ for p in params: p.grad = None
 # agreed order on both (three equal-size parameters: a mismatch would sum different parameters without any error)
 eq = [torch.full((64,), float(j + 1), dtype=torch.float64, requires_grad=True) for j in range(3)]
 for mode in ("all_reduce", "rs_ag"):
-    arena = GradArena(eq, chunk_bytes=256, mode=mode, overlap=True)
+    arena = GradArena(eq, chunk_bytes=256, mode=mode, overlap=True, merge_small=False)      # one unit per parameter: the order matters
     for it in range(3):                                     # step 0 agrees on the order, steps 1.. issue from the hooks
         arena.zero()
         if rank == 0:
@@ -216,7 +216,7 @@ for mode in ("all_reduce", "rs_ag"):
     arena.close()
 # ---- ONE backward per step: a second one whose gradients arrive after their unit's exchange went out must raise (it
 # used to be left out of the exchange silently)
-arena = GradArena(eq, chunk_bytes=256, mode="all_reduce", overlap=True)
+arena = GradArena(eq, chunk_bytes=256, mode="all_reduce", overlap=True, merge_small=False)
 for it in range(3):
     arena.zero()
     sum(e.sum() for e in eq).backward()
@@ -252,6 +252,7 @@ arena_a = GradArena(pa, chunk_bytes=1024, mode="rs_ag", overlap=True)
 opt_a = adam_mod.ShardedFusedAdam([{"params": [p], "lr": lr} for p, lr in zip(pa, lrs)], arena_a, eps=1e-15)
 assert all(p.data_ptr() == opt_a.pflat[o:].data_ptr() for p, o in zip(pa, arena_a.offsets))      # the parameters moved into the flat buffer
 assert opt_a.exp_avg.numel() * world == arena_a.flat.numel()                                     # moments / world
+assert any(u[0] == "g" for u in arena_a.units)        # the small tensors share one exchange unit: its slices span parameters with different learning rates
 arena_b = GradArena(pb, chunk_bytes=1024, mode="all_reduce", overlap=True)
 m_b, v_b = [torch.zeros_like(p) for p in pb], [torch.zeros_like(p) for p in pb]
 for it in range(1, 4):
