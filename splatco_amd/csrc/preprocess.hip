@@ -273,8 +273,11 @@ preprocess_kernel(int64_t P, int M, const float* __restrict__ means3D, const flo
             //  * a rect of more than 32 tiles: the per-tile record verdicts of its tiles 32.. do not fit live_bits; the
             //    backward zeroes those records first and sums them unconditionally (zero_far_records_kernel)
             const unsigned long long w_nf = lanes(nonfinite3(rgb[0], rgb[1], rgb[2])), w_big = lanes(tt > 32u);
-            if ((w_nf | w_big) != 0ull && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
-                atomicOr(plan_flags, (unsigned long long)((w_nf ? SCR_PLAN_NONFINITE_COLOUR : 0) | (w_big ? SCR_PLAN_LARGE_RECTS : 0)));
+            if ((w_nf | w_big) != 0ull) {      // the first ACTIVE lane reports (lane 0 may be culled or past the end)
+                const unsigned long long active = lanes(true);
+                if ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == __builtin_ctzll(active))
+                    atomicOr(plan_flags, (unsigned long long)((w_nf ? SCR_PLAN_NONFINITE_COLOUR : 0) | (w_big ? SCR_PLAN_LARGE_RECTS : 0)));
+            }
             uint32_t rlo = (uint32_t)ft.rminx | ((uint32_t)ft.rminy << 16);
             uint32_t rhi = (uint32_t)ft.rmaxx | ((uint32_t)ft.rmaxy << 16);
             // blend-ready conic: A = -Qxx/2, B = -Qxy, C = -Qyy/2 (exact scalings of Q)

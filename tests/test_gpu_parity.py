@@ -660,3 +660,27 @@ def test_non_finite_inputs_follow_the_reference_skip_semantics(oracle, case):
     _, _, stt = R.rasterize_forward(R._CSettings(rs), t(g["means3D"]), t(g["opacities"]), t(g["scales"]), t(g["rotations"]), None,
                                     None, t(g["colors"]))
     assert bool(stt.flags & _C.PLAN_NONFINITE_COLOUR) == expect_flag
+
+
+def test_plan_flags_are_reported_by_any_lane(oracle):
+    """The plan flags are raised by ONE lane per wave: it must be an active one.  Every Gaussian that sits in lane 0 of its
+    wave is culled here (behind the camera) and a single Gaussian in the middle of a wave carries the NaN colour / the large
+    rect: the flags must still arrive."""
+    from splatco_amd import _C, rasterizer as R
+    cam, g = small_scene(P=512, W=320, H=200, seed=12)
+    g = {k: np.array(v, copy=True) for k, v in g.items()}
+    g["means3D"][::64] = [0.0, 0.0, -50.0]                      # lane 0 of every wave: behind the camera
+    t = lambda a: torch.tensor(a, device=_dev())
+    run = lambda: R.rasterize_forward(R._CSettings(_settings(cam, g["bg"])), t(g["means3D"]), t(g["opacities"]), t(g["scales"]),
+                                      t(g["rotations"]), None, None, t(g["colors"]))[2]
+    st = run()
+    assert st.flags == 0 and (st.radii.cpu().numpy()[::64] == 0).all()
+    f = oracle.forward(oracle_settings(oracle, cam, g["bg"]), g["means3D"], g["opacities"], g["scales"], g["rotations"],
+                       colors_precomp=g["colors"])
+    vis = np.nonzero((f["radii"] > 0) & (np.arange(512) % 64 > 8))[0]
+    g["colors"][vis[3], 1] = np.nan
+    assert run().flags == _C.PLAN_NONFINITE_COLOUR
+    g["scales"][vis[10]] = [2.0, 1.5, 1.0]                      # a splat over most of the 260 tiles
+    assert run().flags == _C.PLAN_NONFINITE_COLOUR | _C.PLAN_LARGE_RECTS
+    g["colors"][vis[3], 1] = 0.5
+    assert run().flags == _C.PLAN_LARGE_RECTS
