@@ -670,6 +670,7 @@ def test_plan_flags_are_reported_by_any_lane(oracle):
     cam, g = small_scene(P=512, W=320, H=200, seed=12)
     g = {k: np.array(v, copy=True) for k, v in g.items()}
     g["means3D"][::64] = [0.0, 0.0, -50.0]                      # lane 0 of every wave: behind the camera
+    g["scales"] *= 0.2                                          # no rect of more than 32 tiles to begin with
     t = lambda a: torch.tensor(a, device=_dev())
     run = lambda: R.rasterize_forward(R._CSettings(_settings(cam, g["bg"])), t(g["means3D"]), t(g["opacities"]), t(g["scales"]),
                                       t(g["rotations"]), None, None, t(g["colors"]))[2]
