@@ -811,7 +811,10 @@ def run_anchor_config(args, rank, world, dev):
                 a2.close()
                 return ms
             ms_ar = exchange("all_reduce")
-            ms_rs = exchange("rs_ag") if dist.get_backend() == "nccl" else None      # gloo (developer runs) has no reduce_scatter_tensor
+            try:
+                ms_rs = exchange("rs_ag")
+            except RuntimeError:                             # a backend without reduce_scatter_tensor (older gloo builds)
+                ms_rs = None
             arena.bind()
             allreduce_info = allreduce_report(
                 arena.nbytes(), ms_ar if args.exchange == "all_reduce" else ms_rs, world,

@@ -310,13 +310,6 @@ __device__ inline uint32_t quadrant_mask(float4 r0, float4 r1, int tile_x0, int 
     return mask;
 }
 
-// ---- developer builds with -DSCR_PHASE_TIMING: a kernel stamps the wall clock (100 MHz) at its phase boundaries and
-// the leader thread of every workgroup / wave adds the per-phase ticks into a device array that
-// scr_debug_phase_ticks(which, out[16]) reads and clears (which: 0 = mlp_heads backward, 1 = mlp_heads forward,
-// 2 = plane-gradient cell gather).  tools/exp/phase_probe.py prints the shares.  The stamps are fenced with sched_barrier(0); the product build contains none of this.
-#define SCR_PHASES(n)
-#define SCR_PHASE(k)
-#define SCR_PHASES_FLUSH(arr, n, leader)
 
 // Several buffers cleared by ONE kernel launch (preprocess.hip).  hipMemsetAsync costs a 5 us fill kernel AND 8 - 11 us of
 // idle stream time in front of it per call (profiles/r03x_step_gaps.txt): one per forward pass at cfg1, eighteen per

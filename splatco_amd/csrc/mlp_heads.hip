@@ -308,8 +308,8 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
     const int64_t tile0 = (int64_t)blockIdx.x * MH_WAVES + wave, tstep = (int64_t)gridDim.x * MH_WAVES;
     if (tile0 < tiles) load_tile(tile0);
     // The phases of a tile are fenced with sched_barrier(0): left alone, the scheduler (one wave per SIMD, 500 registers)
-    // moves pieces of one phase into another and ends up 12 % slower than the fenced order (found with a phase-stamped
-    // build, tools/exp/phase_probe.py: the stamps' fences alone made the kernel faster).
+    // moves pieces of one phase into another and ends up 12 % slower than the fenced order (found in round 2 with a
+    // phase-stamped developer build: the stamps' fences alone made the kernel faster; profiles/HISTORY.md).
     for (int64_t tile = tile0; tile < tiles; tile += tstep) {
         const int64_t v = tile * 16 + n;
         const bool valid = v < V;

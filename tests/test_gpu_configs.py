@@ -95,6 +95,32 @@ def test_cfg2_5M_anchors_plane2800(oracle):
     assert torch.equal(again, out["render"].detach())                     # bit-reproducible at 15 M Gaussians
 
 
+def test_bench_sharded_optimizer_and_dry_run():
+    """`bench.py --gpus 2 --config cfg3 --exchange rs_ag --optimizer sharded` (adam.ShardedFusedAdam: reduce-scatter, Adam on
+    this rank's half, all-gather of the parameters) prints its line; `--dry-run-ranks` prints the collective sequence of a
+    step instead, identical on both ranks, and no timing."""
+    env = dict(os.environ, SPLATCO_BENCH_ONE_DEVICE="1", SPLATCO_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg3", "--anchors", "200000",
+            "--exchange", "rs_ag", "--optimizer", "sharded"]
+    r = subprocess.run(base + ["--steps", "2", "--warmup", "2"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "ShardedFusedAdam" in out["config"]["optimizer"]
+    assert out["allreduce"]["mode"] == "rs_ag" and out["allreduce"]["ms"] > 0 and "exchange" not in out
+    assert "every 4th step" in out["config"]["tv"] and out["tv_pass"]["ms"] > 0
+    d = subprocess.run(base + ["--dry-run-ranks"], capture_output=True, text=True, env={k: v for k, v in env.items() if not k.startswith("SPLATCO_BENCH")},
+                       timeout=900)
+    assert d.returncode == 0, d.stdout[-2000:] + d.stderr[-4000:]
+    seqs = [json.loads(l[l.index('{"dry_run_ranks"'):]) for l in d.stdout.splitlines() if '{"dry_run_ranks"' in l]
+    assert len(seqs) == 2 and all(q["identical_on_all_ranks"] and q["dry_run_ranks"] == 2 for q in seqs)
+    names = {e["collective"] for e in seqs[0]["sequence"]}
+    assert names == {"reduce_scatter_tensor", "all_gather_into_tensor", "broadcast"}, names
+    n_rs = sum(e["count"] for e in seqs[0]["sequence"] if e["collective"] == "reduce_scatter_tensor")
+    n_ag = sum(e["count"] for e in seqs[0]["sequence"] if e["collective"] == "all_gather_into_tensor")
+    assert n_rs == n_ag > 0 and "UNMEASURED" in seqs[0]["status"] and not any(l.startswith('{"metric"') for l in d.stdout.splitlines())
+
+
 @pytest.mark.parametrize("config", ["cfg1", "cfg3"])
 def test_bench_starts_its_own_ranks(config):
     """`python bench.py --gpus 2` with no launcher starts two ranks itself (configs[3]/[4] code path; both ranks on the
