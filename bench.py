@@ -684,7 +684,7 @@ def run_anchor_config(args, rank, world, dev):
         idle = {id(p) for p in pc.feat_planes._feat.inactive_parameters()}     # plane levels above activate_level: grad None in the reference
         rest = [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad and id(p) not in idle]
         groups.append({"params": rest, "lr": 1e-3, "name": "mlp_and_feat_planes"})
-        arena = GradArena([p for grp in groups for p in grp["params"]], mode=args.exchange)
+        arena = GradArena([p for grp in groups for p in grp["params"]], mode=args.exchange, sparse_rows=args.sparse_exchange)
         if args.optimizer == "hip":         # csrc/adam.hip: the reference's Adam(l, lr=0.0, eps=1e-15) as one streaming pass per group
             from splatco_amd.adam import FusedAdam
             opt = FusedAdam(groups, eps=1e-15)
@@ -946,6 +946,9 @@ def main():
                     help="cfg3/cfg4: splatco_amd.adam.FusedAdam (csrc/adam.hip), torch.optim.Adam(fused=True), or "
                          "splatco_amd.adam.ShardedFusedAdam (needs --exchange rs_ag: reduce-scatter, Adam on 1/N of the parameters, "
                          "all-gather of the parameters)")
+    ap.add_argument("--sparse-exchange", action="store_true",
+                    help="cfg3/cfg4: exchange the per-anchor gradients row-sparse (only the anchors some view of the step sees; used "
+                         "when that union is below 60 %% of the anchors -- never at the synthetic scenes, where every view sees ~92 %%)")
     ap.add_argument("--dry-run-ranks", action="store_true",
                     help="with --gpus N: run the N ranks on ONE device over gloo, log every collective of one step (name, bytes, "
                          "order), check that all ranks issue the same sequence and print it -- the sequence the first RCCL run "

@@ -190,7 +190,8 @@ class GradArena:
     SMALL = 1 << 16      # elements: parameters up to this size are merged with their small neighbours into one exchange unit
 
     def __init__(self, params: Sequence[torch.Tensor], chunk_bytes: int = 256 << 20, mode: str = "all_reduce",
-                 overlap: bool = True, anchor_ranges: int = 8, merge_small: bool = True):
+                 overlap: bool = True, anchor_ranges: int = 8, merge_small: bool = True, sparse_rows: bool = False,
+                 sparse_threshold: float = 0.6):
         self.params = [p for p in params if p is not None and p.requires_grad]
         assert self.params, "no trainable parameters"
         assert mode in ("all_reduce", "rs_ag")
@@ -200,6 +201,10 @@ class GradArena:
         self.itemsize = self.params[0].element_size()
         self.mode, self.overlap = mode, overlap
         self.small = self.SMALL if merge_small else 0
+        # row-sparse exchange of the per-anchor units (set_row_union): opt-in, used when the union of the ranks' visible
+        # anchors is below `sparse_threshold` of all anchors
+        self.sparse_rows, self.sparse_threshold = bool(sparse_rows), float(sparse_threshold)
+        self._rows, self._packed, self.last_union_fraction = None, [], None
         rank, world = world_info()
         self.world = world
         self.align = align = 64 * max(world, 1)          # elements: every parameter starts on a 256-byte, world-divisible boundary
@@ -344,6 +349,7 @@ class GradArena:
                 if i not in self._sink_ids:
                     v.zero_()
             sink.fresh, sink.pending = True, 0
+        self._rows, self._packed = None, []               # set_row_union() decides anew every step
         self._begin_step()
         self.bind()
 
@@ -356,9 +362,58 @@ class GradArena:
                 self.views[i].zero_()
             sink.fresh = False
 
+    # ---- row-sparse exchange of the per-anchor units --------------------------------------------------------------
+    def set_row_union(self, visible_local):
+        """SURVEY.md 8e ("optional sparsification"): an anchor that NO view of the step sees has an all-zero gradient row
+        on every rank (the gather's backward writes zeros for invisible anchors), so only the rows of the UNION of the ranks'
+        visible anchors need to travel.  Call once per step, after zero() and before backward(), on every rank, with the OR of
+        this rank's views' visibility masks ([N] bool / uint8; all zeros for a rank without views).  One MAX all-reduce of the
+        byte mask + one host read of the per-range row counts (every rank derives the same message sizes from the same
+        union); if the union holds less than `sparse_threshold` of the anchors, the sink's range units are exchanged as
+        PACKED rows (gather -> all_reduce -> scatter back at reduce()) instead of whole ranges.  At MatrixCity scale a view
+        sees a small part of the scene: 5.7 GB of per-anchor gradient shrink with the union.  Needs the gradient sink and a
+        full exchange (not reduce(gather=False))."""
+        self._rows, self._packed, self.last_union_fraction = None, [], None
+        if not self.sparse_rows or self._sink is None or self.world == 1:
+            return False
+        N = self.params[self._sink_ids[0]].shape[0]
+        u = torch.zeros(N, dtype=torch.uint8, device=self.flat.device)      # (a copy: the caller's mask stays what it was)
+        if visible_local is not None:
+            assert visible_local.shape == (N,)
+            u.copy_(visible_local)
+        dist.all_reduce(u, op=dist.ReduceOp.MAX)
+        rows = [torch.nonzero(u[n0:n1]).squeeze(1) + n0 for n0, n1 in self.sink_ranges]      # (one host read each)
+        total = sum(int(r.numel()) for r in rows)
+        self.last_union_fraction = total / max(N, 1)
+        if self.last_union_fraction < self.sparse_threshold:
+            self._rows = rows
+        return self._rows is not None
+
+    def _issue_packed(self, r):
+        """Range r of the sink as packed rows: [U_r, 32 | 3 | 30 | 6] gathered into one buffer, one all_reduce."""
+        rows = self._rows[r]
+        parts = [self.views[i].reshape(self.views[i].shape[0], -1).index_select(0, rows) for i in self._sink_ids]
+        packed = torch.cat([p.reshape(-1) for p in parts]) if rows.numel() else self.flat.new_zeros(0)
+        if packed.numel():
+            self._work.append(dist.all_reduce(packed, op=dist.ReduceOp.SUM, async_op=True))
+        self._packed.append((rows, packed, [p.shape[1] for p in parts]))
+
+    def _unpack(self):
+        for rows, packed, widths in self._packed:
+            off = 0
+            for i, w in zip(self._sink_ids, widths):
+                n = rows.numel() * w
+                if n:
+                    self.views[i].reshape(self.views[i].shape[0], -1).index_copy_(0, rows, packed[off:off + n].view(rows.numel(), w))
+                off += n
+        self._packed = []
+
     # ---- issue ---------------------------------------------------------------------------------------------------
     def _issue(self, k):
         self._issued[k] = True
+        if self._rows is not None and self.units[k][0] == "s":
+            self._issue_packed(self.units[k][1])
+            return
         for a, b in self.unit_pieces[k]:
             piece = self.flat[a:b]
             if self.mode == "all_reduce":
@@ -436,6 +491,8 @@ class GradArena:
         all-gathers the parameters instead of the gradients (adam.ShardedFusedAdam: Adam's work and moments / world)."""
         if not gather and self.mode != "rs_ag":
             raise ValueError("GradArena.reduce(gather=False) needs mode='rs_ag'")
+        if not gather and self._rows is not None:
+            raise ValueError("GradArena.reduce(gather=False) after set_row_union(): the packed rows are exchanged in full")
         self._settle_sink()
         if self.world > 1:
             order = self._order if self._order is not None else list(range(len(self.units)))
@@ -449,6 +506,8 @@ class GradArena:
             for w in self._work:
                 w.wait()
             self._work, self._pending = [], []
+            self._unpack()
+            self._rows = None
             if self._order is None and self.overlap:
                 self._agree_order()
         return self.flat

@@ -91,9 +91,15 @@ def collaborative_step(pc, views, gt_images, pipe, bg_color, optimizer=None, buc
     rank, world = world_info()
     device = params[0].device
     total, out, vis, rendered = None, None, None, []
+    from .adam import ShardedFusedAdam
+    sharded = isinstance(optimizer, ShardedFusedAdam)
+    want_union = arena is not None and arena.sparse_rows and not sharded and world > 1
+    union = None
     try:
         for k, (cam, gt) in enumerate(zip(shard_views(views), shard_views(gt_images))):
             vis = prefilter_voxel(cam, pc, pipe, bg_color)
+            if want_union:
+                union = vis.clone() if union is None else union.logical_or_(vis)
             out = render(cam, pc, pipe, bg_color, visible_mask=vis, retain_grad=True)
             gt = gt.to(out["render"].device, non_blocking=True)
             loss = view_loss(out["render"], gt, out["scaling"])
@@ -104,12 +110,14 @@ def collaborative_step(pc, views, gt_images, pipe, bg_color, optimizer=None, buc
             term, _ = consistency_loss(rendered, consistency_weight, device=device)
             if term is not None:
                 total = term if total is None else total + term
+        if want_union:
+            # only the rows of anchors SOME view of the step sees need to travel (GradArena.set_row_union); every rank takes
+            # part, also one without views
+            arena.set_row_union(union)
         if total is not None:
             total.backward()
     finally:
         pc._grad_sink = None
-    from .adam import ShardedFusedAdam
-    sharded = isinstance(optimizer, ShardedFusedAdam)
     if sharded and optimizer.arena is not arena:
         raise ValueError("collaborative_step: the ShardedFusedAdam was built on another GradArena")
     if arena is not None:

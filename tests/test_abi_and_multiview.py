@@ -335,6 +335,32 @@ for b, v in zip(both, vals):
 same = torch.equal if world == 2 else (lambda x, y: torch.allclose(x, y, rtol=1e-6, atol=1e-6))
 for key, flat in results.items():
     assert same(flat, results[("all_reduce", 1)]), key
+# ---- row-sparse exchange (SURVEY.md 8e): only the rows of anchors SOME rank sees travel -- same result as the dense exchange
+mask = torch.rand(Na, generator=torch.Generator().manual_seed(50 + rank)) < 0.25       # this rank's visible anchors
+mvals = [v * mask[:, None] for v in vals]                                                # zero rows where invisible (the gather's backward)
+sparse_out = {}
+for sparse in (False, True):
+    for mode in ("all_reduce", "rs_ag"):
+        arena = GradArena([other] + pa, chunk_bytes=4096, mode=mode, overlap=True, anchor_ranges=4, sparse_rows=sparse, sparse_threshold=0.9)
+        sink = arena.attach_sink(pa)
+        for it in range(2):
+            arena.zero()
+            took = arena.set_row_union(mask if rank != world - 1 or it == 0 else None)      # (second step: the last rank has no views)
+            assert took == sparse and (not sparse or 0.2 < arena.last_union_fraction < 0.9)
+            (other * oval).sum().backward()
+            last_has_views = not (rank == world - 1 and it == 1)
+            for r, (n0, n1) in enumerate(sink.ranges):
+                for t, v in zip(sink.tensors, mvals):
+                    t[n0:n1] = v[n0:n1] if last_has_views else 0.0
+                sink.fresh = False
+                if rank == 0:
+                    sink.on_range(r)
+            arena.reduce()
+            sparse_out[(sparse, mode, it)] = arena.flat.clone()
+        arena.close()
+for mode in ("all_reduce", "rs_ag"):
+    for it in range(2):
+        assert same(sparse_out[(True, mode, it)], sparse_out[(False, mode, it)]), ("row-sparse exchange", mode, it)
 a1 = GradArena([other] + pa, anchor_ranges=1)
 for i, b in zip(range(1, 5), both):
     assert same(results[("all_reduce", 4)][a1.offsets[i]:a1.offsets[i] + b.numel()].view_as(b), b)

@@ -106,12 +106,15 @@ for mode, cw in (("all_reduce", 0.05), ("rs_ag", 0.0))[:int(sys.argv[2])]:
     pc_a, params_a, den_a, _ = make()
     pc_b, params_b, den_b, _ = make()
     assert all(torch.equal(a, b) for a, b in zip(params_a, params_b))
-    arena = GradArena(params_a, chunk_bytes=4 << 20, mode=mode, anchor_ranges=4)       # several pieces per large parameter
+    # several pieces per large parameter; the rs_ag case also exchanges the per-anchor gradients ROW-SPARSE (only the rows of
+    # the union of the ranks' visible anchors travel, GradArena.set_row_union; the threshold is lifted so that it always packs)
+    arena = GradArena(params_a, chunk_bytes=4 << 20, mode=mode, anchor_ranges=4, sparse_rows=(mode == "rs_ag"), sparse_threshold=1.01)
     for it in range(2):         # step 0 goes out from reduce() and agrees on the order; step 1 issues from the hooks / ranges
         loss_a, out_a, _ = collaborative_step(pc_a, views, gts, pipe, bg, consistency_weight=cw, densifier=den_a, arena=arena,
                                                   iteration=4 * (it + 1), tv_weight=TVW)
         loss_b, own, cross = sequential(pc_b, params_b, den_b, cw)
     assert arena._order is not None and arena._sink is not None and len(arena.sink_ranges) == 4
+    assert (arena.last_union_fraction is not None and 0.5 < arena.last_union_fraction <= 1.0) == (mode == "rs_ag")
     assert arena._cursor == len(arena.units)
     worst = 0.0
     for i, (pa, pb) in enumerate(zip(params_a, params_b)):
