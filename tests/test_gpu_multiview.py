@@ -219,7 +219,9 @@ def test_sharded_step_equals_the_sequential_loop_on_the_hip_path(tmp_path, world
                         "8" if world == 8 else "4"],
                        capture_output=True, text=True, env=env, timeout=1500)
     print(r.stdout[-3000:])
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
+    # (the ranks' own tracebacks sit far above the launcher's summary: pick them out)
+    tb = "\n".join(l for l in r.stderr.splitlines() if "]:" in l and ("Error" in l or "assert" in l or "line " in l))[-3000:]
+    assert r.returncode == 0, tb + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == world
 
 
