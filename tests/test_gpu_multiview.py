@@ -125,7 +125,9 @@ for mode, cw in (("all_reduce", 0.05), ("rs_ag", 0.0))[:int(sys.argv[2])]:
         # the per-anchor tensors, the planes and the weight matrices; the handful of parameters with a few dozen elements
         # (attention MLP / window weights, biases) are each a sum over millions of signed terms, where the same
         # reordering shows at 1e-5 of the (cancelled) result
-        assert r <= (1e-6 if pa.numel() >= 1000 else 2e-5), (mode, i, tuple(pa.shape), r)
+        # (... and the more ranks, the more partial sums meet in the collective's own order: the bar for those few grows with
+        # the world size; a failed comparison prints the figure)
+        assert r <= (1e-6 if pa.numel() >= 1000 else 2e-5 * max(1, world // 2)), (mode, i, tuple(pa.shape), r)
     # losses: a cross-rank pair is evaluated by both owners (each differentiates its own image): it counts twice in the
     # sum of the local losses
     tl = loss_a.clone().double()
