@@ -133,7 +133,8 @@ for mode, cw in (("all_reduce", 0.05), ("rs_ag", 0.0))[:int(sys.argv[2])]:
     tl = loss_a.clone().double()
     dist.all_reduce(tl)
     want = float(loss_b) + float(cross)
-    assert abs(float(tl) - want) <= 1e-6 * abs(want), (float(tl), want)
+    # (fp32 sums of up to 8 view losses + 28 pair terms in two different orders: a few 1e-7 each)
+    assert abs(float(tl) - want) <= 1e-5 * abs(want), (float(tl), want)
     # densification statistics: the last view's (rendered by rank 1) on every rank
     for name in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"):
         a, b = getattr(den_a, name), getattr(den_b, name)
