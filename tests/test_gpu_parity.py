@@ -437,12 +437,13 @@ def _fp64_on_fp32_records(oracle, st, f):
 
 CERTIFY = 1e-5         # a gradient row is "pinned by binary32" when the fp32 oracle's own row is this close to fp64
 # On the rows binary32 does not pin: (device's distance from fp64) / max(fp32 oracle's distance, 2-ulp noise floor), L2 over the
-# set.  MEASURED over the 27 branch-(b) scenes of seeds 0-4 (profiles/r04_stress.txt, one figure per scene and tensor, 70 in
-# all): worst 1.40, per seed 1.28 / 1.37 / 0.99 / 1.06 / 1.40.  The bar is that maximum with 40 % head-room (it was a guessed 10
-# in round 3).  Against the fp32 oracle's distance ALONE the device is at 1.00 in the median, 2.1 at the 90th percentile and 19.8
-# at worst -- where the oracle happens to land within a fraction of the noise floor; tools/exp/shift_study.py shows the same
-# spread (0.87 median, 17.9 worst) between two fp32 evaluations that differ only in how they associate the same sums.
-UNPINNED_RATIO_MAX = 2.0
+# set.  MEASURED: over the 27 branch-(b) scenes of this test's seeds 0-4 (profiles/r04_stress.txt, 70 figures) the worst is 1.40
+# (per seed 1.28 / 1.37 / 0.99 / 1.06 / 1.40); over 100 further scenes (seeds 5-14, tools/stress_parity.py,
+# profiles/r04_stress_more.txt) 2.74.  The bar is 3 (round 3 had guessed 10).  Against the fp32 oracle's distance ALONE the
+# device is at 1.00 in the median, 2.1 at the 90th percentile and 19.8 at worst -- where the oracle happens to land within a
+# fraction of the noise floor; tools/exp/shift_study.py shows the same spread (0.87 median, 17.9 worst) between two fp32
+# evaluations that differ only in how they associate the same sums.
+UNPINNED_RATIO_MAX = 3.0
 
 
 def stress_case(oracle, rng, verbose=False, info=None):
@@ -454,7 +455,7 @@ def stress_case(oracle, rng, verbose=False, info=None):
           to a few per cent and whose covariance chain divides by a vanishing determinant: ANY fp32 evaluation -- the
           scalar fp32 oracle included -- is 1e-3 .. 1e-2 off on those rows, so no fp32 tolerance can hold there.  The
           fraction of such rows is printed, and on them the device must still be no further from fp64 (L2 over the
-          set) than UNPINNED_RATIO_MAX (2: the measured maximum 1.40 plus head-room) times the larger of (i) the fp32 oracle's own distance and (ii) the NOISE FLOOR of the fp32
+          set) than UNPINNED_RATIO_MAX (3: measured maxima 1.40 on this test's 50 scenes, 2.74 on 100 more) times the larger of (i) the fp32 oracle's own distance and (ii) the NOISE FLOOR of the fp32
           projection chain: how far the fp32 oracle's own chain moves when its inputs (the per-Gaussian screen-space
           sums, which no fp32 summation knows better) are jiggled by +-2 ulp -- for such a Gaussian two correct fp32
           evaluations differ by O(1) (tools/exp/moment_check.py: identical moments to 1e-7, means3D.z anywhere in

@@ -13,17 +13,24 @@ from test_gpu_parity import stress_case
 
 
 def main(n=40, seed=0, seeds=1, verbose=0):
-    bad = 0
+    bad, ratios = 0, []
     orc.build()
     for s in range(seed, seed + seeds):
         rng = np.random.default_rng(s)
         for it in range(n):
+            info = {}
             try:
-                line = stress_case(orc, rng, verbose=bool(verbose))
+                line = stress_case(orc, rng, verbose=bool(verbose), info=info)
             except AssertionError as e:
                 bad += 1
                 line = "FAIL " + str(e)[:300]
-            print(f"[{s}/{it}] {line}", flush=True)
+            rs = {k: round(v["ratio"], 2) for k, v in info.get("branch_b", {}).items()}
+            ratios += list(rs.values())
+            print(f"[{s}/{it}] {line[:260]}" + (f" || branch (b) ratios device / max(oracle, noise): {rs}" if rs else ""), flush=True)
+    ratios.sort()
+    if ratios:
+        print(f"branch (b) ratios over {len(ratios)} (scene, tensor) pairs: median {ratios[len(ratios) // 2]:.2f}, p90 {ratios[int(len(ratios) * 0.9)]:.2f}, "
+              f"max {ratios[-1]:.2f}")
     print("failures:", bad)
     return bad
 
