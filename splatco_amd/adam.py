@@ -152,6 +152,14 @@ class ShardedFusedAdam:
     def nbytes_state(self):
         return 2 * self.exp_avg.numel() * self.exp_avg.element_size()
 
+    @property
+    def state(self):
+        # torch.optim.Optimizer.state does not exist here: code that edits per-parameter moments in place (the optimizer
+        # surgery of densification, scene/gaussian_model.py:738-818) has to go through the per-parameter layout
+        raise AttributeError("ShardedFusedAdam keeps its moments as flat per-rank shards: use full_state() to obtain them in "
+                             "torch.optim.Adam's per-parameter layout (e.g. to run AnchorDensifier.adjust_anchor on a torch / FusedAdam "
+                             "optimizer built from it), then build a new GradArena + ShardedFusedAdam and load_full_state()")
+
     @torch.no_grad()
     def step(self):
         """After arena.reduce(gather=False): update this rank's slices, then all-gather the parameters."""
