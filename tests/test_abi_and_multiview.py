@@ -336,7 +336,7 @@ same = torch.equal if world == 2 else (lambda x, y: torch.allclose(x, y, rtol=1e
 for key, flat in results.items():
     assert same(flat, results[("all_reduce", 1)]), key
 # ---- row-sparse exchange (SURVEY.md 8e): only the rows of anchors SOME rank sees travel -- same result as the dense exchange
-mask = torch.rand(Na, generator=torch.Generator().manual_seed(50 + rank)) < 0.25       # this rank's visible anchors
+mask = torch.rand(Na, generator=torch.Generator().manual_seed(50 + rank)) < 0.5 / world      # this rank's visible anchors (union: ~40 %)
 mvals = [v * mask[:, None] for v in vals]                                                # zero rows where invisible (the gather's backward)
 sparse_out = {}
 for sparse in (False, True):
@@ -346,7 +346,7 @@ for sparse in (False, True):
         for it in range(2):
             arena.zero()
             took = arena.set_row_union(mask if rank != world - 1 or it == 0 else None)      # (second step: the last rank has no views)
-            assert took == sparse and (not sparse or 0.2 < arena.last_union_fraction < 0.9)
+            assert took == sparse and (not sparse or 0.1 < arena.last_union_fraction < 0.9)
             (other * oval).sum().backward()
             last_has_views = not (rank == world - 1 and it == 1)
             for r, (n0, n1) in enumerate(sink.ranges):
