@@ -237,6 +237,10 @@ def test_deep_list_variants_forced_on_small_scenes(oracle, scene):
     for k in o["grads"]:
         assert np.array_equal(o["grads"][k], base["grads"][k]), k
     if scene == "large_rects":
+        # debug mode (pipe.debug): every kernel -- the far-record clearing included -- is followed by a stream synchronisation
+        # and an error check; same bits
+        dbg = _run_gpu(cam, g, dL=dL, ref=f, debug=True)
+        assert np.array_equal(dbg["color"], base["color"]) and all(np.array_equal(dbg["grads"][k], base["grads"][k]) for k in base["grads"])
         from splatco_amd import rasterizer as R
         t = lambda a: torch.tensor(a, device=_dev())
         _, _, stt = R.rasterize_forward(R._CSettings(_settings(cam, g["bg"])), t(g["means3D"]), t(g["opacities"]), t(g["scales"]),
@@ -630,7 +634,7 @@ def test_non_finite_inputs_follow_the_reference_skip_semantics(oracle, case):
     st = oracle_settings(oracle, cam, g["bg"])
     f = oracle.forward(st, g["means3D"], g["opacities"], g["scales"], g["rotations"], colors_precomp=g["colors"])
     dL = rng.standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
-    o = _run_gpu(cam, g, dL=dL, ref=f)
+    o = _run_gpu(cam, g, dL=dL, ref=f, debug=(case == "inf_colour"))      # (one case also under pipe.debug: the SAFE kernels with a sync + check behind each)
     assert np.array_equal(o["radii"], f["radii"]) and np.array_equal(o["tiles_touched"], f["tiles_touched"])
     assert o["num_rendered"] == f["num_rendered"] and np.array_equal(o["point_list"], f["point_list"])
     if case == "nan_mean_scale_rotation":
