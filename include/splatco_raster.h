@@ -89,7 +89,12 @@ int scr_mark_visible(int64_t P, const float* means3D, const float* viewmatrix, u
  * with this bit run the kernels' select-based instantiations and give the reference's result, NaN for NaN. */
 enum { SCR_PLAN_NONFINITE_COLOUR = 1,
        SCR_PLAN_LARGE_RECTS = 2 };  /* some Gaussian's tile rect has more than 32 tiles: scr_backward clears the gradient
-                                     * records of its further tiles before the blend backward fills in the ones it writes */
+                                     * records of its further tiles before the blend backward fills in the ones it writes.
+                                     * The backward takes THIS bit from geom_buf (where the forward left it), not from its
+                                     * plan_flags argument: a stale argument cannot leave uninitialised records in the sums.
+                                     * SCR_PLAN_NONFINITE_COLOUR selects a kernel instantiation on the host and is taken
+                                     * from the argument (a wrong value there only changes how NaN colours spread); with
+                                     * settings->debug the argument is compared with geom_buf's word and a mismatch fails. */
 int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* scales,
                      const float* rotations, const float* cov3D_precomp, const float* opacities,
                      const float* shs, const float* colors_precomp, const scr_settings* settings,

@@ -121,7 +121,8 @@ class ShardedFusedAdam:
         if len(self._group_of) != len(arena.params):
             raise ValueError("ShardedFusedAdam: the groups must cover exactly the arena's parameters")
         self.world = arena.world
-        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.active = arena.active                 # collectives are issued (multiview.collectives_on() when the arena was built)
+        self.rank = dist.get_rank() if self.active else 0
         # parameters move into ONE flat buffer with the arena's layout (p.data becomes a view of it)
         self.pflat = torch.zeros_like(arena.flat)
         for p, o in zip(arena.params, arena.offsets):
@@ -179,7 +180,7 @@ class ShardedFusedAdam:
             _adam_apply(entries, b1, b2, self.eps, self.pflat.device)
         for i in range(len(self.steps)):
             self.steps[i] += 1
-        if self.world > 1:
+        if self.active:
             work = []
             for pieces in self.arena.unit_pieces:
                 for a, b in pieces:
@@ -201,7 +202,7 @@ class ShardedFusedAdam:
         for (i, a, b), so in zip(self.slices, self._state_off):
             full_m[a:b] = self.exp_avg[so:so + b - a]
             full_v[a:b] = self.exp_avg_sq[so:so + b - a]
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(full_m)          # the ranks' slices are disjoint: the sum assembles them
             dist.all_reduce(full_v)
         out = {}

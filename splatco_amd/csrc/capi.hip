@@ -357,11 +357,19 @@ int scr_backward(int64_t P, int32_t M, int64_t I, int64_t plan_flags, const floa
     // a value no earlier call of this process used (and that uninitialised memory is unlikely to hold): see blend.hip
     static std::atomic<unsigned long long> stamp_counter{0x5ca1ab1e00000000ull};
     const unsigned long long stamp = ++stamp_counter;
+    if (settings->debug) {      // the flags the caller carried from scr_forward_plan against the ones the forward left in geom_buf
+        unsigned long long dev_flags = 0;
+        HIP_TRY(hipMemcpyAsync(&dev_flags, gv.total + 3, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if ((long long)dev_flags != (long long)plan_flags)
+            return fail("plan_flags %lld passed to scr_backward, but the forward pass of this geom_buf raised %llu", (long long)plan_flags, dev_flags);
+    }
     if (I > 0) {
-        if (plan_flags & SCR_PLAN_LARGE_RECTS) {
-            launch_zero_far_records(P, gv, (GradRec*)scratch, st);
-            CHECK_LAUNCH("zero_far_records_kernel", settings->debug, st);
-        }
+        // records 32.. of large rects are cleared whatever plan_flags says: the kernel reads the forward's verdict from
+        // geom_buf and leaves at once when there are none (2 us), so a stale argument cannot make preprocess_backward sum
+        // uninitialised scratch
+        launch_zero_far_records(P, gv, (GradRec*)scratch, st);
+        CHECK_LAUNCH("zero_far_records_kernel", settings->debug, st);
         { ProfScope ps_(SCR_PROF_BLEND_BACKWARD, st);
           launch_blend_backward(ks, gv, bv, iv, dL_dcolor, (GradRec*)scratch, stamp, deep_lists(I, Grid(ks.H, ks.W).tiles),
                                 record_flags(I, Grid(ks.H, ks.W).tiles), (plan_flags & SCR_PLAN_NONFINITE_COLOUR) != 0, st); }

@@ -676,9 +676,13 @@ void launch_preprocess_backward(int64_t P, int M, const float* means3D, const fl
 
 // ---- gradient records 32.. of every Gaussian whose rect has more than 32 tiles: cleared before the blend backward writes
 // the ones it has something for.  One wave per 64 Gaussians; the (rare) large ones are cleared by the whole wave, 256 bytes
-// per store instruction.  Launched only when the plan reported SCR_PLAN_LARGE_RECTS.
-__global__ void __launch_bounds__(256) zero_far_records_kernel(int64_t P, const uint32_t* __restrict__ tiles_touched,
+// per store instruction.  Launched by every backward; leaves at once unless the forward raised SCR_PLAN_LARGE_RECTS.
+__global__ void __launch_bounds__(256) zero_far_records_kernel(int64_t P, const unsigned long long* __restrict__ total,
+                                                               const uint32_t* __restrict__ tiles_touched,
                                                                const uint32_t* __restrict__ point_offsets, uint32_t* __restrict__ rec_words) {
+    // the forward's own verdict, where it left it on the device (geom_buf): nothing here depends on what the caller passed
+    // back as plan_flags -- a stale or zero argument cannot leave uninitialised records for preprocess_backward to sum
+    if ((total[3] & (unsigned long long)SCR_PLAN_LARGE_RECTS) == 0ull) return;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const uint32_t n = i < P ? tiles_touched[i] : 0u;
@@ -694,7 +698,7 @@ __global__ void __launch_bounds__(256) zero_far_records_kernel(int64_t P, const 
 }
 void launch_zero_far_records(int64_t P, const GeomView& gv, GradRec* grad_rec, hipStream_t st) {
     if (P <= 0) return;
-    zero_far_records_kernel<<<nblk(P, 256), 256, 0, st>>>(P, gv.tiles_touched, gv.point_offsets, (uint32_t*)grad_rec);
+    zero_far_records_kernel<<<nblk(P, 256), 256, 0, st>>>(P, gv.total, gv.tiles_touched, gv.point_offsets, (uint32_t*)grad_rec);
 }
 
 // ---- ZeroList: blockIdx.y = buffer, blockIdx.x = 16 KB piece of it

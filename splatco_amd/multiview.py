@@ -12,6 +12,7 @@ the same code on CPU (tests).  Gradients travel as ONE flat fp32 bucket: xGMI is
 (7 links x ~153 GB/s per GPU), so a ring all-reduce is bound by a single link and a few large
 messages beat many small ones.
 """
+import os
 from typing import Callable, Iterable, List, Sequence
 
 import torch
@@ -22,6 +23,26 @@ def world_info():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+_FORCE_COLLECTIVES = os.environ.get("SPLATCO_FORCE_COLLECTIVES", "0") == "1"
+
+
+def force_collectives(on: bool):
+    """A ONE-rank process group normally issues no collective at all (every exchange below is skipped when there is nobody
+    to exchange with).  force_collectives(True) (or SPLATCO_FORCE_COLLECTIVES=1) makes a one-rank group run the very same
+    sequence of collectives a larger one does -- each a copy onto itself -- so that the communication library (RCCL on
+    MI355X) loads, builds its communicator and executes every call shape of the exchange on a single GPU.  Set it before
+    building a GradArena (the arena fixes its behaviour at construction)."""
+    global _FORCE_COLLECTIVES
+    _FORCE_COLLECTIVES = bool(on)
+
+
+def collectives_on() -> bool:
+    """Do the exchange steps issue their collectives?  More than one rank -- or a one-rank group under force_collectives."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or _FORCE_COLLECTIVES
 
 
 def shard_views(views: Sequence, rank: int = None, world: int = None) -> List:
@@ -55,7 +76,7 @@ def _agree(flag: bool, signature: int, device) -> bool:
     """True only if `flag` is True and `signature` identical on EVERY rank (one 12-byte MIN all-reduce).  The
     in-place and the packed path move the same number of elements in different orders, so a split decision -- or
     two ranks whose gradients tile their buffers in different orders -- would sum misaligned data silently."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_on():
         return flag
     t = torch.tensor([1 if flag else 0, signature, -signature], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -132,7 +153,7 @@ def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = N
     else:
         in_place = _agree(arena is not None, sig, dev)
     if in_place:
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if collectives_on():
             _sum_over_ranks(arena, shape)
         return arena
     n = sum(p.numel() for p in params)
@@ -146,7 +167,7 @@ def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = N
         else:
             bucket[off:off + k].copy_(p.grad.reshape(-1))
         off += k
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_on():
         _sum_over_ranks(bucket, shape)
     off = 0
     for p in params:
@@ -207,6 +228,7 @@ class GradArena:
         self._rows, self._packed, self.last_union_fraction = None, [], None
         rank, world = world_info()
         self.world = world
+        self.active = collectives_on()                   # collectives are issued (a one-rank group: only under force_collectives)
         self.align = align = 64 * max(world, 1)          # elements: every parameter starts on a 256-byte, world-divisible boundary
         self.offsets, total = [], 0
         for p in self.params:
@@ -220,7 +242,7 @@ class GradArena:
         self._work, self._handles, self._pending = [], [], []
         self._layout()
         self.bind()
-        if overlap and world > 1:
+        if overlap and self.active:
             for i, p in enumerate(self.params):
                 self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
@@ -295,7 +317,7 @@ class GradArena:
         where reduce(gather=False) leaves the summed gradient (the whole piece when there is one rank).  A function of the
         shapes, the world size and the rank only -- the layout adam.ShardedFusedAdam keeps its moments in."""
         import bisect
-        rank = dist.get_rank() if self.world > 1 else 0
+        rank = dist.get_rank() if self.active else 0
         out = []
         for pieces in self.unit_pieces:
             for a, b in pieces:
@@ -334,7 +356,7 @@ class GradArena:
             self._sink = GradSink(*[self.views[i] for i in self._sink_ids])
         self._layout()
         if self._sink is not None:
-            self._sink.ranges = list(self.sink_ranges) if (self.overlap and self.world > 1) else None
+            self._sink.ranges = list(self.sink_ranges) if (self.overlap and self.active) else None
             self._sink.on_range = self._range_done
         return self._sink
 
@@ -374,7 +396,7 @@ class GradArena:
         sees a small part of the scene: 5.7 GB of per-anchor gradient shrink with the union.  Needs the gradient sink and a
         full exchange (not reduce(gather=False))."""
         self._rows, self._packed, self.last_union_fraction = None, [], None
-        if not self.sparse_rows or self._sink is None or self.world == 1:
+        if not self.sparse_rows or self._sink is None or not self.active:
             return False
         N = self.params[self._sink_ids[0]].shape[0]
         u = torch.zeros(N, dtype=torch.uint8, device=self.flat.device)      # (a copy: the caller's mask stays what it was)
@@ -426,7 +448,7 @@ class GradArena:
 
     def _flush(self):
         """Issue the contiguous ready prefix of the agreed order (nothing before the order is agreed)."""
-        if self._order is None or self.world == 1:
+        if self._order is None or not self.active:
             return
         while self._cursor < len(self._order) and self._ready[self._order[self._cursor]]:
             self._issue(self._order[self._cursor])
@@ -494,7 +516,7 @@ class GradArena:
         if not gather and self._rows is not None:
             raise ValueError("GradArena.reduce(gather=False) after set_row_union(): the packed rows are exchanged in full")
         self._settle_sink()
-        if self.world > 1:
+        if self.active:
             order = self._order if self._order is not None else list(range(len(self.units)))
             for k in order[self._cursor:] if self._order is not None else order:
                 assert not self._issued[k]
@@ -549,7 +571,7 @@ def consistency_loss(local: Sequence, weight: float = 0.05, device=None):
     items = [(int(i), g, r, True) for i, g, r in local]
     if device is None and local:
         device = local[0][1].device
-    if world > 1:
+    if collectives_on():
         if device is None:
             raise ValueError("consistency_loss: a rank without local views must pass device= (the collectives need "
                              "buffers on the communicator's device)")

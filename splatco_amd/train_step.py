@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 
 from .losses import view_loss
-from .multiview import GradArena, allreduce_gradients, consistency_loss, shard_views, world_info
+from .multiview import GradArena, allreduce_gradients, collectives_on, consistency_loss, shard_views, world_info
 from .renderer import prefilter_voxel, render
 from .tv import tv_due
 
@@ -37,7 +37,7 @@ def sync_densification_stats(densifier, n_views, out, vis, device):
                                                     out["visibility_filter"], out["selection_mask"])
             from .expand import visible_indices
             vis_idx = visible_indices(vis)
-    if world > 1:
+    if collectives_on():
         head = torch.tensor([vis_idx.numel() if rank == owner else 0], dtype=torch.int64, device=device)
         dist.broadcast(head, src=owner)
         V = int(head.item())
@@ -93,7 +93,7 @@ def collaborative_step(pc, views, gt_images, pipe, bg_color, optimizer=None, buc
     total, out, vis, rendered = None, None, None, []
     from .adam import ShardedFusedAdam
     sharded = isinstance(optimizer, ShardedFusedAdam)
-    want_union = arena is not None and arena.sparse_rows and not sharded and world > 1
+    want_union = arena is not None and arena.sparse_rows and not sharded and arena.active
     union = None
     try:
         for k, (cam, gt) in enumerate(zip(shard_views(views), shard_views(gt_images))):

@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 import torch
 
+from util import run_ranks
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -418,10 +420,6 @@ def test_multiview_sharded_grads_equal_sequential_loop(tmp_path, world, n_views)
     still take part in every collective in the agreed order)."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-                        "--master-addr", "127.0.0.1", "--master-port", str(29629 + world + n_views), str(script), ROOT,
-                        str(n_views)],
-                       capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("ok") == world
+    ok, msg = run_ranks(script, [ROOT, n_views], world, tmp_path, timeout=900)
+    assert ok, msg
+    assert msg.count(" ok") == world

@@ -173,6 +173,72 @@ def test_plane_sample_backward_matches_grid_sample(A, B, R):
     assert torch.isfinite(p1.grad).all()
 
 
+@pytest.mark.parametrize("A,B,R", [(70, 70, 5), (133, 97, 10), (256, 256, 15), (40, 40, 2)])
+def test_plane_gradients_do_not_depend_on_the_order_of_the_points(A, B, R):
+    """csrc/triplane.hip, exact cell sums (64-bit fixed point on a per-tile grid): the plane gradient is a function of the
+    SET of points -- the same bits for any permutation of the rows (which changes every arrival order in the scatter and
+    in the cell ranks far more than two runs of the same call do), run after run; and it is the correctly rounded sum of
+    its fp32 terms to 2^-24 (torch's fp32 atomics are an order of magnitude further from that sum).  R = 15 takes the two-round path (more than ten channels), R = 2 the
+    two-workgroups-per-CU instantiation.  A non-finite gradient value sends its tile through the fp32 sums: NaN reaches
+    exactly the nodes torch's backward poisons."""
+    import torch.nn.functional as F
+    from splatco_amd.triplane import plane_sample
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(A * 7 + R)
+    V = 400_000
+    grid = torch.rand(V, 2, device=dev, generator=g) * 2.2 - 1.1
+    grid[:50_000] = grid[:50_000] * 0.02 + 0.3                          # a dense clump: thousands of points per cell, several chunks per tile
+    grid[50_000:51_000] = torch.randint(0, 2, (1000, 2), device=dev, generator=g).float() * 2 - 1
+    # gradients over six decades, so that quiet tiles next to loud ones are covered
+    w = torch.randn(V, R, device=dev, generator=g) * torch.exp(torch.rand(V, 1, device=dev, generator=g) * 14 - 7)
+
+    def grad_of(order, wts=w, dtype=torch.float32, ours=True):
+        p = torch.zeros(1, R, A, B, device=dev, dtype=dtype, requires_grad=True)
+        gr, ww = grid[order].to(dtype), wts[order].to(dtype)
+        o = plane_sample(p, gr) if ours else F.grid_sample(p, gr.view(1, 1, -1, 2), mode="bilinear", align_corners=True).flatten(0, 2).T
+        (o * ww).sum().backward()
+        return p.grad
+
+    ident = torch.arange(V, device=dev)
+    base = grad_of(ident)
+    assert torch.equal(grad_of(ident), base)
+    for seed in (1, 2):
+        perm = torch.randperm(V, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+        assert torch.equal(grad_of(perm), base), "plane gradient depends on the order of the points"
+    assert torch.equal(grad_of(ident.flip(0)), base)
+    # the yardstick: the kernel's own fp32 weights and fp32 products (tp_cell's operation order), summed in fp64 -- what
+    # an exact summation of the same terms gives.  (Against an all-fp64 grid_sample both fp32 evaluations sit at ~5e-6:
+    # the bilinear fractions of an fp32 coordinate times 132 carry 1e-5 of rounding, shared by torch and this kernel.)
+    ix, iy = ((grid[:, 0] + 1.0) * 0.5) * float(B - 1), ((grid[:, 1] + 1.0) * 0.5) * float(A - 1)
+    fx, fy = ix.floor(), iy.floor()
+    fb, fa, b0, a0 = ix - fx, iy - fy, fx.long(), fy.long()
+    exact = torch.zeros(R, A * B, device=dev, dtype=torch.float64)
+    for da, db, wt in ((0, 0, (1.0 - fa) * (1.0 - fb)), (0, 1, (1.0 - fa) * fb), (1, 0, fa * (1.0 - fb)), (1, 1, fa * fb)):
+        a, b = a0 + da, b0 + db
+        ok = (a >= 0) & (a < A) & (b >= 0) & (b < B)
+        exact.index_add_(1, (a * B + b)[ok], (w[ok] * wt[ok, None]).T.double())
+    exact = exact.view(1, R, A, B)
+    t32 = grad_of(ident, ours=False)
+    ours_err = float((base.double() - exact).norm() / exact.norm())
+    torch_err = float((t32.double() - exact).norm() / exact.norm())
+    print(f"[plane backward {A}x{B} R={R}] rel-L2 to the exact sum of the same fp32 terms: this kernel {ours_err:.2e}, torch's fp32 atomics {torch_err:.2e}")
+    # one rounding to fp32 per node (rms 2^-25.5 of the node) plus the fixed-point grid (2^-30 of the tile's largest gradient
+    # value per term; the terms of the few points folded in from one cell outside the plane are rounded in another order)
+    assert ours_err <= 2.0 ** -24, (ours_err, torch_err)
+    assert float((base.double() - exact).abs().max()) <= 2.0 ** -23 * float(exact.abs().max())
+    ref64 = exact
+    # non-finite values: as torch
+    wn = w.clone()
+    wn[123_456, 0] = float("nan")
+    wn[234_567, R - 1] = float("inf")
+    ours_n, torch_n = grad_of(ident, wn), grad_of(ident, wn, ours=False)
+    assert torch.equal(torch.isfinite(ours_n), torch.isfinite(torch_n))
+    fin = torch.isfinite(torch_n)
+    assert 0 < int((~fin).sum()) <= 8
+    assert float((ours_n[fin].double() - ref64[fin]).norm() / ref64[fin].norm()) <= 1e-5       # the poisoned tile: fp32 sums
+    assert torch.equal(grad_of(ident, torch.zeros_like(w)), torch.zeros_like(base))              # all-zero gradients: a zero tile maximum
+
+
 @pytest.mark.parametrize("V", [200_000, 300_000])   # below / above triplane.CHANNEL_LAST_MIN_POINTS (both plane layouts)
 @pytest.mark.parametrize("TA", [False, True])
 def test_triplane_forward_backward_matches_grid_sample(TA, V):

@@ -70,3 +70,65 @@ def stress_scene(rng):
     g = dict(means3D=means.astype(f), scales=scales.astype(f), rotations=q.astype(f), opacities=op.astype(f),
              colors=col.astype(f), bg=rng.uniform(0, 1, 3).astype(f))
     return cam, g, float(rng.choice([0.5, 1.0, 1.7]))
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_ranks(script, argv, world, tmp_path, timeout=1500, env_extra=None):
+    """Start `world` ranks of `script` as plain child processes (RANK / WORLD_SIZE / MASTER_* in the environment, a free
+    rendezvous port, no elastic launcher in between), each with its own stdout / stderr file under tmp_path.  Returns
+    (ok, message): on failure the message ENDS with the first failing rank's own stderr tail -- the one thing a truncated
+    log must still show."""
+    import os
+    import signal
+    import subprocess
+    import sys
+    import time
+    port = free_port()
+    procs, files = [], []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(env_extra or {})
+        out, err = open(tmp_path / f"rank{r}.out", "w"), open(tmp_path / f"rank{r}.err", "w")
+        files += [out, err]
+        procs.append(subprocess.Popen([sys.executable, str(script)] + [str(a) for a in argv], stdout=out, stderr=err, env=env,
+                                      start_new_session=True))
+    deadline, first_bad, timed_out = time.time() + timeout, None, False
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad and first_bad is None:
+            first_bad = bad[0]
+            deadline = min(deadline, time.time() + 20)      # the peers of a dead rank block in their next collective
+        if all(c is not None for c in codes):
+            break
+        if time.time() > deadline:
+            timed_out = first_bad is None
+            for p in procs:
+                if p.poll() is None:
+                    try:
+                        os.killpg(p.pid, signal.SIGKILL)     # exactly the session started above
+                    except ProcessLookupError:
+                        pass
+            for p in procs:
+                p.wait()
+            break
+        time.sleep(0.2)
+    for f in files:
+        f.close()
+    outs = [(tmp_path / f"rank{r}.out").read_text() for r in range(world)]
+    if first_bad is None and not timed_out:
+        return True, "\n".join(outs)
+    errs = [(tmp_path / f"rank{r}.err").read_text() for r in range(world)]
+    who = 0 if first_bad is None else first_bad
+    msg = [f"exit codes {[p.returncode for p in procs]}" + (f", timed out after {timeout} s" if timed_out else "")]
+    msg += [f"--- rank {r} stdout tail ---\n{o[-(4000 if r == who else 300):]}" for r, o in enumerate(outs)]
+    msg += [f"--- rank {who} (first to fail) stderr tail ---\n{errs[who][-2500:]}"]
+    return False, "\n".join(msg)
