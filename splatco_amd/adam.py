@@ -167,6 +167,11 @@ class ShardedFusedAdam:
         import torch.distributed as dist
         if self._layout_seen != self.arena.layout_version:
             self._shard()
+        for p, o in zip(self.arena.params, self.arena.offsets):
+            if p.data_ptr() != self.pflat.data_ptr() + o * self.pflat.element_size():
+                # adjust_anchor / sort_anchors REPLACE parameters: the new tensor would never be stepped, silently
+                raise RuntimeError("ShardedFusedAdam.step: a parameter no longer lives in the optimizer's flat buffer (it was replaced, "
+                                   "e.g. by densification): build a new GradArena + ShardedFusedAdam and load_full_state()")
         b1, b2 = self.betas
         flat, entries = self.arena.flat, []
         for (i, a, b), so in zip(self.slices, self._state_off):
@@ -196,19 +201,32 @@ class ShardedFusedAdam:
     # ---- conversion to / from torch.optim.Adam's per-parameter state (densification surgery, checkpoints)
     @torch.no_grad()
     def full_state(self):
-        """{parameter index: {"step", "exp_avg", "exp_avg_sq"}} with full-size moments, identical on every rank."""
+        """{parameter index: {"step", "exp_avg", "exp_avg_sq"}} with full-size moments, identical on every rank.  One moment
+        at a time: the shards are laid into ONE full-size buffer and completed by an all-gather per exchange piece (every
+        rank's slice of a piece is its 1/world of it, exactly the layout of the parameter all-gather in step()); the result
+        is handed out as VIEWS of that buffer -- one full-size transient per moment instead of four (two buffers all-reduced,
+        then a clone of every parameter's moments: 4 x 5.7 GB per rank at 20 M anchors, at the point of the run -- a
+        re-layout, densification, a checkpoint -- where head-room is smallest)."""
         import torch.distributed as dist
-        full_m, full_v = torch.zeros_like(self.pflat), torch.zeros_like(self.pflat)
-        for (i, a, b), so in zip(self.slices, self._state_off):
-            full_m[a:b] = self.exp_avg[so:so + b - a]
-            full_v[a:b] = self.exp_avg_sq[so:so + b - a]
-        if self.active:
-            dist.all_reduce(full_m)          # the ranks' slices are disjoint: the sum assembles them
-            dist.all_reduce(full_v)
-        out = {}
-        for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
-            out[i] = {"step": torch.tensor(float(self.steps[i])), "exp_avg": full_m[o:o + p.numel()].view_as(p).clone(),
-                      "exp_avg_sq": full_v[o:o + p.numel()].view_as(p).clone()}
+        out = {i: {"step": torch.tensor(float(self.steps[i]))} for i in range(len(self.arena.params))}
+        for key, shard in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+            full = torch.zeros_like(self.pflat)
+            for (i, a, b), so in zip(self.slices, self._state_off):
+                full[a:b] = shard[so:so + b - a]
+            if self.active and self._layout_seen != self.arena.layout_version:
+                # called from _shard() after the arena changed its unit table: the shards still follow the OLD table, the
+                # arena's pieces the new one -- the ranks' slices are disjoint in any case, so a SUM assembles them
+                dist.all_reduce(full)
+            elif self.active:
+                work = []
+                for pieces in self.arena.unit_pieces:
+                    for a, b in pieces:
+                        n = (b - a) // self.world
+                        work.append(dist.all_gather_into_tensor(full[a:b], full[a + self.rank * n:a + (self.rank + 1) * n], async_op=True))
+                for w in work:
+                    w.wait()
+            for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+                out[i][key] = full[o:o + p.numel()].view_as(p)
         return out
 
     @torch.no_grad()

@@ -273,18 +273,21 @@ __device__ inline SplatForm splat_form(float4 r0, float4 r1) {
 // another line through the box (a valid upper bound of the minimum, equal to it when 0 is inside the box: q = 0), so no
 // case distinction is left.  Everything that depends on one axis only is shared by the two quadrants of a row / column.
 // The splat is kept when either candidate stays within the threshold plus the rounding margin of its own terms.
-__device__ inline uint32_t quadrant_mask(float4 r0, float4 r1, int tile_x0, int tile_y0) {
+// S = edge of the four boxes in pixels: 8 = the quadrants of a tile (origin = the tile's), 4 = the 4x4-pixel sub-blocks of a
+// quadrant (origin = the quadrant's; blend.hip packs four of them into a wave).  Bit (hy << 1) | hx.
+template <int S>
+__device__ inline uint32_t box_mask4(float4 r0, float4 r1, int box_x0, int box_y0) {
     const SplatForm f = splat_form(r0, r1);
     if (!f.ok) return 0xfu;
-    const float x0 = (float)tile_x0, y0 = (float)tile_y0;
+    const float x0 = (float)box_x0, y0 = (float)box_y0;
     float dxl[2], dxh[2], dyl[2], dyh[2];     // d = mean - pixel over the half's columns / rows (low, high end)
     float cx[2], cy[2], qx[2], qy[2], bcx[2], bcy[2], sy[2], sx[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        dxh[h] = f.mx - (x0 + (float)(8 * h));
-        dxl[h] = f.mx - (x0 + (float)(8 * h + 7));
-        dyh[h] = f.my - (y0 + (float)(8 * h));
-        dyl[h] = f.my - (y0 + (float)(8 * h + 7));
+        dxh[h] = f.mx - (x0 + (float)(S * h));
+        dxl[h] = f.mx - (x0 + (float)(S * h + S - 1));
+        dyh[h] = f.my - (y0 + (float)(S * h));
+        dyl[h] = f.my - (y0 + (float)(S * h + S - 1));
         cx[h] = __builtin_amdgcn_fmed3f(0.0f, dxl[h], dxh[h]);
         cy[h] = __builtin_amdgcn_fmed3f(0.0f, dyl[h], dyh[h]);
         qx[h] = f.a * cx[h] * cx[h];          // the fixed coordinate's own term
@@ -309,6 +312,7 @@ __device__ inline uint32_t quadrant_mask(float4 r0, float4 r1, int tile_x0, int 
     }
     return mask;
 }
+__device__ inline uint32_t quadrant_mask(float4 r0, float4 r1, int tile_x0, int tile_y0) { return box_mask4<8>(r0, r1, tile_x0, tile_y0); }
 
 
 // Several buffers cleared by ONE kernel launch (preprocess.hip).  hipMemsetAsync costs a 5 us fill kernel AND 8 - 11 us of

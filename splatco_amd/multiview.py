@@ -212,7 +212,7 @@ class GradArena:
 
     def __init__(self, params: Sequence[torch.Tensor], chunk_bytes: int = 256 << 20, mode: str = "all_reduce",
                  overlap: bool = True, anchor_ranges: int = 8, merge_small: bool = True, sparse_rows: bool = False,
-                 sparse_threshold: float = 0.6):
+                 sparse_threshold: float = 0.6, check_rows: bool = False):
         self.params = [p for p in params if p is not None and p.requires_grad]
         assert self.params, "no trainable parameters"
         assert mode in ("all_reduce", "rs_ag")
@@ -226,6 +226,7 @@ class GradArena:
         # anchors is below `sparse_threshold` of all anchors
         self.sparse_rows, self.sparse_threshold = bool(sparse_rows), float(sparse_threshold)
         self._rows, self._packed, self.last_union_fraction = None, [], None
+        self.check_rows, self._union = bool(check_rows), None      # debug: assert the zero-row invariant of the packed exchange
         rank, world = world_info()
         self.world = world
         self.active = collectives_on()                   # collectives are issued (a one-rank group: only under force_collectives)
@@ -404,9 +405,14 @@ class GradArena:
             assert visible_local.shape == (N,)
             u.copy_(visible_local)
         dist.all_reduce(u, op=dist.ReduceOp.MAX)
-        rows = [torch.nonzero(u[n0:n1]).squeeze(1) + n0 for n0, n1 in self.sink_ranges]      # (one host read each)
-        total = sum(int(r.numel()) for r in rows)
+        # ONE compaction and ONE host read: the sorted row list of the whole union, cut at the range borders
+        allrows = torch.nonzero(u).squeeze(1)
+        edges = torch.tensor([n0 for n0, _ in self.sink_ranges] + [N], device=u.device)
+        cuts = torch.searchsorted(allrows, edges).tolist()
+        rows = [allrows[cuts[r]:cuts[r + 1]] for r in range(len(self.sink_ranges))]
+        total = int(allrows.numel())
         self.last_union_fraction = total / max(N, 1)
+        self._union = u if self.check_rows else None
         if self.last_union_fraction < self.sparse_threshold:
             self._rows = rows
         return self._rows is not None
@@ -414,6 +420,18 @@ class GradArena:
     def _issue_packed(self, r):
         """Range r of the sink as packed rows: [U_r, 32 | 3 | 30 | 6] gathered into one buffer, one all_reduce."""
         rows = self._rows[r]
+        if self.check_rows and self._union is not None:
+            # THE INVARIANT the packed exchange rests on: a row outside the union of the ranks' visible anchors is exactly
+            # zero on every rank (every per-anchor gradient reaches the sink through the visible gather, whose backward
+            # writes zeros for invisible anchors).  A gradient that arrived another way would be dropped from the sum
+            # without a trace -- check_rows=True (debug) looks.
+            n0, n1 = self.sink_ranges[r]
+            out = self._union[n0:n1] == 0
+            for i in self._sink_ids:
+                v = self.views[i].reshape(self.views[i].shape[0], -1)[n0:n1]
+                if bool((v[out] != 0).any()):
+                    raise RuntimeError(f"GradArena: per-anchor parameter {i} has a non-zero gradient row outside the union of the "
+                                       f"visible anchors (range {r}): the row-sparse exchange would drop it")
         parts = [self.views[i].reshape(self.views[i].shape[0], -1).index_select(0, rows) for i in self._sink_ids]
         packed = torch.cat([p.reshape(-1) for p in parts]) if rows.numel() else self.flat.new_zeros(0)
         if packed.numel():

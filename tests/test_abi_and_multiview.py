@@ -343,7 +343,8 @@ mvals = [v * mask[:, None] for v in vals]                                       
 sparse_out = {}
 for sparse in (False, True):
     for mode in ("all_reduce", "rs_ag"):
-        arena = GradArena([other] + pa, chunk_bytes=4096, mode=mode, overlap=True, anchor_ranges=4, sparse_rows=sparse, sparse_threshold=0.9)
+        arena = GradArena([other] + pa, chunk_bytes=4096, mode=mode, overlap=True, anchor_ranges=4, sparse_rows=sparse, sparse_threshold=0.9,
+                          check_rows=True)
         sink = arena.attach_sink(pa)
         for it in range(2):
             arena.zero()
@@ -363,6 +364,28 @@ for sparse in (False, True):
 for mode in ("all_reduce", "rs_ag"):
     for it in range(2):
         assert same(sparse_out[(True, mode, it)], sparse_out[(False, mode, it)]), ("row-sparse exchange", mode, it)
+# check_rows (debug): a gradient row OUTSIDE the union of the visible anchors -- which the packed exchange would drop from the sum
+# without a trace -- is refused.  Every rank plants one (the check is local; all ranks raise at the same range, none is left
+# inside a collective)
+arena = GradArena([other] + pa, chunk_bytes=4096, mode="all_reduce", overlap=False, anchor_ranges=4, sparse_rows=True, sparse_threshold=0.9,
+                  check_rows=True)
+sink = arena.attach_sink(pa)
+arena.zero()
+union = torch.zeros(Na, dtype=torch.uint8)
+union[:300] = 1
+assert arena.set_row_union(union)
+for t, v in zip(sink.tensors, vals):
+    t.zero_()
+    t[:300] = v[:300]
+sink.tensors[2][900, 5] = 1.0
+sink.fresh = False
+try:
+    arena.reduce()
+    raise SystemExit("a non-zero row outside the union went through the packed exchange")
+except RuntimeError as e:
+    assert "outside the union" in str(e)
+arena.close()
+dist.barrier()
 a1 = GradArena([other] + pa, anchor_ranges=1)
 for i, b in zip(range(1, 5), both):
     assert same(results[("all_reduce", 4)][a1.offsets[i]:a1.offsets[i] + b.numel()].view_as(b), b)

@@ -120,7 +120,7 @@ for mode, cw in (("all_reduce", 0.05), ("rs_ag", 0.0))[:int(sys.argv[2])]:
     assert all(torch.equal(a, b) for a, b in zip(params_a, params_b))
     # several pieces per large parameter; the rs_ag case also exchanges the per-anchor gradients ROW-SPARSE (only the rows of
     # the union of the ranks' visible anchors travel, GradArena.set_row_union; the threshold is lifted so that it always packs)
-    arena = GradArena(params_a, chunk_bytes=4 << 20, mode=mode, anchor_ranges=4, sparse_rows=(mode == "rs_ag"), sparse_threshold=1.01)
+    arena = GradArena(params_a, chunk_bytes=4 << 20, mode=mode, anchor_ranges=4, sparse_rows=(mode == "rs_ag"), sparse_threshold=1.01, check_rows=True)
     gen_p = torch.Generator(device=dev).manual_seed(1234)
     for it in range(2):         # step 0 goes out from reduce() and agrees on the order; step 1 issues from the hooks / ranges
         loss_a, out_a, _ = collaborative_step(pc_a, views, gts, pipe, bg, consistency_weight=cw, densifier=den_a, arena=arena,

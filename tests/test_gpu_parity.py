@@ -451,7 +451,7 @@ ULP32 = 2.0 ** -23
 UNPINNED_RATIO_MAX = 3.0
 
 
-def _one_ulp_response(oracle, st, f64, dL_eff, g, b64, trials=2):
+def _one_ulp_response(oracle, st, f64, dL_eff, g, b64, trials=6):
     """Per tensor, per Gaussian: the largest row-relative change of the fp64 gradient over `trials` random one-ulp
     (binary32, random sign) perturbations of the factors the backward multiplies and sums: the splat records' conic,
     opacity and colour, the forward's transmittances, dL/dpixel, and the Gaussian's own means / scales / quaternion.  A
@@ -499,7 +499,7 @@ def stress_case(oracle, rng, verbose=False, info=None):
     b = oracle.backward(st, f, dL_eff, g["means3D"], g["scales"], g["rotations"], colors_precomp=g["colors"])
     e32 = {k: rel_l2(o["grads"][k], b[k]) for k in STRESS_NAMES}
     worst = max(e32.values())
-    note = ""
+    note, fails = "", []
     if worst > GRAD_TOL or verbose:
         f64 = _fp64_on_fp32_records(oracle, st, f)
         more = (f64["n_contrib"] != f["n_contrib"]) & (dL_eff != 0).any(axis=0)
@@ -521,12 +521,23 @@ def stress_case(oracle, rng, verbose=False, info=None):
                   for _ in range(3)]
         b64 = {k: np.asarray(b64[k], np.float64) for k in STRESS_NAMES}
         response = _one_ulp_response(oracle, st, f64, dL_eff, g, b64)
+        rm2, rconic, _, rcol = oracle.blend_backward(st, f, dL_eff, raw_moments=True)
+        braw = oracle.preprocess_backward(st, f, rm2, rconic, rcol, g["means3D"], g["scales"], g["rotations"])
         for k in STRESS_NAMES:
             if e32[k] <= GRAD_TOL and not verbose:
                 continue
             dev, o32, ref = o["grads"][k].astype(np.float64), b[k].astype(np.float64), b64[k]
-            pinned = response[k] <= CERTIFY * np.linalg.norm(ref.reshape(len(ref), -1), axis=1)      # (rows without a gradient: pinned)
-            e_pinned = rel_l2(dev[pinned], o32[pinned])
+            # (rows without a gradient: pinned).  The probe perturbs what enters the evaluation, not the roundings INSIDE it (the
+            # determinant a c - b^2 of a needle cancels between two rounded products; the sums over ten thousand pixels round
+            # at every step): the scalar fp32 oracle is one more witness -- a row it cannot hold is not one binary32 pins.
+            # Either signal alone marks the row; a row is certified only when its mathematics AND an independent fp32
+            # evaluation say so (rounds 3-4 used the second signal alone: rows could be certified by the oracle's luck).
+            rn = np.linalg.norm(ref.reshape(len(ref), -1), axis=1)
+            row = lambda a_: np.linalg.norm((np.asarray(a_, np.float64) - ref).reshape(len(ref), -1), axis=1)
+            pinned = (response[k] <= CERTIFY * rn) & (row(o32) <= CERTIFY * rn)
+            if braw.get(k) is not None:      # ... and the fp32 oracle in the DEVICE's formulation of the screen-space sums (raw
+                pinned &= row(braw[k]) <= CERTIFY * rn       # moments per 8x8 quadrant, shifted to the splat's centre) is a third witness
+            e_pinned, e_pinned_o32 = rel_l2(dev[pinned], ref[pinned]), rel_l2(o32[pinned], ref[pinned])
             loose = ~pinned
             d_dev, d_o32 = np.linalg.norm(dev[loose] - ref[loose]), np.linalg.norm(o32[loose] - ref[loose])
             d_noise = max(float(np.linalg.norm((tr[k].astype(np.float64) - o32)[loose])) for tr in trials) \
@@ -535,23 +546,27 @@ def stress_case(oracle, rng, verbose=False, info=None):
             note += (f" {k}: {e32[k]:.1e} over all rows; {loose.sum()} of {vis.sum()} visible rows not pinned by fp32 "
                      f"(device {d_dev / max(np.linalg.norm(ref[loose]), 1e-300):.1e}, fp32 oracle "
                      f"{d_o32 / max(np.linalg.norm(ref[loose]), 1e-300):.1e}, one-ulp response / noise floor "
-                     f"{d_noise / max(np.linalg.norm(ref[loose]), 1e-300):.1e} from fp64 there), pinned rows {e_pinned:.1e};")
+                     f"{d_noise / max(np.linalg.norm(ref[loose]), 1e-300):.1e} from fp64 there), pinned rows: device {e_pinned:.1e}, "
+                     f"fp32 oracle {e_pinned_o32:.1e} from fp64;")
             if e32[k] > GRAD_TOL:
                 ratio = d_dev / max(d_o32, d_noise, 1e-300)
                 if info is not None:
                     info.setdefault("branch_b", {})[k] = {"all_rows": e32[k], "unpinned_rows": int(loose.sum()),
                                                            "visible_rows": int(vis.sum()), "pinned_rel_l2": e_pinned,
                                                            "ratio": ratio, "ratio_vs_oracle": d_dev / max(d_o32, 1e-300)}
-                assert e_pinned <= GRAD_TOL, (k, "rows binary32 pins (one-ulp response < 1e-5)", e_pinned)
-                assert ratio <= UNPINNED_RATIO_MAX, (k, "ill-conditioned rows vs fp64: device", d_dev, "fp32 oracle", d_o32,
-                                                     "noise floor", d_noise, "ratio", ratio)
+                if not e_pinned <= GRAD_TOL:
+                    fails.append((k, "rows binary32 pins (one-ulp response <= 1e-5): device vs fp64", e_pinned))
+                if not ratio <= UNPINNED_RATIO_MAX:
+                    fails.append((k, "ill-conditioned rows vs fp64: device", d_dev, "fp32 oracle", d_o32, "noise floor", d_noise, "ratio", ratio))
     ranges = f["ranges"]
     if info is not None:
         info.update({"P": int(g["means3D"].shape[0]), "visible": int((f["radii"] > 0).sum()), "worst": float(worst),
                      "image": f"{cam.image_width}x{cam.image_height}", "I": int(f["num_rendered"])})
-    return (f"P={g['means3D'].shape[0]} {cam.image_width}x{cam.image_height} I={f['num_rendered']} "
+    line = (f"P={g['means3D'].shape[0]} {cam.image_width}x{cam.image_height} I={f['num_rendered']} "
             f"max tile={(ranges[:, 1].astype(np.int64) - ranges[:, 0]).max()} vis={(f['radii'] > 0).sum()} "
             f"worst grad {worst:.1e}" + (" |" + note if note else ""))
+    assert not fails, (fails, line)
+    return line
 
 
 # How far the stress set may lean on branch (b) of stress_case.  Measured over seeds 0-4 on the round-3 kernels

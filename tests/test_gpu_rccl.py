@@ -47,7 +47,7 @@ def make(force, mode, sparse=False, sharded=False):
     rest = [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad and id(p) not in idle]
     groups.append({"params": rest, "lr": 1e-3, "name": "mlp_and_feat_planes"})
     params = [p for grp in groups for p in grp["params"]]
-    arena = GradArena(params, chunk_bytes=4 << 20, mode=mode, anchor_ranges=4, sparse_rows=sparse, sparse_threshold=1.01)
+    arena = GradArena(params, chunk_bytes=4 << 20, mode=mode, anchor_ranges=4, sparse_rows=sparse, sparse_threshold=1.01, check_rows=True)
     assert arena.active == force and arena.world == 1
     opt = ShardedFusedAdam(groups, arena, eps=1e-15) if sharded else FusedAdam(groups, eps=1e-15)
     den = AnchorDensifier(pc, torch.optim.Adam(groups, eps=1e-15), voxel_size=0.01, seed=77)

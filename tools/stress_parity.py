@@ -23,10 +23,10 @@ def main(n=40, seed=0, seeds=1, verbose=0):
                 line = stress_case(orc, rng, verbose=bool(verbose), info=info)
             except AssertionError as e:
                 bad += 1
-                line = "FAIL " + str(e)[:300]
+                line = "FAIL " + str(e)[:2500]
             rs = {k: round(v["ratio"], 2) for k, v in info.get("branch_b", {}).items()}
             ratios += list(rs.values())
-            print(f"[{s}/{it}] {line[:260]}" + (f" || branch (b) ratios device / max(oracle, noise): {rs}" if rs else ""), flush=True)
+            print(f"[{s}/{it}] {line[:2600] if line.startswith('FAIL') else line[:260]}" + (f" || branch (b) ratios device / max(oracle, noise): {rs}" if rs else ""), flush=True)
     ratios.sort()
     if ratios:
         print(f"branch (b) ratios over {len(ratios)} (scene, tensor) pairs: median {ratios[len(ratios) // 2]:.2f}, p90 {ratios[int(len(ratios) * 0.9)]:.2f}, "
