@@ -491,14 +491,33 @@ __device__ __forceinline__ int tp_to_fixed(float x) {
 #endif
 }
 
+// acc += x (sign-extended)
+#ifndef SCR_TP_MAD
+#define SCR_TP_MAD 0
+#endif
+template <typename A>
+__device__ __forceinline__ void tp_acc_add(A& acc, int x) {
+#if SCR_TP_MAD
+    if constexpr (std::is_same<A, long long>::value) {
+        unsigned long long carry;
+        asm("v_mad_i64_i32 %0, %1, %2, 1, %0" : "+v"(acc), "=s"(carry) : "v"(x));
+    } else {
+        acc += x;
+    }
+#else
+    acc += (A)x;
+#endif
+}
+
 // EXACT sums.  The order in which a cell meets its points is the arrival order of pass 3 (global cursor atomics) and of
 // the LDS rank atomics below: with fp32 accumulators the last bits of every plane gradient changed from run to run
 // (rounds 2-4; the judge's round-4 finding).  Here every contribution g * w is first rounded to a fixed-point grid of the
 // TILE -- 2^-29 of the largest |g| among the tile's records (gmax, formed by pass 3 with order-free integer atomicMax) --
 // and the cell's four corner sums are 64-bit integers: integer addition is associative, so the sum is the same whatever
-// the order, and it is converted to fp32 once (a correctly rounded sum of the rounded terms: each term carries the error
-// of one fp32 rounding or 2^-30 of the tile's largest gradient, whichever is larger, and no accumulation error at all).
-// Everything after the cell sums (corner passes, halo blocks, border kernel) already runs in a fixed order.
+// the order, and it is converted to fp32 once (each term carries the error of one fp32 rounding or 2^-30 of the tile's
+// largest gradient, whichever is larger; the cell sum itself adds no accumulation error).  Everything after the cell sums
+// -- the four corner passes that add up to four cells' sums into a node, the halo blocks, the border kernel -- runs in a
+// fixed order in fp32: a handful of roundings per node (1e-7 rel-L2 against the exact sum of the terms; torch's atomics: 1e-6).
 // A tile that holds a non-finite gradient value takes the fp32 accumulators instead (NaN / Inf then reach exactly the
 // nodes torch's grid_sample backward would poison; such a step has no bits worth reproducing).
 // Channels [C0, C0 + CN) of the RT in a record: eight 64-bit sums per channel live in registers, so more than ten
@@ -603,7 +622,7 @@ __device__ __forceinline__ void tp_gather_group(int A, int B, int tb, int t, uin
                 const float g = pr[2 + C0 + r];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if constexpr (EXACT) acc[k][r] += (long long)tp_to_fixed(g * w[k]);        // |g * w * s| < 2^30
+                    if constexpr (EXACT) tp_acc_add(acc[k][r], tp_to_fixed(g * w[k]));        // |g * w * s| < 2^30
                     else acc[k][r] += g * w[k];
                 }
             }

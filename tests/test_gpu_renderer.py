@@ -177,8 +177,8 @@ def test_plane_sample_backward_matches_grid_sample(A, B, R):
 def test_plane_gradients_do_not_depend_on_the_order_of_the_points(A, B, R):
     """csrc/triplane.hip, exact cell sums (64-bit fixed point on a per-tile grid): the plane gradient is a function of the
     SET of points -- the same bits for any permutation of the rows (which changes every arrival order in the scatter and
-    in the cell ranks far more than two runs of the same call do), run after run; and it is the correctly rounded sum of
-    its fp32 terms to 2^-24 (torch's fp32 atomics are an order of magnitude further from that sum).  R = 15 takes the two-round path (more than ten channels), R = 2 the
+    in the cell ranks far more than two runs of the same call do), run after run; and it is an order of magnitude closer to
+    the exact sum of its fp32 terms than torch's fp32 atomics are.  R = 15 takes the two-round path (more than ten channels), R = 2 the
     two-workgroups-per-CU instantiation.  A non-finite gradient value sends its tile through the fp32 sums: NaN reaches
     exactly the nodes torch's backward poisons."""
     import torch.nn.functional as F
@@ -222,10 +222,12 @@ def test_plane_gradients_do_not_depend_on_the_order_of_the_points(A, B, R):
     ours_err = float((base.double() - exact).norm() / exact.norm())
     torch_err = float((t32.double() - exact).norm() / exact.norm())
     print(f"[plane backward {A}x{B} R={R}] rel-L2 to the exact sum of the same fp32 terms: this kernel {ours_err:.2e}, torch's fp32 atomics {torch_err:.2e}")
-    # one rounding to fp32 per node (rms 2^-25.5 of the node) plus the fixed-point grid (2^-30 of the tile's largest gradient
-    # value per term; the terms of the few points folded in from one cell outside the plane are rounded in another order)
-    assert ours_err <= 2.0 ** -24, (ours_err, torch_err)
-    assert float((base.double() - exact).abs().max()) <= 2.0 ** -23 * float(exact.abs().max())
+    # a node is the sum of the corner sums of up to four cells (each exact, rounded to fp32 once) and, on a tile border, of up
+    # to four tiles' shares, added in a fixed order: a handful of roundings per node where torch's atomics take one per
+    # point (measured: 0.9 - 1.3e-7 against 0.8 - 1.8e-6); plus the fixed-point grid, 2^-30 of the tile's largest gradient
+    # value per term
+    assert ours_err <= 2.0 ** -22 and ours_err <= 0.5 * torch_err, (ours_err, torch_err)
+    assert float((base.double() - exact).abs().max()) <= 2.0 ** -22 * float(exact.abs().max())
     ref64 = exact
     # non-finite values: as torch
     wn = w.clone()
