@@ -493,7 +493,7 @@ __device__ __forceinline__ int tp_to_fixed(float x) {
 
 // acc += x (sign-extended)
 #ifndef SCR_TP_MAD
-#define SCR_TP_MAD 0
+#define SCR_TP_MAD 1     // v_mad_i64_i32 acc, x, 1, acc: one instruction where the sign extension + 64-bit add take two (-4 % / -9 % on the R = 5 / 10 kernels)
 #endif
 template <typename A>
 __device__ __forceinline__ void tp_acc_add(A& acc, int x) {
