@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 23
+#define SCR_ABI_VERSION 24
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -181,7 +181,8 @@ int scr_tpa_backward_stats(int32_t R, int32_t H, int32_t W, const float* davg, c
  * gaussian_renderer/__init__.py:68-111 (mask = neural_opacity > 0; repeat / cat / boolean index /
  * split; sigmoid, normalize, FMA) as one streaming pass.  Candidate c = anchor v * k + slot; kept
  * candidates keep their order.  V anchors, k offsets per anchor, n = V*k candidates:
- *   neural_opacity[n], color[n,3], scale_rot[n,7], offsets[n,3] (= _offset[V,k,3]),
+ *   neural_opacity[n], color[n,3], scale_rot[n,7], offsets (= _offset[V,k,3]: the 3 k floats of an anchor contiguous, the
+ *   anchors' rows offsets_ld floats apart -- 3 k when packed, 72 when they are columns 35.. of scr_anchor_gather's g_fea),
  *   grid_scaling[V,6], anchor[V,3]  ->  xyz[P,3], color_out[P,3], opacity[P], scaling[P,3], rot[P,4],
  *   out_index[n] int32 (compacted index or -1), mask_out[n] uint8 (may be NULL).
  * scr_expand_plan counts the kept candidates (stream-synchronises once, like the boolean index it
@@ -198,10 +199,10 @@ int scr_expand_plan(int64_t n_candidates, const float* neural_opacity, void* scr
 int scr_mask_index_plan(int64_t n, const uint8_t* mask, void* scratch, int64_t* num_set_host, void* stream);
 int scr_mask_index_run(int64_t n, const uint8_t* mask, const void* scratch, int64_t* index, int64_t* inverse, void* stream);
 int scr_expand_run(int64_t V, int32_t k, const float* neural_opacity, const float* color,
-                   const float* scale_rot, const float* offsets, const float* grid_scaling,
+                   const float* scale_rot, const float* offsets, int32_t offsets_ld, const float* grid_scaling,
                    const float* anchor, const void* scratch, int32_t* out_index, uint8_t* mask_out,
                    float* xyz, float* color_out, float* opacity, float* scaling, float* rot, void* stream);
-int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const float* offsets,
+int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const float* offsets, int32_t offsets_ld,
                         const float* grid_scaling, const int32_t* out_index, const float* g_xyz,
                         const float* g_color, const float* g_opacity, const float* g_scaling,
                         const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
@@ -292,7 +293,9 @@ int scr_scaling_reg_backward(int64_t P, const float* scaling, const float* g, fl
  * the four visible-anchor gathers, exp(_scaling) and the [V,71] concatenation in one pass.  visible_index[V] int64 = the
  * visible anchors in order; outputs feat[V,32], anchor[V,3], offsets[V,30], grid_scaling[V,6] = exp(scaling) and
  * g_fea[V,71] = cat of the four, with row stride g_fea_ld = 71 (packed) or 72 (16-byte aligned rows, the pad column
- * written as 0 / ignored on the way back: what the fused BatchNorm-Linear wants).  The backward takes V (rows of the upstream gradients), inverse_index[N] int64 (row of every anchor, -1 = not visible) and
+ * written as 0 / ignored on the way back: what the fused BatchNorm-Linear wants).  feat_out and offsets_out may be NULL
+ * (with g_fea_ld = 72): their consumers then read columns 0..31 / 35..64 of g_fea through a row stride (scr_mlp_heads_*:
+ * feat_ld, scr_expand_*: offsets_ld) and 62 of the 143 floats per anchor are not written twice.  The backward takes V (rows of the upstream gradients), inverse_index[N] int64 (row of every anchor, -1 = not visible) and
  * the upstream gradients of the five outputs (any may be NULL) and overwrites EVERY element of the four parameter
  * gradients [N,32] / [N,3] / [N,30] / [N,6] (zeros for invisible anchors; d exp applied): no atomics, no memset.
  * accumulate != 0: ADDS to what the four arrays hold instead (a further view of the same step writing into the same
@@ -355,17 +358,18 @@ int scr_norm_linear_backward(int64_t V, int32_t d, const float* x, int32_t ldx, 
  *   its two halves geo_a | geo_b [V,32], the outputs of FeaturePlanes' two GEMMs, scene/gaussian_model.py:160-168)
  *   out_opacity[V,10] = tanh(W2o relu(W1[0:32] x + b1[0:32]) + b2o);  out_color[V,30] = sigmoid(... [32:64] ...);
  *   out_cov[V,70] = W2v relu(W1[64:96] x + b1[64:96]) + b2v
+ * feat rows are feat_ld floats apart (32 when packed; 16-byte aligned rows, feat_ld a multiple of 4).
  * w1[96,99] / b1[96] are the three first layers stacked (opacity, colour, cov).  hidden_save (opaque,
  * scr_mlp_heads_hidden_bytes) keeps the hidden layer for the backward pass.  The backward overwrites every output:
  * d_feat[V,32], d_anchor[V,3] (through ob_view), d_geo_a / d_geo_b [V,32] and the parameter gradients; weight-gradient partial
  * sums go through `partial` (scr_mlp_heads_partial_bytes) and are added in a fixed order (bit-reproducible). */
 size_t scr_mlp_heads_hidden_bytes(int64_t V);
 size_t scr_mlp_heads_partial_bytes(int64_t V);
-int scr_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
+int scr_mlp_heads_forward(int64_t V, const float* feat, int32_t feat_ld, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
                           const float* w1, const float* b1, const float* w2o, const float* b2o, const float* w2c,
                           const float* b2c, const float* w2v, const float* b2v, void* hidden_save, float* out_opacity,
                           float* out_color, float* out_cov, void* stream);
-int scr_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
+int scr_mlp_heads_backward(int64_t V, const float* feat, int32_t feat_ld, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
                            const float* w1, const float* w2o, const float* w2c, const float* w2v, const void* hidden_save,
                            const float* out_opacity, const float* out_color, const float* g_opacity, const float* g_color,
                            const float* g_cov, void* partial, float* d_feat, float* d_anchor, float* d_geo_a, float* d_geo_b, float* d_w1,

@@ -33,7 +33,7 @@ SYMBOLS = [
 ]
 PLAN_NONFINITE_COLOUR, PLAN_LARGE_RECTS = 1, 2      # SCR_PLAN_*
 PROF_COUNT = 19
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 (DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS, DBG_QMASK,
  DBG_GM_INDEX) = range(9)
@@ -103,8 +103,8 @@ def _load():
     lib.scr_debug_get.argtypes = [C.c_int, i64, i64, i32, i32, vp, vp, vp, vp, vp]
     lib.scr_expand_scratch_bytes.argtypes = [C.c_int64]
     lib.scr_expand_plan.argtypes = [i64, vp, vp, C.POINTER(C.c_int64), vp]
-    lib.scr_expand_run.argtypes = [i64, i32] + [vp] * 15
-    lib.scr_expand_backward.argtypes = [i64, i32] + [vp] * 16 + [i64, vp]
+    lib.scr_expand_run.argtypes = [i64, i32, vp, vp, vp, vp, i32] + [vp] * 11
+    lib.scr_expand_backward.argtypes = [i64, i32, vp, vp, i32] + [vp] * 14 + [i64, vp]
     for f in ("scr_expand_plan", "scr_expand_run", "scr_expand_backward"):
         getattr(lib, f).restype = C.c_int
     lib.scr_plane_sample_scratch_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32]
@@ -162,8 +162,8 @@ def _load():
     lib.scr_statis_compute.restype = lib.scr_statis_apply.restype = C.c_int
     lib.scr_mlp_heads_hidden_bytes.argtypes = lib.scr_mlp_heads_partial_bytes.argtypes = [i64]
     lib.scr_mlp_heads_hidden_bytes.restype = lib.scr_mlp_heads_partial_bytes.restype = C.c_size_t
-    lib.scr_mlp_heads_forward.argtypes = [i64] + [vp] * 18
-    lib.scr_mlp_heads_backward.argtypes = [i64] + [vp] * 29
+    lib.scr_mlp_heads_forward.argtypes = [i64, vp, i32] + [vp] * 17
+    lib.scr_mlp_heads_backward.argtypes = [i64, vp, i32] + [vp] * 28
     lib.scr_mlp_heads_forward.restype = lib.scr_mlp_heads_backward.restype = C.c_int
     lib.scr_anchor_gather.argtypes = [i64] + [vp] * 10 + [i32, vp]
     lib.scr_anchor_gather_backward.argtypes = [i64, i64] + [vp] * 7 + [i32] + [vp] * 4 + [i32, vp]

@@ -59,13 +59,18 @@ class _AnchorGather(torch.autograd.Function):
         idx = idx.contiguous().long()
         V, N, dev = idx.numel(), anchor.shape[0], anchor.device
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        # g_fea rows padded to 72 floats: 16-byte aligned rows for the fused BatchNorm-Linear (csrc/normlinear.hip)
-        feat, anc, off, gs, g_fea = new(V, 32), new(V, 3), new(V, 10, 3), new(V, 6), new(V, 72)[:, :71]
+        # g_fea rows padded to 72 floats: 16-byte aligned rows for the fused BatchNorm-Linear (csrc/normlinear.hip).
+        # feat and the offsets are NOT written a second time: they are columns 0..31 / 35..64 of g_fea, and their readers
+        # (csrc/mlp_heads.hip, csrc/expand.hip) take a row stride -- 62 of 143 floats per anchor less to write (1.1 GB at
+        # configs[2]).  The two small ones (anchor 3, scaling 6) keep their packed copies.
+        g72 = new(V, 72)
+        anc, gs, g_fea = new(V, 3), new(V, 6), g72[:, :71]
+        feat, off = g72[:, :32], g72[:, 35:65].unflatten(1, (10, 3))
         if V:
             with torch.cuda.device(dev):
                 _C.check(_C.lib.scr_anchor_gather(V, idx.data_ptr(), anchor_feat.data_ptr(), anchor.data_ptr(),
-                                                  offset.data_ptr(), scaling.data_ptr(), feat.data_ptr(), anc.data_ptr(),
-                                                  off.data_ptr(), gs.data_ptr(), g_fea.data_ptr(), 72, _stream()))
+                                                  offset.data_ptr(), scaling.data_ptr(), None, anc.data_ptr(),
+                                                  None, gs.data_ptr(), g72.data_ptr(), 72, _stream()))
         inv = getattr(idx, "_scr_inverse", None)       # left by expand.mask_indices: position of every anchor in idx, -1 = invisible
         if inv is not None and (inv.shape != (N,) or inv.device != dev):
             inv = None

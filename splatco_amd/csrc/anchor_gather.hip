@@ -111,9 +111,10 @@ anchor_gather_kernel(int64_t V, const int64_t* __restrict__ idx, const float* __
     __syncthreads();
     // ---- the workgroup's chunks of the five outputs are contiguous
     ag_store_chunk(g_fea + v0 * ldg, tile, rows * ldg, ldg, 0);      // ldg = 71 (packed) or 72 = AG_LD (a straight copy)
-    ag_store_chunk(feat + v0 * AG_FEAT, tile, rows * AG_FEAT, AG_FEAT, 0);
+    // (feat / offsets NULL: their consumers -- the MLP heads, the expansion -- read the columns of g_fea through a row stride)
+    if (feat) ag_store_chunk(feat + v0 * AG_FEAT, tile, rows * AG_FEAT, AG_FEAT, 0);
     ag_store_chunk(anchor + v0 * 3, tile, rows * 3, 3, 32);
-    ag_store_chunk(offsets + v0 * AG_OFF, tile, rows * AG_OFF, AG_OFF, 35);
+    if (offsets) ag_store_chunk(offsets + v0 * AG_OFF, tile, rows * AG_OFF, AG_OFF, 35);
     ag_store_chunk(grid_scaling + v0 * 6, tile, rows * 6, 6, 65);
 }
 

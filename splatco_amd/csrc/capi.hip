@@ -493,22 +493,23 @@ int scr_mask_index_run(int64_t n, const uint8_t* mask, const void* scratch, int6
 }
 
 int scr_expand_run(int64_t V, int32_t k, const float* neural_opacity, const float* color,
-                   const float* scale_rot, const float* offsets, const float* grid_scaling,
+                   const float* scale_rot, const float* offsets, int32_t offsets_ld, const float* grid_scaling,
                    const float* anchor, const void* scratch, int32_t* out_index, uint8_t* mask_out,
                    float* xyz, float* color_out, float* opacity, float* scaling, float* rot, void* stream) {
     if (V < 0 || k <= 0) return fail("bad V / k");
+    if (offsets_ld < 3 * k) return fail("offsets_ld %d: the offset rows of an anchor are 3 k = %d floats long", offsets_ld, 3 * k);
     if (V == 0) return 0;
     if (!neural_opacity || !color || !scale_rot || !offsets || !grid_scaling || !anchor || !scratch || !out_index)
         return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
     { ProfScope ps_(SCR_PROF_EXPAND, st);
-      launch_expand_run(V * k, k, neural_opacity, color, scale_rot, offsets, grid_scaling, anchor,
+      launch_expand_run(V * k, k, neural_opacity, color, scale_rot, offsets, offsets_ld, grid_scaling, anchor,
                         (const uint32_t*)scratch, out_index, mask_out, xyz, color_out, opacity, scaling, rot, st); }
     CHECK_LAUNCH("expand_run_kernel", 0, st);
     return 0;
 }
 
-int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const float* offsets,
+int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const float* offsets, int32_t offsets_ld,
                         const float* grid_scaling, const int32_t* out_index, const float* g_xyz,
                         const float* g_color, const float* g_opacity, const float* g_scaling,
                         const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
@@ -516,13 +517,14 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
                         void* stream) {
     if (V < 0 || k <= 0) return fail("bad V / k");
     if (g_reg && P <= 0) return fail("scr_expand_backward: g_reg needs P = the number of selected candidates");
+    if (offsets_ld < 3 * k) return fail("offsets_ld %d: the offset rows of an anchor are 3 k = %d floats long", offsets_ld, 3 * k);
     if (V == 0) return 0;
     if (!scale_rot || !offsets || !grid_scaling || !out_index || !d_neural_opacity || !d_color || !d_scale_rot ||
         !d_offsets || !d_grid_scaling || !d_anchor)
         return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
     { ProfScope ps_(SCR_PROF_EXPAND_BACKWARD, st);
-      launch_expand_backward(V, k, scale_rot, offsets, grid_scaling, out_index, g_xyz, g_color, g_opacity, g_scaling,
+      launch_expand_backward(V, k, scale_rot, offsets, offsets_ld, grid_scaling, out_index, g_xyz, g_color, g_opacity, g_scaling,
                              g_rot, d_neural_opacity, d_color, d_scale_rot, d_offsets, d_grid_scaling, d_anchor, g_reg, P, st); }
     CHECK_LAUNCH("expand_backward_kernel", 0, st);
     return 0;
@@ -733,9 +735,10 @@ int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anch
     if (V < 0) return fail("V < 0");
     if (g_fea_ld != 71 && g_fea_ld != 72) return fail("g_fea row stride must be 71 (packed) or 72 (16-byte aligned rows)");
     if (V == 0) return 0;
-    if (!visible_index || !anchor_feat || !anchor || !offset || !scaling || !feat_out || !anchor_out || !offsets_out ||
-        !grid_scaling_out || !g_fea_out)
+    if (!visible_index || !anchor_feat || !anchor || !offset || !scaling || !anchor_out || !grid_scaling_out || !g_fea_out)
         return fail("NULL argument");
+    if ((!feat_out || !offsets_out) && g_fea_ld != 72)
+        return fail("feat_out / offsets_out may be NULL (their consumers read the columns of g_fea) only with 16-byte aligned g_fea rows (ld 72)");
     launch_anchor_gather(V, visible_index, anchor_feat, anchor, offset, scaling, feat_out, anchor_out, offsets_out,
                          grid_scaling_out, g_fea_out, g_fea_ld, (hipStream_t)stream);
     CHECK_LAUNCH("anchor_gather_kernel", 0, (hipStream_t)stream);
@@ -847,37 +850,39 @@ int scr_norm_linear_backward(int64_t V, int32_t d, const float* x, int32_t ldx, 
 size_t scr_mlp_heads_hidden_bytes(int64_t V) { return mlp_heads_hidden_bytes(V > 0 ? V : 1); }
 size_t scr_mlp_heads_partial_bytes(int64_t V) { return mlp_heads_partial_bytes(V > 0 ? V : 1); }
 
-int scr_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
+int scr_mlp_heads_forward(int64_t V, const float* feat, int32_t feat_ld, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
                           const float* w1, const float* b1, const float* w2o, const float* b2o, const float* w2c,
                           const float* b2c, const float* w2v, const float* b2v, void* hidden_save, float* out_opacity,
                           float* out_color, float* out_cov, void* stream) {
     if (V < 0) return fail("V < 0");
+    if (feat_ld < 32 || feat_ld % 4 != 0 || ((uintptr_t)feat & 15) != 0) return fail("feat rows: 32 floats, 16-byte aligned, feat_ld a multiple of 4 (got %d)", feat_ld);
     if (V == 0) return 0;
     if (!feat || !anchor || !campos || !geo_a || !geo_b || !w1 || !b1 || !w2o || !b2o || !w2c || !b2c || !w2v || !b2v || !hidden_save ||
         !out_opacity || !out_color || !out_cov)
         return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
     { ProfScope ps_(SCR_PROF_MLP_HEADS, st);
-      launch_mlp_heads_forward(V, feat, anchor, campos, geo_a, geo_b, w1, b1, w2o, b2o, w2c, b2c, w2v, b2v, hidden_save, out_opacity,
+      launch_mlp_heads_forward(V, feat, feat_ld, anchor, campos, geo_a, geo_b, w1, b1, w2o, b2o, w2c, b2c, w2v, b2v, hidden_save, out_opacity,
                                out_color, out_cov, st); }
     CHECK_LAUNCH("mlp_heads_forward_kernel", 0, st);
     return 0;
 }
 
-int scr_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
+int scr_mlp_heads_backward(int64_t V, const float* feat, int32_t feat_ld, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
                            const float* w1, const float* w2o, const float* w2c, const float* w2v, const void* hidden_save,
                            const float* out_opacity, const float* out_color, const float* g_opacity, const float* g_color,
                            const float* g_cov, void* partial, float* d_feat, float* d_anchor, float* d_geo_a, float* d_geo_b, float* d_w1,
                            float* d_b1, float* d_w2o, float* d_b2o, float* d_w2c, float* d_b2c, float* d_w2v, float* d_b2v,
                            void* stream) {
     if (V <= 0) return fail("V <= 0");
+    if (feat_ld < 32 || feat_ld % 4 != 0 || ((uintptr_t)feat & 15) != 0) return fail("feat rows: 32 floats, 16-byte aligned, feat_ld a multiple of 4 (got %d)", feat_ld);
     if (!feat || !anchor || !campos || !geo_a || !geo_b || !w1 || !w2o || !w2c || !w2v || !hidden_save || !out_opacity || !out_color ||
         !g_opacity || !g_color || !g_cov || !partial || !d_feat || !d_anchor || !d_geo_a || !d_geo_b || !d_w1 || !d_b1 || !d_w2o || !d_b2o ||
         !d_w2c || !d_b2c || !d_w2v || !d_b2v)
         return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
     { ProfScope ps_(SCR_PROF_MLP_HEADS_BACKWARD, st);
-      launch_mlp_heads_backward(V, feat, anchor, campos, geo_a, geo_b, w1, w2o, w2c, w2v, hidden_save, out_opacity, out_color, g_opacity,
+      launch_mlp_heads_backward(V, feat, feat_ld, anchor, campos, geo_a, geo_b, w1, w2o, w2c, w2v, hidden_save, out_opacity, out_color, g_opacity,
                                 g_color, g_cov, partial, d_feat, d_anchor, d_geo_a, d_geo_b, d_w1, d_b1, d_w2o, d_b2o, d_w2c, d_b2c, d_w2v,
                                 d_b2v, st); }
     CHECK_LAUNCH("mlp_heads_backward_kernel", 0, st);

@@ -380,10 +380,10 @@ void launch_mask_count(int64_t n, const uint8_t* mask, uint32_t* wg_count, unsig
 void launch_mask_index(int64_t n, const uint8_t* mask, const uint32_t* wg_offset, int64_t* index, int64_t* inverse,
                        hipStream_t st);
 void launch_expand_run(int64_t n, int k, const float* neural_opacity, const float* color, const float* scale_rot,
-                       const float* offsets, const float* grid_scaling, const float* anchor,
+                       const float* offsets, int ldo, const float* grid_scaling, const float* anchor,
                        const uint32_t* wg_offset, int32_t* out_index, uint8_t* mask_out, float* xyz,
                        float* color_out, float* opacity, float* scaling, float* rot, hipStream_t st);
-void launch_expand_backward(int64_t V, int k, const float* scale_rot, const float* offsets,
+void launch_expand_backward(int64_t V, int k, const float* scale_rot, const float* offsets, int ldo,
                             const float* grid_scaling, const int32_t* out_index, const float* g_xyz,
                             const float* g_color, const float* g_opacity, const float* g_scaling,
                             const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
@@ -415,11 +415,11 @@ int launch_norm_linear_backward(int64_t V, int d, const float* x, int ldx, const
                                 hipStream_t st);
 size_t mlp_heads_hidden_bytes(int64_t V);
 size_t mlp_heads_partial_bytes(int64_t V);
-void launch_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
+void launch_mlp_heads_forward(int64_t V, const float* feat, int ldf, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
                               const float* w1, const float* b1, const float* w2o, const float* b2o, const float* w2c,
                               const float* b2c, const float* w2v, const float* b2v, void* hidden_save, float* out_o,
                               float* out_c, float* out_v, hipStream_t st);
-void launch_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
+void launch_mlp_heads_backward(int64_t V, const float* feat, int ldf, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,
                                const float* w1, const float* w2o, const float* w2c, const float* w2v,
                                const void* hidden_save, const float* out_o, const float* out_c, const float* g_o,
                                const float* g_c, const float* g_v, void* partial, float* d_feat, float* d_anchor,

@@ -136,7 +136,7 @@ mask_index_kernel(int64_t n, const uint8_t* __restrict__ mask, const uint32_t* _
 // pass 3: expand + compact
 __global__ void __launch_bounds__(EXP_THREADS)
 expand_run_kernel(int64_t n, int k, const float* __restrict__ neural_opacity, const float* __restrict__ color,
-                  const float* __restrict__ scale_rot, const float* __restrict__ offsets,
+                  const float* __restrict__ scale_rot, const float* __restrict__ offsets, int ldo,
                   const float* __restrict__ grid_scaling, const float* __restrict__ anchor,
                   const uint32_t* __restrict__ wg_offset, int32_t* __restrict__ out_index,
                   uint8_t* __restrict__ mask_out, float* __restrict__ xyz, float* __restrict__ color_out,
@@ -187,7 +187,7 @@ expand_run_kernel(int64_t n, int k, const float* __restrict__ neural_opacity, co
         for (int c = 0; c < 3; ++c) {
             color_out[3 * p + c] = color[3 * i + c];
             scaling[3 * p + c] = gs[3 + c] * (1.0f / (1.0f + __expf(-sr[c])));
-            xyz[3 * p + c] = anchor[3 * v + c] + offsets[3 * i + c] * gs[c];
+            xyz[3 * p + c] = anchor[3 * v + c] + offsets[v * ldo + 3 * (i - v * k) + c] * gs[c];     // offsets rows: ldo floats apart (3 k when packed)
         }
         const float q0 = sr[3], q1 = sr[4], q2 = sr[5], q3 = sr[6];
         const float inv = 1.0f / fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);
@@ -205,7 +205,7 @@ expand_run_kernel(int64_t n, int k, const float* __restrict__ neural_opacity, co
 
 __global__ void __launch_bounds__(1024)
 expand_backward_kernel(int64_t V, int k, int apw, const float* __restrict__ scale_rot,
-                       const float* __restrict__ offsets, const float* __restrict__ grid_scaling,
+                       const float* __restrict__ offsets, int ldo, const float* __restrict__ grid_scaling,
                        const int32_t* __restrict__ out_index,
                        const float* __restrict__ g_xyz, const float* __restrict__ g_color,
                        const float* __restrict__ g_opacity, const float* __restrict__ g_scaling,
@@ -244,7 +244,7 @@ expand_backward_kernel(int64_t V, int k, int apw, const float* __restrict__ scal
                 const float gx = g_xyz[3 * (size_t)p + ch];
                 acc9[6 + ch] = gx;
                 dof[ch] = gx * gs[ch];
-                acc9[ch] = gx * offsets[3 * i + ch];
+                acc9[ch] = gx * offsets[v * ldo + 3 * (i - v * k) + ch];
                 acc9[3 + ch] = gsc[ch] * sg[ch];
                 dsr[ch] = gsc[ch] * gs[3 + ch] * sg[ch] * (1.0f - sg[ch]);
             }
@@ -307,16 +307,16 @@ void launch_mask_index(int64_t n, const uint8_t* mask, const uint32_t* wg_offset
 }
 
 void launch_expand_run(int64_t n, int k, const float* neural_opacity, const float* color, const float* scale_rot,
-                       const float* offsets, const float* grid_scaling, const float* anchor,
+                       const float* offsets, int ldo, const float* grid_scaling, const float* anchor,
                        const uint32_t* wg_offset, int32_t* out_index, uint8_t* mask_out, float* xyz,
                        float* color_out, float* opacity, float* scaling, float* rot, hipStream_t st) {
     const uint32_t nwg = (uint32_t)((n + EXP_PER_WG - 1) / EXP_PER_WG);
-    expand_run_kernel<<<nwg, EXP_THREADS, 0, st>>>(n, k, neural_opacity, color, scale_rot, offsets, grid_scaling,
+    expand_run_kernel<<<nwg, EXP_THREADS, 0, st>>>(n, k, neural_opacity, color, scale_rot, offsets, ldo, grid_scaling,
                                                    anchor, wg_offset, out_index, mask_out, xyz, color_out, opacity,
                                                    scaling, rot);
 }
 
-void launch_expand_backward(int64_t V, int k, const float* scale_rot, const float* offsets,
+void launch_expand_backward(int64_t V, int k, const float* scale_rot, const float* offsets, int ldo,
                             const float* grid_scaling, const int32_t* out_index, const float* g_xyz,
                             const float* g_color, const float* g_opacity, const float* g_scaling,
                             const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
@@ -325,7 +325,7 @@ void launch_expand_backward(int64_t V, int k, const float* scale_rot, const floa
     const int apw = max(1, min(32, (48 * 1024) / (k * 9 * (int)sizeof(float))));
     const int threads = min(1024, ((apw * k + 63) / 64) * 64);
     expand_backward_kernel<<<(unsigned)((V + apw - 1) / apw), threads, (size_t)apw * k * 9 * sizeof(float), st>>>(
-        V, k, apw, scale_rot, offsets, grid_scaling, out_index, g_xyz, g_color, g_opacity, g_scaling, g_rot,
+        V, k, apw, scale_rot, offsets, ldo, grid_scaling, out_index, g_xyz, g_color, g_opacity, g_scaling, g_rot,
         d_neural_opacity, d_color, d_scale_rot, d_offsets, d_grid_scaling, d_anchor, g_reg,
         P > 0 ? (float)(1.0 / (double)P) : 0.0f);
 }

@@ -77,7 +77,7 @@ __device__ __forceinline__ float mh_tanh(float z) { return 1.0f - 2.0f * __built
 
 // ---------------------------------------------------------------- forward
 __global__ void __launch_bounds__(64 * MH_WAVES, 2)
-mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, const float* __restrict__ anchor,
+mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, int ldf, const float* __restrict__ anchor,
                          const float* __restrict__ campos, const float* __restrict__ geo_a,
                          const float* __restrict__ geo_b, MhWeights w, f4* __restrict__ hidden_save, float* __restrict__ out_o, float* __restrict__ out_c,
                          float* __restrict__ out_v) {
@@ -122,7 +122,7 @@ mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, const float*
         const int64_t vc = valid ? v : V - 1;       // loads stay in bounds, results of padding anchors are dropped
         f4 xb[MH_KB];
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) xb[blk] = *(const f4*)(feat + vc * MH_FEAT + 16 * blk + 4 * g);
+        for (int blk = 0; blk < 2; ++blk) xb[blk] = *(const f4*)(feat + vc * ldf + 16 * blk + 4 * g);
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk)   // geo_fea = (geo_a | geo_b): the two halves come from two GEMMs, never concatenated
             xb[2 + blk] = *(const f4*)((blk < 2 ? geo_a : geo_b) + vc * (MH_GEO / 2) + 16 * (blk & 1) + 4 * g);
@@ -205,7 +205,7 @@ constexpr int MH_STAGE_A = 128 * MH_AS;                                    // dZ
 constexpr int MH_STAGE_B = 96 * MH_AS > 16 * MH_XS ? 96 * MH_AS : 16 * MH_XS;   // H^T [96][.], then X [16][.]
 
 __global__ void __launch_bounds__(64 * MH_WAVES, 1)
-mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float* __restrict__ anchor,
+mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, int ldf, const float* __restrict__ anchor,
                           const float* __restrict__ campos, const float* __restrict__ geo_a,
                           const float* __restrict__ geo_b, MhWeights w, const f4* __restrict__ hidden_save, const float* __restrict__ out_o,
                           const float* __restrict__ out_c, const float* __restrict__ g_o,
@@ -371,7 +371,7 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, const float
         // ---- dX^T = W1^T dPre^T -> d feat, d geo_fea, d ob_view
         f4 xb[MH_KB];
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) xb[blk] = *(const f4*)(feat + vc * MH_FEAT + 16 * blk + 4 * g);
+        for (int blk = 0; blk < 2; ++blk) xb[blk] = *(const f4*)(feat + vc * ldf + 16 * blk + 4 * g);
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk)
             xb[2 + blk] = *(const f4*)((blk < 2 ? geo_a : geo_b) + vc * (MH_GEO / 2) + 16 * (blk & 1) + 4 * g);
@@ -522,16 +522,16 @@ static int mh_grid(int64_t V, int per_cu = 1) {
 size_t mlp_heads_hidden_bytes(int64_t V) { return align_up((size_t)((V + 15) / 16) * MH_MT * 64 * sizeof(f4)); }
 size_t mlp_heads_partial_bytes(int64_t V) { return align_up((size_t)mh_grid(V) * MH_WAVES * MH_PART * sizeof(float)); }
 
-void launch_mlp_heads_forward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a,
+void launch_mlp_heads_forward(int64_t V, const float* feat, int ldf, const float* anchor, const float* campos, const float* geo_a,
                               const float* geo_b, const float* w1, const float* b1, const float* w2o, const float* b2o, const float* w2c,
                               const float* b2c, const float* w2v, const float* b2v, void* hidden_save, float* out_o,
                               float* out_c, float* out_v, hipStream_t st) {
     MhWeights w{w1, b1, {w2o, w2c, w2v}, {b2o, b2c, b2v}};
-    mlp_heads_forward_kernel<<<mh_grid(V, 2), 64 * MH_WAVES, 0, st>>>(V, feat, anchor, campos, geo_a, geo_b, w, (f4*)hidden_save, out_o,
+    mlp_heads_forward_kernel<<<mh_grid(V, 2), 64 * MH_WAVES, 0, st>>>(V, feat, ldf, anchor, campos, geo_a, geo_b, w, (f4*)hidden_save, out_o,
                                                                    out_c, out_v);
 }
 
-void launch_mlp_heads_backward(int64_t V, const float* feat, const float* anchor, const float* campos, const float* geo_a,
+void launch_mlp_heads_backward(int64_t V, const float* feat, int ldf, const float* anchor, const float* campos, const float* geo_a,
                                const float* geo_b, const float* w1, const float* w2o, const float* w2c, const float* w2v,
                                const void* hidden_save, const float* out_o, const float* out_c, const float* g_o,
                                const float* g_c, const float* g_v, void* partial, float* d_feat, float* d_anchor,
@@ -539,7 +539,7 @@ void launch_mlp_heads_backward(int64_t V, const float* feat, const float* anchor
                                float* d_b2c, float* d_w2v, float* d_b2v, hipStream_t st) {
     MhWeights w{w1, nullptr, {w2o, w2c, w2v}, {nullptr, nullptr, nullptr}};
     const int grid = mh_grid(V);
-    mlp_heads_backward_kernel<<<grid, 64 * MH_WAVES, 0, st>>>(V, feat, anchor, campos, geo_a, geo_b, w, (const f4*)hidden_save,
+    mlp_heads_backward_kernel<<<grid, 64 * MH_WAVES, 0, st>>>(V, feat, ldf, anchor, campos, geo_a, geo_b, w, (const f4*)hidden_save,
                                                               out_o, out_c, g_o, g_c, g_v, d_feat, d_anchor, d_geo_a, d_geo_b,
                                                               (float*)partial);
     mlp_heads_reduce_kernel<<<(MH_PART + 31) / 32, 256, 0, st>>>(grid * MH_WAVES, (const float*)partial, d_w1, d_b1, d_w2o,

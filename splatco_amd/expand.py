@@ -21,8 +21,14 @@ class _ExpandCompact(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         f = lambda t: t.contiguous().float()
         neural_opacity, color, scale_rot = f(neural_opacity).reshape(-1), f(color), f(scale_rot)
-        offsets, grid_scaling, anchor = f(offsets).reshape(-1, 3), f(grid_scaling), f(anchor)
+        grid_scaling, anchor = f(grid_scaling), f(anchor)
         V, dev = anchor.shape[0], anchor.device
+        # offsets [V,k,3] may be columns 35..64 of the gather's [V,72] matrix (anchor_gather: not written a second time)
+        if (offsets.dtype == torch.float32 and offsets.dim() == 3 and offsets.shape[1:] == (k, 3) and offsets.stride()[1:] == (3, 1)
+                and offsets.stride(0) >= 3 * k and V > 1):
+            offsets = offsets.detach()
+        else:
+            offsets = f(offsets).reshape(V, k, 3)
         n = V * k
         scratch = torch.empty(max(_C.lib.scr_expand_scratch_bytes(n), 1), dtype=torch.uint8, device=dev)
         cnt = C.c_int64(0)
@@ -36,7 +42,7 @@ class _ExpandCompact(torch.autograd.Function):
         if n:
             with torch.cuda.device(dev):
                 _C.check(_C.lib.scr_expand_run(V, k, _ptr(neural_opacity), _ptr(color), _ptr(scale_rot), _ptr(offsets),
-                                               _ptr(grid_scaling), _ptr(anchor), scratch.data_ptr(), out_index.data_ptr(),
+                                               offsets.stride(0), _ptr(grid_scaling), _ptr(anchor), scratch.data_ptr(), out_index.data_ptr(),
                                                mask.data_ptr(), _ptr(xyz), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot),
                                                _stream(dev)))
         ctx.save_for_backward(scale_rot, offsets, grid_scaling, out_index)
@@ -62,7 +68,7 @@ class _ExpandCompact(torch.autograd.Function):
         d_no, d_col, d_sr, d_off, d_gs, d_an = new(n, 1), new(n, 3), new(n, 7), new(V, k, 3), new(V, 6), new(V, 3)
         if n:
             with torch.cuda.device(dev):
-                _C.check(_C.lib.scr_expand_backward(V, k, _ptr(scale_rot), _ptr(offsets), _ptr(grid_scaling),
+                _C.check(_C.lib.scr_expand_backward(V, k, _ptr(scale_rot), _ptr(offsets), offsets.stride(0), _ptr(grid_scaling),
                                                     out_index.data_ptr(), _ptr(g_xyz), _ptr(g_col), _ptr(g_opa),
                                                     _ptr(g_sca), _ptr(g_rot), d_no.data_ptr(), d_col.data_ptr(),
                                                     d_sr.data_ptr(), d_off.data_ptr(), d_gs.data_ptr(), d_an.data_ptr(),

@@ -31,7 +31,11 @@ class _MlpHeads(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, anchor, campos, geo_a, geo_b, w1, b1, w2o, b2o, w2c, b2c, w2v, b2v):
         c = lambda t: t.detach().contiguous().float()
-        feat, anchor, campos, geo_a, geo_b = c(feat), c(anchor), c(campos), c(geo_a), c(geo_b)
+        # feat may be columns 0..31 of the gather's [V,72] matrix (anchor_gather: not written a second time): read in place
+        in_place = (feat.dtype == torch.float32 and feat.dim() == 2 and feat.stride(1) == 1 and feat.stride(0) % 4 == 0
+                    and feat.data_ptr() % 16 == 0 and feat.shape[0] > 1)
+        feat = feat.detach() if in_place else c(feat)
+        anchor, campos, geo_a, geo_b = c(anchor), c(campos), c(geo_a), c(geo_b)
         ws = [c(t) for t in (w1, b1, w2o, b2o, w2c, b2c, w2v, b2v)]
         V, dev = feat.shape[0], feat.device
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -39,7 +43,7 @@ class _MlpHeads(torch.autograd.Function):
         hidden = torch.empty(_C.lib.scr_mlp_heads_hidden_bytes(V), dtype=torch.uint8, device=dev)
         if V:
             with torch.cuda.device(dev):
-                _C.check(_C.lib.scr_mlp_heads_forward(V, feat.data_ptr(), anchor.data_ptr(), campos.data_ptr(), geo_a.data_ptr(),
+                _C.check(_C.lib.scr_mlp_heads_forward(V, feat.data_ptr(), feat.stride(0), anchor.data_ptr(), campos.data_ptr(), geo_a.data_ptr(),
                                                       geo_b.data_ptr(), *[t.data_ptr() for t in ws], hidden.data_ptr(), out_o.data_ptr(),
                                                       out_c.data_ptr(), out_v.data_ptr(), _stream()))
         ctx.save_for_backward(feat, anchor, campos, geo_a, geo_b, ws[0], ws[2], ws[4], ws[6], hidden, out_o, out_c)
@@ -62,7 +66,7 @@ class _MlpHeads(torch.autograd.Function):
             partial = torch.empty(_C.lib.scr_mlp_heads_partial_bytes(V), dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
                 _C.check(_C.lib.scr_mlp_heads_backward(
-                    V, feat.data_ptr(), anchor.data_ptr(), campos.data_ptr(), geo_a.data_ptr(), geo_b.data_ptr(), w1.data_ptr(), w2o.data_ptr(),
+                    V, feat.data_ptr(), feat.stride(0), anchor.data_ptr(), campos.data_ptr(), geo_a.data_ptr(), geo_b.data_ptr(), w1.data_ptr(), w2o.data_ptr(),
                     w2c.data_ptr(), w2v.data_ptr(), hidden.data_ptr(), out_o.data_ptr(), out_c.data_ptr(), g_o.data_ptr(),
                     g_c.data_ptr(), g_v.data_ptr(), partial.data_ptr(), d_feat.data_ptr(), d_anchor.data_ptr(),
                     d_geo_a.data_ptr(), d_geo_b.data_ptr(), d_w1.data_ptr(), d_b1.data_ptr(), d_w2o.data_ptr(), d_b2o.data_ptr(), d_w2c.data_ptr(),
