@@ -683,22 +683,27 @@ __global__ void __launch_bounds__(256) zero_far_records_kernel(int64_t P, const 
     // the forward's own verdict, where it left it on the device (geom_buf): nothing here depends on what the caller passed
     // back as plan_flags -- a stale or zero argument cannot leave uninitialised records for preprocess_backward to sum
     if ((total[3] & (unsigned long long)SCR_PLAN_LARGE_RECTS) == 0ull) return;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const uint32_t n = i < P ? tiles_touched[i] : 0u;
-    const uint32_t end = (i < P && n > 32u) ? point_offsets[i] : 0u;      // inclusive scan: one past the Gaussian's last record
-    unsigned long long big = lanes(n > 32u);
-    while (big) {
-        const int src = __builtin_ctzll(big);
-        big &= big - 1;
-        const uint32_t n_s = (uint32_t)__shfl((int)n, src, WAVE), end_s = (uint32_t)__shfl((int)end, src, WAVE);
-        const size_t w0 = (size_t)(end_s - n_s + 32u) * GRAD_F, w1 = (size_t)end_s * GRAD_F;      // dwords
-        for (size_t w = w0 + lane; w < w1; w += WAVE) rec_words[w] = 0u;
+    // (a capped grid walking the Gaussians: every backward launches this kernel, and 61 000 workgroups that leave at once
+    // still cost 15 us at 15.6 M Gaussians)
+    for (int64_t base = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); base < P; base += (int64_t)gridDim.x * 256) {
+        const int64_t i = base + lane;
+        const uint32_t n = i < P ? tiles_touched[i] : 0u;
+        const uint32_t end = (i < P && n > 32u) ? point_offsets[i] : 0u;      // inclusive scan: one past the Gaussian's last record
+        unsigned long long big = lanes(n > 32u);
+        while (big) {
+            const int src = __builtin_ctzll(big);
+            big &= big - 1;
+            const uint32_t n_s = (uint32_t)__shfl((int)n, src, WAVE), end_s = (uint32_t)__shfl((int)end, src, WAVE);
+            const size_t w0 = (size_t)(end_s - n_s + 32u) * GRAD_F, w1 = (size_t)end_s * GRAD_F;      // dwords
+            for (size_t w = w0 + lane; w < w1; w += WAVE) rec_words[w] = 0u;
+        }
     }
 }
 void launch_zero_far_records(int64_t P, const GeomView& gv, GradRec* grad_rec, hipStream_t st) {
     if (P <= 0) return;
-    zero_far_records_kernel<<<nblk(P, 256), 256, 0, st>>>(P, gv.total, gv.tiles_touched, gv.point_offsets, (uint32_t*)grad_rec);
+    const int64_t want = (P + 255) / 256;
+    zero_far_records_kernel<<<(unsigned)(want < 2048 ? want : 2048), 256, 0, st>>>(P, gv.total, gv.tiles_touched, gv.point_offsets, (uint32_t*)grad_rec);
 }
 
 // ---- ZeroList: blockIdx.y = buffer, blockIdx.x = 16 KB piece of it

@@ -859,30 +859,42 @@ triplane_forward_kernel(int64_t V, const float* __restrict__ coords, int cs, con
     }
 }
 
-// plane [R][A][B] (the reference's layout) -> row pairs [A-1][B][2][R] for tp_sample_plane_rp: one streaming pass
+// plane [R][A][B] (the reference's layout) -> row pairs [A-1][B][2][R] for tp_sample_plane_rp: one streaming pass.
+// A workgroup owns 256 columns of one row PAIR: its output is one contiguous run of 256 x 2 R floats, written as whole
+// 16-byte pieces out of an LDS tile (round 4 wrote it straight from registers: 2 R dword stores per thread, 8 R bytes
+// apart between neighbouring lanes -- 1 TB/s; every plane row is read twice now, both times coalesced).
 template <int R>
 __global__ void __launch_bounds__(256)
 plane_row_pairs_kernel(int A, int B, const float* __restrict__ plane, float* __restrict__ pairs) {
-    const int b = blockIdx.x * 256 + threadIdx.x, a = blockIdx.y;
-    if (b >= B) return;
-    float v[R];
+    __shared__ __attribute__((aligned(16))) float tile[256 * 2 * R];      // [column][row of the pair][channel]
+    const int b0 = blockIdx.x * 256, a = blockIdx.y;                       // a = 0 .. A - 2
+    const int nb = min(256, B - b0), t = threadIdx.x;
+    if (t < nb) {
+        float v[2][R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) v[r] = plane[((size_t)r * A + a) * B + b];
-    if (a < A - 1) {
-        float* d = pairs + (((size_t)a * B + b) * 2) * R;
+        for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-        for (int r = 0; r < R; ++r) d[r] = v[r];
+            for (int r = 0; r < R; ++r) v[sl][r] = plane[((size_t)r * A + a + sl) * B + b0 + t];
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int r = 0; r < R; ++r) tile[(t * 2 + sl) * R + r] = v[sl][r];
     }
-    if (a > 0) {
-        float* d = pairs + (((size_t)(a - 1) * B + b) * 2 + 1) * R;
-#pragma unroll
-        for (int r = 0; r < R; ++r) d[r] = v[r];
+    __syncthreads();
+    float* dst = pairs + ((size_t)a * B + b0) * 2 * R;
+    const int count = nb * 2 * R;
+    if (((uintptr_t)dst & 15) == 0) {
+        for (int q = t; q < (count >> 2); q += 256) *(float4*)(dst + 4 * q) = *(const float4*)&tile[4 * q];
+        for (int e = (count & ~3) + t; e < count; e += 256) dst[e] = tile[e];
+    } else {
+        for (int e = t; e < count; e += 256) dst[e] = tile[e];
     }
 }
 
 int launch_plane_row_pairs(int R, int A, int B, const float* plane, float* pairs, hipStream_t st) {
     if (R < 1 || R > TP_MAX_R) return 1;
-    const dim3 grid((unsigned)((B + 255) / 256), (unsigned)A);
+    if (A < 2) return 0;
+    const dim3 grid((unsigned)((B + 255) / 256), (unsigned)(A - 1));
 #define SCR_TP_RP(RR) case RR: plane_row_pairs_kernel<RR><<<grid, 256, 0, st>>>(A, B, plane, pairs); break;
     switch (R) {
         SCR_TP_RP(1) SCR_TP_RP(2) SCR_TP_RP(3) SCR_TP_RP(4) SCR_TP_RP(5) SCR_TP_RP(6) SCR_TP_RP(7) SCR_TP_RP(8)
