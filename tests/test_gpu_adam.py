@@ -174,3 +174,85 @@ def test_scr_adam_step_rejects_bad_arguments_without_a_gpu():
     assert lib.scr_adam_step(1, t, 1.0, 0.999, 1e-15, None) != 0 and "beta" in err()
     t[0].step_size = float("inf")                                                 # step 0: lr / (1 - beta1^0) does not exist
     assert lib.scr_adam_step(1, t, 0.9, 0.999, 1e-15, None) != 0 and "bias" in err()
+
+
+@pytest.mark.gpu
+def test_sharded_adam_survives_densification_through_full_state():
+    """The documented densification path of adam.ShardedFusedAdam (its `.state` raises): full_state() -> the optimizer surgery
+    of adjust_anchor on a torch.optim.Adam built from it (scene/gaussian_model.py:738-818) -> a NEW GradArena +
+    ShardedFusedAdam + load_full_state().  Same parameters and moments afterwards as FusedAdam carried through the same
+    densification; and the OLD sharded optimizer refuses to step once its parameters were replaced (it would skip them
+    silently)."""
+    from splatco_amd.adam import ShardedFusedAdam
+    from splatco_amd.densify import AnchorDensifier
+    from splatco_amd.multiview import GradArena
+    from splatco_amd.synthetic import synthetic_anchor_model
+    dev = torch.device("cuda:0")
+    names = ("anchor", "offset", "anchor_feat", "scaling")
+
+    def groups_of(pc):
+        return [{"params": [getattr(pc, "_" + n)], "lr": 1e-3 * (j + 1), "name": n} for j, n in enumerate(names)]
+
+    def fill_stats(den, pc, gen):
+        N, k = pc._anchor.shape[0], pc.n_offsets
+        den.offset_gradient_accum[:] = torch.rand(N * k, 1, device=dev, generator=gen)
+        den.offset_denom[:] = 60
+        den.opacity_accum[:] = torch.rand(N, 1, device=dev, generator=gen) * 2
+        den.anchor_demon[:] = 100
+
+    def grads(params, gen, scale):
+        return [torch.randn(p.shape, device=dev, generator=gen) * scale for p in params]
+
+    # ---- sharded side
+    pc_a = synthetic_anchor_model(20_000, 9, dev, plane_size=64)
+    groups_a = groups_of(pc_a)
+    params_a = [g["params"][0] for g in groups_a]
+    arena = GradArena(params_a, mode="rs_ag")
+    opt_a = ShardedFusedAdam(groups_a, arena, eps=1e-15)
+    # ---- replicated side
+    pc_b = synthetic_anchor_model(20_000, 9, dev, plane_size=64)
+    groups_b = groups_of(pc_b)
+    params_b = [g["params"][0] for g in groups_b]
+    opt_b = FusedAdam(groups_b, eps=1e-15)
+    gen = torch.Generator(device=dev).manual_seed(6)
+    for _ in range(2):
+        for v, pb, g in zip(arena.views, params_b, grads(params_b, gen, 1e-2)):
+            v.copy_(g)
+            pb.grad = g
+        opt_a.step()
+        opt_b.step()
+    for a, b in zip(params_a, params_b):
+        assert torch.equal(a, b)
+    # ---- densification: the sharded moments travel through torch.optim.Adam's per-parameter layout
+    full = opt_a.full_state()
+    tmp = torch.optim.Adam(groups_a, eps=1e-15, foreach=False, fused=False)
+    for i, p in enumerate(params_a):
+        tmp.state[p] = {"step": full[i]["step"].clone(), "exp_avg": full[i]["exp_avg"].clone(), "exp_avg_sq": full[i]["exp_avg_sq"].clone()}
+    den_a, den_b = AnchorDensifier(pc_a, tmp, voxel_size=0.01, seed=5), AnchorDensifier(pc_b, opt_b, voxel_size=0.01, seed=5)
+    for den, pc in ((den_a, pc_a), (den_b, pc_b)):
+        fill_stats(den, pc, torch.Generator(device=dev).manual_seed(7))
+        den.adjust_anchor(iteration=100, check_interval=100, grad_threshold=0.012)
+    n_new = pc_a._anchor.shape[0]
+    assert n_new != 20_000 and n_new == pc_b._anchor.shape[0]
+    with pytest.raises(RuntimeError, match="no longer lives"):      # the old optimizer's parameters were replaced
+        opt_a.step()
+    new_groups = [{"params": list(g["params"]), "lr": g["lr"], "name": g["name"]} for g in tmp.param_groups]
+    new_params = [g["params"][0] for g in new_groups]
+    assert all(p is getattr(pc_a, "_" + n) for p, n in zip(new_params, names))
+    arena.close()
+    arena2 = GradArena(new_params, mode="rs_ag")
+    opt_a2 = ShardedFusedAdam(new_groups, arena2, eps=1e-15)
+    opt_a2.load_full_state({i: tmp.state[p] for i, p in enumerate(new_params)})
+    params_b2 = [g["params"][0] for g in opt_b.param_groups]
+    gen = torch.Generator(device=dev).manual_seed(8)
+    for v, pb, g in zip(arena2.views, params_b2, grads(params_b2, gen, 1e-3)):
+        v.copy_(g)
+        pb.grad = g
+    opt_a2.step()
+    opt_b.step()
+    after = opt_a2.full_state()
+    for i, (a, b) in enumerate(zip(new_params, params_b2)):
+        assert a.shape == b.shape and torch.equal(a, b), (names[i], float((a - b).abs().max()))
+        assert torch.equal(after[i]["exp_avg"], opt_b.state[b]["exp_avg"]) and torch.equal(after[i]["exp_avg_sq"], opt_b.state[b]["exp_avg_sq"])
+        assert float(after[i]["step"]) == float(opt_b.state[b]["step"]) == 3.0
+    arena2.close()
