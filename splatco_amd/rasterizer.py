@@ -211,17 +211,19 @@ class _RasterizeGaussians(torch.autograd.Function):
         means3D, scales, rotations, cov3D, sh, colors, opacities = ctx.saved_tensors
         dev, P, cs = means3D.device, st.P, st.cs
         g = _dev_f32(grad_out_color, "grad_out_color")
-        # All per-Gaussian gradients are carved from ONE arena, parameter gradients first and adjacent
-        # (means2D, a per-view statistic, last): when the operator's inputs are leaves their .grad tensors
+        # All per-Gaussian PARAMETER gradients are carved from ONE arena, adjacent (means2D, a per-view statistic, is a
+        # tensor of its own): when the operator's inputs are leaves their .grad tensors
         # alias the arena, and multiview.allreduce_gradients reduces it in place without packing copies.
         widths = [3, 3 if colors is not None else 0, 3 * st.M if sh is not None else 0, 1,
-                  3 if cov3D is None else 0, 4 if cov3D is None else 0, 6 if cov3D is not None else 0, 3]
+                  3 if cov3D is None else 0, 4 if cov3D is None else 0, 6 if cov3D is not None else 0]
         arena = torch.empty(P * sum(widths), dtype=torch.float32, device=dev)
         parts, off = [], 0
         for w in widths:
             parts.append(arena[off:off + P * w].view(P, w) if w else None)
             off += P * w
-        g_means3D, g_col, g_sh, g_op, g_scales, g_rot, g_cov, g_means2D = parts
+        g_means3D, g_col, g_sh, g_op, g_scales, g_rot, g_cov = parts
+        # a tensor of its own: the caller may KEEP it as viewspace_points.grad (renderer.keep_grad) without pinning the arena
+        g_means2D = torch.empty(P, 3, dtype=torch.float32, device=dev)
         if g_sh is not None:
             g_sh = g_sh.view(P, st.M, 3)
         del arena, parts

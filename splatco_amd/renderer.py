@@ -142,11 +142,32 @@ class _ZeroCarrier(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, like, dtype):
         ctx.set_materialize_grads(False)
-        return torch.zeros_like(like, dtype=dtype)
+        out = torch.zeros_like(like, dtype=dtype)
+        import weakref
+        ctx.out_ref = weakref.ref(out)
+        return out
 
     @staticmethod
     def backward(ctx, grad):
+        # `retain_grad()` on the result makes autograd CLONE the incoming gradient into .grad (187 MB and 0.12 ms at
+        # configs[2], 0.6 ms at configs[4]); keep_grad() below asks this node to hand the tensor over as it is instead --
+        # the rasterizer's backward allocates dL/dmeans2D as a tensor of its own for exactly that.  One backward per
+        # render (train.py:240): a second one REPLACES the gradient where retain_grad would add.
+        out = ctx.out_ref()
+        if out is not None and grad is not None and getattr(out, "_scr_keep_grad", False):
+            out.grad = grad
         return None, None, None
+
+
+def keep_grad(screenspace_points):
+    """screenspace_points.retain_grad() (gaussian_renderer/__init__.py:134-138) without the copy: after backward(),
+    .grad is the rasterizer's dL/dmeans2D itself."""
+    if not screenspace_points.requires_grad:          # under no_grad (as the reference's `try: retain_grad()`)
+        return
+    if isinstance(getattr(screenspace_points, "grad_fn", None), _ZeroCarrier._backward_cls):
+        screenspace_points._scr_keep_grad = True
+    else:
+        screenspace_points.retain_grad()
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, visible_mask=None, retain_grad=False):
@@ -159,10 +180,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, visible_m
     # train.py:185-186) -- same contract, without the extra pass over [P, 3] that the `+ 0` costs (_ZeroCarrier)
     screenspace_points = _ZeroCarrier.apply(torch.empty(0, device=xyz.device, requires_grad=True), xyz, pc.get_anchor.dtype)
     if retain_grad:
-        try:
-            screenspace_points.retain_grad()
-        except RuntimeError:          # under no_grad the tensor does not require grad (as the reference's does not)
-            pass
+        keep_grad(screenspace_points)
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, bg_color, scaling_modifier, pipe.debug))
     rendered_image, radii = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=color,
                                        opacities=opacity, scales=scaling, rotations=rot, cov3D_precomp=None)

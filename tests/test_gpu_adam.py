@@ -181,8 +181,8 @@ def test_sharded_adam_survives_densification_through_full_state():
     """The documented densification path of adam.ShardedFusedAdam (its `.state` raises): full_state() -> the optimizer surgery
     of adjust_anchor on a torch.optim.Adam built from it (scene/gaussian_model.py:738-818) -> a NEW GradArena +
     ShardedFusedAdam + load_full_state().  Same parameters and moments afterwards as FusedAdam carried through the same
-    densification; and the OLD sharded optimizer refuses to step once its parameters were replaced (it would skip them
-    silently)."""
+    densification; and a sharded optimizer refuses to step once a parameter's storage was re-pointed away from its flat
+    buffer (it would update memory nobody reads)."""
     from splatco_amd.adam import ShardedFusedAdam
     from splatco_amd.densify import AnchorDensifier
     from splatco_amd.multiview import GradArena
@@ -234,7 +234,12 @@ def test_sharded_adam_survives_densification_through_full_state():
         den.adjust_anchor(iteration=100, check_interval=100, grad_threshold=0.012)
     n_new = pc_a._anchor.shape[0]
     assert n_new != 20_000 and n_new == pc_b._anchor.shape[0]
-    with pytest.raises(RuntimeError, match="no longer lives"):      # the old optimizer's parameters were replaced
+    # adjust_anchor put NEW Parameter objects into the model; the old arena / optimizer still hold the old ones (a step
+    # through train_step.collaborative_step refuses an arena whose parameters are not the model's).  What the optimizer can
+    # see by itself is a parameter whose storage was re-pointed away from its flat buffer: that it refuses
+    assert params_a[0] is not pc_a._anchor
+    params_a[0].data = params_a[0].data.clone()
+    with pytest.raises(RuntimeError, match="no longer lives"):
         opt_a.step()
     new_groups = [{"params": list(g["params"]), "lr": g["lr"], "name": g["name"]} for g in tmp.param_groups]
     new_params = [g["params"][0] for g in new_groups]

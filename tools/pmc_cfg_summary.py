@@ -50,17 +50,21 @@ def read(d, counter):
 def main(out_txt, out_json, d_fetch, d_write):
     fetch, nf = read(d_fetch, "FETCH_SIZE")
     write, nw = read(d_write, "WRITE_SIZE")
+    # the two passes are two runs of bench.py, and its settle phase may take a different number of steps in each: every
+    # pass is normalised by ITS OWN step count (round 5: the write pass of r05z ran 9 steps, the fetch pass 7, and dividing
+    # both by 7 inflated every WRITE_SIZE by 9 / 7)
     steps = max(nf.get("filter_kernel", 1), 1)
+    steps_w = max(nw.get("filter_kernel", 1), 1)
     by_class = collections.Counter()
     with open(out_txt, "w") as f:
         f.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only), per STEP of the configuration\n")
-        f.write(f"# ({steps} steps); traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM section)\n")
+        f.write(f"# ({steps} steps in the FETCH_SIZE pass, {steps_w} in the WRITE_SIZE pass); traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM section)\n")
         f.write(f"{'kernel':34s} {'launches/step':>13s} {'fetch MB':>10s} {'write MB':>10s} {'traffic MB':>11s}  class\n")
         for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0))):
-            t = (2 * fetch[k] + write.get(k, 0)) * 1024 / steps
+            t = 2 * fetch[k] * 1024 / steps + write.get(k, 0) * 1024 / steps_w
             cls = next((c for p, c in CLASSES if k.startswith(p)), k)
             by_class[cls] += t
-            f.write(f"{k:34s} {nf[k] / steps:13.1f} {fetch[k] * 1024 / steps / 1e6:10.1f} {write.get(k, 0) * 1024 / steps / 1e6:10.1f} "
+            f.write(f"{k:34s} {nf[k] / steps:13.1f} {fetch[k] * 1024 / steps / 1e6:10.1f} {write.get(k, 0) * 1024 / steps_w / 1e6:10.1f} "
                     f"{t / 1e6:11.1f}  {cls}\n")
     table = {k: int(v) for k, v in by_class.items()}
     table["_provenance"] = stamp("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --config <cfg> --steps 3 "
