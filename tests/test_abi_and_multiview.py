@@ -446,3 +446,75 @@ def test_multiview_sharded_grads_equal_sequential_loop(tmp_path, world, n_views)
     ok, msg = run_ranks(script, [ROOT, n_views], world, tmp_path, timeout=900)
     assert ok, msg
     assert msg.count(" ok") == world
+
+
+def test_forced_collectives_in_a_one_rank_group_equal_no_collectives(tmp_path):
+    """multiview.force_collectives: a ONE-rank group runs the very sequence of collectives a larger one does (each a copy onto
+    itself) -- what tests/test_gpu_rccl.py drives through RCCL on the GPU, here over gloo on CPU tensors: GradArena in both
+    exchange shapes, the row-sparse exchange, ShardedFusedAdam's parameter all-gather and full_state()."""
+    script = tmp_path / "one_rank.py"
+    script.write_text(r'''
+import sys, math, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from splatco_amd import multiview
+from splatco_amd.multiview import GradArena
+import splatco_amd.adam as adam_mod
+from torch_restatements import adam_apply_torch
+adam_mod._adam_apply = adam_apply_torch            # CPU stand-in of csrc/adam.hip (the product has no CPU path)
+dist.init_process_group("gloo")
+assert dist.get_world_size() == 1
+calls = {}
+for name in ("all_reduce", "reduce_scatter_tensor", "all_gather_into_tensor"):
+    def wrap(fn, name=name):
+        def f(*a, **k):
+            calls[name] = calls.get(name, 0) + 1
+            return fn(*a, **k)
+        return f
+    setattr(dist, name, wrap(getattr(dist, name)))
+gen = torch.Generator().manual_seed(3)
+shapes = ((300, 32), (300, 3), (300, 30), (300, 6), (64, 32), (5,))
+vals = [torch.randn(*s, generator=gen) for s in shapes]
+mask = torch.rand(300, generator=gen) < 0.4
+out = {}
+for force in (False, True):
+    multiview.force_collectives(force)
+    assert multiview.collectives_on() == force
+    for mode, sparse in (("all_reduce", False), ("rs_ag", False), ("all_reduce", True)):
+        ps = [torch.zeros(*s, requires_grad=True) for s in shapes]
+        arena = GradArena(ps, chunk_bytes=1024, mode=mode, anchor_ranges=4, sparse_rows=sparse, sparse_threshold=0.9, check_rows=True)
+        assert arena.active == force
+        sink = arena.attach_sink(ps[:4])
+        for it in range(2):
+            arena.zero()
+            took = arena.set_row_union(mask)
+            assert took == (sparse and force)
+            (ps[4] * vals[4]).sum().backward()
+            ps[5].grad.copy_(vals[5])
+            for t, v in zip(sink.tensors, vals[:4]):
+                t.copy_(v * mask[:, None])
+            sink.fresh = False
+            arena.reduce()
+        out[(force, mode, sparse)] = arena.flat.clone()
+        arena.close()
+    # the sharded optimizer: reduce-scatter only, Adam on the owned slices, parameter all-gather; full_state()
+    ps = [v.clone().requires_grad_(True) for v in vals]
+    arena = GradArena(ps, chunk_bytes=1024, mode="rs_ag")
+    opt = adam_mod.ShardedFusedAdam([{"params": [p], "lr": 1e-2} for p in ps], arena, eps=1e-15)
+    for it in range(2):
+        arena.zero()
+        sum((p * p).sum() for p in ps).backward()
+        arena.reduce(gather=False)
+        opt.step()
+    out[(force, "sharded")] = torch.cat([p.detach().reshape(-1) for p in ps] + [st[k].reshape(-1) for st in opt.full_state().values() for k in ("exp_avg", "exp_avg_sq")])
+    arena.close()
+    if not force:
+        assert not calls, calls
+for key in [k for k in out if k[0]]:
+    assert torch.equal(out[key], out[(False,) + key[1:]]), key
+assert {"all_reduce", "reduce_scatter_tensor", "all_gather_into_tensor"} <= set(calls), calls
+dist.destroy_process_group()
+print("rank 0 ok", calls)
+''')
+    ok, msg = run_ranks(script, [ROOT], 1, tmp_path, timeout=300)
+    assert ok, msg
+    assert msg.count(" ok") == 1
