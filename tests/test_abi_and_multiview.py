@@ -518,3 +518,25 @@ print("rank 0 ok", calls)
     ok, msg = run_ranks(script, [ROOT], 1, tmp_path, timeout=300)
     assert ok, msg
     assert msg.count(" ok") == 1
+
+
+def test_row_stride_arguments_are_validated_before_anything_is_launched():
+    """ABI 24: the MLP heads take the row stride of `feat`, the expansion that of the offsets (both may be columns of the
+    gather's [V,72] matrix); the gather's feat / offsets outputs may be NULL only with 16-byte aligned g_fea rows.  Host-side
+    checks, no device needed."""
+    from splatco_amd import _C
+    lib = _C.lib
+    err = lambda: lib.scr_last_error().decode()
+    p = 4096                                   # a non-null, 16-byte aligned stand-in address: the checks below come first
+    # offsets rows shorter than 3 k floats
+    assert lib.scr_expand_run(8, 10, p, p, p, p, 29, p, p, p, p, None, p, p, p, p, p, None) != 0 and "offsets_ld" in err()
+    assert lib.scr_expand_backward(8, 10, p, p, 12, p, p, p, p, p, p, p, p, p, p, p, p, p, None, 0, None) != 0 and "offsets_ld" in err()
+    # feat rows: at least 32 floats, a multiple of 4, 16-byte aligned
+    heads_f = lambda feat, ld: lib.scr_mlp_heads_forward(8, feat, ld, *([p] * 17))
+    assert heads_f(p, 31) != 0 and "feat" in err()
+    assert heads_f(p, 70) != 0 and "feat" in err()
+    assert heads_f(p + 4, 72) != 0 and "feat" in err()
+    assert lib.scr_mlp_heads_backward(8, p, 30, *([p] * 28)) != 0 and "feat" in err()
+    # the gather may skip its feat / offsets outputs only next to a [V,72] matrix
+    assert lib.scr_anchor_gather(8, p, p, p, p, p, None, p, None, p, p, 71, None) != 0 and "NULL" in err()
+    assert lib.scr_anchor_gather(8, p, p, p, p, p, p, None, p, p, p, 72, None) != 0 and "NULL" in err()      # anchor_out is not optional
