@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 24
+#define SCR_ABI_VERSION 25
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -303,9 +303,13 @@ int scr_scaling_reg_backward(int64_t P, const float* scaling, const float* g, fl
  * A RANGE of anchors [n0, n0 + N) with n0 a multiple of 64 is the same call on offset pointers (inverse_index + n0, the
  * four gradient arrays + n0 rows; the upstream arrays and V -- their total row count -- unchanged): the sharded step
  * finishes the per-anchor gradients range by range so that a range's exchange overlaps the next range's kernel. */
+/* col_stats_out (may be NULL): scr_anchor_gather_stat_rows(V) rows of [2][80] floats -- per workgroup, the sums of
+ * (x - x[0]) and (x - x[0])^2 over its rows of g_fea, column by column: the BatchNorm that reads g_fea takes them
+ * (scr_norm_linear_forward: col_stats) instead of making a statistics pass of its own over the matrix. */
+int32_t scr_anchor_gather_stat_rows(int64_t V);
 int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anchor_feat, const float* anchor,
                       const float* offset, const float* scaling, float* feat_out, float* anchor_out, float* offsets_out,
-                      float* grid_scaling_out, float* g_fea_out, int32_t g_fea_ld, void* stream);
+                      float* grid_scaling_out, float* g_fea_out, int32_t g_fea_ld, float* col_stats_out, void* stream);
 int scr_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inverse_index, const float* grid_scaling, const float* d_feat,
                                const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                const float* d_g_fea, int32_t g_fea_ld, float* g_anchor_feat, float* g_anchor,
@@ -345,8 +349,12 @@ int scr_norm_fold_backward(int32_t L, int32_t d, const int32_t* widths_host, con
 int scr_norm_running_stats(int32_t L, int32_t d, const int32_t* widths_host, const int32_t* cols_host, const uint8_t* col_at_host,
                            const float* momentum_host, void* const* running_mean_host, void* const* running_var_host,
                            void* const* num_batches_host, const float* mean, const float* var, int64_t n, void* stream);
+/* col_stats / col_stat_rows (NULL / 0: the statistics pass runs here): column statistics the producer of x already formed --
+ * col_stat_rows rows of [2][80] floats, the sums of (x - x[0]) and (x - x[0])^2 over disjoint row sets that cover x
+ * (scr_anchor_gather: col_stats_out); combined in fp64 like the partial sums of the built-in pass. */
 int scr_norm_linear_forward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* G, const float* c, float eps,
-                            float* y, float* mean, float* var, float* inv, void* scratch, void* stream);
+                            float* y, float* mean, float* var, float* inv, void* scratch, const float* col_stats,
+                            int32_t col_stat_rows, void* stream);
 int scr_norm_linear_backward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* G,
                              const float* mean, const float* inv, float* dx, int32_t lddx, float* dG, float* dc,
                              void* scratch, void* stream);

@@ -26,14 +26,14 @@ SYMBOLS = [
     "scr_scaling_reg_scratch_bytes", "scr_scaling_reg_forward", "scr_scaling_reg_backward",
     "scr_tpa_scratch_bytes", "scr_tpa_stats", "scr_tpa_forward", "scr_tpa_backward", "scr_tpa_backward_stats",
     "scr_statis_compute", "scr_statis_apply", "scr_copy_probe",
-    "scr_knn", "scr_knn_curvature", "scr_anchor_gather", "scr_anchor_gather_backward", "scr_mlp_heads_hidden_bytes", "scr_mlp_heads_partial_bytes", "scr_mlp_heads_forward", "scr_mlp_heads_backward",
+    "scr_knn", "scr_knn_curvature", "scr_anchor_gather_stat_rows", "scr_anchor_gather", "scr_anchor_gather_backward", "scr_mlp_heads_hidden_bytes", "scr_mlp_heads_partial_bytes", "scr_mlp_heads_forward", "scr_mlp_heads_backward",
     "scr_norm_linear_scratch_bytes", "scr_norm_linear_forward", "scr_norm_linear_backward",
     "scr_norm_fold", "scr_norm_fold_backward", "scr_norm_running_stats", "scr_box_coords", "scr_forward_plan_run",
     "scr_profile_stride", "scr_debug_force_deep_lists", "scr_adam_step", "scr_tv_add_grad",
 ]
 PLAN_NONFINITE_COLOUR, PLAN_LARGE_RECTS = 1, 2      # SCR_PLAN_*
 PROF_COUNT = 19
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 (DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS, DBG_QMASK,
  DBG_GM_INDEX) = range(9)
@@ -124,7 +124,7 @@ def _load():
     lib.scr_triplane_backward.restype = C.c_int
     lib.scr_norm_linear_scratch_bytes.argtypes = [C.c_int64]
     lib.scr_norm_linear_scratch_bytes.restype = C.c_size_t
-    lib.scr_norm_linear_forward.argtypes = [i64, i32, vp, i32, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp]
+    lib.scr_norm_linear_forward.argtypes = [i64, i32, vp, i32, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.scr_norm_linear_forward.restype = C.c_int
     lib.scr_norm_linear_backward.argtypes = [i64, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.scr_norm_linear_backward.restype = C.c_int
@@ -165,7 +165,9 @@ def _load():
     lib.scr_mlp_heads_forward.argtypes = [i64, vp, i32] + [vp] * 17
     lib.scr_mlp_heads_backward.argtypes = [i64, vp, i32] + [vp] * 28
     lib.scr_mlp_heads_forward.restype = lib.scr_mlp_heads_backward.restype = C.c_int
-    lib.scr_anchor_gather.argtypes = [i64] + [vp] * 10 + [i32, vp]
+    lib.scr_anchor_gather.argtypes = [i64] + [vp] * 10 + [i32, vp, vp]
+    lib.scr_anchor_gather_stat_rows.argtypes = [i64]
+    lib.scr_anchor_gather_stat_rows.restype = C.c_int32
     lib.scr_anchor_gather_backward.argtypes = [i64, i64] + [vp] * 7 + [i32] + [vp] * 4 + [i32, vp]
     lib.scr_anchor_gather.restype = lib.scr_anchor_gather_backward.restype = C.c_int
     lib.scr_knn.argtypes = [i64, i32, C.POINTER(C.c_float), vp, vp, vp, vp, vp]

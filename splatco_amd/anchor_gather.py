@@ -66,11 +66,14 @@ class _AnchorGather(torch.autograd.Function):
         g72 = new(V, 72)
         anc, gs, g_fea = new(V, 3), new(V, 6), g72[:, :71]
         feat, off = g72[:, :32], g72[:, 35:65].unflatten(1, (10, 3))
+        # the column statistics of g_fea for the BatchNorm that reads it, formed while the rows are in LDS (one row of partial
+        # sums per workgroup): the fused BatchNorm-Linear skips its own pass over the matrix (gather_anchors hangs them on g_fea)
+        stats = new(_C.lib.scr_anchor_gather_stat_rows(V), 2, 80) if V else new(0, 2, 80)
         if V:
             with torch.cuda.device(dev):
                 _C.check(_C.lib.scr_anchor_gather(V, idx.data_ptr(), anchor_feat.data_ptr(), anchor.data_ptr(),
                                                   offset.data_ptr(), scaling.data_ptr(), None, anc.data_ptr(),
-                                                  None, gs.data_ptr(), g72.data_ptr(), 72, _stream()))
+                                                  None, gs.data_ptr(), g72.data_ptr(), 72, stats.data_ptr(), _stream()))
         inv = getattr(idx, "_scr_inverse", None)       # left by expand.mask_indices: position of every anchor in idx, -1 = invisible
         if inv is not None and (inv.shape != (N,) or inv.device != dev):
             inv = None
@@ -78,10 +81,11 @@ class _AnchorGather(torch.autograd.Function):
         ctx.N, ctx.sink = N, sink
         if sink is not None:
             sink.pending += 1
-        return feat, anc, off, gs, g_fea
+        ctx.mark_non_differentiable(stats)
+        return feat, anc, off, gs, g_fea, stats
 
     @staticmethod
-    def backward(ctx, d_feat, d_anc, d_off, d_gs, d_g_fea):
+    def backward(ctx, d_feat, d_anc, d_off, d_gs, d_g_fea, _d_stats=None):
         idx, gs, *rest = ctx.saved_tensors
         N, V, dev = ctx.N, idx.numel(), idx.device
         if rest:
@@ -143,4 +147,7 @@ def gather_anchors(pc, idx):
         if not ok:      # falling back to autograd here would ADD into gradient memory the arena did not clear
             raise RuntimeError("the gradient sink does not match the model's per-anchor parameters "
                                "(rebuild the GradArena after adjust_anchor / sort_anchors)")
-    return _AnchorGather.apply(idx, sink, pc._anchor_feat, pc._anchor, pc._offset, pc._scaling)
+    feat, anc, off, gs, g_fea, stats = _AnchorGather.apply(idx, sink, pc._anchor_feat, pc._anchor, pc._offset, pc._scaling)
+    if stats.shape[0]:
+        g_fea._scr_col_stats = stats          # scene_model._norm_linear hands them to the fused BatchNorm-Linear
+    return feat, anc, off, gs, g_fea

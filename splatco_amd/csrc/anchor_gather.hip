@@ -54,14 +54,36 @@ __device__ __forceinline__ void ag_store_chunk(float* __restrict__ dst, const fl
     }
 }
 
+// Column statistics of g_fea for the BatchNorm that reads it (csrc/normlinear.hip): the workgroup has every 64 rows of the
+// matrix in LDS anyway, so it also sums (x - x[0]) and (x - x[0])^2 per column over ITS rows -- a workgroup walks several
+// tiles (capped grid) and writes one row [2][NL_DP] of partial sums at the end; the single-workgroup finish kernel of the
+// BatchNorm-Linear combines them in fp64 exactly as it combines the partials of its own statistics pass, which is then
+// skipped (1.3 GB read and 0.26 ms at configs[2]).  Thread (c = t % 72, rg = t / 72 < 3) sums column c over rows rg, rg + 3, ..
+constexpr int AG_MAX_WGS = 2048;
+int anchor_gather_stat_rows(int64_t V) {
+    const int64_t tiles = (V + AG_ROWS - 1) / AG_ROWS;
+    return (int)(tiles < AG_MAX_WGS ? (tiles > 0 ? tiles : 1) : AG_MAX_WGS);
+}
+
 __global__ void __launch_bounds__(AG_THREADS)
 anchor_gather_kernel(int64_t V, const int64_t* __restrict__ idx, const float* __restrict__ p_feat,
                      const float* __restrict__ p_anchor, const float* __restrict__ p_offset,
                      const float* __restrict__ p_scaling, float* __restrict__ feat, float* __restrict__ anchor,
-                     float* __restrict__ offsets, float* __restrict__ grid_scaling, float* __restrict__ g_fea, int ldg) {
+                     float* __restrict__ offsets, float* __restrict__ grid_scaling, float* __restrict__ g_fea, int ldg,
+                     float* __restrict__ stats) {
     __shared__ __attribute__((aligned(16))) float tile[AG_ROWS * AG_LD];
     __shared__ int64_t rowsrc[AG_ROWS];
-    const int64_t v0 = (int64_t)blockIdx.x * AG_ROWS;
+    __shared__ float red[2][3][AG_LD];
+    const int sc = threadIdx.x % AG_LD, srg = threadIdx.x / AG_LD;      // statistics: this thread's column and row group
+    float shift = 0.0f, ssum = 0.0f, ssq = 0.0f;
+    if (stats && srg < 3 && sc < AG_COLS) {      // row 0 of the matrix = the first visible anchor's parameters (the same expf as below)
+        const int64_t i0 = idx[0];
+        shift = sc < 32 ? p_feat[i0 * AG_FEAT + sc] : sc < 35 ? p_anchor[i0 * 3 + sc - 32]
+              : sc < 65 ? p_offset[i0 * AG_OFF + sc - 35] : expf(p_scaling[i0 * 6 + sc - 65]);
+    }
+    const int64_t ntiles = (V + AG_ROWS - 1) / AG_ROWS;
+    for (int64_t ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+    const int64_t v0 = ti * AG_ROWS;
     const int rows = (int)min((int64_t)AG_ROWS, V - v0);
     if (threadIdx.x < AG_ROWS) rowsrc[threadIdx.x] = threadIdx.x < rows ? idx[v0 + threadIdx.x] : 0;
     __syncthreads();
@@ -116,6 +138,27 @@ anchor_gather_kernel(int64_t V, const int64_t* __restrict__ idx, const float* __
     ag_store_chunk(anchor + v0 * 3, tile, rows * 3, 3, 32);
     if (offsets) ag_store_chunk(offsets + v0 * AG_OFF, tile, rows * AG_OFF, AG_OFF, 35);
     ag_store_chunk(grid_scaling + v0 * 6, tile, rows * 6, 6, 65);
+    if (stats && srg < 3 && sc < AG_COLS) {
+        for (int r = srg; r < rows; r += 3) {
+            const float t = tile[r * AG_LD + sc] - shift;
+            ssum += t;
+            ssq += t * t;
+        }
+    }
+    __syncthreads();      // the tile is free for the next one
+    }
+    if (stats) {
+        if (srg < 3) {
+            red[0][srg][sc] = ssum;
+            red[1][srg][sc] = ssq;
+        }
+        __syncthreads();
+        if (threadIdx.x < AG_COLS) {
+            float* row = stats + (size_t)blockIdx.x * 2 * NL_DP;
+            row[threadIdx.x] = (red[0][0][threadIdx.x] + red[0][1][threadIdx.x]) + red[0][2][threadIdx.x];
+            row[NL_DP + threadIdx.x] = (red[1][0][threadIdx.x] + red[1][1][threadIdx.x]) + red[1][2][threadIdx.x];
+        }
+    }
 }
 
 // A contiguous chunk of `count` upstream floats starting at src (any 4-byte alignment: it starts at the first visible row
@@ -254,10 +297,10 @@ anchor_gather_backward_kernel(int64_t N, int64_t V, const int64_t* __restrict__ 
 
 void launch_anchor_gather(int64_t V, const int64_t* idx, const float* p_feat, const float* p_anchor, const float* p_offset,
                           const float* p_scaling, float* feat, float* anchor, float* offsets, float* grid_scaling,
-                          float* g_fea, int ldg, hipStream_t st) {
+                          float* g_fea, int ldg, float* stats, hipStream_t st) {
     if (V <= 0) return;
-    anchor_gather_kernel<<<(unsigned)((V + AG_ROWS - 1) / AG_ROWS), AG_THREADS, 0, st>>>(
-        V, idx, p_feat, p_anchor, p_offset, p_scaling, feat, anchor, offsets, grid_scaling, g_fea, ldg);
+    anchor_gather_kernel<<<(unsigned)anchor_gather_stat_rows(V), AG_THREADS, 0, st>>>(
+        V, idx, p_feat, p_anchor, p_offset, p_scaling, feat, anchor, offsets, grid_scaling, g_fea, ldg, stats);
 }
 
 void launch_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inv, const float* grid_scaling, const float* d_feat,

@@ -729,9 +729,11 @@ int scr_scaling_reg_backward(int64_t P, const float* scaling, const float* g, fl
 }
 
 // ---- visible-anchor gather (anchor_gather.hip)
+int32_t scr_anchor_gather_stat_rows(int64_t V) { return anchor_gather_stat_rows(V > 0 ? V : 1); }
+
 int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anchor_feat, const float* anchor,
                       const float* offset, const float* scaling, float* feat_out, float* anchor_out, float* offsets_out,
-                      float* grid_scaling_out, float* g_fea_out, int32_t g_fea_ld, void* stream) {
+                      float* grid_scaling_out, float* g_fea_out, int32_t g_fea_ld, float* col_stats_out, void* stream) {
     if (V < 0) return fail("V < 0");
     if (g_fea_ld != 71 && g_fea_ld != 72) return fail("g_fea row stride must be 71 (packed) or 72 (16-byte aligned rows)");
     if (V == 0) return 0;
@@ -740,7 +742,7 @@ int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anch
     if ((!feat_out || !offsets_out) && g_fea_ld != 72)
         return fail("feat_out / offsets_out may be NULL (their consumers read the columns of g_fea) only with 16-byte aligned g_fea rows (ld 72)");
     launch_anchor_gather(V, visible_index, anchor_feat, anchor, offset, scaling, feat_out, anchor_out, offsets_out,
-                         grid_scaling_out, g_fea_out, g_fea_ld, (hipStream_t)stream);
+                         grid_scaling_out, g_fea_out, g_fea_ld, col_stats_out, (hipStream_t)stream);
     CHECK_LAUNCH("anchor_gather_kernel", 0, (hipStream_t)stream);
     return 0;
 }
@@ -818,13 +820,15 @@ int scr_norm_running_stats(int32_t L, int32_t d, const int32_t* widths_host, con
 size_t scr_norm_linear_scratch_bytes(int64_t V) { return norm_linear_scratch_bytes(V > 0 ? V : 1); }
 
 int scr_norm_linear_forward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* G, const float* c, float eps,
-                            float* y, float* mean, float* var, float* inv, void* scratch, void* stream) {
+                            float* y, float* mean, float* var, float* inv, void* scratch, const float* col_stats,
+                            int32_t col_stat_rows, void* stream) {
     if (V < 1 || d < 1 || ldx < d) return fail("bad sizes");
+    if ((col_stats != nullptr) != (col_stat_rows > 0)) return fail("col_stats and col_stat_rows go together (NULL / 0: the statistics pass runs here)");
     if (!x || !G || !c || !y || !mean || !var || !inv || !scratch) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
     int rc;
     { ProfScope ps_(SCR_PROF_NORM_LINEAR, st);
-      rc = launch_norm_linear_forward(V, d, x, ldx, G, c, eps, y, mean, var, inv, scratch, st); }
+      rc = launch_norm_linear_forward(V, d, x, ldx, G, c, eps, y, mean, var, inv, scratch, col_stats, col_stat_rows, st); }
     if (rc == 1) return fail("d = %d input columns exceed the supported 80", d);
     CHECK_LAUNCH("norm_linear_forward", 0, st);
     return 0;

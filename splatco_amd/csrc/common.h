@@ -397,9 +397,11 @@ void launch_statis_apply(int64_t V, int k, const int64_t* visible_index, const f
                          float* opacity_accum, float* anchor_demon, float* offset_gradient_accum, float* offset_denom,
                          hipStream_t st);
 
+constexpr int NL_DP = 80;               // padded width of the BatchNorm-Linear's coefficient rows AND of a row of column statistics
+int anchor_gather_stat_rows(int64_t V);  // workgroups of the gather = rows of the column statistics it can produce
 void launch_anchor_gather(int64_t V, const int64_t* idx, const float* p_feat, const float* p_anchor, const float* p_offset,
                           const float* p_scaling, float* feat, float* anchor, float* offsets, float* grid_scaling,
-                          float* g_fea, int ldg, hipStream_t st);
+                          float* g_fea, int ldg, float* stats, hipStream_t st);
 void launch_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inv, const float* grid_scaling, const float* d_feat,
                                    const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                    const float* d_g_fea, int ldg, float* g_feat, float* g_anchor, float* g_offset,
@@ -409,7 +411,8 @@ void launch_knn(int64_t N, int k, const float* grid9, const float* sorted_pts, c
 void launch_knn_curvature(int64_t N, int k, const float* pts, const int64_t* idx, float* curvature, hipStream_t st);
 size_t norm_linear_scratch_bytes(int64_t V);
 int launch_norm_linear_forward(int64_t V, int d, const float* x, int ldx, const float* G, const float* c, float eps, float* y,
-                               float* mean, float* var, float* inv, void* scratch, hipStream_t st);
+                               float* mean, float* var, float* inv, void* scratch, const float* stats, int stat_rows,
+                               hipStream_t st);
 int launch_norm_linear_backward(int64_t V, int d, const float* x, int ldx, const float* dy, int lddy, const float* G,
                                 const float* mean, const float* inv, float* dx, int lddx, float* dG, float* dc, void* scratch,
                                 hipStream_t st);

@@ -30,7 +30,7 @@ typedef float nlf4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ nlf4 nl_mfma(float a, float b, nlf4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 constexpr int NL_OUT = 32;              // output features of the Linear (FeaturePlanes: out_dim = 32)
-constexpr int NL_DP = 80;               // columns of x supported (padded width of every coefficient row)
+// (NL_DP = 80, common.h: columns of x supported = padded width of every coefficient row)
 constexpr int NL_SLAB = 2048;           // rows per statistics workgroup, at least (sizes the scratch; see nl_stat_slab)
 constexpr int NL_HSIZE = NL_OUT * NL_DP + NL_OUT;   // dy^T x (padded) + column sums of dy
 
@@ -413,11 +413,18 @@ static inline unsigned nl_grid(int64_t V, K kernel) {
     return (unsigned)(wgs < cap ? (wgs > 0 ? wgs : 1) : cap);
 }
 
+// stats (may be NULL): column statistics the PRODUCER of x already formed -- stat_rows rows of [2][NL_DP] floats, sums of
+// (x - x[0]) and (x - x[0])^2 over disjoint sets of rows that cover x (the anchor gather holds every 64 rows of its matrix
+// in LDS anyway: csrc/anchor_gather.hip) -- then the statistics pass over x (1.3 GB at configs[2]) is skipped.
 int launch_norm_linear_forward(int64_t V, int d, const float* x, int ldx, const float* G, const float* c, float eps, float* y,
-                               float* mean, float* var, float* inv, void* scratch, hipStream_t st) {
+                               float* mean, float* var, float* inv, void* scratch, const float* stats, int stat_rows,
+                               hipStream_t st) {
     if (d < 1 || d > NL_DP) return 1;
     float* coef = (float*)scratch;
     float* spart = (float*)((char*)scratch + align_up((size_t)NLC_END * 4));
+    if (stats && stat_rows > 0) {
+        nl_stats_finish_kernel<<<1, 1024, 0, st>>>(V, d, stat_rows, x, stats, G, c, eps, mean, var, inv, coef);
+    } else {
     // slabs of 2048 rows until they are more than the chip holds at once (8 workgroups per CU), then one round of larger
     // slabs: 2246 workgroups on 2048 places ran a second round at a tenth of the machine, and the single-workgroup finish
     // kernel read 9 k partials at 18 M rows
@@ -428,6 +435,7 @@ int launch_norm_linear_forward(int64_t V, int d, const float* x, int ldx, const 
     if (d <= 64) nl_stats_partial_kernel<64><<<nwg, 256, 0, st>>>(V, d, (int)slab, x, ldx, spart);
     else nl_stats_partial_kernel<128><<<nwg, 256, 0, st>>>(V, d, (int)slab, x, ldx, spart);
     nl_stats_finish_kernel<<<1, 1024, 0, st>>>(V, d, nwg, x, spart, G, c, eps, mean, var, inv, coef);
+    }
     const bool al = ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
 #define SCR_NL_FWD(QQ)                                                                                                              \
     case QQ:                                                                                                                        \

@@ -116,7 +116,7 @@ class _NormLinearFn(torch.autograd.Function):
                 and G.shape[0] == 32 and x.shape[1] <= 80 and x.stride(1) == 1)
 
     @staticmethod
-    def forward(ctx, x, G, c, eps):
+    def forward(ctx, x, G, c, eps, col_stats=None):
         ctx.fused = _NormLinearFn.fused_ok(x, G)
         if ctx.fused:
             from . import _C
@@ -126,10 +126,14 @@ class _NormLinearFn(torch.autograd.Function):
             y = torch.empty(V, 32, dtype=torch.float32, device=x.device)
             mean, var, inv = (torch.empty(d, dtype=torch.float32, device=x.device) for _ in range(3))
             scratch = torch.empty(_C.lib.scr_norm_linear_scratch_bytes(V), dtype=torch.uint8, device=x.device)
+            # column statistics the producer of x formed on the way (anchor_gather): [rows, 2, 80] partial sums about x[0]
+            ok_stats = (col_stats is not None and col_stats.is_cuda and col_stats.dtype == torch.float32 and col_stats.dim() == 3
+                        and col_stats.shape[1:] == (2, 80) and col_stats.shape[0] > 0 and col_stats.is_contiguous())
             with torch.cuda.device(x.device):
                 _C.check(_C.lib.scr_norm_linear_forward(V, d, x.data_ptr(), x.stride(0), Gc.data_ptr(), cc.data_ptr(), float(eps),
                                                         y.data_ptr(), mean.data_ptr(), var.data_ptr(), inv.data_ptr(),
-                                                        scratch.data_ptr(), _stream()))
+                                                        scratch.data_ptr(), col_stats.data_ptr() if ok_stats else None,
+                                                        col_stats.shape[0] if ok_stats else 0, _stream()))
             ctx.save_for_backward(x, Gc, mean, inv)
             ctx.mark_non_differentiable(mean, var)
             return y, mean, var
@@ -161,7 +165,7 @@ class _NormLinearFn(torch.autograd.Function):
                 _C.check(_C.lib.scr_norm_linear_backward(V, d, x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), G.data_ptr(),
                                                          mean.data_ptr(), inv.data_ptr(), dx.data_ptr() if need_dx else None,
                                                          ldx, dG.data_ptr(), dc.data_ptr(), scratch.data_ptr(), _stream()))
-            return dx, dG, dc, None
+            return dx, dG, dc, None, None
         if dy.stride(1) != 1:      # a column block of a wider gradient (row stride > width) is fine for every op below
             dy = dy.contiguous()
         sdy = dy.sum(0)
@@ -174,7 +178,7 @@ class _NormLinearFn(torch.autograd.Function):
             k0 = -inv * u / V - mean * k1
             dx = torch.addmm(k0, dy, G * inv)
             dx.addcmul_(x, k1)
-        return dx, H, sdy, None
+        return dx, H, sdy, None, None
 
 
 def _ptr_table(tensors):
@@ -268,7 +272,9 @@ def _norm_linear(x, bns, linears, col_at=None):
         at_idx = torch.as_tensor(list(col_at), dtype=torch.long, device=x.device)
         G = torch.zeros_like(G).index_copy(1, at_idx, G)
     assert all(bn.eps == bns[0].eps for bn in bns)
-    y, mean, var = _NormLinearFn.apply(x, G, c, bns[0].eps)
+    # (statistics the producer of x left on it -- anchor_gather -- are only valid for x as it is: same rows, no column map)
+    stats = getattr(x, "_scr_col_stats", None) if col_at is None else None
+    y, mean, var = _NormLinearFn.apply(x, G, c, bns[0].eps, stats)
     with torch.no_grad():
         n = x.shape[0]
         track = [bn for bn in bns if bn.track_running_stats and bn.training]

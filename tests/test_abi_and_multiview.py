@@ -521,7 +521,7 @@ print("rank 0 ok", calls)
 
 
 def test_row_stride_arguments_are_validated_before_anything_is_launched():
-    """ABI 24: the MLP heads take the row stride of `feat`, the expansion that of the offsets (both may be columns of the
+    """ABI 24 / 25: the MLP heads take the row stride of `feat`, the expansion that of the offsets (both may be columns of the
     gather's [V,72] matrix); the gather's feat / offsets outputs may be NULL only with 16-byte aligned g_fea rows.  Host-side
     checks, no device needed."""
     from splatco_amd import _C
@@ -538,5 +538,8 @@ def test_row_stride_arguments_are_validated_before_anything_is_launched():
     assert heads_f(p + 4, 72) != 0 and "feat" in err()
     assert lib.scr_mlp_heads_backward(8, p, 30, *([p] * 28)) != 0 and "feat" in err()
     # the gather may skip its feat / offsets outputs only next to a [V,72] matrix
-    assert lib.scr_anchor_gather(8, p, p, p, p, p, None, p, None, p, p, 71, None) != 0 and "NULL" in err()
-    assert lib.scr_anchor_gather(8, p, p, p, p, p, p, None, p, p, p, 72, None) != 0 and "NULL" in err()      # anchor_out is not optional
+    assert lib.scr_anchor_gather(8, p, p, p, p, p, None, p, None, p, p, 71, None, None) != 0 and "NULL" in err()
+    assert lib.scr_anchor_gather(8, p, p, p, p, p, p, None, p, p, p, 72, None, None) != 0 and "NULL" in err()      # anchor_out is not optional
+    # producer statistics for the BatchNorm-Linear: pointer and row count go together
+    assert lib.scr_norm_linear_forward(8, 71, p, 72, p, p, 1e-5, p, p, p, p, p, p, 0, None) != 0 and "col_stats" in err()
+    assert lib.scr_anchor_gather_stat_rows(1) == 1 and lib.scr_anchor_gather_stat_rows(64 * 5000) == 2048

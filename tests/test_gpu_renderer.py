@@ -611,6 +611,43 @@ def test_fused_anchor_gather_matches_the_torch_ops():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N", [40, 50_001, 700_003])      # one partial tile; 782 workgroups; more tiles than workgroups (capped grid)
+def test_gather_produced_column_statistics_feed_the_batchnorm(N):
+    """The anchor gather sums (x - x[0]) and (x - x[0])^2 per column of g_fea while its rows sit in LDS
+    (csrc/anchor_gather.hip); the fused BatchNorm-Linear takes those partial sums instead of a statistics pass of its own
+    (scr_norm_linear_forward: col_stats).  Same mean / variance / output as its own pass to fp32 summation order, and
+    against float64; exp(scaling) columns (large mean, small spread) included."""
+    from splatco_amd import scene_model as sm
+    from splatco_amd.anchor_gather import gather_anchors
+    from splatco_amd.scene_model import AnchorGaussianModel
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(N)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    pc = AnchorGaussianModel(plane_size=16, num_channels=15).to(dev)
+    pc.set_anchors(r(N, 3) * 2, r(N, 10, 3), r(N, 32) * 3 + 0.5, r(N, 6) * 0.3 - 3)
+    idx = (torch.rand(N, device=dev, generator=g) < 0.8).nonzero().squeeze(1)
+    with torch.no_grad():
+        *_, g_fea = gather_anchors(pc, idx)
+    stats = g_fea._scr_col_stats
+    V = idx.numel()
+    assert stats.shape == (min(-(-V // 64), 2048), 2, 80)
+    G, c = r(32, 71) * 0.2, r(32)
+    y1, m1, v1 = sm._NormLinearFn.apply(g_fea, G, c, 1e-5, stats)
+    y0, m0, v0 = sm._NormLinearFn.apply(g_fea, G, c, 1e-5)
+    x64 = g_fea.double()
+    m64, v64 = x64.mean(0), x64.var(0, unbiased=False)
+    sd64 = v64.sqrt()
+    for name, got_m, got_v in (("gather", m1, v1), ("own pass", m0, v0)):
+        em, ev = float(((got_m.double() - m64).abs() / sd64).max()), float(((got_v.double() - v64).abs() / v64).max())
+        print(f"[column statistics, N = {N}, {name}] mean off by {em:.1e} standard deviations at worst, variance by {ev:.1e} of itself")
+        assert em <= 1e-5 and ev <= 2e-5, (name, em, ev)
+    y64 = ((x64 - m64) * torch.rsqrt(v64 + 1e-5)) @ G.double().t() + c.double()
+    for y in (y1, y0):
+        assert float((y.double() - y64).abs().max()) <= 2e-5 * float(y64.abs().max())
+    assert float((y1 - y0).abs().max()) <= 1e-5 * float(y0.abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("V,d,ld", [(2, 60, 60), (15, 71, 71), (1000, 60, 64), (4099, 71, 71), (100003, 60, 60), (100003, 71, 71),
                                     (65536, 30, 30), (20000, 80, 80), (20000, 16, 99), (33333, 7, 7),
                                     (4_400_003, 60, 60)])      # more statistics slabs than the chip holds: the slabs grow
