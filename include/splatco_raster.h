@@ -303,10 +303,12 @@ int scr_scaling_reg_backward(int64_t P, const float* scaling, const float* g, fl
  * A RANGE of anchors [n0, n0 + N) with n0 a multiple of 64 is the same call on offset pointers (inverse_index + n0, the
  * four gradient arrays + n0 rows; the upstream arrays and V -- their total row count -- unchanged): the sharded step
  * finishes the per-anchor gradients range by range so that a range's exchange overlaps the next range's kernel. */
-/* col_stats_out (may be NULL): scr_anchor_gather_stat_rows(V) rows of [2][80] floats -- per workgroup, the sums of
- * (x - x[0]) and (x - x[0])^2 over its rows of g_fea, column by column: the BatchNorm that reads g_fea takes them
- * (scr_norm_linear_forward: col_stats) instead of making a statistics pass of its own over the matrix. */
+/* col_stats_out (may be NULL): a buffer of scr_anchor_gather_stat_buffer_rows(V) rows of [2][80] floats whose first
+ * scr_anchor_gather_stat_rows(V) rows receive the sums of (x - x[0]) and (x - x[0])^2 over disjoint row sets of g_fea, column
+ * by column (the rest is per-tile scratch): the BatchNorm that reads g_fea takes them (scr_norm_linear_forward: col_stats)
+ * instead of making a statistics pass of its own over the matrix. */
 int32_t scr_anchor_gather_stat_rows(int64_t V);
+int64_t scr_anchor_gather_stat_buffer_rows(int64_t V);
 int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anchor_feat, const float* anchor,
                       const float* offset, const float* scaling, float* feat_out, float* anchor_out, float* offsets_out,
                       float* grid_scaling_out, float* g_fea_out, int32_t g_fea_ld, float* col_stats_out, void* stream);

@@ -26,7 +26,7 @@ SYMBOLS = [
     "scr_scaling_reg_scratch_bytes", "scr_scaling_reg_forward", "scr_scaling_reg_backward",
     "scr_tpa_scratch_bytes", "scr_tpa_stats", "scr_tpa_forward", "scr_tpa_backward", "scr_tpa_backward_stats",
     "scr_statis_compute", "scr_statis_apply", "scr_copy_probe",
-    "scr_knn", "scr_knn_curvature", "scr_anchor_gather_stat_rows", "scr_anchor_gather", "scr_anchor_gather_backward", "scr_mlp_heads_hidden_bytes", "scr_mlp_heads_partial_bytes", "scr_mlp_heads_forward", "scr_mlp_heads_backward",
+    "scr_knn", "scr_knn_curvature", "scr_anchor_gather_stat_rows", "scr_anchor_gather_stat_buffer_rows", "scr_anchor_gather", "scr_anchor_gather_backward", "scr_mlp_heads_hidden_bytes", "scr_mlp_heads_partial_bytes", "scr_mlp_heads_forward", "scr_mlp_heads_backward",
     "scr_norm_linear_scratch_bytes", "scr_norm_linear_forward", "scr_norm_linear_backward",
     "scr_norm_fold", "scr_norm_fold_backward", "scr_norm_running_stats", "scr_box_coords", "scr_forward_plan_run",
     "scr_profile_stride", "scr_debug_force_deep_lists", "scr_adam_step", "scr_tv_add_grad",
@@ -168,6 +168,8 @@ def _load():
     lib.scr_anchor_gather.argtypes = [i64] + [vp] * 10 + [i32, vp, vp]
     lib.scr_anchor_gather_stat_rows.argtypes = [i64]
     lib.scr_anchor_gather_stat_rows.restype = C.c_int32
+    lib.scr_anchor_gather_stat_buffer_rows.argtypes = [i64]
+    lib.scr_anchor_gather_stat_buffer_rows.restype = C.c_int64
     lib.scr_anchor_gather_backward.argtypes = [i64, i64] + [vp] * 7 + [i32] + [vp] * 4 + [i32, vp]
     lib.scr_anchor_gather.restype = lib.scr_anchor_gather_backward.restype = C.c_int
     lib.scr_knn.argtypes = [i64, i32, C.POINTER(C.c_float), vp, vp, vp, vp, vp]

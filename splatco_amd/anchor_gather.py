@@ -68,7 +68,7 @@ class _AnchorGather(torch.autograd.Function):
         feat, off = g72[:, :32], g72[:, 35:65].unflatten(1, (10, 3))
         # the column statistics of g_fea for the BatchNorm that reads it, formed while the rows are in LDS (one row of partial
         # sums per workgroup): the fused BatchNorm-Linear skips its own pass over the matrix (gather_anchors hangs them on g_fea)
-        stats = new(_C.lib.scr_anchor_gather_stat_rows(V), 2, 80) if V else new(0, 2, 80)
+        stats = new(_C.lib.scr_anchor_gather_stat_buffer_rows(V), 2, 80) if V else new(0, 2, 80)
         if V:
             with torch.cuda.device(dev):
                 _C.check(_C.lib.scr_anchor_gather(V, idx.data_ptr(), anchor_feat.data_ptr(), anchor.data_ptr(),
@@ -81,6 +81,7 @@ class _AnchorGather(torch.autograd.Function):
         ctx.N, ctx.sink = N, sink
         if sink is not None:
             sink.pending += 1
+        stats = stats[:_C.lib.scr_anchor_gather_stat_rows(V)] if V else stats      # what the consumer reads (per-tile rows behind it)
         ctx.mark_non_differentiable(stats)
         return feat, anc, off, gs, g_fea, stats
 

@@ -55,14 +55,39 @@ __device__ __forceinline__ void ag_store_chunk(float* __restrict__ dst, const fl
 }
 
 // Column statistics of g_fea for the BatchNorm that reads it (csrc/normlinear.hip): the workgroup has every 64 rows of the
-// matrix in LDS anyway, so it also sums (x - x[0]) and (x - x[0])^2 per column over ITS rows -- a workgroup walks several
-// tiles (capped grid) and writes one row [2][NL_DP] of partial sums at the end; the single-workgroup finish kernel of the
-// BatchNorm-Linear combines them in fp64 exactly as it combines the partials of its own statistics pass, which is then
-// skipped (1.3 GB read and 0.26 ms at configs[2]).  Thread (c = t % 72, rg = t / 72 < 3) sums column c over rows rg, rg + 3, ..
-constexpr int AG_MAX_WGS = 2048;
-int anchor_gather_stat_rows(int64_t V) {
-    const int64_t tiles = (V + AG_ROWS - 1) / AG_ROWS;
+// matrix in LDS anyway, so it also sums (x - x[0]) and (x - x[0])^2 per column over ITS rows and writes one row [2][NL_DP] of
+// partial sums; beyond 2048 tiles a second kernel adds the tiles' rows into 2048 (fixed order), and the single-workgroup
+// finish kernel of the BatchNorm-Linear combines those in fp64 exactly as it combines the partials of its own statistics
+// pass, which is then skipped.  (A capped grid of workgroups WALKING the tiles, one row of sums per workgroup and no second
+// kernel, was measured first: the gather went from 0.57 to 0.68 ms with the statistics switched off -- workgroups that loop
+// in step load together and store together; one tile per workgroup with the reduction and the row written per TILE: 0.74 ms.
+// Eight consecutive tiles per workgroup: 0.65 ms + 5 us for the second kernel, same box.)  What is skipped: 1.3 GB read and
+// 0.26 ms at configs[2].  Thread (q = t % 18, rg = t / 18 < 14) sums the four columns 4 q .. 4 q + 3 over rows rg, rg + 14, ..:
+// one ds_read_b128 per row.
+#ifndef SCR_AG_MAX_WGS
+#define SCR_AG_MAX_WGS 2048
+#endif
+constexpr int AG_MAX_WGS = SCR_AG_MAX_WGS;
+#ifndef SCR_AG_TPW
+#define SCR_AG_TPW 8
+#endif
+constexpr int AG_TPW = SCR_AG_TPW;      // consecutive 64-row tiles per workgroup: one row of statistics (and its reduction) per workgroup
+int anchor_gather_stat_rows(int64_t V) {      // rows the consumer reads
+    const int64_t tiles = (V + AG_ROWS * AG_TPW - 1) / (AG_ROWS * AG_TPW);
     return (int)(tiles < AG_MAX_WGS ? (tiles > 0 ? tiles : 1) : AG_MAX_WGS);
+}
+int64_t anchor_gather_stat_buffer_rows(int64_t V) {      // rows of the buffer: the consumer's, then one per workgroup when a second kernel reduces them
+    const int64_t tiles = (V + AG_ROWS * AG_TPW - 1) / (AG_ROWS * AG_TPW);
+    return tiles <= AG_MAX_WGS ? (tiles > 0 ? tiles : 1) : AG_MAX_WGS + tiles;
+}
+
+// rows AG_MAX_WGS.. (one per tile) -> rows 0 .. AG_MAX_WGS - 1: row r = sum of tile rows r, r + AG_MAX_WGS, ... in that order
+__global__ void __launch_bounds__(2 * NL_DP) anchor_gather_stat_reduce_kernel(int64_t tiles, float* __restrict__ stats) {
+    const float* in = stats + (size_t)AG_MAX_WGS * 2 * NL_DP;
+    float a = 0.0f;
+    if (threadIdx.x % NL_DP < AG_LD)      // (the tiles write 72 of a row's 80 columns)
+        for (int64_t t = blockIdx.x; t < tiles; t += AG_MAX_WGS) a += in[(size_t)t * 2 * NL_DP + threadIdx.x];
+    stats[(size_t)blockIdx.x * 2 * NL_DP + threadIdx.x] = a;
 }
 
 __global__ void __launch_bounds__(AG_THREADS)
@@ -73,17 +98,22 @@ anchor_gather_kernel(int64_t V, const int64_t* __restrict__ idx, const float* __
                      float* __restrict__ stats) {
     __shared__ __attribute__((aligned(16))) float tile[AG_ROWS * AG_LD];
     __shared__ int64_t rowsrc[AG_ROWS];
-    __shared__ float red[2][3][AG_LD];
-    const int sc = threadIdx.x % AG_LD, srg = threadIdx.x / AG_LD;      // statistics: this thread's column and row group
-    float shift = 0.0f, ssum = 0.0f, ssq = 0.0f;
-    if (stats && srg < 3 && sc < AG_COLS) {      // row 0 of the matrix = the first visible anchor's parameters (the same expf as below)
+    constexpr int SQ = AG_LD / 4, SRG = AG_THREADS / SQ;               // 18 column quads x 14 row groups = 252 threads
+    const int sq = threadIdx.x % SQ, srg = threadIdx.x / SQ;           // statistics: this thread's column quad and row group
+    float shift[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ssum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ssq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (stats && srg < SRG) {      // row 0 of the matrix = the first visible anchor's parameters (the same expf as below)
         const int64_t i0 = idx[0];
-        shift = sc < 32 ? p_feat[i0 * AG_FEAT + sc] : sc < 35 ? p_anchor[i0 * 3 + sc - 32]
-              : sc < 65 ? p_offset[i0 * AG_OFF + sc - 35] : expf(p_scaling[i0 * 6 + sc - 65]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sc = 4 * sq + j;
+            shift[j] = sc < 32 ? p_feat[i0 * AG_FEAT + sc] : sc < 35 ? p_anchor[i0 * 3 + sc - 32]
+                     : sc < 65 ? p_offset[i0 * AG_OFF + sc - 35] : sc < AG_COLS ? expf(p_scaling[i0 * 6 + sc - 65]) : 0.0f;
+        }
     }
-    const int64_t ntiles = (V + AG_ROWS - 1) / AG_ROWS;
-    for (int64_t ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
-    const int64_t v0 = ti * AG_ROWS;
+    for (int tk = 0; tk < AG_TPW; ++tk) {
+    const int64_t v0 = ((int64_t)blockIdx.x * AG_TPW + tk) * AG_ROWS;
+    if (v0 >= V) break;
+    if (tk) __syncthreads();      // the previous tile's readers are done with the LDS tile
     const int rows = (int)min((int64_t)AG_ROWS, V - v0);
     if (threadIdx.x < AG_ROWS) rowsrc[threadIdx.x] = threadIdx.x < rows ? idx[v0 + threadIdx.x] : 0;
     __syncthreads();
@@ -138,25 +168,32 @@ anchor_gather_kernel(int64_t V, const int64_t* __restrict__ idx, const float* __
     ag_store_chunk(anchor + v0 * 3, tile, rows * 3, 3, 32);
     if (offsets) ag_store_chunk(offsets + v0 * AG_OFF, tile, rows * AG_OFF, AG_OFF, 35);
     ag_store_chunk(grid_scaling + v0 * 6, tile, rows * 6, 6, 65);
-    if (stats && srg < 3 && sc < AG_COLS) {
-        for (int r = srg; r < rows; r += 3) {
-            const float t = tile[r * AG_LD + sc] - shift;
-            ssum += t;
-            ssq += t * t;
+    if (stats && srg < SRG) {
+        for (int r = srg; r < rows; r += SRG) {
+            const float4 v = *(const float4*)&tile[r * AG_LD + 4 * sq];      // (the pad column holds 0 and has shift 0)
+            const float t[4] = {v.x - shift[0], v.y - shift[1], v.z - shift[2], v.w - shift[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ssum[j] += t[j];
+                ssq[j] += t[j] * t[j];
+            }
         }
     }
-    __syncthreads();      // the tile is free for the next one
     }
     if (stats) {
-        if (srg < 3) {
-            red[0][srg][sc] = ssum;
-            red[1][srg][sc] = ssq;
+        __syncthreads();      // every thread is done with the tile
+        float* red = tile;      // [2][SRG][AG_LD]: 8 KB of the (now free) tile
+        if (srg < SRG) {
+            *(float4*)&red[(0 * SRG + srg) * AG_LD + 4 * sq] = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
+            *(float4*)&red[(1 * SRG + srg) * AG_LD + 4 * sq] = make_float4(ssq[0], ssq[1], ssq[2], ssq[3]);
         }
         __syncthreads();
-        if (threadIdx.x < AG_COLS) {
-            float* row = stats + (size_t)blockIdx.x * 2 * NL_DP;
-            row[threadIdx.x] = (red[0][0][threadIdx.x] + red[0][1][threadIdx.x]) + red[0][2][threadIdx.x];
-            row[NL_DP + threadIdx.x] = (red[1][0][threadIdx.x] + red[1][1][threadIdx.x]) + red[1][2][threadIdx.x];
+        if (threadIdx.x < 2 * AG_LD) {
+            const int which = threadIdx.x / AG_LD, c = threadIdx.x % AG_LD;
+            float a = 0.0f;
+#pragma unroll
+            for (int g = 0; g < SRG; ++g) a += red[(which * SRG + g) * AG_LD + c];      // fixed order
+            stats[((size_t)blockIdx.x * 2 + which) * NL_DP + c] = c < AG_COLS ? a : 0.0f;
         }
     }
 }
@@ -299,8 +336,12 @@ void launch_anchor_gather(int64_t V, const int64_t* idx, const float* p_feat, co
                           const float* p_scaling, float* feat, float* anchor, float* offsets, float* grid_scaling,
                           float* g_fea, int ldg, float* stats, hipStream_t st) {
     if (V <= 0) return;
-    anchor_gather_kernel<<<(unsigned)anchor_gather_stat_rows(V), AG_THREADS, 0, st>>>(
-        V, idx, p_feat, p_anchor, p_offset, p_scaling, feat, anchor, offsets, grid_scaling, g_fea, ldg, stats);
+    const int64_t tiles = (V + AG_ROWS * AG_TPW - 1) / (AG_ROWS * AG_TPW);      // workgroups
+    // per-workgroup statistics rows: the consumer's rows themselves up to AG_MAX_WGS workgroups, behind them otherwise
+    float* tile_stats = stats ? stats + (tiles <= AG_MAX_WGS ? 0 : (size_t)AG_MAX_WGS * 2 * NL_DP) : nullptr;
+    anchor_gather_kernel<<<(unsigned)tiles, AG_THREADS, 0, st>>>(
+        V, idx, p_feat, p_anchor, p_offset, p_scaling, feat, anchor, offsets, grid_scaling, g_fea, ldg, tile_stats);
+    if (stats && tiles > AG_MAX_WGS) anchor_gather_stat_reduce_kernel<<<AG_MAX_WGS, 2 * NL_DP, 0, st>>>(tiles, stats);
 }
 
 void launch_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inv, const float* grid_scaling, const float* d_feat,

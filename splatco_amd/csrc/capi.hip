@@ -730,6 +730,7 @@ int scr_scaling_reg_backward(int64_t P, const float* scaling, const float* g, fl
 
 // ---- visible-anchor gather (anchor_gather.hip)
 int32_t scr_anchor_gather_stat_rows(int64_t V) { return anchor_gather_stat_rows(V > 0 ? V : 1); }
+int64_t scr_anchor_gather_stat_buffer_rows(int64_t V) { return anchor_gather_stat_buffer_rows(V > 0 ? V : 1); }
 
 int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anchor_feat, const float* anchor,
                       const float* offset, const float* scaling, float* feat_out, float* anchor_out, float* offsets_out,

@@ -398,7 +398,8 @@ void launch_statis_apply(int64_t V, int k, const int64_t* visible_index, const f
                          hipStream_t st);
 
 constexpr int NL_DP = 80;               // padded width of the BatchNorm-Linear's coefficient rows AND of a row of column statistics
-int anchor_gather_stat_rows(int64_t V);  // workgroups of the gather = rows of the column statistics it can produce
+int anchor_gather_stat_rows(int64_t V);  // rows of column statistics the gather hands to the BatchNorm-Linear
+int64_t anchor_gather_stat_buffer_rows(int64_t V);      // rows of the buffer it needs for them (per-tile rows behind the result)
 void launch_anchor_gather(int64_t V, const int64_t* idx, const float* p_feat, const float* p_anchor, const float* p_offset,
                           const float* p_scaling, float* feat, float* anchor, float* offsets, float* grid_scaling,
                           float* g_fea, int ldg, float* stats, hipStream_t st);

@@ -542,4 +542,5 @@ def test_row_stride_arguments_are_validated_before_anything_is_launched():
     assert lib.scr_anchor_gather(8, p, p, p, p, p, p, None, p, p, p, 72, None, None) != 0 and "NULL" in err()      # anchor_out is not optional
     # producer statistics for the BatchNorm-Linear: pointer and row count go together
     assert lib.scr_norm_linear_forward(8, 71, p, 72, p, p, 1e-5, p, p, p, p, p, p, 0, None) != 0 and "col_stats" in err()
-    assert lib.scr_anchor_gather_stat_rows(1) == 1 and lib.scr_anchor_gather_stat_rows(64 * 5000) == 2048
+    assert lib.scr_anchor_gather_stat_rows(1) == 1 and lib.scr_anchor_gather_stat_rows(64 * 50000) == 2048
+    assert lib.scr_anchor_gather_stat_buffer_rows(1) == 1 and lib.scr_anchor_gather_stat_buffer_rows(64 * 50000) > 2048
