@@ -570,9 +570,16 @@ def pair_consistency(gen1, real1, gen2, real2):
     """Cross-view consistency term of one view pair (train.py:208-217):
     ssim(real1, real2) * |mean |(real1 - real2) - (gen1 - gen2)||  if the two ground-truth views are alike
     (SSIM > 0.6), else 0."""
-    from .losses import l1_loss, ssim
+    from .losses import l1_loss, l1_ssim, ssim
     gen1, gen2, real1, real2 = align_images(gen1, gen2, real1, real2)
-    s = ssim(real1, real2)
+    if real1.is_cuda and real1.dim() == 3 and not (real1.requires_grad or real2.requires_grad):
+        # SSIM of two ground-truth images: a constant of the step.  Through the fused kernel (csrc/ssim.hip, forward only) --
+        # the framework's five grouped 11x11 convolutions run as MIOpen's naive kernels on this stack: 12 ms EACH at 640 x 360
+        # (profiles/HISTORY.md, round 5), a second per view pair at 1080p
+        with torch.no_grad():
+            s = l1_ssim(real1.contiguous(), real2.contiguous())[1]
+    else:
+        s = ssim(real1, real2)
     if not bool(s > 0.6):
         return None
     return s * torch.abs(l1_loss(real1 - real2, gen1 - gen2))
