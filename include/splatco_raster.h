@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 25
+#define SCR_ABI_VERSION 26
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -288,6 +288,16 @@ int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, con
 size_t scr_scaling_reg_scratch_bytes(int64_t P);
 int scr_scaling_reg_forward(int64_t P, const float* scaling, void* scratch, float* out, void* stream);
 int scr_scaling_reg_backward(int64_t P, const float* scaling, const float* g, float* dscaling, void* stream);
+
+/* The L1 of the cross-view consistency term of the mv loop (train.py:208-217: `l1_loss(real_img1 - real_img2, gen_img1 - gen_img2)`):
+ * out[0] = mean over the n elements of | (real1 - real2) - (gen1 - gen2) | for four equally shaped images, and its gradient
+ * d_gen1 = -g[0] sign(.) / n, d_gen2 = +g[0] sign(.) / n (either may be NULL: in the sharded step a rank differentiates its own
+ * image only).  One streaming pass per direction, ordered partial sums (deterministic); no host read. */
+size_t scr_pair_l1_scratch_bytes(int64_t n);
+int scr_pair_l1_forward(int64_t n, const float* gen1, const float* gen2, const float* real1, const float* real2, void* scratch,
+                        float* out, void* stream);
+int scr_pair_l1_backward(int64_t n, const float* gen1, const float* gen2, const float* real1, const float* real2, const float* g,
+                         float* d_gen1, float* d_gen2, void* stream);
 
 /* ---- the head of generate_neural_gaussians (gaussian_renderer/__init__.py:23-31) for the reference's sizes (feat 32, 10 offsets):
  * the four visible-anchor gathers, exp(_scaling) and the [V,71] concatenation in one pass.  visible_index[V] int64 = the

@@ -24,6 +24,7 @@ SYMBOLS = [
     "scr_expand_backward", "scr_mask_index_plan", "scr_mask_index_run", "scr_plane_sample_scratch_bytes", "scr_plane_sample_backward", "scr_triplane_backward_multi_scratch_bytes", "scr_triplane_backward_multi", "scr_plane_row_pairs", "scr_triplane_forward", "scr_triplane_backward_scratch_bytes", "scr_triplane_backward",
     "scr_l1_ssim_scratch_bytes", "scr_l1_ssim_forward", "scr_l1_ssim_backward",
     "scr_scaling_reg_scratch_bytes", "scr_scaling_reg_forward", "scr_scaling_reg_backward",
+    "scr_pair_l1_scratch_bytes", "scr_pair_l1_forward", "scr_pair_l1_backward",
     "scr_tpa_scratch_bytes", "scr_tpa_stats", "scr_tpa_forward", "scr_tpa_backward", "scr_tpa_backward_stats",
     "scr_statis_compute", "scr_statis_apply", "scr_copy_probe",
     "scr_knn", "scr_knn_curvature", "scr_anchor_gather_stat_rows", "scr_anchor_gather_stat_buffer_rows", "scr_anchor_gather", "scr_anchor_gather_backward", "scr_mlp_heads_hidden_bytes", "scr_mlp_heads_partial_bytes", "scr_mlp_heads_forward", "scr_mlp_heads_backward",
@@ -33,7 +34,7 @@ SYMBOLS = [
 ]
 PLAN_NONFINITE_COLOUR, PLAN_LARGE_RECTS = 1, 2      # SCR_PLAN_*
 PROF_COUNT = 19
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 (DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS, DBG_QMASK,
  DBG_GM_INDEX) = range(9)
@@ -146,6 +147,11 @@ def _load():
     lib.scr_scaling_reg_forward.argtypes = [i64, vp, vp, vp, vp]
     lib.scr_scaling_reg_backward.argtypes = [i64, vp, vp, vp, vp]
     lib.scr_scaling_reg_forward.restype = lib.scr_scaling_reg_backward.restype = C.c_int
+    lib.scr_pair_l1_scratch_bytes.argtypes = [i64]
+    lib.scr_pair_l1_scratch_bytes.restype = C.c_size_t
+    lib.scr_pair_l1_forward.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp]
+    lib.scr_pair_l1_backward.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.scr_pair_l1_forward.restype = lib.scr_pair_l1_backward.restype = C.c_int
     lib.scr_mask_index_plan.argtypes = [i64, vp, vp, C.POINTER(C.c_int64), vp]
     lib.scr_mask_index_run.argtypes = [i64, vp, vp, vp, vp, vp]
     lib.scr_mask_index_plan.restype = lib.scr_mask_index_run.restype = C.c_int

@@ -728,6 +728,30 @@ int scr_scaling_reg_backward(int64_t P, const float* scaling, const float* g, fl
     return 0;
 }
 
+// ---- the L1 of the cross-view consistency term (ssim.hip)
+size_t scr_pair_l1_scratch_bytes(int64_t n) { return pair_l1_scratch_bytes(n > 0 ? n : 1); }
+
+int scr_pair_l1_forward(int64_t n, const float* gen1, const float* gen2, const float* real1, const float* real2, void* scratch,
+                        float* out, void* stream) {
+    if (n <= 0) return fail("n <= 0");
+    if (!gen1 || !gen2 || !real1 || !real2 || !scratch || !out) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_L1_SSIM, st); launch_pair_l1_forward(n, gen1, gen2, real1, real2, scratch, out, st); }
+    CHECK_LAUNCH("pair_l1_partial_kernel", 0, st);
+    return 0;
+}
+
+int scr_pair_l1_backward(int64_t n, const float* gen1, const float* gen2, const float* real1, const float* real2, const float* g,
+                         float* d_gen1, float* d_gen2, void* stream) {
+    if (n <= 0) return fail("n <= 0");
+    if (!gen1 || !gen2 || !real1 || !real2 || !g) return fail("NULL argument");
+    if (!d_gen1 && !d_gen2) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    { ProfScope ps_(SCR_PROF_L1_SSIM_BACKWARD, st); launch_pair_l1_backward(n, gen1, gen2, real1, real2, g, d_gen1, d_gen2, st); }
+    CHECK_LAUNCH("pair_l1_backward_kernel", 0, st);
+    return 0;
+}
+
 // ---- visible-anchor gather (anchor_gather.hip)
 int32_t scr_anchor_gather_stat_rows(int64_t V) { return anchor_gather_stat_rows(V > 0 ? V : 1); }
 int64_t scr_anchor_gather_stat_buffer_rows(int64_t V) { return anchor_gather_stat_buffer_rows(V > 0 ? V : 1); }

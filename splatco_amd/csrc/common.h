@@ -445,6 +445,11 @@ void launch_tpa_backward_stats(int R, int64_t HW, const float* davg, const float
 
 size_t l1_ssim_scratch_bytes(int C, int H, int W, int with_grad);
 size_t scaling_reg_scratch_bytes(int64_t P);
+size_t pair_l1_scratch_bytes(int64_t n);
+void launch_pair_l1_forward(int64_t n, const float* g1, const float* g2, const float* r1, const float* r2, void* scratch, float* out,
+                            hipStream_t st);
+void launch_pair_l1_backward(int64_t n, const float* g1, const float* g2, const float* r1, const float* r2, const float* g, float* d1,
+                             float* d2, hipStream_t st);
 void launch_scaling_reg_forward(int64_t P, const float* s, void* scratch, float* out, hipStream_t st);
 void launch_scaling_reg_backward(int64_t P, const float* s, const float* g, float* ds, hipStream_t st);
 void launch_l1_ssim_forward(int C, int H, int W, const float* img1, const float* img2, void* scratch,

@@ -242,6 +242,48 @@ scaling_reg_backward_kernel(int64_t P, const float* __restrict__ s, const float*
     ds[3 * r + 2] = w * (a * b);
 }
 
+// ---- the L1 of the cross-view consistency term (train.py:208-217): mean | (real1 - real2) - (gen1 - gen2) | over the n elements of
+// four equally shaped images, and its gradient with respect to gen1 / gen2 (+- sign / n).  The framework spends a dozen
+// elementwise kernels per view pair on it (0.3 ms at 1080p; six pairs per --mv 4 step); here one pass per direction.  The
+// differences are formed in binary32 in the reference's order, the sum in binary64 per workgroup and in a fixed order.
+constexpr int PL1_PER_WG = 256 * 16;
+__global__ void __launch_bounds__(256)
+pair_l1_partial_kernel(int64_t n, const float* __restrict__ g1, const float* __restrict__ g2, const float* __restrict__ r1,
+                       const float* __restrict__ r2, double* __restrict__ partial) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const int64_t e0 = (int64_t)blockIdx.x * PL1_PER_WG;
+    for (int64_t e = e0 + threadIdx.x; e < min(n, e0 + PL1_PER_WG); e += 256)
+        acc += (double)fabsf((r1[e] - r2[e]) - (g1[e] - g2[e]));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, WAVE);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(256)
+pair_l1_backward_kernel(int64_t n, const float* __restrict__ g1, const float* __restrict__ g2, const float* __restrict__ r1,
+                        const float* __restrict__ r2, const float* __restrict__ g, float inv_n, float* __restrict__ d1,
+                        float* __restrict__ d2) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const float d = (r1[e] - r2[e]) - (g1[e] - g2[e]);       // d |d| / d gen1 = -sign(d), / d gen2 = +sign(d); sign(0) = 0 as torch.abs
+    const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f), w = g[0] * inv_n;
+    if (d1) d1[e] = -sg * w;
+    if (d2) d2[e] = sg * w;
+}
+size_t pair_l1_scratch_bytes(int64_t n) { return align_up((size_t)((n + PL1_PER_WG - 1) / PL1_PER_WG + 1) * 8); }
+void launch_pair_l1_forward(int64_t n, const float* g1, const float* g2, const float* r1, const float* r2, void* scratch, float* out,
+                            hipStream_t st) {
+    const int nb = (int)((n + PL1_PER_WG - 1) / PL1_PER_WG);
+    pair_l1_partial_kernel<<<nb, 256, 0, st>>>(n, g1, g2, r1, r2, (double*)scratch);
+    scaling_reg_finish_kernel<<<1, 1024, 0, st>>>(nb, (const double*)scratch, 1.0 / (double)n, out);
+}
+void launch_pair_l1_backward(int64_t n, const float* g1, const float* g2, const float* r1, const float* r2, const float* g, float* d1,
+                             float* d2, hipStream_t st) {
+    pair_l1_backward_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(n, g1, g2, r1, r2, g, (float)(1.0 / (double)n), d1, d2);
+}
+
 size_t scaling_reg_scratch_bytes(int64_t P) { return align_up((size_t)((P + SREG_ROWS - 1) / SREG_ROWS + 1) * 8); }
 void launch_scaling_reg_forward(int64_t P, const float* s, void* scratch, float* out, hipStream_t st) {
     const int nb = (int)((P + SREG_ROWS - 1) / SREG_ROWS);

@@ -83,6 +83,48 @@ class _L1Ssim(torch.autograd.Function):
         return dx, None
 
 
+class _PairL1(torch.autograd.Function):
+    """mean |(real1 - real2) - (gen1 - gen2)| of four equally shaped device images (the L1 of the cross-view consistency
+    term, train.py:208-217) in one pass per direction (csrc/ssim.hip); the gradient flows to gen1 / gen2."""
+
+    @staticmethod
+    def forward(ctx, gen1, gen2, real1, real2):
+        from . import _C
+        from .rasterizer import _stream
+        c = lambda t: t.detach().contiguous().float()
+        gen1, gen2, real1, real2 = c(gen1), c(gen2), c(real1), c(real2)
+        n, dev = gen1.numel(), gen1.device
+        scratch = torch.empty(_C.lib.scr_pair_l1_scratch_bytes(n), dtype=torch.uint8, device=dev)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _C.check(_C.lib.scr_pair_l1_forward(n, gen1.data_ptr(), gen2.data_ptr(), real1.data_ptr(), real2.data_ptr(),
+                                                scratch.data_ptr(), out.data_ptr(), _stream(dev)))
+        ctx.save_for_backward(gen1, gen2, real1, real2)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _C
+        from .rasterizer import _stream
+        gen1, gen2, real1, real2 = ctx.saved_tensors
+        n, dev = gen1.numel(), gen1.device
+        g = g.contiguous().float().reshape(1)
+        d1 = torch.empty_like(gen1) if ctx.needs_input_grad[0] else None
+        d2 = torch.empty_like(gen2) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(dev):
+            _C.check(_C.lib.scr_pair_l1_backward(n, gen1.data_ptr(), gen2.data_ptr(), real1.data_ptr(), real2.data_ptr(), g.data_ptr(),
+                                                 None if d1 is None else d1.data_ptr(), None if d2 is None else d2.data_ptr(),
+                                                 _stream(dev)))
+        return d1, d2, None, None
+
+
+def pair_l1(gen1, gen2, real1, real2):
+    """l1_loss(real1 - real2, gen1 - gen2) (train.py:213): the fused op on the GPU, the reference's ops elsewhere."""
+    if gen1.is_cuda and gen1.shape == gen2.shape == real1.shape == real2.shape and gen1.numel() > 0 and not (real1.requires_grad or real2.requires_grad):
+        return _PairL1.apply(gen1, gen2, real1, real2)
+    return l1_loss(real1 - real2, gen1 - gen2)
+
+
 def l1_ssim(image, gt_image):
     """Fused (l1_loss, ssim) for [3,H,W] device images; falls back to the torch ops on CPU."""
     if image.is_cuda and image.dim() == 3:

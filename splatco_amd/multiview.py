@@ -566,23 +566,31 @@ def align_images(*imgs):                                        # train.py:79-96
     return tuple(i[:, :h, :w] for i in imgs)
 
 
-def pair_consistency(gen1, real1, gen2, real2):
-    """Cross-view consistency term of one view pair (train.py:208-217):
-    ssim(real1, real2) * |mean |(real1 - real2) - (gen1 - gen2)||  if the two ground-truth views are alike
-    (SSIM > 0.6), else 0."""
-    from .losses import l1_loss, l1_ssim, ssim
-    gen1, gen2, real1, real2 = align_images(gen1, gen2, real1, real2)
+def pair_similarity(real1, real2):
+    """SSIM of two ground-truth views as a 0-dim tensor (train.py:210) -- no host read here, so that a caller with many pairs
+    can read all the verdicts at once."""
+    from .losses import l1_ssim, ssim
+    real1, real2 = align_images(real1, real2)
     if real1.is_cuda and real1.dim() == 3 and not (real1.requires_grad or real2.requires_grad):
         # SSIM of two ground-truth images: a constant of the step.  Through the fused kernel (csrc/ssim.hip, forward only) --
         # the framework's five grouped 11x11 convolutions run as MIOpen's naive kernels on this stack: 12 ms EACH at 640 x 360
         # (profiles/HISTORY.md, round 5), a second per view pair at 1080p
         with torch.no_grad():
-            s = l1_ssim(real1.contiguous(), real2.contiguous())[1]
-    else:
-        s = ssim(real1, real2)
-    if not bool(s > 0.6):
+            return l1_ssim(real1.contiguous(), real2.contiguous())[1]
+    return ssim(real1, real2)
+
+
+def pair_consistency(gen1, real1, gen2, real2, similarity=None, alike=None):
+    """Cross-view consistency term of one view pair (train.py:208-217):
+    ssim(real1, real2) * |mean |(real1 - real2) - (gen1 - gen2)||  if the two ground-truth views are alike
+    (SSIM > 0.6), else 0 (None).  similarity / alike: pair_similarity(real1, real2) and its verdict when the caller has
+    them already (consistency_loss reads the verdicts of all pairs with one host read)."""
+    from .losses import pair_l1
+    gen1, gen2, real1, real2 = align_images(gen1, gen2, real1, real2)
+    s = pair_similarity(real1, real2) if similarity is None else similarity
+    if not (bool(s > 0.6) if alike is None else alike):
         return None
-    return s * torch.abs(l1_loss(real1 - real2, gen1 - gen2))
+    return s * torch.abs(pair_l1(gen1, gen2, real1, real2))
 
 
 def consistency_loss(local: Sequence, weight: float = 0.05, device=None):
@@ -616,16 +624,16 @@ def consistency_loss(local: Sequence, weight: float = 0.05, device=None):
                     items.append((i, pair[0], pair[1], False))
     items.sort(key=lambda t: t[0])
     grad_term, value = None, 0.0
-    for a in range(len(items)):
-        for b in range(a + 1, len(items)):
-            (_, g1, r1, own1), (_, g2, r2, own2) = items[a], items[b]
-            if not (own1 or own2):
-                continue
-            t = pair_consistency(g1, r1, g2, r2)
-            if t is None:
-                continue
-            grad_term = t if grad_term is None else grad_term + t
-            value = value + t.detach() * (1.0 if (own1 and own2) else 0.5)
+    pairs = [(a, b) for a in range(len(items)) for b in range(a + 1, len(items)) if items[a][3] or items[b][3]]
+    sims = [pair_similarity(*align_images(items[a][1], items[b][1], items[a][2], items[b][2])[2:]) for a, b in pairs]
+    alike = (torch.stack([s.detach().reshape(()) for s in sims]) > 0.6).tolist() if sims else []   # ONE host read for all pairs
+    for (a, b), s, ok in zip(pairs, sims, alike):
+        (_, g1, r1, own1), (_, g2, r2, own2) = items[a], items[b]
+        t = pair_consistency(g1, r1, g2, r2, similarity=s, alike=ok)
+        if t is None:
+            continue
+        grad_term = t if grad_term is None else grad_term + t
+        value = value + t.detach() * (1.0 if (own1 and own2) else 0.5)
     if grad_term is None:
         return None, value
     return weight * grad_term, weight * value

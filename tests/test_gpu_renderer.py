@@ -949,6 +949,35 @@ def test_scaling_regulariser_matches_torch_prod(P):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 1, 1), (3, 37, 53), (3, 1080, 1920)])
+def test_fused_pair_l1_matches_the_reference_ops(shape):
+    """csrc/ssim.hip pair_l1_* against l1_loss(real1 - real2, gen1 - gen2) (train.py:213): value to 2 ulp of the fp32
+    mean, gradients equal to 2 ulp (same sign pattern, sign(0) = 0 in both; 1/n may be rounded once more or less), to gen1 only / gen2 only / both;
+    the sum is taken in double so the value does not depend on the launch shape."""
+    from splatco_amd.losses import l1_loss, pair_l1
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(shape[1])
+    r1, r2, a0, b0 = (torch.rand(*shape, device=dev, generator=g) for _ in range(4))
+    b0[..., :1] = a0[..., :1] - (r1[..., :1] - r2[..., :1])                  # residuals at / next to zero
+    for need in ((True, True), (True, False), (False, True)):
+        outs = []
+        for fused in (True, False):
+            a, b = a0.clone().requires_grad_(need[0]), b0.clone().requires_grad_(need[1])
+            loss = pair_l1(a, b, r1, r2) if fused else l1_loss(r1 - r2, a - b)
+            (loss * 0.37).backward()
+            outs.append((loss.detach(), a.grad, b.grad))
+        (lf, af, bf), (lt, at, bt) = outs
+        exact = ((r1 - r2) - (a0 - b0)).abs().double().mean()
+        assert abs(lf.double() - exact) <= 2.0 ** -23 * exact + 1e-12, (lf.item(), exact.item())
+        assert abs(lf.double() - exact) <= abs(lt.double() - exact) + 2.0 ** -24 * exact + 1e-12
+        for x, y, n in ((af, at, need[0]), (bf, bt, need[1])):
+            assert (x is None) == (not n) and (y is None) == (not n)
+            if n:
+                assert torch.equal(x.sign(), y.sign()) and torch.allclose(x, y, rtol=2.0 ** -22, atol=0)
+    assert pair_l1(a0, b0, r1, r2).item() == pair_l1(a0.clone(), b0.clone(), r1.clone(), r2.clone()).item()
+
+
+@pytest.mark.gpu
 def test_scaling_regulariser_through_the_expansion_tap():
     """losses.scaling_reg on the `scaling` output of expand_compact sends its gradient through the expansion's tap
     (csrc/expand.hip adds it to dL/dscaling while reading it): every input gradient equals what the torch chain
