@@ -233,9 +233,12 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
  * The points' coordinates and gradient pieces are first moved into per-tile runs of records (32x32-cell tiles), then
  * summed per node in registers; the nodes on a tile's border go through a per-tile halo block and are added across the
  * (up to four) tiles that share them in a fixed order by a last small pass: no floating-point atomics anywhere, every element
- * of the plane gradient is written exactly once.  What remains of run-to-run variation is the ORDER in which a cell's
- * points are summed (their positions in the tile's run follow integer atomics): plane gradients are reproducible up to
- * the rounding of that order (1e-7 relative), unlike every other output of this library, which is bit-reproducible.  R <= 16 (with planes = 2: two passes above R = 5); scratch from
+ * of the plane gradient is written exactly once.  The cell sums are EXACT: every term g * w is rounded to a fixed-point
+ * grid of its tile (2^-29 of the tile's largest |gradient value|) and summed in 64-bit integers, so the plane gradient
+ * is a function of the SET of points -- the same bits in any order, run after run (a tile that holds a non-finite value
+ * is summed in fp32 instead).  A crowded tile (more than 16 K records and four times the plane's mean: a flat or a
+ * contracted scene) is cut into segments summed by a workgroup each; their integer sums add up to the same bits.
+ * R <= 16 (with planes = 2: two passes above R = 5); scratch from
  * scr_plane_sample_scratch_bytes(V, A, B, R * planes).  The sample positions get no gradient (the reference detaches
  * them, scene/gaussian_model.py:210).
  *

@@ -20,6 +20,7 @@
 // shares with its neighbours go to a per-tile halo block and are added across tiles in a fixed order by
 // tp_border_sum_kernel: no float atomics at all (round 2 flushed the border nodes with device atomics: 6.3 M per cfg2
 // step, 0.56 ms of the 2.3 ms the plane backward took).
+// A crowded tile (a flat or contracted scene) is cut into segments, one workgroup each (tp_scan_proj, tp_split_finish_kernel).
 // Round 1 kept an index list per tile and gathered coordinates and gradients through it (0.43 ms per plane at
 // 4.6 M points, 5.2 ms per cfg2 step); records + one pass per grid + cell-centred sums: 3.2 ms per step.
 #include "common.h"
@@ -99,6 +100,9 @@ struct TpProj {
     int col0, col1;                       // first gradient column of the plane (and of the second plane sampled with it)
     uint32_t *count, *start, *cursor;     // [tiles], [tiles + 1], [tiles]
     uint32_t* gmax;                       // [tiles]: bits of the largest |gradient value| among the tile's records (pass 3)
+    uint32_t *seg, *pfirst;               // [tiles + 1] first pass-4 workgroup of a tile, [tiles] first partial-sum slot of a split tile
+    uint32_t* split;                      // [0]: number of split tiles, [1 ...]: their indices
+    long long* part;                      // partial cell sums of the segments of split tiles (shared by the projections of a call)
     float* rec;                           // [V][tp_rec(R * NP)]
     float* halo;                          // [tiles][TP_BORDER][R * NP]: every tile's sums for the nodes on its border
 };
@@ -140,24 +144,62 @@ tp_count_kernel(int64_t V, const float* __restrict__ coords, int cs, TpProjSet p
     }
 }
 
-// pass 2 (one workgroup per projection): exclusive scan of the tile counts -> start[tiles + 1]; cursor = 0
+// A tile's run is summed by ONE workgroup of pass 4 -- unless the tile is crowded: a scene is not a uniform cloud (a city
+// seen from above is a sheet: two of its three projections collapse onto one row of tiles; a contracted scene sits in the
+// middle of every plane), and a workgroup per tile then leaves 20 workgroups with 200 k records each while the chip
+// idles (4.6 M points: 1.1 ms uniform, 4.9 ms as a sheet).  A tile with more than TP_SPLIT_MIN records AND more than four
+// times the plane's mean is cut into segments of TP_SEG records, one workgroup each; the segments' cell sums are 64-bit
+// integers, so they add up to the same bits whichever records a segment happens to hold (tp_split_finish_kernel adds them).
+#ifndef SCR_TP_SEG
+#define SCR_TP_SEG 8192
+#endif
+constexpr uint32_t TP_SEG = SCR_TP_SEG, TP_SPLIT_MIN = 2 * TP_SEG;
+// upper bounds: a split tile holds more than TP_SPLIT_MIN of the at most V records of a projection
+static inline size_t tp_max_split_tiles(int64_t V) { return (size_t)(V > 0 ? V : 0) / TP_SPLIT_MIN + 1; }
+static inline size_t tp_max_split_segments(int64_t V) { return (size_t)(V > 0 ? V : 0) / TP_SEG + tp_max_split_tiles(V) + 1; }
+
+// pass 2 (one workgroup per projection): exclusive scan of the tile counts -> start[tiles + 1]; cursor = 0; pass 4's
+// workgroups per tile (0 for an empty tile) -> seg[tiles + 1]; partial-sum slots of split tiles -> pfirst[tiles]
+__device__ __forceinline__ void tp_scan_proj(const TpProj& pj, uint32_t* lds) {
+    uint32_t mine = 0;
+    for (int i = threadIdx.x; i < pj.tiles; i += 1024) mine += pj.count[i];
+    uint32_t total;
+    (void)tp_block_scan(mine, lds, total);
+    const uint32_t crowded = max(TP_SPLIT_MIN, (uint32_t)min((unsigned long long)0xffffffffu, 4ull * (total / (uint32_t)pj.tiles)));
+    uint32_t carry = 0, carry_s = 0, carry_p = 0, carry_l = 0;
+    for (int base = 0; base < pj.tiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < pj.tiles ? pj.count[i] : 0u;
+        const uint32_t ns = v == 0 ? 0u : (v > crowded ? (v + TP_SEG - 1) / TP_SEG : 1u), np = ns > 1 ? ns : 0u;
+        uint32_t tot, tot_s, tot_p;
+        const uint32_t ex = tp_block_scan(v, lds, tot);
+        const uint32_t ex_s = tp_block_scan(ns, lds, tot_s);
+        const uint32_t ex_p = tp_block_scan(np, lds, tot_p);
+        uint32_t tot_l;
+        const uint32_t ex_l = tp_block_scan(np ? 1u : 0u, lds, tot_l);
+        if (i < pj.tiles) {
+            pj.start[i] = carry + ex;
+            pj.cursor[i] = 0;
+            pj.seg[i] = carry_s + ex_s;
+            pj.pfirst[i] = carry_p + ex_p;
+            if (np) pj.split[1 + carry_l + ex_l] = (uint32_t)i;
+        }
+        carry += tot;
+        carry_s += tot_s;
+        carry_p += tot_p;
+        carry_l += tot_l;
+    }
+    if (threadIdx.x == 0) {
+        pj.start[pj.tiles] = carry;
+        pj.seg[pj.tiles] = carry_s;
+        pj.split[0] = carry_l;
+    }
+}
 __global__ void __launch_bounds__(1024)
 tp_scan_kernel(TpProjSet ps) {
     __shared__ uint32_t lds[1024 / WAVE];
     const TpProj pj = blockIdx.x == 0 ? ps.p[0] : (blockIdx.x == 1 ? ps.p[1] : ps.p[2]);
-    uint32_t carry = 0;
-    for (int base = 0; base < pj.tiles; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < pj.tiles ? pj.count[i] : 0u;
-        uint32_t tot;
-        const uint32_t ex = tp_block_scan(v, lds, tot);
-        if (i < pj.tiles) {
-            pj.start[i] = carry + ex;
-            pj.cursor[i] = 0;
-        }
-        carry += tot;
-    }
-    if (threadIdx.x == 0) pj.start[pj.tiles] = carry;
+    tp_scan_proj(pj, lds);
 }
 
 // pass 3: one RECORD per (point, projection), grouped by tile: {grid x, grid y, the RT = R * NP gradient values}.
@@ -350,19 +392,7 @@ __global__ void __launch_bounds__(1024)
 tp_scan9_kernel(TpProjSet9 ps) {
     __shared__ uint32_t lds[1024 / WAVE];
     const TpProj pj = ps.p[blockIdx.x];
-    uint32_t carry = 0;
-    for (int base = 0; base < pj.tiles; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < pj.tiles ? pj.count[i] : 0u;
-        uint32_t tot;
-        const uint32_t ex = tp_block_scan(v, lds, tot);
-        if (i < pj.tiles) {
-            pj.start[i] = carry + ex;
-            pj.cursor[i] = 0;
-        }
-        carry += tot;
-    }
-    if (threadIdx.x == 0) pj.start[pj.tiles] = carry;
+    tp_scan_proj(pj, lds);
 }
 
 // grid g (0..2) has RTg channels per projection (0 = grid absent); its projection q owns columns
@@ -522,11 +552,21 @@ __device__ __forceinline__ void tp_acc_add(A& acc, int x) {
 // nodes torch's grid_sample backward would poison; such a step has no bits worth reproducing).
 // Channels [C0, C0 + CN) of the RT in a record: eight 64-bit sums per channel live in registers, so more than ten
 // channels go in two rounds over the tile's run (RT = 15 / 16).
+template <int R, int NP, int CN, bool EXACT, typename ACC>
+__device__ __forceinline__ void tp_finish_tile(int A, int B, int tb, int t, int C0, ACC (&acc)[4][CN], double s_inv,
+                                               float* __restrict__ grad_plane0, float* __restrict__ grad_plane1, float* __restrict__ halo,
+                                               float* raw);
+
+// A split tile (nseg > 1, exact sums only): this workgroup sums the records [lo, hi) of segment `sidx` and leaves its cell
+// sums in its slot of `part` ([segment][corner][channel][cell]); tp_split_finish_kernel adds the slots up and finishes the
+// tile.  (One kernel with a "last one to arrive finishes" counter was tried first: the device-scope fences it needs write
+// back and invalidate the XCD's whole L2 on this chip -- the split made the crowded case slower, 0.31 -> 0.59 ms per plane.)
 template <int R, int NP, int C0, int CN, bool EXACT>
 __device__ __forceinline__ void tp_gather_group(int A, int B, int tb, int t, uint32_t lo, uint32_t hi, float s_fwd, double s_inv,
                                                 const float* __restrict__ rec, float* __restrict__ grad_plane0,
                                                 float* __restrict__ grad_plane1, float* __restrict__ halo,
-                                                unsigned char* tpn_lds) {
+                                                unsigned char* tpn_lds, uint32_t nseg = 1, uint32_t sidx = 0,
+                                                long long* part = nullptr) {
     constexpr int RT = R * NP, REC = tp_rec(RT);
     constexpr int CHUNK = tpn_chunk<RT>();
     constexpr int PPT = (CHUNK + TPN_THREADS - 1) / TPN_THREADS;
@@ -629,6 +669,28 @@ __device__ __forceinline__ void tp_gather_group(int A, int B, int tb, int t, uin
         }
         __syncthreads();
     }
+    if constexpr (EXACT) {
+        if (nseg > 1) {       // a segment of a split tile: the sums go to this segment's slot, tp_split_finish_kernel adds the slots up
+            long long* mine = part + sidx * ((size_t)4 * RT * TPN_CELLS);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int r = 0; r < CN; ++r) mine[(size_t)(k * RT + C0 + r) * TPN_CELLS + c] = acc[k][r];
+            return;
+        }
+    }
+    tp_finish_tile<R, NP, CN, EXACT>(A, B, tb, t, C0, acc, s_inv, grad_plane0, grad_plane1, halo, raw);
+}
+
+// the end of a tile: the cells' corner sums meet in an LDS image of the tile's 33 x 33 nodes and go out
+// (channels [C0, C0 + CN) of the RT in the tile's outputs)
+template <int R, int NP, int CN, bool EXACT, typename ACC>
+__device__ __forceinline__ void tp_finish_tile(int A, int B, int tb, int t, int C0, ACC (&acc)[4][CN], double s_inv,
+                                               float* __restrict__ grad_plane0, float* __restrict__ grad_plane1, float* __restrict__ halo,
+                                               float* raw) {
+    constexpr int RT = R * NP;
+    const int ta = t / tb, tbb = t % tb;
+    const int c = threadIdx.x;
     // ---- corner sums -> nodes (LDS image of the 33 x 33 nodes, CN channels)
     for (int i = threadIdx.x; i < TPN_NODES * CN; i += TPN_THREADS) raw[i] = 0.0f;
     __syncthreads();
@@ -670,34 +732,79 @@ constexpr int TPN_GROUP = 10;      // channels per round of the exact sums (8 re
 #endif
 template <int R, int NP>
 __global__ void __launch_bounds__(TPN_THREADS, (R * NP <= SCR_TPN_SMALL ? 8 : 4))
-tp_cell_gather_kernel(int A, int B, int tb, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ gmax,
-                      const float* __restrict__ rec, float* __restrict__ grad_plane0 /*[R][A][B]*/,
+tp_cell_gather_kernel(int A, int B, int tb, int tiles, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ seg,
+                      const uint32_t* __restrict__ pfirst, long long* __restrict__ part, const uint32_t* __restrict__ gmax, const float* __restrict__ rec, float* __restrict__ grad_plane0 /*[R][A][B]*/,
                       float* __restrict__ grad_plane1, float* __restrict__ halo /*[tiles][TP_BORDER][R * NP]*/) {
     constexpr int RT = R * NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char tpn_lds[];
-    const int t = blockIdx.x;
-    const uint32_t lo = tile_start[t], hi = tile_start[t + 1];
-    if (lo == hi) return;
+    // workgroup -> (tile, segment): seg[] is the running count of workgroups (none for an empty tile, several for a crowded one)
+    const uint32_t wg = blockIdx.x;
+    if (wg >= seg[tiles]) return;
+    int t = 0;
+    for (int above = tiles; above - t > 1;) {                   // seg[t] <= wg < seg[above]
+        const int mid = (t + above) >> 1;
+        if (seg[mid] <= wg) t = mid; else above = mid;
+    }
+    const uint32_t sidx = wg - seg[t];
+    uint32_t nseg = seg[t + 1] - seg[t];
+    uint32_t lo = tile_start[t], hi = tile_start[t + 1];
     const uint32_t mx = gmax[t];
     const int ex = (int)(mx >> 23);                             // biased exponent of the tile's largest |g| (0: zero / denormal)
     if (ex == 255) {                                            // Inf / NaN among the records: fp32 sums, torch's propagation
-        tp_gather_group<R, NP, 0, RT, false>(A, B, tb, t, lo, hi, 1.0f, 1.0, rec, grad_plane0, grad_plane1, halo, tpn_lds);
+        if (sidx == 0)                                          // (float sums depend on their order: the whole run in one workgroup)
+            tp_gather_group<R, NP, 0, RT, false>(A, B, tb, t, lo, hi, 1.0f, 1.0, rec, grad_plane0, grad_plane1, halo, tpn_lds);
         return;
+    }
+    long long* slots = nullptr;
+    if (nseg > 1) {
+        slots = part + (size_t)pfirst[t] * ((size_t)4 * RT * TPN_CELLS);
+        lo += sidx * TP_SEG;
+        hi = min(hi, lo + TP_SEG);
     }
     // scale 2^(29 - e) with |g| < 2^(e + 1): |g * w * s| < 2^30 for every weight w <= 1; both factors stay normal floats
     const int e = min(max(ex - 127, -96), 126);                 // (largest |g| below 2^-96: the grid is 2^-125, finer than any fp32 sum could tell)
     const float s_fwd = __uint_as_float((uint32_t)(29 - e + 127) << 23);
     const double s_inv = __longlong_as_double((long long)(e - 29 + 1023) << 52);
     if constexpr (RT <= TPN_GROUP) {
-        tp_gather_group<R, NP, 0, RT, true>(A, B, tb, t, lo, hi, s_fwd, s_inv, rec, grad_plane0, grad_plane1, halo, tpn_lds);
+        tp_gather_group<R, NP, 0, RT, true>(A, B, tb, t, lo, hi, s_fwd, s_inv, rec, grad_plane0, grad_plane1, halo, tpn_lds, nseg, sidx,
+                                            slots);
     } else {
         constexpr int H = (RT + 1) / 2;
-        tp_gather_group<R, NP, 0, H, true>(A, B, tb, t, lo, hi, s_fwd, s_inv, rec, grad_plane0, grad_plane1, halo, tpn_lds);
+        tp_gather_group<R, NP, 0, H, true>(A, B, tb, t, lo, hi, s_fwd, s_inv, rec, grad_plane0, grad_plane1, halo, tpn_lds, nseg, sidx,
+                                           slots);
         __syncthreads();
-        tp_gather_group<R, NP, H, RT - H, true>(A, B, tb, t, lo, hi, s_fwd, s_inv, rec, grad_plane0, grad_plane1, halo, tpn_lds);
+        tp_gather_group<R, NP, H, RT - H, true>(A, B, tb, t, lo, hi, s_fwd, s_inv, rec, grad_plane0, grad_plane1, halo, tpn_lds, nseg,
+                                                sidx, slots);
     }
 }
 
+
+// pass 4b: the split tiles.  One workgroup per (entry of the split list, channel) -- launched for as many entries as a call
+// could have, most leave at once: the segments' integer cell sums added up (any order gives the same integers) and the tile
+// finished exactly as an unsplit one.  (One workgroup per tile read its 26 segments x 20 sums per thread one after the
+// other: 0.47 ms of the sheet's 2.0.)
+template <int R, int NP>
+__global__ void __launch_bounds__(TPN_THREADS)
+tp_split_finish_kernel(int A, int B, int tb, const uint32_t* __restrict__ split, const uint32_t* __restrict__ seg, const uint32_t* __restrict__ pfirst,
+                       const long long* __restrict__ part, const uint32_t* __restrict__ gmax, float* __restrict__ grad_plane0,
+                       float* __restrict__ grad_plane1, float* __restrict__ halo) {
+    constexpr int RT = R * NP;
+    constexpr size_t SLOT = (size_t)4 * RT * TPN_CELLS;
+    __shared__ float img[TPN_NODES];
+    if (blockIdx.x >= split[0]) return;
+    const int t = (int)split[1 + blockIdx.x], ch = blockIdx.y;
+    const uint32_t nseg = seg[t + 1] - seg[t];
+    const int ex = (int)(gmax[t] >> 23);
+    if (ex == 255) return;                                      // non-finite values: the tile was summed in fp32 by one workgroup
+    const int e = min(max(ex - 127, -96), 126);
+    const double s_inv = __longlong_as_double((long long)(e - 29 + 1023) << 52);
+    const long long* slots = part + (size_t)pfirst[t] * SLOT + threadIdx.x;
+    long long acc[4][1] = {{0}, {0}, {0}, {0}};
+    for (uint32_t o = 0; o < nseg; ++o)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k][0] += slots[o * SLOT + (size_t)(k * RT + ch) * TPN_CELLS];
+    tp_finish_tile<R, NP, 1, true>(A, B, tb, t, ch, acc, s_inv, grad_plane0, grad_plane1, halo, img);
+}
 
 // pass 5: the nodes on tile borders.  One thread per plane node that lies on a tile boundary line: the shares of the (up to
 // four) tiles that own it, added in the fixed order (upper-left, upper-right, lower-left, lower-right tile); a tile
@@ -930,15 +1037,20 @@ int launch_triplane_forward(int64_t V, const float* coords, int cs, const float*
 }
 
 static inline size_t tp_tiles(int A, int B) { return (size_t)((A + TP_TILE - 1) / TP_TILE) * ((B + TP_TILE - 1) / TP_TILE); }
+constexpr size_t TP_HEAD_ZEROED = 2, TP_HEAD_WORDS = 6;     // words per tile: count, gmax (zeroed every call) | start, cursor, seg, pfirst (+ 4), then the list of split tiles
 static inline size_t tp_proj_bytes(int64_t V, int A, int B, int channels) {
-    return align_up((4 * tp_tiles(A, B) + 2) * 4) + align_up((size_t)(V > 0 ? V : 1) * tp_rec(channels) * 4) +
+    return align_up((TP_HEAD_WORDS * tp_tiles(A, B) + 5 + tp_max_split_tiles(V)) * 4) + align_up((size_t)(V > 0 ? V : 1) * tp_rec(channels) * 4) +
            align_up(tp_tiles(A, B) * TP_BORDER * channels * 4);
 }
+// partial cell sums of split tiles: one block for all projections of a call (their pass-4 kernels run one after the other)
+static inline size_t tp_part_bytes(int64_t V, int channels) {
+    return align_up(tp_max_split_segments(V) * 4 * (size_t)channels * TP_TILE * TP_TILE * sizeof(long long));
+}
 
-size_t triplane_scratch_bytes(int64_t V, int A, int B, int channels) { return tp_proj_bytes(V, A, B, channels); }
+size_t triplane_scratch_bytes(int64_t V, int A, int B, int channels) { return tp_proj_bytes(V, A, B, channels) + tp_part_bytes(V, channels); }
 
 size_t triplane_backward_scratch_bytes(int64_t V, int X, int Y, int Z, int channels) {
-    return tp_proj_bytes(V, X, Y, channels) + tp_proj_bytes(V, X, Z, channels) + tp_proj_bytes(V, Y, Z, channels);
+    return tp_proj_bytes(V, X, Y, channels) + tp_proj_bytes(V, X, Z, channels) + tp_proj_bytes(V, Y, Z, channels) + tp_part_bytes(V, channels);
 }
 
 static char* tp_carve(TpProj& pj, int64_t V, int channels, char* scratch) {
@@ -948,10 +1060,16 @@ static char* tp_carve(TpProj& pj, int64_t V, int channels, char* scratch) {
     pj.gmax = pj.count + pj.tiles;
     pj.start = pj.gmax + pj.tiles;
     pj.cursor = pj.start + pj.tiles + 1;
-    pj.rec = (float*)(scratch + align_up((4 * (size_t)pj.tiles + 2) * 4));
+    pj.seg = pj.cursor + pj.tiles;
+    pj.pfirst = pj.seg + pj.tiles + 1;
+    pj.split = pj.pfirst + pj.tiles + 1;
+    pj.part = nullptr;                              // set by the caller once all projections are carved
+    pj.rec = (float*)(scratch + align_up((TP_HEAD_WORDS * (size_t)pj.tiles + 5 + tp_max_split_tiles(V)) * 4));
     pj.halo = (float*)((char*)pj.rec + align_up((size_t)(V > 0 ? V : 1) * tp_rec(channels) * 4));
     return scratch + tp_proj_bytes(V, pj.A, pj.B, channels);
 }
+// pass 4's grid: a workgroup per non-empty tile, and the extra ones of split tiles
+static inline unsigned tp_gather_grid(const TpProj& pj, int64_t V) { return (unsigned)(pj.tiles + tp_max_split_segments(V)); }
 
 constexpr int TP_HIST_MAX_TILES = 16384;   // 64 KB of LDS histogram (+ 64 KB of tile maxima in pass 3) per workgroup, over the projections of a pass
 
@@ -998,8 +1116,11 @@ static void tp_backward_launch(int64_t V, const float* coords, int cs, const flo
         (void)hipGetLastError();      // a refused attribute shows up as a launch error
     }
     for (int q = 0; q < ps.n; ++q) {
-        tp_cell_gather_kernel<R, NP><<<ps.p[q].tiles, TPN_THREADS, tpn_lds_bytes<R * NP>(), st>>>(
-            ps.p[q].A, ps.p[q].B, ps.p[q].tb, ps.p[q].start, ps.p[q].gmax, ps.p[q].rec, gp0[q], gp1[q], ps.p[q].halo);
+        tp_cell_gather_kernel<R, NP><<<tp_gather_grid(ps.p[q], V), TPN_THREADS, tpn_lds_bytes<R * NP>(), st>>>(
+            ps.p[q].A, ps.p[q].B, ps.p[q].tb, ps.p[q].tiles, ps.p[q].start, ps.p[q].seg, ps.p[q].pfirst, ps.p[q].part,
+            ps.p[q].gmax, ps.p[q].rec, gp0[q], gp1[q], ps.p[q].halo);
+        tp_split_finish_kernel<R, NP><<<dim3((unsigned)tp_max_split_tiles(V), R * NP), TPN_THREADS, 0, st>>>(ps.p[q].A, ps.p[q].B, ps.p[q].tb, ps.p[q].split, ps.p[q].seg, ps.p[q].pfirst,
+                                                                              ps.p[q].part, ps.p[q].gmax, gp0[q], gp1[q], ps.p[q].halo);
         tp_border_sum_kernel<R, NP><<<dim3((unsigned)((ps.p[q].B + 255) / 256), (unsigned)ps.p[q].A), 256, 0, st>>>(
             ps.p[q].A, ps.p[q].B, ps.p[q].tb, ps.p[q].start, ps.p[q].halo, gp0[q], gp1[q]);
     }
@@ -1032,11 +1153,12 @@ static int tp_backward(int64_t V, const float* coords, int cs, int R, int planes
         sc = tp_carve(pj, V, R * planes, sc);
         if (pj.tiles > TP_HIST_MAX_TILES) return 2;
         total += pj.tiles;
-        zl.add(pj.count, (size_t)pj.tiles * 8, st);        // + gmax
+        zl.add(pj.count, (size_t)pj.tiles * TP_HEAD_ZEROED * 4, st);        // + gmax
         zl.add(gp0[q], (size_t)R * pj.A * pj.B * 4, st);
         if (planes == 2) zl.add(gp1[q], (size_t)R * pj.A * pj.B * 4, st);
     }
     launch_zero(zl, st);
+    for (int q = 0; q < nproj; ++q) ps.p[q].part = (long long*)sc;
     for (int q = nproj; q < 3; ++q) ps.p[q] = ps.p[0];
     if (V <= 0) return 0;
     if (total > TP_HIST_MAX_TILES) {     // the three histograms do not fit one workgroup's LDS: one projection per pass
@@ -1070,12 +1192,16 @@ static int tp_backward(int64_t V, const float* coords, int cs, int R, int planes
 // pass handles (the caller falls back to one call per grid).
 size_t triplane_multi_scratch_bytes(int64_t V, int ngrids, const int* R, const int* X, const int* Y, const int* Z) {
     size_t b = 0;
-    for (int g = 0; g < ngrids; ++g) b += triplane_backward_scratch_bytes(V, X[g], Y[g], Z[g], R[g]);
-    return b;
+    int widest = 1;
+    for (int g = 0; g < ngrids; ++g) {
+        b += tp_proj_bytes(V, X[g], Y[g], R[g]) + tp_proj_bytes(V, X[g], Z[g], R[g]) + tp_proj_bytes(V, Y[g], Z[g], R[g]);
+        widest = R[g] > widest ? R[g] : widest;
+    }
+    return b + tp_part_bytes(V, widest);
 }
 
 template <int RR, int NPX>
-static void tp_gather_launch(const TpProj& pj, float* gp, hipStream_t st) {
+static void tp_gather_launch(const TpProj& pj, int64_t V, float* gp, hipStream_t st) {
     static bool big_lds[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1085,7 +1211,10 @@ static void tp_gather_launch(const TpProj& pj, float* gp, hipStream_t st) {
         if (e == hipSuccess && dev >= 0 && dev < 64) big_lds[dev] = true;
         (void)hipGetLastError();
     }
-    tp_cell_gather_kernel<RR, NPX><<<pj.tiles, TPN_THREADS, tpn_lds_bytes<RR * NPX>(), st>>>(pj.A, pj.B, pj.tb, pj.start, pj.gmax, pj.rec, gp, gp, pj.halo);
+    tp_cell_gather_kernel<RR, NPX><<<tp_gather_grid(pj, V), TPN_THREADS, tpn_lds_bytes<RR * NPX>(), st>>>(
+        pj.A, pj.B, pj.tb, pj.tiles, pj.start, pj.seg, pj.pfirst, pj.part, pj.gmax, pj.rec, gp, gp, pj.halo);
+    tp_split_finish_kernel<RR, NPX><<<dim3((unsigned)tp_max_split_tiles(V), RR * NPX), TPN_THREADS, 0, st>>>(pj.A, pj.B, pj.tb, pj.split, pj.seg, pj.pfirst, pj.part,
+                                                                                                       pj.gmax, gp, gp, pj.halo);
     tp_border_sum_kernel<RR, NPX><<<dim3((unsigned)((pj.B + 255) / 256), (unsigned)pj.A), 256, 0, st>>>(pj.A, pj.B, pj.tb, pj.start, pj.halo, gp, gp);
 }
 
@@ -1118,11 +1247,12 @@ int launch_triplane_backward_multi(int64_t V, const float* coords, int cs, int n
             pj.col0 = pj.col1 = col[g] + q * R[g];
             sc = tp_carve(pj, V, R[g], sc);
             total += pj.tiles;
-            zl.add(pj.count, (size_t)pj.tiles * 8, st);        // + gmax
+            zl.add(pj.count, (size_t)pj.tiles * TP_HEAD_ZEROED * 4, st);        // + gmax
             zl.add(grad_planes[3 * g + q], (size_t)R[g] * pj.A * pj.B * 4, st);
         }
     }
     launch_zero(zl, st);
+    for (int q = 0; q < ps.n; ++q) ps.p[q].part = (long long*)sc;
     for (int q = ps.n; q < 9; ++q) ps.p[q] = ps.p[0];
     if (total > TP_HIST_MAX_TILES) return 3;
     if (V <= 0) return 0;
@@ -1145,9 +1275,9 @@ int launch_triplane_backward_multi(int64_t V, const float* coords, int cs, int n
 #undef SCR_TP_S9
     for (int g = 0; g < ngrids; ++g)
         for (int q = 0; q < 3; ++q) {
-            if (R[g] == 15) tp_gather_launch<15, 1>(ps.p[3 * g + q], grad_planes[3 * g + q], st);
-            else if (R[g] == 10) tp_gather_launch<10, 1>(ps.p[3 * g + q], grad_planes[3 * g + q], st);
-            else tp_gather_launch<5, 1>(ps.p[3 * g + q], grad_planes[3 * g + q], st);
+            if (R[g] == 15) tp_gather_launch<15, 1>(ps.p[3 * g + q], V, grad_planes[3 * g + q], st);
+            else if (R[g] == 10) tp_gather_launch<10, 1>(ps.p[3 * g + q], V, grad_planes[3 * g + q], st);
+            else tp_gather_launch<5, 1>(ps.p[3 * g + q], V, grad_planes[3 * g + q], st);
         }
     return 0;
 }

@@ -1,6 +1,8 @@
 """Per-kernel times of the tri-plane forward / backward at cfg2's point count and grid set (uniform random points):
 attention grid 700 (6 planes) + plain 700 + plain 1400 into one [V,60] matrix.
-usage: [SPLATCO_RASTER_LIB=variant.so] python tools/exp/tp_backward_probe.py [V] [order: random|lex]"""
+usage: [SPLATCO_RASTER_LIB=variant.so] python tools/exp/tp_backward_probe.py [V] [order: random|lex] [shape: uniform|sheet|centre]
+sheet: |z| < 0.02 (a city seen from above: two of the three projections collapse onto a strip of tiles);
+centre: 80 % of the points in the central [-0.25, 0.25]^3 (a contracted scene)."""
 import sys
 
 import torch
@@ -14,6 +16,12 @@ order = sys.argv[2] if len(sys.argv) > 2 else "random"
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
 ind = torch.rand(V, 3, device=dev, generator=g) * 2 - 1
+shape = sys.argv[3] if len(sys.argv) > 3 else "uniform"
+if shape == "sheet":
+    ind[:, 2] *= 0.02
+elif shape == "centre":
+    m = torch.rand(V, device=dev, generator=g) < 0.8
+    ind[m] *= 0.25
 if order == "lex":
     q = ((ind + 1) / 2 * (1 << 20)).long()
     ind = ind[torch.argsort((q[:, 0] << 40) | (q[:, 1] << 20) | q[:, 2])].contiguous()
