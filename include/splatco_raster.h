@@ -236,7 +236,7 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
  * of the plane gradient is written exactly once.  The cell sums are EXACT: every term g * w is rounded to a fixed-point
  * grid of its tile (2^-29 of the tile's largest |gradient value|) and summed in 64-bit integers, so the plane gradient
  * is a function of the SET of points -- the same bits in any order, run after run (a tile that holds a non-finite value
- * is summed in fp32 instead).  A crowded tile (more than 16 K records and four times the plane's mean: a flat or a
+ * is summed in fp32 instead).  A crowded tile (more than 16 K records and 1/256 of the plane's: a flat or a
  * contracted scene) is cut into segments summed by a workgroup each; their integer sums add up to the same bits.
  * R <= 16 (with planes = 2: two passes above R = 5); scratch from
  * scr_plane_sample_scratch_bytes(V, A, B, R * planes).  The sample positions get no gradient (the reference detaches

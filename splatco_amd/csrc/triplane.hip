@@ -147,8 +147,9 @@ tp_count_kernel(int64_t V, const float* __restrict__ coords, int cs, TpProjSet p
 // A tile's run is summed by ONE workgroup of pass 4 -- unless the tile is crowded: a scene is not a uniform cloud (a city
 // seen from above is a sheet: two of its three projections collapse onto one row of tiles; a contracted scene sits in the
 // middle of every plane), and a workgroup per tile then leaves 20 workgroups with 200 k records each while the chip
-// idles (4.6 M points: 1.1 ms uniform, 4.9 ms as a sheet).  A tile with more than TP_SPLIT_MIN records AND more than four
-// times the plane's mean is cut into segments of TP_SEG records, one workgroup each; the segments' cell sums are 64-bit
+// idles (4.6 M points: 1.1 ms uniform, 4.9 ms as a sheet).  A tile with more than TP_SPLIT_MIN records AND more than
+// 1 / 256 of the plane's (twice what each of the 512 workgroups the chip holds at once would get of an even split: a uniform
+// cloud is left alone however large) is cut into segments of TP_SEG records, one workgroup each; the segments' cell sums are 64-bit
 // integers, so they add up to the same bits whichever records a segment happens to hold (tp_split_finish_kernel adds them).
 #ifndef SCR_TP_SEG
 #define SCR_TP_SEG 8192
@@ -165,7 +166,7 @@ __device__ __forceinline__ void tp_scan_proj(const TpProj& pj, uint32_t* lds) {
     for (int i = threadIdx.x; i < pj.tiles; i += 1024) mine += pj.count[i];
     uint32_t total;
     (void)tp_block_scan(mine, lds, total);
-    const uint32_t crowded = max(TP_SPLIT_MIN, (uint32_t)min((unsigned long long)0xffffffffu, 4ull * (total / (uint32_t)pj.tiles)));
+    const uint32_t crowded = max(TP_SPLIT_MIN, total / 256u);     // twice a fair share of the 512 workgroups the chip holds at once
     uint32_t carry = 0, carry_s = 0, carry_p = 0, carry_l = 0;
     for (int base = 0; base < pj.tiles; base += 1024) {
         const int i = base + threadIdx.x;
