@@ -797,17 +797,21 @@ def run_anchor_config(args, rank, world, dev):
     # 1.28 ms per step with the kernels summing to 1.06 -- profiles/HISTORY.md).  Nothing is skipped.
     gc.collect()
     gc.disable()
+    dev_allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         if os.environ.get("SPLATCO_BENCH_TRACE"):        # developer aid: per-step times (adds a sync per step)
             torch.cuda.synchronize()
-            print(f"[trace] step done at {(time.perf_counter() - t0) * 1e3:.1f} ms", file=sys.stderr)
+            ms_ = torch.cuda.memory_stats(dev)
+            print(f"[trace] step done at {(time.perf_counter() - t0) * 1e3:.1f} ms; reserved {ms_.get('reserved_bytes.all.current', 0) / 2**20:.0f} MiB, "
+                  f"device allocs {ms_.get('num_device_alloc', 0)}, frees {ms_.get('num_device_free', 0)}, visible {stats.get('V')}", file=sys.stderr)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    dev_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - dev_allocs0    # hipMalloc calls inside the timed region (0: the pool covered it)
     prof = _C.profile_read()
     _C.profile_enable(False)
     Pt = torch.tensor([stats["P"]], device=dev, dtype=torch.float64)
@@ -862,7 +866,8 @@ def run_anchor_config(args, rank, world, dev):
         "unit": "Msplats/s" if args.config != "cfg4" else "iter/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "allocator_settle_steps": settle, "time_settle_steps": time_settle, "reserved_gib": round(torch.cuda.memory_reserved() / 2**30, 1),
+        "allocator_settle_steps": settle, "time_settle_steps": time_settle, "device_allocs_in_timed_region": int(dev_allocs),
+        "reserved_gib": round(torch.cuda.memory_reserved() / 2**30, 1),
         "config": {"workload": {
             "cfg2": f"cfg2: {N} anchors uniform in [-2,2]^3 (seed {seed}), k=10, tri-planes 700/700/1400 active "
                     f"(plane_size 2800, 15 channels, activate_level 2), 1 view 1920x1080: prefilter_voxel + render() "

@@ -223,3 +223,22 @@ def profile_read():
 def check(rc):
     if rc != 0:
         raise RuntimeError("splatco_raster: " + lib.scr_last_error().decode())
+
+
+def scratch_size(nbytes):
+    """Size class of a large scratch request: above 32 MiB the next multiple of 1/8 of the power of two below it (eight
+    classes per octave, at most 12.5 % more than asked).  The buffers behind these requests scale with the number of
+    visible anchors / Gaussians / tile instances, which drift from step to step while a scene trains: asked for by the
+    byte, a slowly GROWING buffer misses the caching allocator's pool on every step and costs a device allocation each
+    time (cfg3: one 1.9 GB hipMalloc per step, 0.4 ms, and 2 GB more reserved per step -- profiles/HISTORY.md, round 5)."""
+    n = max(int(nbytes), 1)
+    if n < (32 << 20):
+        return n
+    step = 1 << (n.bit_length() - 4)
+    return (n + step - 1) // step * step
+
+
+def scratch(nbytes, device):
+    """Uninitialised device bytes for a kernel's scratch / saved state, in scratch_size() classes."""
+    import torch
+    return torch.empty(scratch_size(nbytes), dtype=torch.uint8, device=device)

@@ -30,7 +30,7 @@ class _ExpandCompact(torch.autograd.Function):
         else:
             offsets = f(offsets).reshape(V, k, 3)
         n = V * k
-        scratch = torch.empty(max(_C.lib.scr_expand_scratch_bytes(n), 1), dtype=torch.uint8, device=dev)
+        scratch = _C.scratch(_C.lib.scr_expand_scratch_bytes(n), dev)
         cnt = C.c_int64(0)
         with torch.cuda.device(dev):           # kernels launch on the CURRENT device: make it the tensors' device
             _C.check(_C.lib.scr_expand_plan(n, _ptr(neural_opacity), scratch.data_ptr(), C.byref(cnt), _stream(dev)))
@@ -127,7 +127,7 @@ def mask_indices(mask, inverse=True):
     m = m.view(torch.uint8) if m.dtype == torch.bool else m
     assert m.dim() == 1 and m.dtype == torch.uint8 and m.is_cuda
     n = m.shape[0]
-    scratch = torch.empty(_C.lib.scr_expand_scratch_bytes(n), dtype=torch.uint8, device=m.device)
+    scratch = _C.scratch(_C.lib.scr_expand_scratch_bytes(n), m.device)
     cnt = C.c_int64(0)
     with torch.cuda.device(m.device):          # the plan call reads its count back on the host: one synchronisation
         _C.check(_C.lib.scr_mask_index_plan(n, m.data_ptr(), scratch.data_ptr(), C.byref(cnt), _stream(m.device)))

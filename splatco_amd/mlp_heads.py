@@ -40,7 +40,7 @@ class _MlpHeads(torch.autograd.Function):
         V, dev = feat.shape[0], feat.device
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         out_o, out_c, out_v = new(V, 10), new(V, 30), new(V, 70)
-        hidden = torch.empty(_C.lib.scr_mlp_heads_hidden_bytes(V), dtype=torch.uint8, device=dev)
+        hidden = _C.scratch(_C.lib.scr_mlp_heads_hidden_bytes(V), dev)
         if V:
             with torch.cuda.device(dev):
                 _C.check(_C.lib.scr_mlp_heads_forward(V, feat.data_ptr(), feat.stride(0), anchor.data_ptr(), campos.data_ptr(), geo_a.data_ptr(),
@@ -63,7 +63,7 @@ class _MlpHeads(torch.autograd.Function):
             for t in (d_w1, d_b1, d_w2o, d_b2o, d_w2c, d_b2c, d_w2v, d_b2v):
                 t.zero_()
         else:
-            partial = torch.empty(_C.lib.scr_mlp_heads_partial_bytes(V), dtype=torch.uint8, device=dev)
+            partial = _C.scratch(_C.lib.scr_mlp_heads_partial_bytes(V), dev)
             with torch.cuda.device(dev):
                 _C.check(_C.lib.scr_mlp_heads_backward(
                     V, feat.data_ptr(), feat.stride(0), anchor.data_ptr(), campos.data_ptr(), geo_a.data_ptr(), geo_b.data_ptr(), w1.data_ptr(), w2o.data_ptr(),

@@ -77,7 +77,7 @@ def _stream(device=None):
 
 
 def _bytes(n, device):
-    return torch.empty(max(int(n), 1), dtype=torch.uint8, device=device)
+    return _C.scratch(n, device)
 
 
 class RasterState:

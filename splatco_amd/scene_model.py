@@ -125,7 +125,7 @@ class _NormLinearFn(torch.autograd.Function):
             Gc, cc = G.detach().contiguous(), c.detach().contiguous().float()
             y = torch.empty(V, 32, dtype=torch.float32, device=x.device)
             mean, var, inv = (torch.empty(d, dtype=torch.float32, device=x.device) for _ in range(3))
-            scratch = torch.empty(_C.lib.scr_norm_linear_scratch_bytes(V), dtype=torch.uint8, device=x.device)
+            scratch = _C.scratch(_C.lib.scr_norm_linear_scratch_bytes(V), x.device)
             # column statistics the producer of x formed on the way (anchor_gather): [rows, 2, 80] partial sums about x[0]
             ok_stats = (col_stats is not None and col_stats.is_cuda and col_stats.dtype == torch.float32 and col_stats.dim() == 3
                         and col_stats.shape[1:] == (2, 80) and col_stats.shape[0] > 0 and col_stats.is_contiguous())
@@ -160,7 +160,7 @@ class _NormLinearFn(torch.autograd.Function):
             dx = torch.empty(V, ldx, dtype=torch.float32, device=x.device)[:, :d] if need_dx else None
             dG = torch.empty(32, d, dtype=torch.float32, device=x.device)
             dc = torch.empty(32, dtype=torch.float32, device=x.device)
-            scratch = torch.empty(_C.lib.scr_norm_linear_scratch_bytes(V), dtype=torch.uint8, device=x.device)
+            scratch = _C.scratch(_C.lib.scr_norm_linear_scratch_bytes(V), x.device)
             with torch.cuda.device(x.device):
                 _C.check(_C.lib.scr_norm_linear_backward(V, d, x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), G.data_ptr(),
                                                          mean.data_ptr(), inv.data_ptr(), dx.data_ptr() if need_dx else None,

@@ -57,7 +57,7 @@ def _backward_from(g, ind, cols, shapes):
     V, n = ind.shape[0], len(shapes)
     R, X, Y, Z = shapes[0][1], shapes[0][2], shapes[0][3], shapes[1][3]
     gp = [torch.empty(s, dtype=torch.float32, device=g.device) for s in shapes]
-    scratch = torch.empty(_C.lib.scr_triplane_backward_scratch_bytes(V, X, Y, Z, R * (n // 3)), dtype=torch.uint8,
+    scratch = torch.empty(_C.scratch_size(_C.lib.scr_triplane_backward_scratch_bytes(V, X, Y, Z, R * (n // 3))), dtype=torch.uint8,
                           device=g.device)
     c_cols = (C.c_int32 * n)(*cols)
     ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in gp])
@@ -130,7 +130,7 @@ def _backward_all(ctx, g, inds):
     ptrs = (C.c_void_p * (3 * ng))(*[t.data_ptr() for t in gp])
     with torch.cuda.device(ind.device):
         nbytes = _C.lib.scr_triplane_backward_multi_scratch_bytes(V, ng, cR, cX, cY, cZ)
-        scratch = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=g.device)
+        scratch = _C.scratch(max(int(nbytes), 16), g.device)
         rc = _C.lib.scr_triplane_backward_multi(V, ind.data_ptr(), ind.stride(0), ng, cR, cX, cY, cZ, ccol, g.data_ptr(),
                                                 g.stride(0), ptrs, scratch.data_ptr(), _stream())
     if rc == 3:
@@ -195,7 +195,7 @@ class _PlaneSample(torch.autograd.Function):
         V = grid.shape[0]
         g = g.contiguous().float()
         grad_plane = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
-        scratch = torch.empty(_C.lib.scr_plane_sample_scratch_bytes(V, A, B, R), dtype=torch.uint8, device=g.device)
+        scratch = _C.scratch(_C.lib.scr_plane_sample_scratch_bytes(V, A, B, R), g.device)
         with torch.cuda.device(g.device):
             _C.check(_C.lib.scr_plane_sample_backward(V, grid.data_ptr(), 2, 0, 1, R, A, B, 1, g.data_ptr(), g.data_ptr(),
                                                       g.stride(0), grad_plane.data_ptr(), grad_plane.data_ptr(),
