@@ -125,10 +125,13 @@ def allreduce_gradients(params: Iterable[torch.Tensor], bucket: torch.Tensor = N
     afterwards raises instead of exchanging misaligned data.
     shape: "all_reduce" | "rs_ag" (see _sum_over_ranks); every rank must pass the same."""
     params = [p for p in params if p is not None and p.requires_grad]
-    if not params or not collectives_on():
-        # nobody to exchange with: the gradients are final where they are (packing and unpacking them would copy
-        # 2 x 1.4 GB per step at 5 M anchors for nothing)
+    if not params:
         return bucket
+    if not collectives_on():
+        # nobody to exchange with: the gradients are final where they are (packing and unpacking them would copy
+        # 2 x 1.4 GB per step at 5 M anchors for nothing); the shared arena is still what the caller gets when there is one
+        arena = _shared_arena(params)
+        return arena if arena is not None else bucket
     dev, dt = params[0].device, params[0].dtype
     arena = _shared_arena(params)
     # the gradients already sit side by side in one buffer (the rasterizer's backward allocates them that way):
