@@ -478,6 +478,40 @@ def valu_object(dom, avg_ms):
 
 
 # ------------------------------------------------------------------ cfg1: the operator
+def settle_clocks(step, world, dev, block_ms=10.0, max_blocks=30):
+    """Untimed steps until the GPU runs at the clocks it HOLDS under this load, right before the timed region.
+    The chip drops its clocks within 20 ms of idling and takes tens of milliseconds of work to bring them back
+    (tools/exp/host_rate_cfg1.py, profiles/r05_clock_ramp.txt: 20 cfg1 steps straight after 100 of them 0.963 ms each; the
+    same 20 steps after 20 ms / 100 ms / 500 ms of idling, or after a 54 ms gc.collect(): 1.059 / 1.068 / 1.067 / 1.076).
+    The bookkeeping between the warm-up and the timed region (reading the warm-up's kernel times, picking the dominant
+    class, the collector pass) IS such a pause, so W = 5 warm-up steps of 1 ms followed by it measured the ramp, not the
+    kernels: 1.08 against 0.96 ms.  Blocks of >= block_ms of steps are run until a block is no longer 1 % faster than the
+    one before it (every rank the same count); the timed region follows without another host pause.  A training loop
+    never idles between steps: the sustained clocks are the ones it sees."""
+    import torch.distributed as dist
+    done, prev, per_block = 0, None, 1
+    for _ in range(max_blocks):
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(per_block):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - ts) / per_block
+        done += per_block
+        calm = torch.tensor([float(prev is not None and dt >= 0.99 * prev)], device=dev)
+        if world > 1:
+            dist.all_reduce(calm, op=dist.ReduceOp.MIN)
+        prev = dt
+        per_block = max(1, int(math.ceil(block_ms * 1e-3 / dt)))       # (the first block is one step: it only sizes the rest)
+        if world > 1:
+            nb = torch.tensor([float(per_block)], device=dev)
+            dist.all_reduce(nb, op=dist.ReduceOp.MAX)
+            per_block = int(nb.item())
+        if calm.item():
+            break
+    return done
+
+
 def run_cfg1(args, rank, world, dev):
     import torch.distributed as dist
     from splatco_amd import _C
@@ -530,29 +564,38 @@ def run_cfg1(args, rank, world, dev):
     # to find the dominant kernel; the timed region then brackets ONLY that class, because each
     # event pair costs a few microseconds of stream time.
     for w in range(args.warmup):
-        if w == max(args.warmup - 3, 0):
-            torch.cuda.synchronize()
-            _C.profile_enable(True)
-            _C.profile_read()
         step()
     torch.cuda.synchronize()
-    warm_prof = _C.profile_read() if args.warmup else {}
+    # three more untimed steps with every launch bracketed (the per-class table), at the clocks the chip holds under load
+    clock_settle, warm_prof = 0, {}
+    if args.warmup:
+        clock_settle = settle_clocks(step, world, dev)
+        _C.profile_enable(True)
+        _C.profile_read()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        warm_prof = _C.profile_read()
     dominant, warm_kern = pick_dominant(warm_prof)
     # the dominant class is timed inside the timed region on every 4th step only: an event pair costs ~6 us of stream time
     # on each side of the launch it brackets (1 % of a cfg1 step); the average is over ceil(K / 4) launches
     _C.profile_enable(dominant, every=4 if args.steps >= 8 else 1)
     _C.profile_read()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     # the interpreter's cyclic collector is parked for the timed region: a generation-2 pass over this process's objects takes
     # milliseconds, and one of them inside 20 steps of 1 ms is a quarter of a millisecond per step (seen once in round 5:
     # 1.28 ms per step with the kernels summing to 1.06 -- profiles/HISTORY.md).  Nothing is skipped.
     gc.collect()
     gc.disable()
+    if args.warmup:
+        clock_settle += settle_clocks(step, world, dev)       # the bookkeeping above was a pause: once more, then straight into the timed region
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    host_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        host_ms.append(time.perf_counter())
         if os.environ.get("SPLATCO_BENCH_TRACE"):        # developer aid: per-step times (adds a sync per step)
             torch.cuda.synchronize()
             print(f"[trace] step done at {(time.perf_counter() - t0) * 1e3:.1f} ms", file=sys.stderr)
@@ -591,6 +634,9 @@ def run_cfg1(args, rank, world, dev):
         "metric": METRIC, "value": world * P / (elapsed / args.steps) / 1e6, "unit": "Msplats/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "clock_settle_steps": clock_settle,      # untimed, after the W warm-up steps: see settle_clocks()
+        # when each step's calls RETURNED to the host, as differences (no synchronisation involved): a host-side stall shows here
+        "host_step_ms": {"median": round(1e3 * float(np.median(np.diff([t0] + host_ms))), 4), "max": round(1e3 * float(np.max(np.diff([t0] + host_ms))), 4)},
         "config": {"workload": "cfg1: 1M synthetic Gaussians (seed 0), 1 view 1920x1080 per GPU, "
                                "GaussianRasterizer forward+backward, colors_precomp + scale/rotation path",
                    "gaussians": P, "image": f"{W}x{H}", "tile_instances": I,
@@ -602,7 +648,7 @@ def run_cfg1(args, rank, world, dev):
                                     "the HBM fraction is reported as the contract asks"),
         "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])},
         "kernel_ms_source": f"{dominant}: HIP events inside the timed region (every 4th step); the other classes: HIP events around "
-                            "every launch of the last three WARM-UP steps, each pair adding ~6 us of stream time on both sides of its "
+                            "every launch of three untimed steps after the warm-up (clocks settled), each pair adding ~6 us of stream time on both sides of its "
                             "launch -- their sum therefore exceeds ms_per_step, which is wall time over K undisturbed steps",
         "hbm_gbs_all_kernels": sum(algorithmic_bytes(k, P, I, npix) for k in kern) / (sum(kern.values()) * 1e-3) / 1e9,
         # every kernel class against ITS byte model, from the per-launch times above
@@ -789,14 +835,15 @@ def run_anchor_config(args, rank, world, dev):
     # on each side of the launch it brackets (1 % of a cfg1 step); the average is over ceil(K / 4) launches
     _C.profile_enable(dominant, every=4 if args.steps >= 8 else 1)
     _C.profile_read()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     # the interpreter's cyclic collector is parked for the timed region: a generation-2 pass over this process's objects takes
     # milliseconds, and one of them inside 20 steps of 1 ms is a quarter of a millisecond per step (seen once in round 5:
     # 1.28 ms per step with the kernels summing to 1.06 -- profiles/HISTORY.md).  Nothing is skipped.
     gc.collect()
     gc.disable()
+    clock_settle = settle_clocks(step, world, dev, max_blocks=6) if args.warmup else 0     # the pause above cooled the chip's clocks
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     dev_allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -866,7 +913,7 @@ def run_anchor_config(args, rank, world, dev):
         "unit": "Msplats/s" if args.config != "cfg4" else "iter/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "allocator_settle_steps": settle, "time_settle_steps": time_settle, "device_allocs_in_timed_region": int(dev_allocs),
+        "allocator_settle_steps": settle, "time_settle_steps": time_settle, "clock_settle_steps": clock_settle, "device_allocs_in_timed_region": int(dev_allocs),
         "reserved_gib": round(torch.cuda.memory_reserved() / 2**30, 1),
         "config": {"workload": {
             "cfg2": f"cfg2: {N} anchors uniform in [-2,2]^3 (seed {seed}), k=10, tri-planes 700/700/1400 active "
