@@ -95,6 +95,66 @@ def test_cfg2_5M_anchors_plane2800(oracle):
     assert torch.equal(again, out["render"].detach())                     # bit-reproducible at 15 M Gaussians
 
 
+def test_training_loop_learns_a_teacher_scene():
+    """Rows a1 - a8 together, as train.py:171-311 strings them: mv = 2 views drawn at random from six, targets rendered from a
+    TEACHER scene of another seed, collaborative_step (prefilter, render, L1 + SSIM + scaling regulariser, the cross-view
+    consistency term from iteration 30 on, one backward, the total-variation term every 4th iteration, densification
+    statistics, FusedAdam) for 120 iterations with adjust_anchor (grow + prune) at 100 -- the image error must FALL (the
+    400-iteration soak of tools/exp/soak_train.py goes from 18.7 to 29 - 30 dB, profiles/r05_soak_train.txt), every parameter
+    stays finite, the anchor set changes and the loop keeps stepping on the new tensors, and once the allocator's pool is
+    warm no step asks the device for memory."""
+    import random
+    from splatco_amd.adam import FusedAdam
+    from splatco_amd.densify import AnchorDensifier
+    from splatco_amd.renderer import prefilter_voxel, render
+    from splatco_amd.synthetic import synthetic_anchor_model, synthetic_views
+    from splatco_amd.train_step import collaborative_step
+    dev = torch.device("cuda:0")
+    W, H, N = 480, 270, 100_000
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
+    bg = torch.ones(3, device=dev)
+    views = [v.to(dev) for v in synthetic_views(6, W, H)]
+    teacher = synthetic_anchor_model(N, 101, dev, plane_size=512)
+    teacher.eval()
+    with torch.no_grad():
+        gts = [render(v, teacher, pipe, bg, visible_mask=prefilter_voxel(v, teacher, pipe, bg))["render"].clamp(0, 1).clone() for v in views]
+    del teacher
+    pc = synthetic_anchor_model(N, 7, dev, plane_size=512)
+    groups = [{"params": [getattr(pc, "_" + n)], "lr": lr, "name": n}
+              for n, lr in (("anchor", 0.0), ("offset", 1e-3), ("anchor_feat", 7.5e-3), ("scaling", 7e-3))]
+    groups.append({"params": [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad], "lr": 2e-3,
+                   "name": "mlp_and_feat_planes"})
+    opt = FusedAdam(groups, eps=1e-15)
+    den = AnchorDensifier(pc, opt, voxel_size=0.01, seed=3)
+    rng = random.Random(0)
+
+    def psnr(i):
+        with torch.no_grad():
+            img = render(views[i], pc, pipe, bg, visible_mask=prefilter_voxel(views[i], pc, pipe, bg))["render"].clamp(0, 1)
+            return float(10 * torch.log10(1.0 / ((img - gts[i]) ** 2).mean()))
+
+    before = [psnr(i) for i in range(6)]
+    first, last, allocs = [], [], None
+    for it in range(1, 121):
+        pick = rng.sample(range(6), 2)
+        loss, out, _ = collaborative_step(pc, [views[i] for i in pick], [gts[i] for i in pick], pipe, bg, optimizer=opt, densifier=den,
+                                          consistency_weight=0.05 if it > 30 else 0.0, iteration=it, tv_weight=4e-7)
+        (first if it <= 10 else last if it > 110 else []).append(loss.detach())
+        if it == 60:
+            allocs = torch.cuda.memory_stats(dev)["num_device_alloc"]
+        if it == 99:
+            assert torch.cuda.memory_stats(dev)["num_device_alloc"] - allocs <= 2, "steady-state steps keep asking the device for memory"
+        if it == 100:
+            den.adjust_anchor(iteration=100, check_interval=100, grad_threshold=0.0002)
+            assert pc._anchor.shape[0] != N, "adjust_anchor neither grew nor pruned: the statistics did not arrive"
+    after = [psnr(i) for i in range(6)]
+    print(f"[teacher scene] PSNR of the six views {[round(b, 1) for b in before]} -> {[round(a, 1) for a in after]} dB; "
+          f"loss {float(torch.stack(first).mean()):.4f} -> {float(torch.stack(last).mean()):.4f}; anchors {N} -> {pc._anchor.shape[0]}")
+    assert all(bool(torch.isfinite(p).all()) for p in pc.parameters())
+    assert float(torch.stack(last).mean()) < 0.6 * float(torch.stack(first).mean())
+    assert sum(after) / 6 > sum(before) / 6 + 3.0 and min(a - b for a, b in zip(after, before)) > 1.0
+
+
 def test_bench_sharded_optimizer_and_dry_run():
     """`bench.py --gpus 2 --config cfg3 --exchange rs_ag --optimizer sharded` (adam.ShardedFusedAdam: reduce-scatter, Adam on
     this rank's half, all-gather of the parameters) prints its line; `--dry-run-ranks` prints the collective sequence of a
