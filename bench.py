@@ -22,6 +22,13 @@ anything touches the GPU and exits with the launcher's code; under an external l
 `roofline` is for the dominant kernel class of the step, timed with HIP events on the launch stream inside the timed
 region (scr_profile_*); `cpu_baseline` is the CPU oracle (oracle/, test infrastructure) timed on the host cores (rank 0,
 N = 1 only).  Nothing here reads /root/reference.
+
+Timing protocol: W untimed warm-up steps; untimed settle steps, each kind counted in the line (`allocator_settle_steps`:
+until torch's caching allocator stops asking the device for memory; `time_settle_steps`: first-use costs of a fresh box;
+`clock_settle_steps`: until the chip is back at the clocks it holds under this load -- it drops them within 20 ms of
+idling, which the bookkeeping between warm-up and timed region is; profiles/r05_clock_ramp.txt); then EXACTLY K steps
+between barrier + synchronize on both sides, the interpreter's cyclic collector parked.  `host_step_ms` (when each step's
+calls returned to the host) and `device_allocs_in_timed_region` tell a disturbed run from a clean one.
 """
 import argparse
 import gc
