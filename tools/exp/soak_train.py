@@ -2,7 +2,9 @@
 total-variation terms, densification statistics every step, adjust_anchor (grow + prune) every 100 iterations, FusedAdam -- against
 ground-truth images rendered from a TEACHER scene (another seed).  Reports per 50 iterations: loss, PSNR of view 0 against its
 target, step time, anchors, reserved memory, device allocations, and whether every parameter is still finite.
-usage: python tools/exp/soak_train.py [iterations] [anchors] [mv]"""
+usage: python tools/exp/soak_train.py [iterations] [anchors] [mv] [WxH] [arena]
+arena: the gradients live in a multiview.GradArena (the anchor gather's backward writes straight into it), rebuilt after every
+adjust_anchor -- the layout the sharded step uses, here with one rank."""
 import math, sys, time, types, random
 import torch
 sys.path.insert(0, ".")
@@ -15,7 +17,8 @@ from splatco_amd.train_step import collaborative_step
 ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200_000
 MV = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-W, H = 640, 360
+W, H = (int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "640x360").split("x"))
+ARENA = len(sys.argv) > 5 and sys.argv[5] == "arena"
 dev = torch.device("cuda:0")
 pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
 bg = torch.ones(3, device=dev)
@@ -30,6 +33,9 @@ groups = [{"params": [getattr(pc, "_" + n)], "lr": lr, "name": n} for n, lr in (
 groups.append({"params": [p for n, p in pc.named_parameters() if not n.startswith("_") and p.requires_grad], "lr": 2e-3, "name": "mlp_and_feat_planes"})
 opt = FusedAdam(groups, eps=1e-15)
 den = AnchorDensifier(pc, opt, voxel_size=0.01, seed=3)
+from splatco_amd.multiview import GradArena
+make_arena = lambda: GradArena([p for grp in opt.param_groups for p in grp["params"]]) if ARENA else None
+arena = make_arena()
 rng = random.Random(0)
 
 
@@ -44,11 +50,14 @@ t_blk, losses = time.perf_counter(), []
 for it in range(1, ITERS + 1):
     pick = rng.sample(range(len(views)), MV)
     cw = 0.05 if 100 < it < 300 else 0.0
-    loss, out, _ = collaborative_step(pc, [views[i] for i in pick], [gts[i] for i in pick], pipe, bg, optimizer=opt, densifier=den,
+    loss, out, _ = collaborative_step(pc, [views[i] for i in pick], [gts[i] for i in pick], pipe, bg, optimizer=opt, densifier=den, arena=arena,
                                       consistency_weight=cw, iteration=it, tv_weight=4e-7)
     losses.append(loss.detach())
     if it % 100 == 0 and it >= 100:
         den.adjust_anchor(iteration=it, check_interval=100, grad_threshold=0.0002)
+        if arena is not None:           # the per-anchor parameters are new tensors now: a new arena over the optimizer's current ones
+            arena.close()
+            arena = make_arena()
     if it % 50 == 0:
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t_blk) / 50
