@@ -63,7 +63,9 @@ for it in range(1, ITERS + 1):
         dt = (time.perf_counter() - t_blk) / 50
         ms = torch.cuda.memory_stats(dev)
         finite = all(bool(torch.isfinite(p).all()) for p in pc.parameters())
-        print(f"it {it}: loss {float(torch.stack(losses).mean()):.4f}, PSNR(view 0) {psnr0():.2f} dB, {dt * 1e3:.1f} ms per step (mv = {MV}), "
+        import resource
+        rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20
+        print(f"it {it}: host peak RSS {rss:.2f} GiB; loss {float(torch.stack(losses).mean()):.4f}, PSNR(view 0) {psnr0():.2f} dB, {dt * 1e3:.1f} ms per step (mv = {MV}), "
               f"{pc._anchor.shape[0]} anchors, reserved {ms['reserved_bytes.all.current'] / 2**30:.2f} GiB, device allocs {ms['num_device_alloc']}, "
               f"all parameters finite: {finite}")
         losses, t_blk = [], time.perf_counter()
