@@ -505,6 +505,8 @@ def settle_clocks(step, world, dev, block_ms=10.0, max_blocks=30):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - ts) / per_block
         done += per_block
+        if os.environ.get("SPLATCO_BENCH_TRACE_SETTLE"):     # developer aid (SPLATCO_BENCH_TRACE would add a sync to every timed step)
+            print(f"[trace] clock settle: block of {per_block} step(s) at {dt * 1e3:.4f} ms per step", file=sys.stderr)
         calm = torch.tensor([float(prev is not None and dt >= 0.99 * prev)], device=dev)
         if world > 1:
             dist.all_reduce(calm, op=dist.ReduceOp.MIN)
