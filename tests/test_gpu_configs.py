@@ -143,7 +143,9 @@ def test_training_loop_learns_a_teacher_scene():
         if it == 60:
             allocs = torch.cuda.memory_stats(dev)["num_device_alloc"]
         if it == 99:
-            assert torch.cuda.memory_stats(dev)["num_device_alloc"] - allocs <= 2, "steady-state steps keep asking the device for memory"
+            # (what this guards against is one allocation PER STEP -- 39 here -- as the drifting instance count caused before
+            # large scratch came in size classes; a handful may still happen when a size class is crossed)
+            assert torch.cuda.memory_stats(dev)["num_device_alloc"] - allocs <= 8, "steady-state steps keep asking the device for memory"
         if it == 100:
             den.adjust_anchor(iteration=100, check_interval=100, grad_threshold=0.0002)
             assert pc._anchor.shape[0] != N, "adjust_anchor neither grew nor pruned: the statistics did not arrive"
