@@ -42,6 +42,27 @@ def test_c_abi_exports_every_declared_symbol():
     assert set(_C.SYMBOLS) == declared
 
 
+def test_large_scratch_comes_in_size_classes():
+    """_C.scratch_size: at least what was asked, at most 12.5 % more, eight classes per octave above 32 MiB, untouched below
+    -- and the plane backward's scratch query covers the partial sums of split tiles (a size query, no device)."""
+    from splatco_amd import _C
+    assert [_C.scratch_size(n) for n in (0, 1, 4096, (32 << 20) - 1)] == [1, 1, 4096, (32 << 20) - 1]
+    prev = 0
+    for n in sorted([(32 << 20) + k * 1_234_567 for k in range(0, 4000, 7)] + [2 ** 31 - 1, 2 ** 31, 2 ** 31 + 1, 3 * 2 ** 33 + 5]):
+        c = _C.scratch_size(n)
+        assert n <= c <= n + n // 8 + 1 and c >= prev, (n, c)
+        assert c % (1 << (n.bit_length() - 4)) == 0
+        prev = c
+    assert len({_C.scratch_size(n) for n in range(1 << 30, 1 << 31, 1 << 20)}) == 9        # eight classes and the octave's end
+    lib = _C.lib
+    V = 4_600_000
+    one = lib.scr_plane_sample_scratch_bytes(V, 700, 700, 5)
+    # records (V x 32 B) + header + halos + (V / 8192 + V / 16384 + 2) slots of 4 x 5 x 1024 64-bit sums
+    slots = V // 8192 + V // 16384 + 2
+    assert one >= V * 32 + slots * 4 * 5 * 1024 * 8
+    assert lib.scr_plane_sample_scratch_bytes(V, 700, 700, 10) > one
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under splatco_amd/ or the drop-in module may
     reference it."""
