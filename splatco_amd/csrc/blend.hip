@@ -357,121 +357,47 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
 }
 
 // ------------------------------------------------------------------ wave64 sums, four splats at a time
-// The nine per-splat partial sums of FOUR consecutive splats (A,B,C,D) are reduced together by
-// FOLDING: every step adds the two halves of TWO registers into one, so the register count halves
-// with the lane span and no lane ever carries a redundant copy:
-//   v_permlane32_swap + add : 36 -> 18 registers  (A|B and C|D share a register)
-//   v_permlane16_swap + add : 18 -> 9             (16-lane rows 0..3 hold splats A, C, B, D)
-//   two bank-masked DPP adds fold two VALUES into one register inside every row:
-//     8-lane step  (row_shl:8 -> lanes 0-7, row_shr:8 -> lanes 8-15)          : 9 -> 5
-//     4-lane step  (row_shl:4 -> banks 0,2, row_shr:4 -> banks 1,3)           : 5 -> 3
-//   two quad_perm adds finish inside each 4-lane group.
-// Result per row: v[0] = (sum0 | sum2 | sum1 | sum3), v[4] = (sum4 | sum6 | sum5 | sum7) by 4-lane
-// group, v[8] = sum8 in lanes 12-15.  20 DPP adds instead of 36 for plain row reductions, always
-// added in the same order (bit-reproducible).  The DPP part is one asm block: hipcc splits the
-// builtin DPP form into v_mov_dpp + v_add pairs padded with s_nop; here independent chains are
-// interleaved so that every DPP source was written at least two instructions earlier (the
-// 2-wait-state VALU-write -> DPP-read hazard); the leading s_nop 1 covers the instruction before the block.
+// What a wave owes per splat are nine sums over its 64 pixels: the six moments of Y = opacity G dL/dalpha about the
+// QUADRANT's origin (weights 1, x, y, x^2, xy, y^2 of the lane's pixel (x, y) = (lane >> 3, lane & 7)) and the three colour
+// gradients sum_pixel (alpha T) dL/dpixel_c.  Reduced IN PLACE (round 2-5: v_permlane32/16_swap folds, then bank-masked
+// DPP adds) that costs 18 two-pass swaps + 17 DPP adds + 20 adds per four splats, and three products per pixel and splat
+// for the colour terms.  Since round 6 the eight values of four splats (Y and alpha T each) go through a wave-private LDS
+// transposition instead: lane (x, y) stores them as eight columns [column][pixel] (eight ds_write_b32, conflict-free),
+// lane (column c = lane >> 3, x = lane & 7) reads back the eight pixels (x, y = 0..7) of its column (two ds_read_b128)
+// and contracts them with per-lane weights that are constants of the tile --
+//     Y columns (c < 4):       (1, y, y^2)                  ->  S0 = sum_y Y,  S1 = sum_y y Y,  S2 = sum_y y^2 Y
+//     alpha T columns (c >= 4): dL/dpixel_0..2 at (x, y)    ->  the three colour sums of the pixel column x
+// -- 24 fmas, the same instruction stream for both kinds.  Three more products (x S0, x^2 S0, x S1; the weight x is 0 in the
+// colour lanes) and the sum over the eight x lanes of a column is left: one bank-masked DPP level that folds the six values
+// into three registers (the 4-lane banks of even parity keep (S0, S1, S2), the odd ones (x S0, x^2 S0, x S1)) and two
+// quad_perm butterflies -- 12 DPP adds.  Per four splats: 27 plain + 12 DPP issues where the folds took 18 swaps + 37;
+// always added in the same order (bit-reproducible).  The DPP part is one asm block: hipcc splits the builtin DPP form into
+// v_mov_dpp + v_add pairs padded with s_nop; here the three chains are interleaved so that every DPP source was written at
+// least two instructions earlier (the 2-wait-state VALU-write -> DPP-read hazard); the leading s_nop 1 covers the
+// instruction before the block.
 #define SCR_DPP(d, s, ctrl) "v_add_f32_dpp " d ", " s ", " s " " ctrl "\n\t"
-__device__ __forceinline__ void row_fold9(float (&v)[9]) {
+// in: s0..s2 = the lane's three direct sums, t0..t2 = their x-weighted companions; out, by parity of the lane's 4-lane bank:
+// s0 = (sum s0 | sum t0), s1 = (sum s1 | sum t1), s2 = (sum s2 | sum t2) over the eight lanes of the column
+__device__ __forceinline__ void column_fold(float& s0, float& s1, float& s2, float t0, float t1, float t2) {
     asm volatile("s_nop 1\n\t"
-                 // 8-lane step: (0,1) (2,3) (4,5) (6,7) -> 0, 2, 4, 6; 8 alone (upper half only)
-                 SCR_DPP("%0", "%0", "row_shl:8 row_mask:0xf bank_mask:0x3")
-                 SCR_DPP("%2", "%2", "row_shl:8 row_mask:0xf bank_mask:0x3")
-                 SCR_DPP("%4", "%4", "row_shl:8 row_mask:0xf bank_mask:0x3")
-                 SCR_DPP("%6", "%6", "row_shl:8 row_mask:0xf bank_mask:0x3")
-                 SCR_DPP("%8", "%8", "row_shr:8 row_mask:0xf bank_mask:0xc")
-                 SCR_DPP("%0", "%1", "row_shr:8 row_mask:0xf bank_mask:0xc")
-                 SCR_DPP("%2", "%3", "row_shr:8 row_mask:0xf bank_mask:0xc")
-                 SCR_DPP("%4", "%5", "row_shr:8 row_mask:0xf bank_mask:0xc")
-                 SCR_DPP("%6", "%7", "row_shr:8 row_mask:0xf bank_mask:0xc")
-                 // 4-lane step: (0,2) -> 0, (4,6) -> 4; 8 alone (lanes 12-15 only)
                  SCR_DPP("%0", "%0", "row_shl:4 row_mask:0xf bank_mask:0x5")
-                 SCR_DPP("%4", "%4", "row_shl:4 row_mask:0xf bank_mask:0x5")
-                 SCR_DPP("%8", "%8", "row_shr:4 row_mask:0xf bank_mask:0x8")
-                 SCR_DPP("%0", "%2", "row_shr:4 row_mask:0xf bank_mask:0xa")
-                 SCR_DPP("%4", "%6", "row_shr:4 row_mask:0xf bank_mask:0xa")
-                 // inside each 4-lane group
-                 SCR_DPP("%8", "%8", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-                 SCR_DPP("%0", "%0", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-                 SCR_DPP("%4", "%4", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-                 SCR_DPP("%8", "%8", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%1", "%1", "row_shl:4 row_mask:0xf bank_mask:0x5")
+                 SCR_DPP("%2", "%2", "row_shl:4 row_mask:0xf bank_mask:0x5")
+                 SCR_DPP("%0", "%3", "row_shr:4 row_mask:0xf bank_mask:0xa")
+                 SCR_DPP("%1", "%4", "row_shr:4 row_mask:0xf bank_mask:0xa")
+                 SCR_DPP("%2", "%5", "row_shr:4 row_mask:0xf bank_mask:0xa")
                  SCR_DPP("%0", "%0", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-                 SCR_DPP("%4", "%4", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-                 "s_nop 1"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                   "+v"(v[8]));
-}
-// The backward pass reduces SEPARABLE sums: a lane's pixel is (x, y) = (lane >> 3, lane & 7) inside the quadrant, so the
-// high lane bits carry x.  The levels that fold x away (permlane32, permlane16, the 8-lane DPP step) only need
-// S0 = Y, S1 = Y x, S2 = Y x^2 and the three colour terms: SIX values, not nine.  What depends on y is made afterwards,
-// from per-row partial sums, with two multiplications by the lane's y: y S0, y S1, y^2 S0.  Then the 4-lane step and
-// the two quad steps fold y away.  Input: v[0..5] = (S0, S1, S2, c0, c1, c2) after fold4 (rows = splats A, C, B, D).
-// Output by 4-lane bank of every row:  v[0] = (M0 | Mxx | Mx | c0),  v[4] = (c1 | My | c2 | Mxy),  myy = (Myy | - | - | -)
-// with M0 = sum Y, Mx = sum Y x, ... the moments about the quadrant's origin.  17 DPP adds + 2 multiplications where
-// row_fold9 takes 20 DPP adds after NINE (instead of six) permlane folds.
-__device__ __forceinline__ void row_fold6(float (&v)[6], float yl, float yl2, float& myy) {
-    float ya;
-    asm volatile("s_nop 1\n\t"
-                 // 8-lane step (x bit 0): (0,1) -> 0, (2,3) -> 2, (4,5) -> 4
-                 SCR_DPP("%0", "%0", "row_shl:8 row_mask:0xf bank_mask:0x3")
-                 SCR_DPP("%2", "%2", "row_shl:8 row_mask:0xf bank_mask:0x3")
-                 SCR_DPP("%4", "%4", "row_shl:8 row_mask:0xf bank_mask:0x3")
-                 SCR_DPP("%0", "%1", "row_shr:8 row_mask:0xf bank_mask:0xc")
-                 SCR_DPP("%2", "%3", "row_shr:8 row_mask:0xf bank_mask:0xc")
-                 SCR_DPP("%4", "%5", "row_shr:8 row_mask:0xf bank_mask:0xc")
-                 // v0 = (S0 | S1) per pixel row y: the y-dependent moments
-                 "v_mul_f32 %6, %0, %8\n\t"     // (y S0 | y S1)
-                 "v_mul_f32 %7, %0, %9\n\t"     // (y^2 S0 | -)
-                 // 4-lane step (y bit 2): (0,2) -> 0, (4,ya) -> 4, myy alone
-                 SCR_DPP("%0", "%0", "row_shl:4 row_mask:0xf bank_mask:0x5")
-                 SCR_DPP("%4", "%4", "row_shl:4 row_mask:0xf bank_mask:0x5")
-                 SCR_DPP("%7", "%7", "row_shl:4 row_mask:0xf bank_mask:0x5")
-                 SCR_DPP("%0", "%2", "row_shr:4 row_mask:0xf bank_mask:0xa")
-                 SCR_DPP("%4", "%6", "row_shr:4 row_mask:0xf bank_mask:0xa")
-                 // inside each 4-lane group (y bits 1, 0)
-                 SCR_DPP("%7", "%7", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%1", "%1", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%2", "%2", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
                  SCR_DPP("%0", "%0", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-                 SCR_DPP("%4", "%4", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-                 SCR_DPP("%7", "%7", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-                 SCR_DPP("%0", "%0", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-                 SCR_DPP("%4", "%4", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%1", "%1", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 SCR_DPP("%2", "%2", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
                  "s_nop 1"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "=&v"(ya), "=&v"(myy)
-                 : "v"(yl), "v"(yl2));
+                 : "+v"(s0), "+v"(s1), "+v"(s2)
+                 : "v"(t0), "v"(t1), "v"(t2));
 }
-__device__ __forceinline__ float fold4(float a, float b, float c, float d) {
-    auto ab = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    auto cd = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(d), false, false);
-    const float sab = __uint_as_float(ab[0]) + __uint_as_float(ab[1]);  // [A.lo+A.hi | B.lo+B.hi]
-    const float scd = __uint_as_float(cd[0]) + __uint_as_float(cd[1]);  // [C.lo+C.hi | D.lo+D.hi]
-    auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(sab), __float_as_uint(scd), false, false);
-    return __uint_as_float(q[0]) + __uint_as_float(q[1]);               // rows: A, C, B, D
-}
-
-// fold4 for Y with the x-moments for free.  A lane's pixel column is x = 4 x2 + 2 x1 + x0 with (x2, x1, x0) = lane bits
-// (5, 4, 3).  The permlane32 swap that folds x2 away leaves the x2 = 1 halves in its second result, the permlane16 swap the
-// x1 = 1 rows: sums of Y over those half-spaces, which is all that sum Y x and sum Y x^2 need --
-//   sum Y x   = 4 H2 + 2 H1 + H0,   sum Y x^2 = 16 H2 + 4 H1 + H0 + 16 H21 + 8 H20 + 4 H10
-// (H_b = sum of Y over x_b = 1, H_bc over x_b = x_c = 1).  The x0 level is row_fold6's 8-lane step: it gets per-lane values
-// whose sum over x0 is the moment (x0f = this lane's x0 as a float selects the H.0 terms).  Four swaps and four adds for Y
-// instead of nine and nine for (Y, Y x, Y x^2), and no per-pixel multiplications by x.
-__device__ __forceinline__ void fold4_moments(float a, float b, float c, float d, float x0f, float& s0, float& s1,
-                                              float& s2) {
-    auto ab = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    auto cd = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(d), false, false);
-    const float sab = __uint_as_float(ab[0]) + __uint_as_float(ab[1]);   // x2 folded away
-    const float scd = __uint_as_float(cd[0]) + __uint_as_float(cd[1]);
-    auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(sab), __float_as_uint(scd), false, false);
-    auto q2 = __builtin_amdgcn_permlane16_swap(ab[1], cd[1], false, false);   // the x2 = 1 halves, folded over x1
-    const float H1 = __uint_as_float(q[1]), H21 = __uint_as_float(q2[1]);
-    const float M0 = __uint_as_float(q[0]) + H1;                          // rows: A, C, B, D
-    const float H2 = __uint_as_float(q2[0]) + H21;
-    s0 = M0;
-    const float t = __builtin_fmaf(4.0f, H2, H1), u = t + H1;            // 4 H2 + H1, 4 H2 + 2 H1
-    s1 = __builtin_fmaf(x0f, M0, u);
-    s2 = __builtin_fmaf(x0f, __builtin_fmaf(2.0f, u, M0), __builtin_fmaf(16.0f, H21, 4.0f * t));
-}
+constexpr int TCS = WAVE + 4;   // words per column of a wave's transposition block (the four extra words keep the two
+                                // columns of a 16-lane row on different banks in the ds_read_b128 above)
 
 // Per-pixel gradient terms of one splat (back-to-front recurrences).  Not decision bearing, so the
 // compiler may contract mul+add pairs here (fewer VALU issues); the tolerance is the gradient bar of
@@ -486,8 +412,8 @@ __device__ __forceinline__ void fold4_moments(float a, float b, float c, float d
 //     combinations of the five moments  sum Y dx, sum Y dy, sum Y dx^2, sum Y dx dy, sum Y dy^2;
 //     the weights are applied once per Gaussian in preprocess_backward_kernel.
 // A wave therefore reduces, per splat: the moments of Y (six: 1, x, y, x^2, xy, y^2 -- taken about the QUADRANT's
-// origin, so that they are separable in the lane's pixel coordinates, see row_fold6; the wave shifts them to the
-// splat's centre once per entry) and the three colour gradients  sum alpha T dL/dpixel_c.
+// origin, so that their weights are constants of the tile; the wave shifts them to the splat's centre once per entry) and
+// the three colour gradients  sum alpha T dL/dpixel_c: a pixel hands over Y and w = alpha T (column_fold and above).
 struct PixState {
     float T, dLp0, dLp1, dLp2;
     float behind, last_alpha, d_last;
@@ -497,23 +423,19 @@ struct PixState {
 // reference skips such a splat altogether.
 template <bool SAFE>
 __device__ __forceinline__ void splat_pixel_grad(PixState& s, float T, float4 b, float cb, float G, float alpha,
-                                                 unsigned long long hit, float& g_0, float& g_c0, float& g_c1, float& g_c2) {
+                                                 unsigned long long hit, float& Y, float& w) {
 #pragma clang fp contract(fast)
     // T = transmittance in front of this splat (group_transmittance)
-    const float w = alpha * T;
+    w = alpha * T;
     // (SAFE: the reference's form of the same interpolation -- it keeps an infinite accumulator infinite where a (d - b) + b
     // makes Inf - Inf of it)
     s.behind = SAFE ? s.last_alpha * s.d_last + (1.0f - s.last_alpha) * s.behind : s.last_alpha * (s.d_last - s.behind) + s.behind;
     float d = b.z * s.dLp0 + b.w * s.dLp1 + cb * s.dLp2;
     if (SAFE) d = sel(hit, d, 0.0f);
-    g_c0 = w * s.dLp0; g_c1 = w * s.dLp1; g_c2 = w * s.dLp2;
-    float Y = G * (T * (d - s.behind));  // G = opacity * exp(power) here: the unclamped alpha times dL/dalpha (straight-through min(0.99, .))
+    Y = G * (T * (d - s.behind));  // G = opacity * exp(power) here: the unclamped alpha times dL/dalpha (straight-through min(0.99, .))
     if (SAFE) Y = sel(hit, Y, 0.0f);     // `behind` is NaN once a NaN colour contributed to this pixel; a skipped splat takes nothing from it
     s.last_alpha = alpha;
     s.d_last = d;
-    // the moments of Y about the quadrant's origin are made INSIDE the reduction: the x-dependent ones from the halves
-    // the first two folding levels leave behind (fold4_moments), the y-dependent ones from row sums (row_fold6)
-    g_0 = Y;
 }
 // Transmittance in front of each of the four splats of a group, walked back to front: T_u = T_(u-1) / (1 - alpha_u).
 // ONE division per group instead of one per splat: the front-most value is T / (om0 om1 om2 om3), correctly rounded
@@ -547,7 +469,7 @@ __device__ __forceinline__ void store16_dword_aligned(void* p, float4 v) {
 
 // ------------------------------------------------------------------ backward
 constexpr int BCH = 64;  // list entries per round: one per lane of each wave
-constexpr int BWD_MIN_WAVES = 5;   // 96 VGPRs: five workgroups per CU (the LDS allows five); no spills
+constexpr int BWD_MIN_WAVES = 4;   // 128 VGPRs, 39.3 KB of LDS: four workgroups per CU; no spills
 constexpr int ACC_BUFS = 2;        // per-round sums double-buffered by round parity (one barrier per round)
 
 template <bool SAFE>       // see blend_forward_kernel / splat_pixel_grad
@@ -566,10 +488,11 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     // reads slots k .. k+3 of each field group: one address register and immediate offsets.  The three
     // pad slots in front stay zero (a partial last group blends them with alpha 0).
     __shared__ float4 st[4][3][BCH + 4];
-    // [round parity][wave]: the nine sums per position, as 16 + 16 + 4 bytes (36 B / entry keeps the
-    // workgroup under 32 KB of LDS: five workgroups per CU)
+    // [round parity][wave]: the nine sums per position, as 16 + 16 + 4 bytes: (M0, Mx, My, Mxx | Mxy, Myy, c0, c1 | c2)
+    // until the wave has shifted them to the splat's centre, the record layout afterwards
     __shared__ float4 accA[ACC_BUFS][4][BCH], accB[ACC_BUFS][4][BCH];
     __shared__ float accC[ACC_BUFS][4][BCH];
+    __shared__ __attribute__((aligned(16))) float tr[4][8 * TCS];    // the waves' transposition blocks (column_fold)
     __shared__ uint32_t wave_max[4];
     const int t = blend_tile((int)blockIdx.x, tiles, order, total);
     if (t < 0) return;
@@ -581,7 +504,6 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     const int px = qx0 + (lane >> 3), py = qy0 + (lane & 7);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const float x0f = (float)((lane >> 3) & 1), yl = (float)(lane & 7), yl2 = yl * yl;
     const float qx0f = (float)qx0, qy0f = (float)qy0;
     const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
     const uint32_t last = inside ? n_contrib[pix] : 0u;
@@ -598,7 +520,37 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     float c099 = 0.99f;
     asm volatile("" : "+v"(c099));  // keep the clamp in a VGPR: VOP2 with a literal issues slower
     SCR_COUNT_DECL;
-    const int comp = (lane >> 2) & 3;  // 4-lane bank of the row: which sum this lane's group ends up with
+    // the reducing role of this lane: column rcol of the transposition block (0-3: Y of the group's splats, 4-7: alpha T),
+    // pixel column rx of the quadrant; its weights for the eight pixels (rx, y)
+    const int rcol = lane >> 3, rx = lane & 7;
+    float wgt[3][8];
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        wgt[0][y] = 1.0f; wgt[1][y] = (float)y; wgt[2][y] = (float)(y * y);
+        if (rcol >= 4) {
+            const bool in = qx0 + rx < W && qy0 + y < H;
+            const size_t q = (size_t)(qy0 + y) * W + (size_t)(qx0 + rx);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wgt[c][y] = in ? dL_dpix[c * hw + q] : 0.0f;
+        }
+    }
+    const float xw = rcol < 4 ? (float)rx : 0.0f;
+    float* const trw = &tr[wave][0];
+    const float* const trr = trw + rcol * TCS + 8 * rx;
+    // where the lane's three sums go (lanes 0 and 4 of every column store): per sum the address of entry 0 in parity 0 and
+    // the entry stride, in bytes -- (M0, My, Myy) from a Y column's even bank, (Mx, Mxx, Mxy) from its odd one, (c0, c1, c2)
+    // from a colour column's even bank
+    const int rkind = rcol >= 4 ? 2 : (lane >> 2) & 1;
+    const bool rstore = (lane & 3) == 0 && (rcol < 4 || ((lane >> 2) & 1) == 0);
+    const int rcu = rcol & 3;                                    // the column's splat of the group
+    char* const accA0 = (char*)&accA[0][wave][0];
+    char* const accB0 = (char*)&accB[0][wave][0];
+    char* const rdst0 = rkind == 0 ? accA0 : rkind == 1 ? accA0 + 4 : accB0 + 8;
+    char* const rdst1 = rkind == 0 ? accA0 + 8 : rkind == 1 ? accA0 + 12 : accB0 + 12;
+    char* const rdst2 = rkind == 0 ? accB0 + 4 : rkind == 1 ? accB0 : (char*)&accC[0][wave][0];
+    const uint32_t rstride2 = rkind == 2 ? 4u : 16u;
+    constexpr uint32_t PAR_A = sizeof(float4) * 4 * BCH, PAR_C = sizeof(float) * 4 * BCH;     // bytes from parity 0 to parity 1
+    const uint32_t rpar2 = rkind == 2 ? PAR_C : PAR_A;
     // per-wave largest contributor count: list positions >= it cannot matter to the wave
     uint32_t wm = last;
 #pragma unroll
@@ -706,9 +658,8 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         // with alpha 0 -- about 1.5 of the ~22 entries a wave holds per round; the full groups stay branch-free.
         auto group = [&](const int k, auto tail) {
             constexpr bool TAIL = decltype(tail)::value;
-            float g[4][4];      // Y and the three colour terms of each splat
+            float Y[4], Wt[4];  // Y and alpha T of each splat
             unsigned long long hits[4] = {0ull, 0ull, 0ull, 0ull};
-            uint32_t jj[4];
             unsigned long long any = 0ull;
             // all four records first (one LDS round trip per group instead of four)
             float4 ra[4], rb[4];
@@ -725,7 +676,6 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 if (TAIL && k - u < 0) {  // wave-uniform
                     Gs[u] = al[u] = 0.0f;
                     om[u] = 1.0f;
-                    jj[u] = 0xffffffffu;
                     SCR_COUNT(13, 1);
                     continue;
                 }
@@ -751,36 +701,48 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 om[u] = 1.0f - al[u];
                 any |= hit;
                 if (SAFE) hits[u] = hit;
-                jj[u] = j;
             }
             group_transmittance(ps.T, om, Tu);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (TAIL && k - u < 0) {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) g[u][v] = 0.0f;
+                    Y[u] = Wt[u] = 0.0f;
                     continue;
                 }
-                splat_pixel_grad<SAFE>(ps, Tu[u], rb[u], rc[u].x, Gs[u], al[u], hits[u], g[u][0], g[u][1], g[u][2], g[u][3]);
+                splat_pixel_grad<SAFE>(ps, Tu[u], rb[u], rc[u].x, Gs[u], al[u], hits[u], Y[u], Wt[u]);
             }
-            float r[6], myy;
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
             if (any) {
-                fold4_moments(g[0][0], g[1][0], g[2][0], g[3][0], x0f, r[0], r[1], r[2]);
+                // the block's stores and loads are LDS operations of ONE wave: they execute in issue order; the compiler
+                // must not move them across each other (it sees per-thread addresses only)
+                asm volatile("" ::: "memory");
 #pragma unroll
-                for (int v = 0; v < 3; ++v) r[3 + v] = fold4(g[0][1 + v], g[1][1 + v], g[2][1 + v], g[3][1 + v]);
-                row_fold6(r, yl, yl2, myy);
+                for (int u = 0; u < 4; ++u) {
+                    trw[u * TCS + lane] = Y[u];
+                    trw[(4 + u) * TCS + lane] = Wt[u];
+                }
+                asm volatile("" ::: "memory");
+                const float4 va = *(const float4*)trr, vb = *(const float4*)(trr + 4);
+                asm volatile("" ::: "memory");
+                const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+                s0 = wgt[0][0] * v[0]; s1 = wgt[1][0] * v[0]; s2 = wgt[2][0] * v[0];
+#pragma unroll
+                for (int y = 1; y < 8; ++y) {
+                    s0 = __builtin_fmaf(wgt[0][y], v[y], s0);
+                    s1 = __builtin_fmaf(wgt[1][y], v[y], s1);
+                    s2 = __builtin_fmaf(wgt[2][y], v[y], s2);
+                }
+                const float t0 = xw * s0, t1 = xw * t0, t2 = xw * s1;      // x S0, x^2 S0, x S1 (colour lanes: 0)
+                column_fold(s0, s1, s2, t0, t1, t2);
             } else {
-                r[0] = r[4] = myy = 0.0f;
                 SCR_COUNT(12, TAIL ? k + 1 : 4);
             }
-            // rows 0 / 1 / 2 / 3 hold splat u = 0 / 2 / 1 / 3 of the group; 4-lane bank q of a row holds
-            // (M0, Mxx, Mx, c0)[q] in r[0], (c1, My, c2, Mxy)[q] in r[4], and bank 0 holds Myy in myy
-            const int row = lane >> 4;
-            const uint32_t jw = row == 0 ? jj[0] : row == 1 ? jj[2] : row == 2 ? jj[1] : jj[3];
-            if ((lane & 3) == 0 && jw != 0xffffffffu) {  // every listed position is written
-                ((float*)&accA[par][wave][jw])[comp] = r[0];
-                ((float*)&accB[par][wave][jw])[comp] = r[4];
-                if (comp == 0) accC[par][wave][jw] = myy;
+            // column rcol & 3 is splat u of the group, entry k - u of the wave's list; every listed position is written
+            if (rstore && (!TAIL || k - rcu >= 0)) {
+                const uint32_t jw = __float_as_uint(((const float2*)&st[wave][2][k + 3 - rcu])->y);
+                *(float*)(rdst0 + par * PAR_A + jw * 16u) = s0;
+                *(float*)(rdst1 + par * PAR_A + jw * 16u) = s1;
+                *(float*)(rdst2 + par * rpar2 + jw * rstride2) = s2;
             }
         };
         int k = cnt - 1;
@@ -796,12 +758,10 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             const uint32_t j = __float_as_uint(st[wave][2][lane + 3].y);
             const float a = ra.x - qx0f, b = ra.y - qy0f;
             const float4 A = accA[par][wave][j], B = accB[par][wave][j];
-            const float myy_ = accC[par][wave][j];
-            const float M0 = A.x, Mxx = A.y, Mx = A.z, My = B.y, Mxy = B.w;
+            const float M0 = A.x, Mx = A.y, My = A.z, Mxx = A.w, Mxy = B.x, Myy = B.y;
             const float t1 = a * M0 - Mx, t2 = b * M0 - My;      // sum Y dx, sum Y dy
             accA[par][wave][j] = make_float4(t1, t2, a * (t1 - Mx) + Mxx, (a * t2 - b * Mx) + Mxy);
-            accB[par][wave][j] = make_float4(b * (t2 - My) + myy_, M0, A.w, B.x);
-            accC[par][wave][j] = B.z;
+            accB[par][wave][j] = make_float4(b * (t2 - My) + Myy, M0, B.z, B.w);
         }
         __syncthreads();  // B: every wave's sums for this round are in acc
         // ---- combine: wave p (< 3) writes part p of the 36-byte gradient record of position `lane`,
