@@ -10,11 +10,11 @@
 // Forward: waves are independent -> one-wave workgroups, no barriers; the next chunk's masks,
 // ids and records are in flight while the current chunk is blended.
 // Backward: the four waves of a tile share one workgroup.  Per (tile, Gaussian) gradient moments are
-// reduced on chip -- a folding reduction inside the wave (permlane swaps whose left-over halves give the
-// x-moments, then bank-masked DPP adds that pack two values per register and make the y-moments from row
-// sums), one LDS slot per (wave, splat), a fixed-order add over the waves that took part -- and written
-// ONCE as a 36-byte record at the instance's Gaussian-major index (so the per-Gaussian reduction reads its
-// records contiguously).  Rounds behind every pixel's last contributor get no records: the tile leaves the
+// reduced on chip -- inside the wave through a wave-private LDS transposition (pixels x values -> columns per
+// value), a per-lane weighted contraction over eight pixels and one bank-masked DPP fold + two quad butterflies
+// over the eight pixel columns (column_fold), one LDS slot per (wave, splat), a fixed-order add over the waves
+// that took part -- and written ONCE as a 36-byte record at the instance's Gaussian-major index (so the
+// per-Gaussian reduction reads its records contiguously).  Rounds behind every pixel's last contributor get no records: the tile leaves the
 // sort key of its first entry without one (cut_key).  No floating-point atomics: results are
 // bit-reproducible.  The per-Gaussian sum over tiles happens in preprocess_backward_kernel.
 //
@@ -499,7 +499,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     const uint32_t lo = ranges[2 * t], n = ranges[2 * t + 1] - lo;
     if (n == 0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;  // wave == quadrant
-    // x in the HIGH lane bits, y in the low ones: the reduction folds x away first (row_fold6)
+    // x in the HIGH lane bits, y in the low ones: lane p stores pixel p = 8 x + y of its columns, lane (c, x) reads (x, 0..7)
     const int qx0 = (t % gx) * TILE + (wave & 1) * 8, qy0 = (t / gx) * TILE + (wave >> 1) * 8;
     const int px = qx0 + (lane >> 3), py = qy0 + (lane & 7);
     const bool inside = px < W && py < H;
