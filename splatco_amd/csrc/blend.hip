@@ -543,6 +543,9 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
     const int rkind = rcol >= 4 ? 2 : (lane >> 2) & 1;
     const bool rstore = (lane & 3) == 0 && (rcol < 4 || ((lane >> 2) & 1) == 0);
     const int rcu = rcol & 3;                                    // the column's splat of the group
+    // (lane masks in SGPR pairs: the list position of the column's splat is selected from the four the group's record reads
+    // broadcast anyway -- an LDS read of its own would be a second exposed round trip per group)
+    const unsigned long long rcu1 = lanes(rcu == 1), rcu2 = lanes(rcu == 2), rcu3 = lanes(rcu == 3);
     char* const accA0 = (char*)&accA[0][wave][0];
     char* const accB0 = (char*)&accB[0][wave][0];
     char* const rdst0 = rkind == 0 ? accA0 : rkind == 1 ? accA0 + 4 : accB0 + 8;
@@ -659,6 +662,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
         auto group = [&](const int k, auto tail) {
             constexpr bool TAIL = decltype(tail)::value;
             float Y[4], Wt[4];  // Y and alpha T of each splat
+            uint32_t jj[4] = {0u, 0u, 0u, 0u};
             unsigned long long hits[4] = {0ull, 0ull, 0ull, 0ull};
             unsigned long long any = 0ull;
             // all four records first (one LDS round trip per group instead of four)
@@ -701,6 +705,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 om[u] = 1.0f - al[u];
                 any |= hit;
                 if (SAFE) hits[u] = hit;
+                jj[u] = j;
             }
             group_transmittance(ps.T, om, Tu);
 #pragma unroll
@@ -739,7 +744,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             }
             // column rcol & 3 is splat u of the group, entry k - u of the wave's list; every listed position is written
             if (rstore && (!TAIL || k - rcu >= 0)) {
-                const uint32_t jw = __float_as_uint(((const float2*)&st[wave][2][k + 3 - rcu])->y);
+                const uint32_t jw = sel(rcu3, jj[3], sel(rcu2, jj[2], sel(rcu1, jj[1], jj[0])));
                 *(float*)(rdst0 + par * PAR_A + jw * 16u) = s0;
                 *(float*)(rdst1 + par * PAR_A + jw * 16u) = s1;
                 *(float*)(rdst2 + par * rpar2 + jw * rstride2) = s2;

@@ -48,7 +48,9 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_a
 __device__ __forceinline__ int mh_kmap(int blk, int j) {
     if (blk < 2) return 16 * blk + j;                  // feat
     if (blk < 6) return 35 + 16 * (blk - 2) + j;       // geo_fea
-    return j < 3 ? 32 + j : (j == 3 ? -1 : -2);        // ob_view, bias
+    // ob_view and the bias sit at j = 0, 4, 8 and 12: K-step t of an MFMA block takes the indices 4 g + t, so all four fall
+    // into K-step 0 and the other three K-steps of the block, all zero, are not issued (forward: 18 of 232 MFMAs per tile)
+    return (j & 3) ? -2 : (j < 12 ? 32 + (j >> 2) : -1);
 }
 // head (0 opacity, 1 colour, 2 cov), first output tile and number of valid outputs of output tile ot
 __device__ __forceinline__ void mh_head_of(int ot, int& head, int& ot0, int& nout) {
@@ -129,7 +131,7 @@ mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, int ldf, con
         {
             const float ox = anchor[3 * vc] - cx, oy = anchor[3 * vc + 1] - cy, oz = anchor[3 * vc + 2] - cz;
             const float inv = 1.0f / sqrtf((ox * ox + oy * oy) + oz * oz);
-            xb[6] = g == 0 ? f4{ox * inv, oy * inv, oz * inv, 1.0f} : f4{0.0f, 0.0f, 0.0f, 0.0f};
+            xb[6] = f4{g == 0 ? ox * inv : (g == 1 ? oy * inv : (g == 2 ? oz * inv : 1.0f)), 0.0f, 0.0f, 0.0f};
         }
         f4 h[MH_MT];
 #pragma unroll
@@ -147,7 +149,7 @@ mlp_heads_forward_kernel(int64_t V, const float* __restrict__ feat, int ldf, con
                 for (int mt = 0; mt < MH_MT; ++mt) a1[(blk + 1) & 1][mt] = A1[mt][blk + 1][lane];
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < (blk == 6 ? 1 : 4); ++t)      // block 6: (ob, bias) in K-step 0, zeros behind (mh_kmap)
 #pragma unroll
                 for (int mt = 0; mt < MH_MT; ++mt) h[mt] = mfma4(a1[blk & 1][mt][t], xb[blk][t], h[mt]);
             __builtin_amdgcn_sched_barrier(0);
@@ -396,7 +398,9 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, int ldf, co
         __builtin_amdgcn_sched_barrier(0);
         const float ox = ax - cx, oy = ay - cy, oz = az - cz;
         const float inv = 1.0f / sqrtf((ox * ox + oy * oy) + oz * oz);
-        xb[6] = g == 0 ? f4{ox * inv, oy * inv, oz * inv, 1.0f} : f4{0.0f, 0.0f, 0.0f, 0.0f};
+        xb[6] = f4{g == 0 ? ox * inv : (g == 1 ? oy * inv : (g == 2 ? oz * inv : 1.0f)), 0.0f, 0.0f, 0.0f};
+        // d ob sits in rows 0, 4, 8 of block 6 (mh_kmap): register 0 of the lanes (n, 0), (n, 1), (n, 2)
+        const float dob1 = __shfl(dx[6][0], n + 16, 64), dob2 = __shfl(dx[6][0], n + 32, 64);
         if (valid) {
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) *(f4*)(d_feat + v * MH_FEAT + 16 * ft + 4 * g) = dx[ft];
@@ -404,10 +408,10 @@ mlp_heads_backward_kernel(int64_t V, const float* __restrict__ feat, int ldf, co
             for (int ft = 2; ft < 6; ++ft) *(f4*)((ft < 4 ? d_geo_a : d_geo_b) + v * (MH_GEO / 2) + 16 * (ft & 1) + 4 * g) = dx[ft];
             if (g == 0) {   // ob = o / |o|:  d o = (d ob - ob <ob, d ob>) / |o|
                 const float ux = ox * inv, uy = oy * inv, uz = oz * inv;
-                const float dot = (ux * dx[6][0] + uy * dx[6][1]) + uz * dx[6][2];
+                const float dot = (ux * dx[6][0] + uy * dob1) + uz * dob2;
                 d_anchor[3 * v] = (dx[6][0] - ux * dot) * inv;
-                d_anchor[3 * v + 1] = (dx[6][1] - uy * dot) * inv;
-                d_anchor[3 * v + 2] = (dx[6][2] - uz * dot) * inv;
+                d_anchor[3 * v + 1] = (dob1 - uy * dot) * inv;
+                d_anchor[3 * v + 2] = (dob2 - uz * dot) * inv;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
