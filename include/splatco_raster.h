@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCR_ABI_VERSION 26
+#define SCR_ABI_VERSION 27
 #define SCR_TILE 16 /* 16x16-pixel tiles: part of the result contract (tile rects, ranges, sort keys) */
 
 /* The 12 fields of GaussianRasterizationSettings, same order (gaussian_renderer/__init__.py:145-158).
@@ -493,6 +493,20 @@ int scr_profile_enable(int mask);
 int scr_profile_stride(int every);
 int scr_profile_read(double* total_ms, int64_t* launches);
 const char* scr_profile_kernel_name(int idx);
+
+/* ---- opt-in stage markers (profiling only; process-global, off by default; ABI 27).
+ * The reference brackets a whole training iteration with a pair of events (train.py:136-137,163,245); a profile of this
+ * library wants the stages inside it.  scr_markers_enable(1) loads the roctx library on first use (librocprofiler-sdk-roctx.so,
+ * then libroctx64.so; nothing is linked or loaded before) and from then on every C-ABI entry point and every kernel class
+ * it launches (the SCR_PROF_* names) opens a roctx range on the calling thread, so that `rocprofv3 --marker-trace
+ * --kernel-trace` attributes a step to scr_forward_plan / scr_forward_run / scr_backward / the anchor-path operators
+ * and, inside them, to scatter / tile sort / blend / preprocess.  Off, a marker is one load and one branch.
+ * scr_marker_push / scr_marker_pop let the host side add its own ranges (splatco_amd/_C.py stage(): prefilter, neural
+ * Gaussians, rasterize, loss, backward, exchange, optimizer); they do nothing while markers are off.
+ * Returns 0, or non-zero with scr_last_error() when no roctx library can be loaded. */
+int scr_markers_enable(int on);
+int scr_marker_push(const char* name);
+int scr_marker_pop(void);
 
 #ifdef __cplusplus
 }

@@ -31,10 +31,11 @@ SYMBOLS = [
     "scr_norm_linear_scratch_bytes", "scr_norm_linear_forward", "scr_norm_linear_backward",
     "scr_norm_fold", "scr_norm_fold_backward", "scr_norm_running_stats", "scr_box_coords", "scr_forward_plan_run",
     "scr_profile_stride", "scr_debug_force_deep_lists", "scr_adam_step", "scr_tv_add_grad",
+    "scr_markers_enable", "scr_marker_push", "scr_marker_pop",
 ]
 PLAN_NONFINITE_COLOUR, PLAN_LARGE_RECTS = 1, 2      # SCR_PLAN_*
 PROF_COUNT = 19
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 (DBG_TILES_TOUCHED, DBG_POINT_OFFSETS, DBG_RANGES, DBG_POINT_LIST, DBG_N_CONTRIB, DBG_FINAL_T, DBG_SPLAT_RECORDS, DBG_QMASK,
  DBG_GM_INDEX) = range(9)
@@ -99,6 +100,12 @@ def _load():
     lib.scr_debug_force_deep_lists.restype = C.c_int
     lib.scr_profile_stride.argtypes = [C.c_int]
     lib.scr_profile_stride.restype = C.c_int
+    lib.scr_markers_enable.argtypes = [C.c_int]
+    lib.scr_markers_enable.restype = C.c_int
+    lib.scr_marker_push.argtypes = [C.c_char_p]
+    lib.scr_marker_push.restype = C.c_int
+    lib.scr_marker_pop.argtypes = []
+    lib.scr_marker_pop.restype = C.c_int
     lib.scr_backward.argtypes = [i64, i32, i64, i64, vp, vp, vp, vp, vp, sp, vp, vp, vp, vp, vp, vp,
                                  vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.scr_debug_get.argtypes = [C.c_int, i64, i64, i32, i32, vp, vp, vp, vp, vp]
@@ -212,6 +219,43 @@ def profile_enable(which, every=1):
     lib.scr_profile_enable(mask)
 
 
+MARKERS = False
+
+
+def markers_enable(on=True):
+    """Opt-in roctx stage markers (include/splatco_raster.h, scr_markers_enable): every C-ABI entry point, every kernel class
+    and the host stages below open a range that `rocprofv3 --marker-trace` records.  Also switched on by SPLATCO_MARKERS=1
+    in the environment when the library is loaded."""
+    global MARKERS
+    check(lib.scr_markers_enable(1 if on else 0))
+    MARKERS = bool(on)
+
+
+class stage:
+    """with stage("rasterize"): ...   A host-side roctx range around a stage of the training iteration (the reference brackets
+    the whole iteration with one event pair, train.py:136-137,163,245).  Off (the default): two attribute reads.  On: the
+    range is closed behind a device synchronisation, so that the kernels it launched lie INSIDE it on the profiler's
+    time line -- marker mode serialises host and device at stage boundaries on purpose; never use it for timing."""
+    __slots__ = ("name", "on")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.on = MARKERS
+        if self.on:
+            lib.scr_marker_push(self.name.encode())
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            lib.scr_marker_pop()
+        return False
+
+
 def profile_read():
     """{kernel name: (total ms, launches)} since the last read (HIP events on the launch stream)."""
     ms = (C.c_double * PROF_COUNT)()
@@ -242,3 +286,7 @@ def scratch(nbytes, device):
     """Uninitialised device bytes for a kernel's scratch / saved state, in scratch_size() classes."""
     import torch
     return torch.empty(scratch_size(nbytes), dtype=torch.uint8, device=device)
+
+
+if os.environ.get("SPLATCO_MARKERS", "") not in ("", "0"):
+    markers_enable(True)

@@ -44,6 +44,7 @@ static int fail(const char* fmt, ...) {
     } while (0)
 
 // ---- opt-in kernel timing (scr_profile_*): hipEvent pairs on the launch stream
+#include <dlfcn.h>
 #include <atomic>
 #include <vector>
 namespace {
@@ -59,9 +60,20 @@ hipEvent_t prof_event() {
     (void)hipEventCreate(&e);
     return e;
 }
+// ---- opt-in stage markers (scr_markers_enable): roctx ranges on the calling thread, the library loaded on first use
+bool g_mark_on = false;
+int (*g_roctx_push)(const char*) = nullptr;
+int (*g_roctx_pop)() = nullptr;
+struct MarkScope {
+    bool on;
+    explicit MarkScope(const char* name) : on(g_mark_on) { if (on) (void)g_roctx_push(name); }
+    ~MarkScope() { if (on) (void)g_roctx_pop(); }
+};
+#define SCR_MARK_FN MarkScope mark_fn_(__func__)
+extern const char* const kProfNames[SCR_PROF_COUNT];
 struct ProfScope {
-    bool on; hipStream_t st; ProfRec r;
-    ProfScope(int idx, hipStream_t s) : on((g_prof_mask >> idx) & 1u), st(s) {
+    bool on; hipStream_t st; ProfRec r; MarkScope mark;
+    ProfScope(int idx, hipStream_t s) : on((g_prof_mask >> idx) & 1u), st(s), mark(kProfNames[idx]) {
         if (on && g_prof_stride > 1) on = (g_prof_seen[idx]++ % g_prof_stride) == 0;
         if (on) { r.idx = idx; r.a = prof_event(); r.b = prof_event(); (void)hipEventRecord(r.a, st); }
     }
@@ -158,6 +170,7 @@ size_t scr_backward_scratch_bytes(int64_t I) { return align_up((size_t)(I > 0 ? 
 int scr_visible_filter(int64_t P, const float* means3D, const float* scales, const float* rotations,
                        const float* cov3D_precomp, const scr_settings* settings, int32_t* radii_out,
                        void* stream) {
+    SCR_MARK_FN;
     if (check_settings(settings)) return 1;
     if (P < 0) return fail("P < 0");
     if (P == 0) return 0;
@@ -172,6 +185,7 @@ int scr_visible_filter(int64_t P, const float* means3D, const float* scales, con
 
 int scr_mark_visible(int64_t P, const float* means3D, const float* viewmatrix, uint8_t* present_out,
                      void* stream) {
+    SCR_MARK_FN;
     if (P < 0) return fail("P < 0");
     if (P == 0) return 0;
     if (!means3D || !viewmatrix || !present_out) return fail("NULL argument");
@@ -251,6 +265,7 @@ int scr_forward_plan(int64_t P, int32_t M, const float* means3D, const float* sc
                      const float* rotations, const float* cov3D_precomp, const float* opacities,
                      const float* shs, const float* colors_precomp, const scr_settings* settings,
                      void* geom_buf, int32_t* radii_out, int64_t* plan_host, void* stream) {
+    SCR_MARK_FN;
     unsigned long long seq = 0;
     const int rc = plan_enqueue(P, M, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, settings, geom_buf,
                                 radii_out, plan_host, (hipStream_t)stream, seq);
@@ -262,6 +277,7 @@ static int forward_run_impl(int64_t P, int64_t I, int64_t max_tile, int64_t plan
 
 int scr_forward_run(int64_t P, int64_t I, int64_t max_tile, int64_t plan_flags, const scr_settings* settings, void* geom_buf,
                     void* binning_buf, void* image_buf, float* out_color, void* stream) {
+    SCR_MARK_FN;
     return forward_run_impl(P, I, max_tile, plan_flags, settings, geom_buf, binning_buf, image_buf, out_color, stream, false);
 }
 
@@ -293,6 +309,7 @@ int scr_forward_plan_run(int64_t P, int32_t M, const float* means3D, const float
                          const float* cov3D_precomp, const float* opacities, const float* shs, const float* colors_precomp,
                          const scr_settings* settings, void* geom_buf, int32_t* radii_out, int64_t* plan_host,
                          void* binning_buf, size_t binning_capacity_bytes, void* image_buf, float* out_color, void* stream) {
+    SCR_MARK_FN;
     if (!plan_host) return fail("plan_host is NULL");
     plan_host[2] = 0;
     hipStream_t st = (hipStream_t)stream;
@@ -341,6 +358,7 @@ int scr_backward(int64_t P, int32_t M, int64_t I, int64_t plan_flags, const floa
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
                  float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                  void* stream) {
+    SCR_MARK_FN;
     if (check_settings(settings)) return 1;
     if (P == 0) return 0;
     if (plan_flags & ~(int64_t)(SCR_PLAN_NONFINITE_COLOUR | SCR_PLAN_LARGE_RECTS)) return fail("plan_flags %lld: not a value scr_forward_plan returned", (long long)plan_flags);
@@ -392,6 +410,7 @@ int scr_debug_force_deep_lists(int mode) {
 
 int scr_debug_get(int which, int64_t P, int64_t I, int32_t H, int32_t W, const void* geom_buf,
                   const void* binning_buf, const void* image_buf, void* out, void* stream) {
+    SCR_MARK_FN;
     hipStream_t st = (hipStream_t)stream;
     Grid g(H, W);
     const void* src = nullptr;
@@ -433,6 +452,7 @@ size_t scr_expand_scratch_bytes(int64_t n) { return align_up((expand_nwg(n) + 1)
 
 int scr_expand_plan(int64_t n, const float* neural_opacity, void* scratch, int64_t* num_selected_host,
                     void* stream) {
+    SCR_MARK_FN;
     if (!num_selected_host) return fail("num_selected_host is NULL");
     *num_selected_host = 0;
     if (n < 0) return fail("n < 0");
@@ -459,6 +479,7 @@ int scr_expand_plan(int64_t n, const float* neural_opacity, void* scratch, int64
 
 // mask -> index list with the expansion's count / scan / write scheme (scratch: scr_expand_scratch_bytes(n))
 int scr_mask_index_plan(int64_t n, const uint8_t* mask, void* scratch, int64_t* num_set_host, void* stream) {
+    SCR_MARK_FN;
     if (!num_set_host) return fail("num_set_host is NULL");
     *num_set_host = 0;
     if (n < 0) return fail("n < 0");
@@ -484,6 +505,7 @@ int scr_mask_index_plan(int64_t n, const uint8_t* mask, void* scratch, int64_t* 
 }
 
 int scr_mask_index_run(int64_t n, const uint8_t* mask, const void* scratch, int64_t* index, int64_t* inverse, void* stream) {
+    SCR_MARK_FN;
     if (n <= 0) return n < 0 ? fail("n < 0") : 0;
     if (!mask || !scratch || (!index && !inverse)) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
@@ -496,6 +518,7 @@ int scr_expand_run(int64_t V, int32_t k, const float* neural_opacity, const floa
                    const float* scale_rot, const float* offsets, int32_t offsets_ld, const float* grid_scaling,
                    const float* anchor, const void* scratch, int32_t* out_index, uint8_t* mask_out,
                    float* xyz, float* color_out, float* opacity, float* scaling, float* rot, void* stream) {
+    SCR_MARK_FN;
     if (V < 0 || k <= 0) return fail("bad V / k");
     if (offsets_ld < 3 * k) return fail("offsets_ld %d: the offset rows of an anchor are 3 k = %d floats long", offsets_ld, 3 * k);
     if (V == 0) return 0;
@@ -515,6 +538,7 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
                         const float* g_rot, float* d_neural_opacity, float* d_color, float* d_scale_rot,
                         float* d_offsets, float* d_grid_scaling, float* d_anchor, const float* g_reg, int64_t P,
                         void* stream) {
+    SCR_MARK_FN;
     if (V < 0 || k <= 0) return fail("bad V / k");
     if (g_reg && P <= 0) return fail("scr_expand_backward: g_reg needs P = the number of selected candidates");
     if (offsets_ld < 3 * k) return fail("offsets_ld %d: the offset rows of an anchor are 3 k = %d floats long", offsets_ld, 3 * k);
@@ -538,6 +562,7 @@ size_t scr_plane_sample_scratch_bytes(int64_t V, int32_t A, int32_t B, int32_t c
 int scr_plane_sample_backward(int64_t V, const float* coords, int32_t cstride, int32_t cx, int32_t cy, int32_t R,
                               int32_t A, int32_t B, int32_t planes, const float* grad_out0, const float* grad_out1,
                               int32_t ld, float* grad_plane0, float* grad_plane1, void* scratch, void* stream) {
+    SCR_MARK_FN;
     if (V < 0 || R <= 0 || A <= 1 || B <= 1) return fail("bad sizes");
     if (planes != 1 && planes != 2) return fail("planes must be 1 or 2");
     if (cstride <= 0 || cx < 0 || cy < 0 || cx >= cstride || cy >= cstride || ld < R) return fail("bad strides");
@@ -561,6 +586,7 @@ size_t scr_triplane_backward_scratch_bytes(int64_t V, int32_t X, int32_t Y, int3
 int scr_triplane_backward(int64_t V, const float* coords, int32_t cstride, int32_t R, int32_t X, int32_t Y, int32_t Z,
                           int32_t planes, const float* grad_out, int32_t ld, const int32_t* cols, float* const* grad_planes,
                           void* scratch, void* stream) {
+    SCR_MARK_FN;
     if (V < 0 || R <= 0 || X <= 1 || Y <= 1 || Z <= 1) return fail("bad sizes");
     if (planes != 1 && planes != 2) return fail("planes must be 1 or 2");
     if (cstride < 3 || ld < R * 3 * planes) return fail("bad strides");
@@ -588,6 +614,7 @@ size_t scr_triplane_backward_multi_scratch_bytes(int64_t V, int32_t ngrids, cons
 int scr_triplane_backward_multi(int64_t V, const float* coords, int32_t cstride, int32_t ngrids, const int32_t* R,
                                 const int32_t* X, const int32_t* Y, const int32_t* Z, const int32_t* col, const float* grad_out,
                                 int32_t ld, float* const* grad_planes, void* scratch, void* stream) {
+    SCR_MARK_FN;
     if (V < 0 || ngrids < 1 || ngrids > 3) return fail("bad sizes");
     if (!R || !X || !Y || !Z || !col || !grad_planes || !scratch || (V > 0 && (!coords || !grad_out))) return fail("NULL argument");
     for (int g = 0; g < ngrids; ++g) {
@@ -605,6 +632,7 @@ int scr_triplane_backward_multi(int64_t V, const float* coords, int32_t cstride,
 }
 
 int scr_plane_row_pairs(int32_t R, int32_t A, int32_t B, const float* plane, float* pairs, void* stream) {
+    SCR_MARK_FN;
     if (A < 2 || B < 2) return fail("bad sizes");
     if (!plane || !pairs) return fail("NULL argument");
     if (launch_plane_row_pairs(R, A, B, plane, pairs, (hipStream_t)stream)) return fail("R = %d channels per plane exceeds the supported 16", R);
@@ -615,6 +643,7 @@ int scr_plane_row_pairs(int32_t R, int32_t A, int32_t B, const float* plane, flo
 int scr_triplane_forward(int64_t V, const float* coords, int32_t cstride, const float* xy, const float* xz,
                          const float* yz, int32_t R, int32_t X, int32_t Y, int32_t Z, int32_t channel_last, float* out,
                          int32_t ld, int32_t col_xy, int32_t col_xz, int32_t col_yz, void* stream) {
+    SCR_MARK_FN;
     if (V < 0 || R <= 0 || X <= 1 || Y <= 1 || Z <= 1) return fail("bad sizes");
     if (cstride < 3 || col_xy < 0 || col_xz < 0 || col_yz < 0 || col_xy + R > ld || col_xz + R > ld || col_yz + R > ld)
         return fail("bad strides");
@@ -639,6 +668,7 @@ static int tpa_bad(int32_t R, int32_t H, int32_t W) {
 
 int scr_tpa_stats(int32_t R, int32_t H, int32_t W, const float* p0, const float* p1, const float* p2, float* avg,
                   float* mx, int32_t* arg, void* scratch, void* stream) {
+    SCR_MARK_FN;
     if (tpa_bad(R, H, W)) return 1;
     if (!p0 || !p1 || !p2 || !avg || !mx || !arg || !scratch) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
@@ -649,6 +679,7 @@ int scr_tpa_stats(int32_t R, int32_t H, int32_t W, const float* p0, const float*
 
 int scr_tpa_forward(int32_t R, int32_t H, int32_t W, const float* p0, const float* p1, const float* p2, const float* ca,
                     const float* w, float* s, uint8_t* am, float* sa, float* pair0, float* pair1, float* pair2, void* stream) {
+    SCR_MARK_FN;
     if (tpa_bad(R, H, W)) return 1;
     if (!p0 || !p1 || !p2 || !ca || !w || !s || !am || !sa || !pair0 || !pair1 || !pair2) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
@@ -660,6 +691,7 @@ int scr_tpa_forward(int32_t R, int32_t H, int32_t W, const float* p0, const floa
 int scr_tpa_backward(int32_t R, int32_t H, int32_t W, const float* p0, const float* p1, const float* p2, const float* ca,
                      const float* w, const float* s, const uint8_t* am, const float* sa, const float* g0, const float* g1,
                      const float* g2, float* d0, float* d1, float* d2, float* dca, float* dw, void* scratch, void* stream) {
+    SCR_MARK_FN;
     if (tpa_bad(R, H, W)) return 1;
     if (!p0 || !p1 || !p2 || !ca || !w || !s || !am || !sa || !g0 || !g1 || !g2 || !d0 || !d1 || !d2 || !dca || !dw || !scratch)
         return fail("NULL argument");
@@ -672,6 +704,7 @@ int scr_tpa_backward(int32_t R, int32_t H, int32_t W, const float* p0, const flo
 
 int scr_tpa_backward_stats(int32_t R, int32_t H, int32_t W, const float* davg, const float* dmax, const int32_t* arg,
                            float* d0, float* d1, float* d2, void* stream) {
+    SCR_MARK_FN;
     if (tpa_bad(R, H, W)) return 1;
     if (!davg || !dmax || !arg || !d0 || !d1 || !d2) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
@@ -687,6 +720,7 @@ size_t scr_l1_ssim_scratch_bytes(int32_t C, int32_t H, int32_t W, int32_t with_g
 
 int scr_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, void* scratch,
                         int32_t with_grad, float* out2, void* stream) {
+    SCR_MARK_FN;
     if (C <= 0 || H <= 0 || W <= 0) return fail("bad image size");
     if (!img1 || !img2 || !scratch || !out2) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
@@ -698,6 +732,7 @@ int scr_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img1, cons
 int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, const float* img2,
                          const void* scratch, const float* g_l1, const float* g_ssim, float* dimg1,
                          void* stream) {
+    SCR_MARK_FN;
     if (C <= 0 || H <= 0 || W <= 0) return fail("bad image size");
     if (!img1 || !img2 || !scratch || !g_l1 || !g_ssim || !dimg1) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
@@ -711,6 +746,7 @@ int scr_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img1, con
 size_t scr_scaling_reg_scratch_bytes(int64_t P) { return scaling_reg_scratch_bytes(P); }
 
 int scr_scaling_reg_forward(int64_t P, const float* scaling, void* scratch, float* out, void* stream) {
+    SCR_MARK_FN;
     if (P <= 0) return fail("P <= 0");
     if (!scaling || !scratch || !out) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
@@ -720,6 +756,7 @@ int scr_scaling_reg_forward(int64_t P, const float* scaling, void* scratch, floa
 }
 
 int scr_scaling_reg_backward(int64_t P, const float* scaling, const float* g, float* dscaling, void* stream) {
+    SCR_MARK_FN;
     if (P <= 0) return fail("P <= 0");
     if (!scaling || !g || !dscaling) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
@@ -733,6 +770,7 @@ size_t scr_pair_l1_scratch_bytes(int64_t n) { return pair_l1_scratch_bytes(n > 0
 
 int scr_pair_l1_forward(int64_t n, const float* gen1, const float* gen2, const float* real1, const float* real2, void* scratch,
                         float* out, void* stream) {
+    SCR_MARK_FN;
     if (n <= 0) return fail("n <= 0");
     if (!gen1 || !gen2 || !real1 || !real2 || !scratch || !out) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
@@ -743,6 +781,7 @@ int scr_pair_l1_forward(int64_t n, const float* gen1, const float* gen2, const f
 
 int scr_pair_l1_backward(int64_t n, const float* gen1, const float* gen2, const float* real1, const float* real2, const float* g,
                          float* d_gen1, float* d_gen2, void* stream) {
+    SCR_MARK_FN;
     if (n <= 0) return fail("n <= 0");
     if (!gen1 || !gen2 || !real1 || !real2 || !g) return fail("NULL argument");
     if (!d_gen1 && !d_gen2) return 0;
@@ -759,6 +798,7 @@ int64_t scr_anchor_gather_stat_buffer_rows(int64_t V) { return anchor_gather_sta
 int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anchor_feat, const float* anchor,
                       const float* offset, const float* scaling, float* feat_out, float* anchor_out, float* offsets_out,
                       float* grid_scaling_out, float* g_fea_out, int32_t g_fea_ld, float* col_stats_out, void* stream) {
+    SCR_MARK_FN;
     if (V < 0) return fail("V < 0");
     if (g_fea_ld != 71 && g_fea_ld != 72) return fail("g_fea row stride must be 71 (packed) or 72 (16-byte aligned rows)");
     if (V == 0) return 0;
@@ -776,6 +816,7 @@ int scr_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inverse_inde
                                const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                const float* d_g_fea, int32_t g_fea_ld, float* g_anchor_feat, float* g_anchor,
                                float* g_offset, float* g_scaling, int32_t accumulate, void* stream) {
+    SCR_MARK_FN;
     if (N < 0 || V < 0) return fail("bad sizes");      // V may exceed N: N can be a range of the anchors (see the header)
     if (g_fea_ld != 71 && g_fea_ld != 72) return fail("g_fea row stride must be 71 (packed) or 72 (16-byte aligned rows)");
     if (N == 0) return 0;
@@ -789,6 +830,7 @@ int scr_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inverse_inde
 
 // ---- normalised tri-plane coordinates of contiguous xyz[V,3] in the box [lo, hi] (triplane.hip)
 int scr_box_coords(int64_t V, const float* xyz, const float* lo_host, const float* hi_host, float* out, void* stream) {
+    SCR_MARK_FN;
     if (V < 0) return fail("V < 0");
     if (V == 0) return 0;
     if (!xyz || !lo_host || !hi_host || !out) return fail("NULL argument");
@@ -802,6 +844,7 @@ int scr_norm_fold(int32_t L, int32_t d, const int32_t* widths_host, const int32_
                   const void* const* lin_weight_host,
                   const void* const* lin_bias_host, const void* const* bn_weight_host, const void* const* bn_bias_host, float* G,
                   float* c, void* stream) {
+    SCR_MARK_FN;
     if (!widths_host || !cols_host || !lin_weight_host || !lin_bias_host || !bn_weight_host || !bn_bias_host || !G || !c)
         return fail("NULL argument");
     if (launch_nl_fold(L, d, widths_host, cols_host, col_at_host, (const float* const*)lin_weight_host, (const float* const*)lin_bias_host,
@@ -815,6 +858,7 @@ int scr_norm_fold_backward(int32_t L, int32_t d, const int32_t* widths_host, con
                            const void* const* lin_weight_host, const void* const* bn_weight_host, const void* const* bn_bias_host,
                            const float* dG, const float* dc, void* const* d_lin_weight_host, void* const* d_lin_bias_host,
                            void* const* d_bn_weight_host, void* const* d_bn_bias_host, void* stream) {
+    SCR_MARK_FN;
     if (!widths_host || !cols_host || !lin_weight_host || !bn_weight_host || !bn_bias_host || !dG || !dc || !d_lin_weight_host ||
         !d_lin_bias_host || !d_bn_weight_host || !d_bn_bias_host)
         return fail("NULL argument");
@@ -831,6 +875,7 @@ int scr_norm_running_stats(int32_t L, int32_t d, const int32_t* widths_host, con
                            const float* momentum_host,
                            void* const* running_mean_host, void* const* running_var_host, void* const* num_batches_host,
                            const float* mean, const float* var, int64_t n, void* stream) {
+    SCR_MARK_FN;
     if (!widths_host || !cols_host || !momentum_host || !running_mean_host || !running_var_host || !mean || !var)
         return fail("NULL argument");
     if (launch_nl_running_stats(L, d, widths_host, cols_host, col_at_host, momentum_host, (float* const*)running_mean_host,
@@ -847,6 +892,7 @@ size_t scr_norm_linear_scratch_bytes(int64_t V) { return norm_linear_scratch_byt
 int scr_norm_linear_forward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* G, const float* c, float eps,
                             float* y, float* mean, float* var, float* inv, void* scratch, const float* col_stats,
                             int32_t col_stat_rows, void* stream) {
+    SCR_MARK_FN;
     if (V < 1 || d < 1 || ldx < d) return fail("bad sizes");
     if ((col_stats != nullptr) != (col_stat_rows > 0)) return fail("col_stats and col_stat_rows go together (NULL / 0: the statistics pass runs here)");
     if (!x || !G || !c || !y || !mean || !var || !inv || !scratch) return fail("NULL argument");
@@ -862,6 +908,7 @@ int scr_norm_linear_forward(int64_t V, int32_t d, const float* x, int32_t ldx, c
 int scr_norm_linear_backward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* G,
                              const float* mean, const float* inv, float* dx, int32_t lddx, float* dG, float* dc,
                              void* scratch, void* stream) {
+    SCR_MARK_FN;
     if (V < 1 || d < 1 || ldx < d || lddy < 32 || (dx && lddx < d)) return fail("bad sizes");
     if (!x || !dy || !G || !mean || !inv || !dG || !dc || !scratch) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
@@ -883,6 +930,7 @@ int scr_mlp_heads_forward(int64_t V, const float* feat, int32_t feat_ld, const f
                           const float* w1, const float* b1, const float* w2o, const float* b2o, const float* w2c,
                           const float* b2c, const float* w2v, const float* b2v, void* hidden_save, float* out_opacity,
                           float* out_color, float* out_cov, void* stream) {
+    SCR_MARK_FN;
     if (V < 0) return fail("V < 0");
     if (feat_ld < 32 || feat_ld % 4 != 0 || ((uintptr_t)feat & 15) != 0) return fail("feat rows: 32 floats, 16-byte aligned, feat_ld a multiple of 4 (got %d)", feat_ld);
     if (V == 0) return 0;
@@ -903,6 +951,7 @@ int scr_mlp_heads_backward(int64_t V, const float* feat, int32_t feat_ld, const 
                            const float* g_cov, void* partial, float* d_feat, float* d_anchor, float* d_geo_a, float* d_geo_b, float* d_w1,
                            float* d_b1, float* d_w2o, float* d_b2o, float* d_w2c, float* d_b2c, float* d_w2v, float* d_b2v,
                            void* stream) {
+    SCR_MARK_FN;
     if (V <= 0) return fail("V <= 0");
     if (feat_ld < 32 || feat_ld % 4 != 0 || ((uintptr_t)feat & 15) != 0) return fail("feat rows: 32 floats, 16-byte aligned, feat_ld a multiple of 4 (got %d)", feat_ld);
     if (!feat || !anchor || !campos || !geo_a || !geo_b || !w1 || !w2o || !w2c || !w2v || !hidden_save || !out_opacity || !out_color ||
@@ -922,6 +971,7 @@ int scr_mlp_heads_backward(int64_t V, const float* feat, int32_t feat_ld, const 
 int scr_statis_compute(int64_t V, int32_t k, const float* neural_opacity, const int32_t* out_index,
                        const uint8_t* update_filter, const float* viewspace_grad, int32_t grad_stride,
                        float* inc_opacity, float* inc_grad, void* stream) {
+    SCR_MARK_FN;
     if (V < 0 || k <= 0 || k > 256 || grad_stride < 2) return fail("bad V / k (1..256) / grad_stride");
     if (V == 0) return 0;
     if (!neural_opacity || !out_index || !inc_opacity || !inc_grad) return fail("NULL argument");
@@ -935,6 +985,7 @@ int scr_statis_compute(int64_t V, int32_t k, const float* neural_opacity, const 
 int scr_statis_apply(int64_t V, int32_t k, const int64_t* visible_index, const float* inc_opacity, const float* inc_grad,
                      float* opacity_accum, float* anchor_demon, float* offset_gradient_accum, float* offset_denom,
                      void* stream) {
+    SCR_MARK_FN;
     if (V < 0 || k <= 0) return fail("bad V / k");
     if (V == 0) return 0;
     if (!visible_index || !inc_opacity || !inc_grad || !opacity_accum || !anchor_demon || !offset_gradient_accum ||
@@ -949,6 +1000,7 @@ int scr_statis_apply(int64_t V, int32_t k, const int64_t* visible_index, const f
 
 // ---- optimizer step (adam.hip)
 int scr_adam_step(int32_t n_tensors, const scr_adam_tensor* tensors, double beta1, double beta2, double eps, void* stream) {
+    SCR_MARK_FN;
     if (n_tensors < 0) return fail("scr_adam_step: n_tensors < 0");
     if (n_tensors == 0) return 0;
     if (!tensors) return fail("scr_adam_step: tensors is NULL");
@@ -967,6 +1019,7 @@ int scr_adam_step(int32_t n_tensors, const scr_adam_tensor* tensors, double beta
 
 // ---- tri-plane total-variation term (tv.hip)
 int scr_tv_add_grad(int32_t n_planes, const scr_tv_plane* planes, void* stream) {
+    SCR_MARK_FN;
     if (n_planes < 0) return fail("scr_tv_add_grad: n_planes < 0");
     if (n_planes == 0) return 0;
     if (!planes) return fail("scr_tv_add_grad: planes is NULL");
@@ -984,6 +1037,7 @@ int scr_tv_add_grad(int32_t n_planes, const scr_tv_plane* planes, void* stream) 
 
 int scr_knn(int64_t N, int32_t k, const float* grid_host, const float* sorted_pts, const int64_t* sorted_id,
             const int32_t* cell_start, int64_t* out_idx, void* stream) {
+    SCR_MARK_FN;
     if (N <= 0 || k <= 0 || k > 16) return fail("scr_knn: need N > 0 and 1 <= k <= 16");
     if (N <= k) return fail("scr_knn: fewer than k + 1 points");
     if (!grid_host || !sorted_pts || !sorted_id || !cell_start || !out_idx) return fail("NULL argument");
@@ -994,6 +1048,7 @@ int scr_knn(int64_t N, int32_t k, const float* grid_host, const float* sorted_pt
 }
 
 int scr_knn_curvature(int64_t N, int32_t k, const float* points, const int64_t* idx, float* curvature, void* stream) {
+    SCR_MARK_FN;
     if (N <= 0 || k < 2) return fail("bad N / k");
     if (!points || !idx || !curvature) return fail("NULL argument");
     launch_knn_curvature(N, k, points, idx, curvature, (hipStream_t)stream);
@@ -1002,6 +1057,7 @@ int scr_knn_curvature(int64_t N, int32_t k, const float* points, const int64_t* 
 }
 
 int scr_copy_probe(const void* src, void* dst, size_t bytes, void* stream) {
+    SCR_MARK_FN;
     if (!src || !dst || bytes < 16) return fail("NULL argument");
     const size_t n = bytes / 16;
     copy_probe_kernel<<<(unsigned)((n + 1023) / 1024), 256, 0, (hipStream_t)stream>>>((const copy_f4*)src, (copy_f4*)dst, n);
@@ -1038,5 +1094,30 @@ int scr_profile_read(double* total_ms, int64_t* launches) {
 }
 
 const char* scr_profile_kernel_name(int idx) { return idx >= 0 && idx < SCR_PROF_COUNT ? kProfNames[idx] : ""; }
+
+int scr_markers_enable(int on) {
+    if (!on) { g_mark_on = false; return 0; }
+    if (!g_roctx_push) {
+        void* h = nullptr;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h && dlsym(h, "roctxRangePushA") && dlsym(h, "roctxRangePop")) break;
+            h = nullptr;
+        }
+        if (!h) return fail("scr_markers_enable: no roctx library (librocprofiler-sdk-roctx.so / libroctx64.so) can be loaded");
+        g_roctx_push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        g_roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
+    }
+    g_mark_on = true;
+    return 0;
+}
+int scr_marker_push(const char* name) {
+    if (g_mark_on && name) (void)g_roctx_push(name);
+    return 0;
+}
+int scr_marker_pop(void) {
+    if (g_mark_on) (void)g_roctx_pop();
+    return 0;
+}
 
 }  // extern "C"

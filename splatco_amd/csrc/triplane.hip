@@ -546,7 +546,13 @@ __device__ __forceinline__ void tp_acc_add(A& acc, int x) {
 // TILE -- 2^-29 of the largest |g| among the tile's records (gmax, formed by pass 3 with order-free integer atomicMax) --
 // and the cell's four corner sums are 64-bit integers: integer addition is associative, so the sum is the same whatever
 // the order, and it is converted to fp32 once (each term carries the error of one fp32 rounding or 2^-30 of the tile's
-// largest gradient, whichever is larger; the cell sum itself adds no accumulation error).  Everything after the cell sums
+// largest gradient, whichever is larger; the cell sum itself adds no accumulation error).
+// DYNAMIC RANGE (stated limit): the grid is per 32 x 32-cell TILE, so a term more than 2^30 below the tile's largest |g|
+// rounds to zero and a node whose every term is that small receives nothing, where fp32 sums would keep it (the reference
+// trains the planes with Adam eps = 1e-15, scene/gaussian_model.py:572, which turns ANY non-zero gradient into a full-size
+// step).  A node fed by n terms is off by at most n 2^-30 gmax(tile) in absolute terms
+// (test_plane_gradient_grid_bounds_the_error_of_quiet_nodes); a per-cell grid would lift the limit at the price of a
+// per-cell maximum pass over the records (not built: nine decades inside one 32 x 32-cell tile has not been observed).  Everything after the cell sums
 // -- the four corner passes that add up to four cells' sums into a node, the halo blocks, the border kernel -- runs in a
 // fixed order in fp32: a handful of roundings per node (1e-7 rel-L2 against the exact sum of the terms; torch's atomics: 1e-6).
 // A tile that holds a non-finite gradient value takes the fp32 accumulators instead (NaN / Inf then reach exactly the
@@ -763,7 +769,9 @@ tp_cell_gather_kernel(int A, int B, int tb, int tiles, const uint32_t* __restric
         hi = min(hi, lo + TP_SEG);
     }
     // scale 2^(29 - e) with |g| < 2^(e + 1): |g * w * s| < 2^30 for every weight w <= 1; both factors stay normal floats
-    const int e = min(max(ex - 127, -96), 126);                 // (largest |g| below 2^-96: the grid is 2^-125, finer than any fp32 sum could tell)
+    // (e = 127, the largest finite exponent, included: s = 2^-98 -- the advisor's round-5 finding: clamped to 126 the
+    // product reached 2^31 and left the int32 range)
+    const int e = min(max(ex - 127, -96), 127);                 // (largest |g| below 2^-96: the grid is 2^-125, finer than any fp32 sum could tell)
     const float s_fwd = __uint_as_float((uint32_t)(29 - e + 127) << 23);
     const double s_inv = __longlong_as_double((long long)(e - 29 + 1023) << 52);
     if constexpr (RT <= TPN_GROUP) {
@@ -797,7 +805,7 @@ tp_split_finish_kernel(int A, int B, int tb, const uint32_t* __restrict__ split,
     const uint32_t nseg = seg[t + 1] - seg[t];
     const int ex = (int)(gmax[t] >> 23);
     if (ex == 255) return;                                      // non-finite values: the tile was summed in fp32 by one workgroup
-    const int e = min(max(ex - 127, -96), 126);
+    const int e = min(max(ex - 127, -96), 127);
     const double s_inv = __longlong_as_double((long long)(e - 29 + 1023) << 52);
     const long long* slots = part + (size_t)pfirst[t] * SLOT + threadIdx.x;
     long long acc[4][1] = {{0}, {0}, {0}, {0}};

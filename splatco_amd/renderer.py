@@ -9,6 +9,7 @@ import math
 
 import torch
 
+from ._C import stage as _C_stage        # opt-in roctx ranges (nothing when off)
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
@@ -173,7 +174,8 @@ def keep_grad(screenspace_points):
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, visible_mask=None, retain_grad=False):
     """gaussian_renderer/__init__.py:118-188.  Background tensor must be on the GPU."""
     is_training = pc.get_color_mlp.training
-    out = generate_neural_gaussians(viewpoint_camera, pc, visible_mask, is_training=is_training)
+    with _C_stage("generate_neural_gaussians"):
+        out = generate_neural_gaussians(viewpoint_camera, pc, visible_mask, is_training=is_training)
     xyz, color, opacity, scaling, rot = out[:5]
     # zero tensor that carries the screen-space mean gradient back to the caller (:133-138): a NON-LEAF that requires grad
     # (the reference's `zeros_like(..., requires_grad=True) + 0`), whose .grad is populated only with retain_grad (:134-138,
@@ -182,8 +184,9 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, visible_m
     if retain_grad:
         keep_grad(screenspace_points)
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, bg_color, scaling_modifier, pipe.debug))
-    rendered_image, radii = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=color,
-                                       opacities=opacity, scales=scaling, rotations=rot, cov3D_precomp=None)
+    with _C_stage("rasterize"):
+        rendered_image, radii = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=color,
+                                           opacities=opacity, scales=scaling, rotations=rot, cov3D_precomp=None)
     res = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
            "radii": radii}
     if is_training:

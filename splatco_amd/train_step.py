@@ -14,6 +14,7 @@ from .losses import view_loss
 from .multiview import GradArena, allreduce_gradients, collectives_on, consistency_loss, shard_views, world_info
 from .renderer import prefilter_voxel, render
 from .tv import tv_due
+from ._C import stage
 
 
 def sync_densification_stats(densifier, n_views, out, vis, device):
@@ -96,40 +97,50 @@ def collaborative_step(pc, views, gt_images, pipe, bg_color, optimizer=None, buc
     want_union = arena is not None and arena.sparse_rows and not sharded and arena.active
     union = None
     try:
+        # (stage(): opt-in roctx ranges, _C.markers_enable / SPLATCO_MARKERS=1; nothing when off)
         for k, (cam, gt) in enumerate(zip(shard_views(views), shard_views(gt_images))):
-            vis = prefilter_voxel(cam, pc, pipe, bg_color)
+            with stage("prefilter_voxel"):
+                vis = prefilter_voxel(cam, pc, pipe, bg_color)
             if want_union:
                 union = vis.clone() if union is None else union.logical_or_(vis)
-            out = render(cam, pc, pipe, bg_color, visible_mask=vis, retain_grad=True)
-            gt = gt.to(out["render"].device, non_blocking=True)
-            loss = view_loss(out["render"], gt, out["scaling"])
-            total = loss if total is None else total + loss
+            with stage("render"):
+                out = render(cam, pc, pipe, bg_color, visible_mask=vis, retain_grad=True)
+            with stage("loss"):
+                gt = gt.to(out["render"].device, non_blocking=True)
+                loss = view_loss(out["render"], gt, out["scaling"])
+                total = loss if total is None else total + loss
             if consistency_weight:
                 rendered.append((rank + k * world, out["render"], gt))
         if consistency_weight:
-            term, _ = consistency_loss(rendered, consistency_weight, device=device)
-            if term is not None:
-                total = term if total is None else total + term
+            with stage("consistency_loss"):
+                term, _ = consistency_loss(rendered, consistency_weight, device=device)
+                if term is not None:
+                    total = term if total is None else total + term
         if want_union:
             # only the rows of anchors SOME view of the step sees need to travel (GradArena.set_row_union); every rank takes
             # part, also one without views
             arena.set_row_union(union)
         if total is not None:
-            total.backward()
+            with stage("backward"):
+                total.backward()
     finally:
         pc._grad_sink = None
     if sharded and optimizer.arena is not arena:
         raise ValueError("collaborative_step: the ShardedFusedAdam was built on another GradArena")
-    if arena is not None:
-        # sharded optimizer: the exchange stops after the reduce-scatter; only this rank's slices of the arena hold the
-        # summed gradient (the optimizer's all-gather distributes the updated PARAMETERS instead)
-        bucket = arena.reduce(gather=not sharded)
-    else:
-        bucket = allreduce_gradients(params, bucket)
+    with stage("gradient_exchange"):
+        if arena is not None:
+            # sharded optimizer: the exchange stops after the reduce-scatter; only this rank's slices of the arena hold the
+            # summed gradient (the optimizer's all-gather distributes the updated PARAMETERS instead)
+            bucket = arena.reduce(gather=not sharded)
+        else:
+            bucket = allreduce_gradients(params, bucket)
     if tv_weight and iteration is not None and tv_due(iteration):
-        pc.feat_planes.tv_loss(tv_weight)
+        with stage("tv_loss"):
+            pc.feat_planes.tv_loss(tv_weight)
     if densifier is not None:
-        sync_densification_stats(densifier, len(views), out, vis, device)
+        with stage("training_statis"):
+            sync_densification_stats(densifier, len(views), out, vis, device)
     if optimizer is not None:
-        optimizer.step()
+        with stage("optimizer_step"):
+            optimizer.step()
     return (total.detach() if total is not None else None), out, bucket

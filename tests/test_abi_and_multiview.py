@@ -42,6 +42,27 @@ def test_c_abi_exports_every_declared_symbol():
     assert set(_C.SYMBOLS) == declared
 
 
+def test_stage_markers_are_off_by_default_and_load_roctx_on_demand():
+    """scr_markers_enable (ABI 27): nothing is loaded before the first enable; enabled, the C-ABI ranges and the host-side
+    stage() ranges push and pop in pairs (roctx without a profiler attached is a no-op library); disabled again, stage() is
+    inert.  No device call is made."""
+    from splatco_amd import _C
+    assert _C.MARKERS is (os.environ.get("SPLATCO_MARKERS", "") not in ("", "0"))
+    _C.markers_enable(True)
+    try:
+        assert _C.MARKERS
+        assert _C.lib.scr_marker_push(b"unit-test") == 0 and _C.lib.scr_marker_pop() == 0
+        with _C.stage("outer") as s:
+            assert s.on
+            with _C.stage("inner"):
+                pass
+    finally:
+        _C.markers_enable(False)
+    assert not _C.MARKERS
+    with _C.stage("off") as s:
+        assert not s.on
+
+
 def test_large_scratch_comes_in_size_classes():
     """_C.scratch_size: at least what was asked, at most 12.5 % more, eight classes per octave above 32 MiB, untouched below
     -- and the plane backward's scratch query covers the partial sums of split tiles (a size query, no device)."""
