@@ -325,10 +325,18 @@ int64_t scr_anchor_gather_stat_buffer_rows(int64_t V);
 int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anchor_feat, const float* anchor,
                       const float* offset, const float* scaling, float* feat_out, float* anchor_out, float* offsets_out,
                       float* grid_scaling_out, float* g_fea_out, int32_t g_fea_ld, float* col_stats_out, void* stream);
+/* Fused dx (ABI 27; nl_coef NULL: off).  g_fea's one consumer is the attribute branch's BatchNorm-Linear, whose backward ends in
+ *     d g_fea[v][n] = k0[n] + g_fea[v][n] k1[n] + sum_m dy[v][m] Gi[m][n]
+ * -- a [V,72] matrix written by one kernel and read back by this one.  Given nl_coef = Gi [32][80] | k0 [80] | k1 [80] (what
+ * scr_norm_linear_backward leaves in coef_out), nl_dy [V,32] (row stride nl_lddy, 16-byte aligned) and nl_x = g_fea [V,71]
+ * (row stride nl_ldx) the backward forms those rows itself, workgroup by workgroup, and ADDS them to whatever d_g_fea
+ * carries (normally NULL then): 1.15 GB less written and read at configs[2], and the whole tail of a step's backward pass
+ * -- dx and the gather -- runs per anchor RANGE, so that a range's exchange overlaps the next range's kernels. */
 int scr_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inverse_index, const float* grid_scaling, const float* d_feat,
                                const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                const float* d_g_fea, int32_t g_fea_ld, float* g_anchor_feat, float* g_anchor,
-                               float* g_offset, float* g_scaling, int32_t accumulate, void* stream);
+                               float* g_offset, float* g_scaling, int32_t accumulate, const float* nl_coef, const float* nl_dy,
+                               int32_t nl_lddy, const float* nl_x, int32_t nl_ldx, void* stream);
 
 /* ---- BatchNorm1d in training mode folded into the Linear(d, 32) that follows it: the two nn.Sequential(BatchNorm1d,
  * Linear) stacks of FeaturePlanes (scene/gaussian_model.py:118-124,160-166) for all active levels at once.  The caller
@@ -370,9 +378,12 @@ int scr_norm_running_stats(int32_t L, int32_t d, const int32_t* widths_host, con
 int scr_norm_linear_forward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* G, const float* c, float eps,
                             float* y, float* mean, float* var, float* inv, void* scratch, const float* col_stats,
                             int32_t col_stat_rows, void* stream);
+/* coef_out (ABI 27; may be NULL): [32 + 2][80] floats that receive Gi = G * inv | k0 | k1, the coefficients of
+ * dx[v][n] = k0[n] + x[v][n] k1[n] + sum_m dy[v][m] Gi[m][n], for a consumer that forms the rows of dx itself
+ * (scr_anchor_gather_backward: nl_coef); with dx NULL the [V,d] matrix is then never written. */
 int scr_norm_linear_backward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* G,
                              const float* mean, const float* inv, float* dx, int32_t lddx, float* dG, float* dc,
-                             void* scratch, void* stream);
+                             void* scratch, float* coef_out, void* stream);
 
 /* ---- the three MLP heads of generate_neural_gaussians (gaussian_renderer/__init__.py:58-93 with the default flags,
  * scene/gaussian_model.py:315-337) as one fp32-MFMA kernel per direction, for the reference's layer sizes

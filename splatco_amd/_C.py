@@ -134,7 +134,7 @@ def _load():
     lib.scr_norm_linear_scratch_bytes.restype = C.c_size_t
     lib.scr_norm_linear_forward.argtypes = [i64, i32, vp, i32, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.scr_norm_linear_forward.restype = C.c_int
-    lib.scr_norm_linear_backward.argtypes = [i64, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    lib.scr_norm_linear_backward.argtypes = [i64, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.scr_norm_linear_backward.restype = C.c_int
     lib.scr_box_coords.argtypes = [i64, vp, vp, vp, vp, vp]
     lib.scr_box_coords.restype = C.c_int
@@ -183,7 +183,7 @@ def _load():
     lib.scr_anchor_gather_stat_rows.restype = C.c_int32
     lib.scr_anchor_gather_stat_buffer_rows.argtypes = [i64]
     lib.scr_anchor_gather_stat_buffer_rows.restype = C.c_int64
-    lib.scr_anchor_gather_backward.argtypes = [i64, i64] + [vp] * 7 + [i32] + [vp] * 4 + [i32, vp]
+    lib.scr_anchor_gather_backward.argtypes = [i64, i64] + [vp] * 7 + [i32] + [vp] * 4 + [i32, vp, vp, i32, vp, i32, vp]
     lib.scr_anchor_gather.restype = lib.scr_anchor_gather_backward.restype = C.c_int
     lib.scr_knn.argtypes = [i64, i32, C.POINTER(C.c_float), vp, vp, vp, vp, vp]
     lib.scr_knn_curvature.argtypes = [i64, i32, vp, vp, vp, vp]

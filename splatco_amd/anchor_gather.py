@@ -51,9 +51,28 @@ class GradSink:
         self.ranges, self.on_range = None, None
 
 
+class DeferredDx:
+    """The hand-over of d g_fea (round 6).  g_fea has ONE consumer on the render path, the BatchNorm-Linear of
+    FeaturePlanes' attribute branch (scene_model._NormLinearFn), whose backward would end by writing dx [V,72] for this
+    op's backward to read back.  gather_anchors hangs one of these on g_fea; the BatchNorm-Linear's backward, finding it,
+    runs only its reductions, leaves the three coefficient blocks of dx = k0 + x k1 + dy Gi here (`coef`, with `dy` and
+    `x` kept alive) and returns a stride-0 ZERO tensor as g_fea's gradient -- a valid gradient that costs no memory and
+    that autograd may add to any other consumer's gradient of g_fea; this op's backward then forms the rows of dx inside
+    its kernel (csrc/anchor_gather.hip, DX) and adds whatever gradient did arrive for g_fea.  If the BatchNorm-Linear's
+    backward never runs (g_fea unused, or the unfused fallback), `coef` stays None and nothing changes."""
+    __slots__ = ("coef", "dy", "x")
+
+    def __init__(self):
+        self.coef = self.dy = self.x = None
+
+    @staticmethod
+    def is_token(t):
+        return t is not None and t.dim() == 2 and t.stride() == (0, 0)
+
+
 class _AnchorGather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, idx, sink, anchor_feat, anchor, offset, scaling):
+    def forward(ctx, idx, sink, box, anchor_feat, anchor, offset, scaling):
         c = lambda t: t.detach().contiguous()
         anchor_feat, anchor, offset, scaling = c(anchor_feat), c(anchor), c(offset), c(scaling)
         idx = idx.contiguous().long()
@@ -78,7 +97,7 @@ class _AnchorGather(torch.autograd.Function):
         if inv is not None and (inv.shape != (N,) or inv.device != dev):
             inv = None
         ctx.save_for_backward(idx, gs, *(() if inv is None else (inv,)))
-        ctx.N, ctx.sink = N, sink
+        ctx.N, ctx.sink, ctx.box = N, sink, box
         if sink is not None:
             sink.pending += 1
         stats = stats[:_C.lib.scr_anchor_gather_stat_rows(V)] if V else stats      # what the consumer reads (per-tile rows behind it)
@@ -96,6 +115,12 @@ class _AnchorGather(torch.autograd.Function):
             inv[idx] = torch.arange(V, device=dev)
         p = lambda t: None if t is None else t.contiguous().float()
         ldg = 71
+        box, nl = ctx.box, (None, None, 0, None, 0)
+        if box is not None and box.coef is not None:
+            # the BatchNorm-Linear's backward left its coefficients instead of dx: the kernel forms the rows (DeferredDx)
+            nl = (box.coef.data_ptr(), box.dy.data_ptr(), box.dy.stride(0), box.x.data_ptr(), box.x.stride(0))
+            if DeferredDx.is_token(d_g_fea):
+                d_g_fea = None                      # the stride-0 zeros it returned for g_fea: nothing else arrived
         if d_g_fea is not None and d_g_fea.dtype == torch.float32 and d_g_fea.stride() == (72, 1):
             ldg = 72                                # rows as the fused BatchNorm-Linear backward leaves them: read in place
         else:
@@ -123,12 +148,14 @@ class _AnchorGather(torch.autograd.Function):
                     _C.check(_C.lib.scr_anchor_gather_backward(
                         n1 - n0, V, inv.data_ptr() + 8 * n0, ptr(gs), ptr(d_feat), ptr(d_anc), ptr(d_off), ptr(d_gs),
                         ptr(d_g_fea), ldg, g_feat.data_ptr() + 4 * 32 * n0, g_anchor.data_ptr() + 4 * 3 * n0,
-                        g_offset.data_ptr() + 4 * 30 * n0, g_scaling.data_ptr() + 4 * 6 * n0, accumulate, _stream(dev)))
+                        g_offset.data_ptr() + 4 * 30 * n0, g_scaling.data_ptr() + 4 * 6 * n0, accumulate, *nl, _stream(dev)))
                 if sink is not None and ranges is sink.ranges:
                     sink.on_range(r)
+        if box is not None:
+            box.coef = box.dy = box.x = None        # (the box outlives the graph on g_fea: let the tensors go)
         if sink is not None:
-            return None, None, None, None, None, None        # written where the optimiser reads them
-        return None, None, g_feat, g_anchor, g_offset, g_scaling
+            return None, None, None, None, None, None, None        # written where the optimiser reads them
+        return None, None, None, g_feat, g_anchor, g_offset, g_scaling
 
 
 def gather_anchors(pc, idx):
@@ -148,7 +175,11 @@ def gather_anchors(pc, idx):
         if not ok:      # falling back to autograd here would ADD into gradient memory the arena did not clear
             raise RuntimeError("the gradient sink does not match the model's per-anchor parameters "
                                "(rebuild the GradArena after adjust_anchor / sort_anchors)")
-    feat, anc, off, gs, g_fea, stats = _AnchorGather.apply(idx, sink, pc._anchor_feat, pc._anchor, pc._offset, pc._scaling)
+    box = DeferredDx() if torch.is_grad_enabled() else None
+    feat, anc, off, gs, g_fea, stats = _AnchorGather.apply(idx, sink, box, pc._anchor_feat, pc._anchor, pc._offset, pc._scaling)
     if stats.shape[0]:
         g_fea._scr_col_stats = stats          # scene_model._norm_linear hands them to the fused BatchNorm-Linear
+        g_fea._scr_col_stats_version = g_fea._version      # ... while nobody has edited g_fea (or feat / offsets, its aliases) in place
+    if box is not None:
+        g_fea._scr_deferred_dx = box          # ... and lets its backward leave coefficients instead of dx (DeferredDx)
     return feat, anc, off, gs, g_fea

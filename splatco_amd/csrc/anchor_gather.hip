@@ -266,19 +266,41 @@ __device__ __forceinline__ void ag_issue_all(AgUpstream& u, int64_t fv, int nv, 
     ag_issue<1, TAIL>(d_grid_scaling ? d_grid_scaling + fv * 6 : nullptr, nv * 6, d_grid_scaling + V * 6, u.gs);
 }
 
-__global__ void __launch_bounds__(AG_THREADS)
+// DX (round 6): the gradient of g_fea is not read but FORMED here.  g_fea's only consumer is the BatchNorm-Linear of the
+// attribute branch, whose backward ends in dx[v][n] = k0[n] + x[v][n] k1[n] + sum_m dy[v][m] Gi[m][n] (csrc/normlinear.hip,
+// nl_bwd_dx_kernel) -- a [V,72] matrix written by one kernel (288 B per row) and read back by this one.  With the three
+// coefficient blocks of that backward (AgDx::coef = Gi [32][NL_DP] | k0 [NL_DP] | k1 [NL_DP]), its upstream gradient dy [V,32]
+// and its input x = g_fea [V,72] this kernel builds the rows of its workgroup itself: wave w takes the sixteen visible rows
+// 16 w .. of the block, 5 column tiles x 8 v_mfma_f32_16x16x4_f32 each (the A operands -- Gi, 10 KB -- come from the CU's L1), and stores them into the LDS tile the other upstream parts are added to.  1.15 GB less
+// written and read at configs[2], one kernel less, and the tail of the backward pass of a step runs PER ANCHOR RANGE: the
+// exchange of a range's gradients goes on the wire while the next range's dx is still being formed (multiview.GradArena).
+struct AgDx {
+    const float* coef;      // NULL: no fused dx
+    const float* dy;        // [V][lddy], 32 columns, 16-byte aligned rows
+    const float* x;         // [V][ldx], AG_COLS columns
+    int lddy, ldx;
+};
+typedef float agf4 __attribute__((ext_vector_type(4)));
+
+template <bool DX, int BPW>
+__global__ void __launch_bounds__(AG_THREADS, 4)      // 128 registers: the 37 KB of LDS allow four workgroups per CU      // DX: 168 registers (three workgroups per CU); else 128, four (37 KB of LDS each)
 anchor_gather_backward_kernel(int64_t N, int64_t V, const int64_t* __restrict__ inv, const float* __restrict__ grid_scaling,
                               const float* __restrict__ d_feat, const float* __restrict__ d_anchor,
                               const float* __restrict__ d_offsets, const float* __restrict__ d_grid_scaling,
                               const float* __restrict__ d_g_fea, int ldg, float* __restrict__ g_feat,
                               float* __restrict__ g_anchor, float* __restrict__ g_offset,
-                              float* __restrict__ g_scaling, int accumulate) {
+                              float* __restrict__ g_scaling, int accumulate, AgDx nl) {
     __shared__ __attribute__((aligned(16))) float tile[AG_ROWS * AG_LD];   // rows = the VISIBLE anchors of the block, in order
     __shared__ __attribute__((aligned(16))) float outt[AG_ROWS * AG_LD];   // rows = the block's 64 anchors
     __shared__ int rowv[AG_ROWS];                                          // row of `tile` of every anchor, -1 = invisible
     __shared__ int64_t first_v;
     __shared__ int nvis;
-    const int64_t n0 = (int64_t)blockIdx.x * AG_ROWS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g4 = lane >> 4;
+#pragma unroll 1      // (unrolled, the eight blocks' loads are interleaved and the kernel takes 248 registers: two workgroups per CU)
+  for (int bi = 0; bi < BPW; ++bi) {
+    const int64_t n0 = ((int64_t)blockIdx.x * BPW + bi) * AG_ROWS;
+    if (n0 >= N) break;                                   // workgroup-uniform
+    if (bi) __syncthreads();                              // the previous block's reads of tile / outt / rowv are done
     const int rows = (int)min((int64_t)AG_ROWS, N - n0);
     // the visible anchors of 64 consecutive anchors own consecutive upstream rows first_v .. first_v + nvis - 1
     int64_t myv = -1;
@@ -299,16 +321,76 @@ anchor_gather_backward_kernel(int64_t N, int64_t V, const int64_t* __restrict__ 
         // the aligned 16-byte pieces of a chunk may start up to 12 bytes before it (inside the tensor: a chunk that starts
         // the tensor is aligned) and end up to 12 bytes after it: only the workgroup holding the last visible rows can
         // leave the tensor that way, and it takes the guarded element-wise path
-        if (fv + nv + 1 < V) ag_issue_all<false>(u, fv, nv, V, ldg, d_g_fea, d_feat, d_anchor, d_offsets, d_grid_scaling);
-        else ag_issue_all<true>(u, fv, nv, V, ldg, d_g_fea, d_feat, d_anchor, d_offsets, d_grid_scaling);
-        const float gsc = (int)threadIdx.x < nv * 6 ? grid_scaling[fv * 6 + threadIdx.x] : 0.0f;      // exp(s) of the rows, for d exp
-        const float gsc2 = (int)threadIdx.x + AG_THREADS < nv * 6 ? grid_scaling[fv * 6 + threadIdx.x + AG_THREADS] : 0.0f;
-        ag_use<5, false>(u.gf, tile, ldg, 0);            // (the pad column lands in tile column 71: unused)
+        // (DX: a gradient that did arrive for g_fea -- a second consumer, rare -- is added in a phase of its own below; its
+        // twenty registers beside the dx phase's would not fit the 128 of four workgroups per CU)
+        const float* gf_now = DX ? nullptr : d_g_fea;
+        float gsc = 0.0f, gsc2 = 0.0f;
+        auto issue_upstream = [&]() {
+            if (fv + nv + 1 < V) ag_issue_all<false>(u, fv, nv, V, ldg, gf_now, d_feat, d_anchor, d_offsets, d_grid_scaling);
+            else ag_issue_all<true>(u, fv, nv, V, ldg, gf_now, d_feat, d_anchor, d_offsets, d_grid_scaling);
+            gsc = (int)threadIdx.x < nv * 6 ? grid_scaling[fv * 6 + threadIdx.x] : 0.0f;      // exp(s) of the rows, for d exp
+            gsc2 = (int)threadIdx.x + AG_THREADS < nv * 6 ? grid_scaling[fv * 6 + threadIdx.x + AG_THREADS] : 0.0f;
+        };
+        // DX: the upstream pieces are issued BEHIND the dx phase.  Issued in front of it (one memory round trip for both) the
+        // two register sets need 158 registers, i.e. three workgroups per CU: 1.22 ms at configs[2] against 1.04 ms this way
+        if (!DX) issue_upstream();
+        if (DX) {
+            // the block's rows of dx, sixteen per wave (at most one round: 4 waves x 16 rows); lane (r16, g4) holds row
+            // 16 rb + r16, columns 16 nt + 4 g4 .. + 3 of every tile nt
+            for (int rb = wave; 16 * rb < nv; rb += AG_THREADS / 64) {
+                const int tr = 16 * rb + r16;
+                const bool ok = tr < nv;
+                const int64_t row = fv + (ok ? tr : 0);
+                const float* dr = nl.dy + (size_t)row * nl.lddy;
+                const float* xr = nl.x + (size_t)row * nl.ldx;
+                agf4 dq[2], xv[5];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) dq[q] = ok ? *(const agf4*)(dr + 16 * q + 4 * g4) : agf4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) {
+                    const int k = 16 * nt + 4 * g4;
+                    agf4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (ok) {
+                        if (k + 3 < AG_COLS && (nl.ldx & 3) == 0) v = *(const agf4*)(xr + k);
+                        else {
+                            if (k < AG_COLS) v.x = xr[k];
+                            if (k + 1 < AG_COLS) v.y = xr[k + 1];
+                            if (k + 2 < AG_COLS) v.z = xr[k + 2];
+                        }
+                    }
+                    xv[nt] = v;
+                }
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) {
+                    const int k = 16 * nt + 4 * g4;
+                    const agf4 k0 = *(const agf4*)(nl.coef + 32 * NL_DP + k), k1 = *(const agf4*)(nl.coef + 33 * NL_DP + k);
+                    agf4 acc = k0 + xv[nt] * k1;
+                    // A[m = column 16 nt + r16][k = dy column 16 q + 4 g4 + j], K-step s = 4 q + j: 10 KB that every wave of the
+                    // chip reads -- they come from the CU's L1 (held in registers across a workgroup's blocks they cost 40
+                    // of the 128 a four-workgroup CU allows, and the kernel spilled)
+                    float ga[8];
+#pragma unroll
+                    for (int s_ = 0; s_ < 8; ++s_) ga[s_] = nl.coef[(16 * (s_ >> 2) + 4 * g4 + (s_ & 3)) * NL_DP + 16 * nt + r16];
+#pragma unroll
+                    for (int s_ = 0; s_ < 8; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s_], dq[s_ >> 2][s_ & 3], acc, 0, 0, 0);
+                    if (ok && k < AG_LD) *(agf4*)&tile[tr * AG_LD + k] = acc;      // (column 71, the pad: k0 = k1 = Gi = 0 there)
+                }
+            }
+        } else {
+            ag_use<5, false>(u.gf, tile, ldg, 0);            // (the pad column lands in tile column 71: unused)
+        }
+        if (DX) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); issue_upstream(); }
         __syncthreads();   // the parts below add into the same cells
         ag_use<3, false>(u.feat, tile, AG_FEAT, 0);
         ag_use<1, false>(u.anc, tile, 3, 32);
         ag_use<3, false>(u.off, tile, AG_OFF, 35);
         ag_use<1, false>(u.gs, tile, 6, 65);
+        if (DX && d_g_fea) {       // kernel-uniform
+            __syncthreads();
+            if (fv + nv + 1 < V) ag_issue<5, false>(d_g_fea + fv * ldg, nv * ldg, d_g_fea + V * ldg, u.gf);
+            else ag_issue<5, true>(d_g_fea + fv * ldg, nv * ldg, d_g_fea + V * ldg, u.gf);
+            ag_use<5, false>(u.gf, tile, ldg, 0);
+        }
         __syncthreads();
         {   // d exp(s) = exp(s) ds
             const int e = threadIdx.x;
@@ -330,6 +412,7 @@ anchor_gather_backward_kernel(int64_t N, int64_t V, const int64_t* __restrict__ 
     ag_store_chunk(g_anchor + n0 * 3, outt, rows * 3, 3, 32, add);
     ag_store_chunk(g_offset + n0 * AG_OFF, outt, rows * AG_OFF, AG_OFF, 35, add);
     ag_store_chunk(g_scaling + n0 * 6, outt, rows * 6, 6, 65, add);
+  }
 }
 
 void launch_anchor_gather(int64_t V, const int64_t* idx, const float* p_feat, const float* p_anchor, const float* p_offset,
@@ -344,13 +427,22 @@ void launch_anchor_gather(int64_t V, const int64_t* idx, const float* p_feat, co
     if (stats && tiles > AG_MAX_WGS) anchor_gather_stat_reduce_kernel<<<AG_MAX_WGS, 2 * NL_DP, 0, st>>>(tiles, stats);
 }
 
+constexpr int AG_DX_BPW = 1;      // blocks of 64 anchors per workgroup of the dx-forming instantiation
+
 void launch_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inv, const float* grid_scaling, const float* d_feat,
                                    const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                    const float* d_g_fea, int ldg, float* g_feat, float* g_anchor, float* g_offset,
-                                   float* g_scaling, int accumulate, hipStream_t st) {
+                                   float* g_scaling, int accumulate, const float* nl_coef, const float* nl_dy, int nl_lddy,
+                                   const float* nl_x, int nl_ldx, hipStream_t st) {
     if (N <= 0) return;
-    anchor_gather_backward_kernel<<<(unsigned)((N + AG_ROWS - 1) / AG_ROWS), AG_THREADS, 0, st>>>(
-        N, V, inv, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea, ldg, g_feat, g_anchor, g_offset, g_scaling, accumulate);
+    const int64_t blocks = (N + AG_ROWS - 1) / AG_ROWS;
+    const AgDx nl{nl_coef, nl_dy, nl_x, nl_lddy, nl_ldx};
+    if (nl_coef)
+        anchor_gather_backward_kernel<true, AG_DX_BPW><<<(unsigned)((blocks + AG_DX_BPW - 1) / AG_DX_BPW), AG_THREADS, 0, st>>>(
+            N, V, inv, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea, ldg, g_feat, g_anchor, g_offset, g_scaling, accumulate, nl);
+    else
+        anchor_gather_backward_kernel<false, 1><<<(unsigned)blocks, AG_THREADS, 0, st>>>(
+            N, V, inv, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea, ldg, g_feat, g_anchor, g_offset, g_scaling, accumulate, nl);
 }
 
 }  // namespace scr

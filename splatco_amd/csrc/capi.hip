@@ -815,15 +815,22 @@ int scr_anchor_gather(int64_t V, const int64_t* visible_index, const float* anch
 int scr_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inverse_index, const float* grid_scaling, const float* d_feat,
                                const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                const float* d_g_fea, int32_t g_fea_ld, float* g_anchor_feat, float* g_anchor,
-                               float* g_offset, float* g_scaling, int32_t accumulate, void* stream) {
+                               float* g_offset, float* g_scaling, int32_t accumulate, const float* nl_coef, const float* nl_dy,
+                               int32_t nl_lddy, const float* nl_x, int32_t nl_ldx, void* stream) {
     SCR_MARK_FN;
     if (N < 0 || V < 0) return fail("bad sizes");      // V may exceed N: N can be a range of the anchors (see the header)
     if (g_fea_ld != 71 && g_fea_ld != 72) return fail("g_fea row stride must be 71 (packed) or 72 (16-byte aligned rows)");
     if (N == 0) return 0;
     if (!inverse_index || !g_anchor_feat || !g_anchor || !g_offset || !g_scaling) return fail("NULL argument");
-    if (d_grid_scaling || d_g_fea) { if (!grid_scaling) return fail("grid_scaling is needed for d exp"); }
+    if (d_grid_scaling || d_g_fea || nl_coef) { if (!grid_scaling) return fail("grid_scaling is needed for d exp"); }
+    if (nl_coef) {
+        if (!nl_dy || !nl_x || nl_lddy < 32 || nl_ldx < 71) return fail("fused dx: dy [V,32] and x = g_fea [V,71] are needed");
+        if (nl_lddy % 4 != 0 || ((uintptr_t)nl_dy & 15) != 0 || ((uintptr_t)nl_coef & 15) != 0)
+            return fail("fused dx: dy and the coefficients must be 16-byte aligned, dy's row stride a multiple of 4 floats");
+    }
     launch_anchor_gather_backward(N, V, inverse_index, grid_scaling, d_feat, d_anchor, d_offsets, d_grid_scaling, d_g_fea, g_fea_ld,
-                                  g_anchor_feat, g_anchor, g_offset, g_scaling, accumulate, (hipStream_t)stream);
+                                  g_anchor_feat, g_anchor, g_offset, g_scaling, accumulate, nl_coef, nl_dy, nl_lddy, nl_x, nl_ldx,
+                                  (hipStream_t)stream);
     CHECK_LAUNCH("anchor_gather_backward_kernel", 0, (hipStream_t)stream);
     return 0;
 }
@@ -907,14 +914,15 @@ int scr_norm_linear_forward(int64_t V, int32_t d, const float* x, int32_t ldx, c
 
 int scr_norm_linear_backward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* G,
                              const float* mean, const float* inv, float* dx, int32_t lddx, float* dG, float* dc,
-                             void* scratch, void* stream) {
+                             void* scratch, float* coef_out, void* stream) {
     SCR_MARK_FN;
     if (V < 1 || d < 1 || ldx < d || lddy < 32 || (dx && lddx < d)) return fail("bad sizes");
     if (!x || !dy || !G || !mean || !inv || !dG || !dc || !scratch) return fail("NULL argument");
     hipStream_t st = (hipStream_t)stream;
     int rc;
     { ProfScope ps_(SCR_PROF_NORM_LINEAR_BACKWARD, st);
-      rc = launch_norm_linear_backward(V, d, x, ldx, dy, lddy, G, mean, inv, dx, lddx, dG, dc, scratch, st); }
+      rc = launch_norm_linear_backward(V, d, x, ldx, dy, lddy, G, mean, inv, dx, lddx, dG, dc, scratch, coef_out, st); }
+    if (rc == 3) return fail("copy of the backward coefficients failed: %s", hipGetErrorString(hipGetLastError()));
     if (rc == 1) return fail("d = %d input columns exceed the supported 80", d);
     if (rc == 2) return fail("dy must be 16-byte aligned with a row stride that is a multiple of 4 floats");
     CHECK_LAUNCH("norm_linear_backward", 0, st);

@@ -406,7 +406,8 @@ void launch_anchor_gather(int64_t V, const int64_t* idx, const float* p_feat, co
 void launch_anchor_gather_backward(int64_t N, int64_t V, const int64_t* inv, const float* grid_scaling, const float* d_feat,
                                    const float* d_anchor, const float* d_offsets, const float* d_grid_scaling,
                                    const float* d_g_fea, int ldg, float* g_feat, float* g_anchor, float* g_offset,
-                                   float* g_scaling, int accumulate, hipStream_t st);
+                                   float* g_scaling, int accumulate, const float* nl_coef, const float* nl_dy, int nl_lddy,
+                                   const float* nl_x, int nl_ldx, hipStream_t st);
 void launch_knn(int64_t N, int k, const float* grid9, const float* sorted_pts, const int64_t* sorted_id,
                 const int32_t* cell_start, int64_t* out_idx, hipStream_t st);
 void launch_knn_curvature(int64_t N, int k, const float* pts, const int64_t* idx, float* curvature, hipStream_t st);
@@ -416,7 +417,7 @@ int launch_norm_linear_forward(int64_t V, int d, const float* x, int ldx, const 
                                hipStream_t st);
 int launch_norm_linear_backward(int64_t V, int d, const float* x, int ldx, const float* dy, int lddy, const float* G,
                                 const float* mean, const float* inv, float* dx, int lddx, float* dG, float* dc, void* scratch,
-                                hipStream_t st);
+                                float* coef_out, hipStream_t st);
 size_t mlp_heads_hidden_bytes(int64_t V);
 size_t mlp_heads_partial_bytes(int64_t V);
 void launch_mlp_heads_forward(int64_t V, const float* feat, int ldf, const float* anchor, const float* campos, const float* geo_a, const float* geo_b,

@@ -447,9 +447,12 @@ int launch_norm_linear_forward(int64_t V, int d, const float* x, int ldx, const 
     return 0;
 }
 
+// coef_out (may be NULL): the coefficients of pass 3 -- Gi [32][NL_DP] | k0 [NL_DP] | k1 [NL_DP], contiguous -- copied out for a
+// consumer that forms the rows of dx itself (csrc/anchor_gather.hip, csrc/triplane.hip pass 3); with dx == NULL pass 3 is
+// not run here at all.
 int launch_norm_linear_backward(int64_t V, int d, const float* x, int ldx, const float* dy, int lddy, const float* G,
                                 const float* mean, const float* inv, float* dx, int lddx, float* dG, float* dc, void* scratch,
-                                hipStream_t st) {
+                                float* coef_out, hipStream_t st) {
     if (d < 1 || d > NL_DP) return 1;
     if (lddy % 4 != 0 || ((uintptr_t)dy & 15) != 0) return 2;
     float* coef = (float*)scratch;
@@ -464,6 +467,9 @@ int launch_norm_linear_backward(int64_t V, int d, const float* x, int ldx, const
 #undef SCR_NL_RED
     nl_bwd_sum_kernel<<<(NL_HSIZE + 31) / 32, 256, 0, st>>>(nwg, bpart, coef);
     nl_bwd_finish_kernel<<<1, 128, 0, st>>>(V, d, G, mean, inv, coef, dG, dc);
+    static_assert(NLC_K0 == NLC_GI + NL_OUT * NL_DP && NLC_K1 == NLC_K0 + NL_DP, "Gi | k0 | k1 are contiguous");
+    if (coef_out && hipMemcpyAsync(coef_out, coef + NLC_GI, (size_t)(NL_OUT + 2) * NL_DP * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return 3;
     if (!dx) return 0;
     const bool al = ldx % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dx & 15) == 0;
 #define SCR_NL_DX(NN)                                                                                                                          \

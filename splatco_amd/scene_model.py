@@ -116,8 +116,9 @@ class _NormLinearFn(torch.autograd.Function):
                 and G.shape[0] == 32 and x.shape[1] <= 80 and x.stride(1) == 1)
 
     @staticmethod
-    def forward(ctx, x, G, c, eps, col_stats=None):
+    def forward(ctx, x, G, c, eps, col_stats=None, defer=None):
         ctx.fused = _NormLinearFn.fused_ok(x, G)
+        ctx.defer = defer if ctx.fused else None      # anchor_gather.DeferredDx: the producer of x forms dx in ITS backward
         if ctx.fused:
             from . import _C
             from .rasterizer import _stream
@@ -156,16 +157,24 @@ class _NormLinearFn(torch.autograd.Function):
             if dy.dtype != torch.float32 or dy.stride(1) != 1 or dy.stride(0) % 4 or dy.data_ptr() % 16:
                 dy = dy.contiguous().float()
             need_dx = ctx.needs_input_grad[0]
+            defer = ctx.defer if need_dx and d == 71 and x.stride(1) == 1 else None
             ldx = (d + 3) // 4 * 4                   # 16-byte aligned rows (the pad columns are never written or read)
-            dx = torch.empty(V, ldx, dtype=torch.float32, device=x.device)[:, :d] if need_dx else None
+            dx = torch.empty(V, ldx, dtype=torch.float32, device=x.device)[:, :d] if need_dx and defer is None else None
             dG = torch.empty(32, d, dtype=torch.float32, device=x.device)
             dc = torch.empty(32, dtype=torch.float32, device=x.device)
+            coef = torch.empty(34, 80, dtype=torch.float32, device=x.device) if defer is not None else None
             scratch = _C.scratch(_C.lib.scr_norm_linear_scratch_bytes(V), x.device)
             with torch.cuda.device(x.device):
                 _C.check(_C.lib.scr_norm_linear_backward(V, d, x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), G.data_ptr(),
-                                                         mean.data_ptr(), inv.data_ptr(), dx.data_ptr() if need_dx else None,
-                                                         ldx, dG.data_ptr(), dc.data_ptr(), scratch.data_ptr(), _stream()))
-            return dx, dG, dc, None, None
+                                                         mean.data_ptr(), inv.data_ptr(), dx.data_ptr() if dx is not None else None,
+                                                         ldx, dG.data_ptr(), dc.data_ptr(), scratch.data_ptr(),
+                                                         coef.data_ptr() if coef is not None else None, _stream()))
+            if defer is not None:
+                # the producer of x (the anchor gather) forms dx = k0 + x k1 + dy Gi inside its own backward kernel: it gets the
+                # coefficients, and autograd a gradient of zeros that occupies no memory (anchor_gather.DeferredDx)
+                defer.coef, defer.dy, defer.x = coef, dy, x
+                dx = torch.zeros((), dtype=torch.float32, device=x.device).expand(V, d)
+            return dx, dG, dc, None, None, None
         if dy.stride(1) != 1:      # a column block of a wider gradient (row stride > width) is fine for every op below
             dy = dy.contiguous()
         sdy = dy.sum(0)
@@ -178,7 +187,7 @@ class _NormLinearFn(torch.autograd.Function):
             k0 = -inv * u / V - mean * k1
             dx = torch.addmm(k0, dy, G * inv)
             dx.addcmul_(x, k1)
-        return dx, H, sdy, None, None
+        return dx, H, sdy, None, None, None
 
 
 def _ptr_table(tensors):
@@ -274,7 +283,10 @@ def _norm_linear(x, bns, linears, col_at=None):
     assert all(bn.eps == bns[0].eps for bn in bns)
     # (statistics the producer of x left on it -- anchor_gather -- are only valid for x as it is: same rows, no column map)
     stats = getattr(x, "_scr_col_stats", None) if col_at is None else None
-    y, mean, var = _NormLinearFn.apply(x, G, c, bns[0].eps, stats)
+    if stats is not None and getattr(x, "_scr_col_stats_version", None) != x._version:
+        stats = None        # x was edited in place since its producer summed its columns: the built-in statistics pass runs
+    defer = getattr(x, "_scr_deferred_dx", None) if col_at is None else None      # the anchor gather forms dx in its backward
+    y, mean, var = _NormLinearFn.apply(x, G, c, bns[0].eps, stats, defer)
     with torch.no_grad():
         n = x.shape[0]
         track = [bn for bn in bns if bn.track_running_stats and bn.training]

@@ -730,6 +730,81 @@ def test_fused_anchor_gather_matches_the_torch_ops():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,second_use", [(40, False), (50_001, False), (50_001, True), (1_400_003, False)])
+def test_gather_backward_forms_the_batchnorm_linear_dx_itself(N, second_use):
+    """Round 6 hand-over (anchor_gather.DeferredDx, csrc/anchor_gather.hip DX): with g_fea feeding the fused BatchNorm-Linear,
+    that op's backward leaves its coefficients and a stride-0 zero gradient instead of the [V,72] dx matrix, and the
+    gather's backward forms dx = k0 + x k1 + dy Gi per workgroup with fp32 MFMAs.  Same parameter gradients as the path that
+    materialises dx (same chain of fp32 FMAs per element up to the order of the 32-term sum: 1e-6 of the tensor's scale),
+    also per anchor RANGE (what the sharded step does), also when g_fea has a second consumer whose gradient autograd adds
+    to the token, and nothing is deferred when the BatchNorm-Linear is not the fused one."""
+    from splatco_amd import anchor_gather as ag
+    from splatco_amd import scene_model as sm
+    from splatco_amd.scene_model import AnchorGaussianModel
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(N + 17)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    params = (r(N, 3) * 2, r(N, 10, 3), r(N, 32) * 3 + 0.5, r(N, 6) * 0.3 - 3)
+    idx = (torch.rand(N, device=dev, generator=g) < 0.8).nonzero().squeeze(1)
+    V = idx.numel()
+    G, c = (r(32, 71) * 0.2).requires_grad_(), r(32).requires_grad_()
+    w_y, w_feat, w_off, w_gs, w_anc, w_g = r(V, 32), r(V, 32), r(V, 10, 3), r(V, 6), r(V, 3), r(V, 71)
+
+    def run(defer, ranges=None):
+        pc = AnchorGaussianModel(plane_size=16, num_channels=15).to(dev)
+        pc.set_anchors(*(t.clone() for t in params))
+        sink = None
+        if ranges:
+            grads = [torch.full_like(p, float("nan")) for p in (pc._anchor_feat, pc._anchor, pc._offset, pc._scaling)]
+            sink = ag.GradSink(*grads)
+            sink.ranges, seen = ranges, []
+            sink.on_range = seen.append
+            pc._grad_sink = sink
+        feat, anc, off, gs, g_fea = ag.gather_anchors(pc, idx)
+        box = g_fea._scr_deferred_dx
+        if not defer:
+            del g_fea._scr_deferred_dx
+        for t in (G, c):
+            t.grad = None
+        y, _, _ = sm._NormLinearFn.apply(g_fea, G, c, 1e-5, getattr(g_fea, "_scr_col_stats", None),
+                                         getattr(g_fea, "_scr_deferred_dx", None))
+        loss = (y * w_y).sum() + (feat * w_feat).sum() + (off * w_off).sum() + (gs * w_gs).sum() + (anc * w_anc).sum()
+        if second_use:
+            loss = loss + (g_fea * w_g).sum()
+        loss.backward()
+        assert box.coef is None                                     # released behind the backward
+        if ranges:
+            assert seen == list(range(len(ranges)))
+            out = grads
+        else:
+            out = [p.grad for p in (pc._anchor_feat, pc._anchor, pc._offset, pc._scaling)]
+        return [t.detach().clone() for t in out] + [G.grad.clone(), c.grad.clone()]
+
+    want = run(False)
+    got = run(True)
+    step = max(64, (N // 3 + 63) // 64 * 64)
+    rng = [(a, min(N, a + step)) for a in range(0, N, step)]
+    got_r = run(True, rng)
+    vis = torch.zeros(N, dtype=torch.bool, device=dev)
+    vis[idx] = True
+    for name, a, b, b2 in zip(("feat", "anchor", "offset", "scaling", "G", "c"), want, got, got_r):
+        scale = float(a.abs().max())
+        assert a.shape == b.shape == b2.shape and torch.isfinite(b).all() and torch.isfinite(b2).all(), name
+        assert float((a - b).abs().max()) <= 2e-6 * scale, (name, float((a - b).abs().max()), scale)
+        assert torch.equal(b, b2), name            # a range is the same kernel on offset pointers: the same bits
+        if name in ("feat", "anchor", "offset", "scaling"):
+            assert bool((b[~vis] == 0).all()), name
+    # the unfused BatchNorm-Linear (torch ops) defers nothing and still agrees
+    sm.NORM_LINEAR_HIP = False
+    try:
+        ref = run(True)
+    finally:
+        sm.NORM_LINEAR_HIP = True
+    for name, a, b in zip(("feat", "anchor", "offset", "scaling"), ref, got):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), name
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N", [40, 50_001, 1_400_003])      # one partial tile; 79 workgroups; more workgroups than statistics rows (second-level reduction)
 def test_gather_produced_column_statistics_feed_the_batchnorm(N):
     """The anchor gather sums (x - x[0]) and (x - x[0])^2 per column of g_fea while its rows sit in LDS
