@@ -253,12 +253,17 @@ int scr_expand_backward(int64_t V, int32_t k, const float* scale_rot, const floa
  * sizes and the first gradient column of every grid (grid g owns columns col[g] .. col[g] + 3 R[g], xy | xz | yz, the
  * grids back to back); grad_planes[3 * ngrids] (host array of device pointers, grid-major) are overwritten.  Returns 3
  * WITHOUT touching anything that matters when the layout is not one the fused pass is built for -- the caller then calls
- * scr_triplane_backward per grid.  Scratch from scr_triplane_backward_multi_scratch_bytes. */
+ * scr_triplane_backward per grid.  Scratch from scr_triplane_backward_multi_scratch_bytes.
+ * Fused dx (ABI 27; nl_coef NULL: off): the sampled matrix's one consumer is the plane branch's BatchNorm-Linear; given
+ * nl_coef = Gi [32][80] | k0 [80] | k1 [80] (scr_norm_linear_backward: coef_out), nl_dy [V,32] and nl_x = the sampled matrix
+ * itself, the pass over the points forms every point's gradient row on the way (dx = k0 + x k1 + dy Gi) instead of reading a
+ * [V, 3 R ngrids] matrix another kernel wrote; grad_out may then be NULL (if not, it is added). */
 size_t scr_triplane_backward_multi_scratch_bytes(int64_t V, int32_t ngrids, const int32_t* R, const int32_t* X, const int32_t* Y,
                                                  const int32_t* Z);
 int scr_triplane_backward_multi(int64_t V, const float* coords, int32_t cstride, int32_t ngrids, const int32_t* R,
                                 const int32_t* X, const int32_t* Y, const int32_t* Z, const int32_t* col, const float* grad_out,
-                                int32_t ld, float* const* grad_planes, void* scratch, void* stream);
+                                int32_t ld, float* const* grad_planes, void* scratch, const float* nl_coef, const float* nl_dy,
+                                int32_t nl_lddy, const float* nl_x, int32_t nl_ldx, void* stream);
 int scr_plane_row_pairs(int32_t R, int32_t A, int32_t B, const float* plane, float* pairs, void* stream);
 int scr_triplane_forward(int64_t V, const float* coords, int32_t cstride, const float* xy, const float* xz,
                          const float* yz, int32_t R, int32_t X, int32_t Y, int32_t Z, int32_t channel_last, float* out,
@@ -381,6 +386,10 @@ int scr_norm_linear_forward(int64_t V, int32_t d, const float* x, int32_t ldx, c
 /* coef_out (ABI 27; may be NULL): [32 + 2][80] floats that receive Gi = G * inv | k0 | k1, the coefficients of
  * dx[v][n] = k0[n] + x[v][n] k1[n] + sum_m dy[v][m] Gi[m][n], for a consumer that forms the rows of dx itself
  * (scr_anchor_gather_backward: nl_coef); with dx NULL the [V,d] matrix is then never written. */
+/* Pass 3 of the backward on its own, from a coefficient block scr_norm_linear_backward left in coef_out: for a consumer of
+ * the coefficients that cannot form the rows itself after all (a layout outside its fused pass). */
+int scr_norm_linear_dx(int64_t V, int32_t d, const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* coef,
+                       float* dx, int32_t lddx, void* stream);
 int scr_norm_linear_backward(int64_t V, int32_t d, const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* G,
                              const float* mean, const float* inv, float* dx, int32_t lddx, float* dG, float* dc,
                              void* scratch, float* coef_out, void* stream);

@@ -31,7 +31,7 @@ SYMBOLS = [
     "scr_norm_linear_scratch_bytes", "scr_norm_linear_forward", "scr_norm_linear_backward",
     "scr_norm_fold", "scr_norm_fold_backward", "scr_norm_running_stats", "scr_box_coords", "scr_forward_plan_run",
     "scr_profile_stride", "scr_debug_force_deep_lists", "scr_adam_step", "scr_tv_add_grad",
-    "scr_markers_enable", "scr_marker_push", "scr_marker_pop",
+    "scr_markers_enable", "scr_marker_push", "scr_marker_pop", "scr_norm_linear_dx",
 ]
 PLAN_NONFINITE_COLOUR, PLAN_LARGE_RECTS = 1, 2      # SCR_PLAN_*
 PROF_COUNT = 19
@@ -123,7 +123,7 @@ def _load():
     lib.scr_plane_row_pairs.argtypes = [i32, i32, i32, vp, vp, vp]
     lib.scr_triplane_backward_multi_scratch_bytes.argtypes = [i64, i32, vp, vp, vp, vp]
     lib.scr_triplane_backward_multi_scratch_bytes.restype = C.c_size_t
-    lib.scr_triplane_backward_multi.argtypes = [i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]
+    lib.scr_triplane_backward_multi.argtypes = [i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp]
     lib.scr_triplane_backward_multi.restype = C.c_int
     lib.scr_plane_row_pairs.restype = C.c_int
     lib.scr_triplane_backward_scratch_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
@@ -136,6 +136,8 @@ def _load():
     lib.scr_norm_linear_forward.restype = C.c_int
     lib.scr_norm_linear_backward.argtypes = [i64, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.scr_norm_linear_backward.restype = C.c_int
+    lib.scr_norm_linear_dx.argtypes = [i64, i32, vp, i32, vp, i32, vp, vp, i32, vp]
+    lib.scr_norm_linear_dx.restype = C.c_int
     lib.scr_box_coords.argtypes = [i64, vp, vp, vp, vp, vp]
     lib.scr_box_coords.restype = C.c_int
     lib.scr_norm_fold.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]

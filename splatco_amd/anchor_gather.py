@@ -60,10 +60,27 @@ class DeferredDx:
     that autograd may add to any other consumer's gradient of g_fea; this op's backward then forms the rows of dx inside
     its kernel (csrc/anchor_gather.hip, DX) and adds whatever gradient did arrive for g_fea.  If the BatchNorm-Linear's
     backward never runs (g_fea unused, or the unfused fallback), `coef` stays None and nothing changes."""
-    __slots__ = ("coef", "dy", "x")
+    __slots__ = ("coef", "dy", "x", "width")
 
-    def __init__(self):
+    def __init__(self, width=71):
         self.coef = self.dy = self.x = None
+        self.width = width          # columns of the matrix this producer can form dx for
+
+    def clear(self):
+        self.coef = self.dy = self.x = None
+
+    def materialise(self):
+        """dx [V, width] as a real matrix (16-byte aligned rows) from the coefficients: for a producer that finds it cannot
+        form the rows inside its own backward after all."""
+        from . import _C
+        from .rasterizer import _stream
+        V, d = self.x.shape
+        ld = (d + 3) // 4 * 4
+        dx = torch.empty(V, ld, dtype=torch.float32, device=self.x.device)[:, :d]
+        with torch.cuda.device(self.x.device):
+            _C.check(_C.lib.scr_norm_linear_dx(V, d, self.x.data_ptr(), self.x.stride(0), self.dy.data_ptr(), self.dy.stride(0),
+                                               self.coef.data_ptr(), dx.data_ptr(), ld, _stream(self.x.device)))
+        return dx
 
     @staticmethod
     def is_token(t):
@@ -152,7 +169,7 @@ class _AnchorGather(torch.autograd.Function):
                 if sink is not None and ranges is sink.ranges:
                     sink.on_range(r)
         if box is not None:
-            box.coef = box.dy = box.x = None        # (the box outlives the graph on g_fea: let the tensors go)
+            box.clear()                             # (the box outlives the graph on g_fea: let the tensors go)
         if sink is not None:
             return None, None, None, None, None, None, None        # written where the optimiser reads them
         return None, None, None, g_feat, g_anchor, g_offset, g_scaling

@@ -613,19 +613,22 @@ size_t scr_triplane_backward_multi_scratch_bytes(int64_t V, int32_t ngrids, cons
 
 int scr_triplane_backward_multi(int64_t V, const float* coords, int32_t cstride, int32_t ngrids, const int32_t* R,
                                 const int32_t* X, const int32_t* Y, const int32_t* Z, const int32_t* col, const float* grad_out,
-                                int32_t ld, float* const* grad_planes, void* scratch, void* stream) {
+                                int32_t ld, float* const* grad_planes, void* scratch, const float* nl_coef, const float* nl_dy,
+                                int32_t nl_lddy, const float* nl_x, int32_t nl_ldx, void* stream) {
     SCR_MARK_FN;
     if (V < 0 || ngrids < 1 || ngrids > 3) return fail("bad sizes");
-    if (!R || !X || !Y || !Z || !col || !grad_planes || !scratch || (V > 0 && (!coords || !grad_out))) return fail("NULL argument");
+    if (!R || !X || !Y || !Z || !col || !grad_planes || !scratch || (V > 0 && (!coords || (!grad_out && !nl_coef)))) return fail("NULL argument");
+    if (nl_coef && (!nl_dy || !nl_x || nl_lddy < 32 || nl_ldx < col[ngrids - 1] + 3 * R[ngrids - 1])) return fail("fused dx: dy [V,32] and x (the sampled matrix) are needed");
     for (int g = 0; g < ngrids; ++g) {
-        if (R[g] < 1 || X[g] < 2 || Y[g] < 2 || Z[g] < 2 || col[g] < 0 || col[g] + 3 * R[g] > ld) return fail("bad grid %d", g);
+        if (R[g] < 1 || X[g] < 2 || Y[g] < 2 || Z[g] < 2 || col[g] < 0 || col[g] + 3 * R[g] > (grad_out ? ld : nl_ldx)) return fail("bad grid %d", g);
         for (int q = 0; q < 3; ++q)
             if (!grad_planes[3 * g + q]) return fail("NULL plane gradient %d", 3 * g + q);
     }
     hipStream_t st = (hipStream_t)stream;
     int rc;
     { ProfScope ps_(SCR_PROF_PLANE_BACKWARD, st);
-      rc = launch_triplane_backward_multi(V, coords, cstride, ngrids, R, X, Y, Z, col, grad_out, ld, grad_planes, scratch, st); }
+      rc = launch_triplane_backward_multi(V, coords, cstride, ngrids, R, X, Y, Z, col, grad_out, ld, grad_planes, scratch, nl_coef, nl_dy,
+                                          nl_lddy, nl_x, nl_ldx, st); }
     if (rc == 3) return 3;      // not a layout of the fused pass: not an error, the caller goes grid by grid
     CHECK_LAUNCH("triplane_backward_multi", 0, st);
     return 0;
@@ -929,6 +932,20 @@ int scr_norm_linear_backward(int64_t V, int32_t d, const float* x, int32_t ldx, 
     return 0;
 }
 
+int scr_norm_linear_dx(int64_t V, int32_t d, const float* x, int32_t ldx, const float* dy, int32_t lddy, const float* coef,
+                       float* dx, int32_t lddx, void* stream) {
+    SCR_MARK_FN;
+    if (V < 1 || d < 1 || ldx < d || lddy < 32 || lddx < d) return fail("bad sizes");
+    if (!x || !dy || !coef || !dx) return fail("NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    { ProfScope ps_(SCR_PROF_NORM_LINEAR_BACKWARD, st);
+      rc = launch_norm_linear_dx(V, d, x, ldx, dy, lddy, coef, dx, lddx, st); }
+    if (rc == 1) return fail("d = %d input columns exceed the supported 80", d);
+    if (rc == 2) return fail("dy must be 16-byte aligned with a row stride that is a multiple of 4 floats");
+    CHECK_LAUNCH("norm_linear_dx", 0, st);
+    return 0;
+}
 
 // ---- MLP heads (mlp_heads.hip)
 size_t scr_mlp_heads_hidden_bytes(int64_t V) { return mlp_heads_hidden_bytes(V > 0 ? V : 1); }

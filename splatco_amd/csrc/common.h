@@ -460,7 +460,10 @@ void launch_l1_ssim_backward(int C, int H, int W, const float* img1, const float
 size_t triplane_multi_scratch_bytes(int64_t V, int ngrids, const int* R, const int* X, const int* Y, const int* Z);
 int launch_triplane_backward_multi(int64_t V, const float* coords, int cs, int ngrids, const int* R, const int* X, const int* Y,
                                    const int* Z, const int* col, const float* grad, int ld, float* const* grad_planes,
-                                   void* scratch, hipStream_t st);
+                                   void* scratch, const float* nl_coef, const float* nl_dy, int nl_lddy, const float* nl_x,
+                                   int nl_ldx, hipStream_t st);
+int launch_norm_linear_dx(int64_t V, int d, const float* x, int ldx, const float* dy, int lddy, const float* coef3, float* dx,
+                          int lddx, hipStream_t st);
 int launch_plane_row_pairs(int R, int A, int B, const float* plane, float* pairs, hipStream_t st);
 size_t triplane_scratch_bytes(int64_t V, int A, int B, int channels);
 size_t triplane_backward_scratch_bytes(int64_t V, int X, int Y, int Z, int channels);

@@ -482,6 +482,24 @@ int launch_norm_linear_backward(int64_t V, int d, const float* x, int ldx, const
     return 0;
 }
 
+// Pass 3 on its own, from a coefficient block a previous launch_norm_linear_backward(coef_out) left (Gi | k0 | k1): for the
+// consumer of those coefficients that finds it cannot form the rows itself after all (layout outside its fused pass).
+int launch_norm_linear_dx(int64_t V, int d, const float* x, int ldx, const float* dy, int lddy, const float* coef3, float* dx,
+                          int lddx, hipStream_t st) {
+    if (d < 1 || d > NL_DP) return 1;
+    if (lddy % 4 != 0 || ((uintptr_t)dy & 15) != 0) return 2;
+    const float* coef = coef3 - NLC_GI;          // the kernel reads coef + NLC_GI / NLC_K0 / NLC_K1 only: contiguous, in this order
+    const bool al = ldx % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dx & 15) == 0;
+#define SCR_NL_DX(NN)                                                                                                                          \
+    case NN:                                                                                                                                   \
+        if (al) nl_bwd_dx_kernel<NN, true><<<nl_grid(V, nl_bwd_dx_kernel<NN, true>), 256, 0, st>>>(V, d, x, ldx, dy, lddy, coef, dx, lddx);     \
+        else nl_bwd_dx_kernel<NN, false><<<nl_grid(V, nl_bwd_dx_kernel<NN, false>), 256, 0, st>>>(V, d, x, ldx, dy, lddy, coef, dx, lddx);      \
+        break;
+    switch ((d + 15) / 16) { SCR_NL_DX(1) SCR_NL_DX(2) SCR_NL_DX(3) SCR_NL_DX(4) SCR_NL_DX(5) }
+#undef SCR_NL_DX
+    return 0;
+}
+
 // ------------------------------------------------------------------ folding the BatchNorm / Linear parameters
 // FeaturePlanes sums L <= 4 pairs Linear_i(BatchNorm_i(.)) over its active levels.  With batch statistics the pairs fold
 // into ONE weight matrix G [32, d] and one bias c [32] (scene_model._norm_linear):

@@ -398,10 +398,17 @@ tp_scan9_kernel(TpProjSet9 ps) {
 
 // grid g (0..2) has RTg channels per projection (0 = grid absent); its projection q owns columns
 // base_g + q * RTg .. + RTg of the span that starts at column span0 (a multiple of 4; rows 16-byte aligned)
-template <int RA, int RB, int RC>
+// DX (round 6): the gradient rows are not read but FORMED here.  The sampled matrix has one consumer, the BatchNorm-Linear of
+// FeaturePlanes' plane branch, whose backward ends in dx[v][n] = k0[n] + x[v][n] k1[n] + sum_m dy[v][m] Gi[m][n]
+// (csrc/normlinear.hip) -- a [V,60] matrix written by one kernel and read back by this one.  With the coefficient blocks
+// (coef = Gi [32][NL_DP] | k0 | k1: uniform, scalar loads), its upstream gradient dy [V,32] and its input x (the sampled
+// matrix itself) every thread builds the row of ITS point: 32 x SPAN fmas on the span it holds in registers anyway.
+// A gradient that did arrive for the matrix from elsewhere (grad != NULL) is added.
+template <int RA, int RB, int RC, bool DX>
 __global__ void __launch_bounds__(TP_THREADS)
 tp_scatter9_kernel(int64_t V, const float* __restrict__ coords, int cs, const float* __restrict__ grad, int ld, int span0,
-                   TpProjSet9 ps) {
+                   TpProjSet9 ps, const float* __restrict__ nl_coef, const float* __restrict__ nl_dy, int nl_lddy,
+                   const float* __restrict__ nl_x, int nl_ldx) {
     constexpr int SPAN = 3 * (RA + RB + RC);
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     int total = 0;
@@ -438,7 +445,37 @@ tp_scatter9_kernel(int64_t V, const float* __restrict__ coords, int cs, const fl
         if (i >= V) break;
         const float x = coords[i * cs], y = coords[i * cs + 1], z = coords[i * cs + 2];
         float span[SPAN];
-        tp_load_span<SPAN, 0>(grad + (size_t)i * ld + span0, span);
+        if constexpr (DX) {
+            tp_load_span<SPAN, 0>(nl_x + (size_t)i * nl_ldx + span0, span);
+            const float* k0 = nl_coef + 32 * NL_DP + span0;
+            const float* k1 = nl_coef + 33 * NL_DP + span0;
+#pragma unroll
+            for (int n = 0; n < SPAN; ++n) span[n] = __builtin_fmaf(span[n], k1[n], k0[n]);
+            const float4* dyr = (const float4*)(nl_dy + (size_t)i * nl_lddy);
+            // eight of the 32 upstream columns per trip (not unrolled: all of dy in registers beside the span spills)
+#pragma unroll 1
+            for (int m8 = 0; m8 < 4; ++m8) {
+                const float4 da = dyr[2 * m8], db = dyr[2 * m8 + 1];
+                const float dv[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+                const float* gi = nl_coef + (8 * m8) * NL_DP + span0;      // uniform: scalar loads
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int n = 0; n < SPAN; ++n) span[n] = __builtin_fmaf(dv[j], gi[j * NL_DP + n], span[n]);
+            }
+            if (grad) {      // kernel-uniform; rows and span0 are 16-byte aligned (launcher), four columns at a time: no second span in registers
+                const float* gr = grad + (size_t)i * ld + span0;
+#pragma unroll
+                for (int n = 0; n + 3 < SPAN; n += 4) {
+                    const float4 e = *(const float4*)(gr + n);
+                    span[n] += e.x; span[n + 1] += e.y; span[n + 2] += e.z; span[n + 3] += e.w;
+                }
+#pragma unroll
+                for (int n = SPAN / 4 * 4; n < SPAN; ++n) span[n] += gr[n];
+            }
+        } else {
+            tp_load_span<SPAN, 0>(grad + (size_t)i * ld + span0, span);
+        }
         int off = 0;
         auto place = [&](auto rt_tag, int g, int base) {
             constexpr int RT = decltype(rt_tag)::value, REC = tp_rec(RT);
@@ -1227,11 +1264,17 @@ static void tp_gather_launch(const TpProj& pj, int64_t V, float* gp, hipStream_t
     tp_border_sum_kernel<RR, NPX><<<dim3((unsigned)((pj.B + 255) / 256), (unsigned)pj.A), 256, 0, st>>>(pj.A, pj.B, pj.tb, pj.start, pj.halo, gp, gp);
 }
 
+// nl_coef (NULL: off): the gradient rows are formed from the BatchNorm-Linear's coefficients, its upstream gradient nl_dy
+// [V,32] and its input nl_x (the sampled matrix, same columns as grad) -- see tp_scatter9_kernel; grad may then be NULL.
 int launch_triplane_backward_multi(int64_t V, const float* coords, int cs, int ngrids, const int* R, const int* X, const int* Y,
                                    const int* Z, const int* col, const float* grad, int ld, float* const* grad_planes,
-                                   void* scratch, hipStream_t st) {
+                                   void* scratch, const float* nl_coef, const float* nl_dy, int nl_lddy, const float* nl_x,
+                                   int nl_ldx, hipStream_t st) {
     if (ngrids < 1 || ngrids > 3 || cs < 3) return 3;
-    if (ld % 4 != 0 || col[0] % 4 != 0 || ((uintptr_t)grad & 15) != 0) return 3;
+    if (col[0] % 4 != 0) return 3;
+    if (grad && (ld % 4 != 0 || ((uintptr_t)grad & 15) != 0)) return 3;
+    if (!grad && !nl_coef) return 3;
+    if (nl_coef && (nl_ldx % 4 != 0 || ((uintptr_t)nl_x & 15) != 0 || nl_lddy % 4 != 0 || ((uintptr_t)nl_dy & 15) != 0)) return 3;
     for (int g = 0; g + 1 < ngrids; ++g)
         if (col[g + 1] != col[g] + 3 * R[g]) return 3;
     const int RA = R[0], RB = ngrids > 1 ? R[1] : 0, RC = ngrids > 2 ? R[2] : 0;
@@ -1271,8 +1314,13 @@ int launch_triplane_backward_multi(int64_t V, const float* coords, int cs, int n
     tp_scan9_kernel<<<ps.n, 1024, 0, st>>>(ps);
 #define SCR_TP_S9(a, b, c)                                               \
     do {                                                                 \
-        tp_allow_lds((const void*)tp_scatter9_kernel<a, b, c>, 2 * hb);  \
-        tp_scatter9_kernel<a, b, c><<<nwg, TP_THREADS, 2 * hb, st>>>(V, coords, cs, grad, ld, col[0], ps); \
+        if (nl_coef) {                                                   \
+            tp_allow_lds((const void*)tp_scatter9_kernel<a, b, c, true>, 2 * hb);  \
+            tp_scatter9_kernel<a, b, c, true><<<nwg, TP_THREADS, 2 * hb, st>>>(V, coords, cs, grad, ld, col[0], ps, nl_coef, nl_dy, nl_lddy, nl_x, nl_ldx); \
+        } else {                                                         \
+            tp_allow_lds((const void*)tp_scatter9_kernel<a, b, c, false>, 2 * hb);  \
+            tp_scatter9_kernel<a, b, c, false><<<nwg, TP_THREADS, 2 * hb, st>>>(V, coords, cs, grad, ld, col[0], ps, nullptr, nullptr, 0, nullptr, 0); \
+        }                                                                \
     } while (0)
     if (RA == 15) {
         if (RB) SCR_TP_S9(15, 5, 0); else SCR_TP_S9(15, 0, 0);

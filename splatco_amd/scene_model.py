@@ -157,7 +157,7 @@ class _NormLinearFn(torch.autograd.Function):
             if dy.dtype != torch.float32 or dy.stride(1) != 1 or dy.stride(0) % 4 or dy.data_ptr() % 16:
                 dy = dy.contiguous().float()
             need_dx = ctx.needs_input_grad[0]
-            defer = ctx.defer if need_dx and d == 71 and x.stride(1) == 1 else None
+            defer = ctx.defer if need_dx and x.stride(1) == 1 and d == getattr(ctx.defer, "width", None) else None
             ldx = (d + 3) // 4 * 4                   # 16-byte aligned rows (the pad columns are never written or read)
             dx = torch.empty(V, ldx, dtype=torch.float32, device=x.device)[:, :d] if need_dx and defer is None else None
             dG = torch.empty(32, d, dtype=torch.float32, device=x.device)
@@ -285,7 +285,7 @@ def _norm_linear(x, bns, linears, col_at=None):
     stats = getattr(x, "_scr_col_stats", None) if col_at is None else None
     if stats is not None and getattr(x, "_scr_col_stats_version", None) != x._version:
         stats = None        # x was edited in place since its producer summed its columns: the built-in statistics pass runs
-    defer = getattr(x, "_scr_deferred_dx", None) if col_at is None else None      # the anchor gather forms dx in its backward
+    defer = getattr(x, "_scr_deferred_dx", None)      # the producer of x (anchor gather / tri-plane sampling) forms dx in ITS backward
     y, mean, var = _NormLinearFn.apply(x, G, c, bns[0].eps, stats, defer)
     with torch.no_grad():
         n = x.shape[0]

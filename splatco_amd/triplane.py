@@ -72,7 +72,8 @@ class _TriPlaneSample(torch.autograd.Function):
     scene/gaussian_model.py:160-166) whose gradient is read in place by every grid's backward."""
 
     @staticmethod
-    def forward(ctx, meta, width, *tensors):
+    def forward(ctx, meta, width, box, *tensors):
+        ctx.box = box
         k, inds, shapes = 0, [], []
         out = None
         for n, cols in meta:
@@ -90,24 +91,40 @@ class _TriPlaneSample(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        if g.dtype != torch.float32 or g.stride(1) != 1:     # a column block of a wider matrix is read in place
+        from .anchor_gather import DeferredDx
+        box = ctx.box
+        nl = None
+        if box is not None and box.coef is not None:
+            # the BatchNorm-Linear that consumed the matrix left its coefficients instead of dx (anchor_gather.DeferredDx):
+            # the fused pass over the points forms every point's gradient row itself
+            nl = box
+            if DeferredDx.is_token(g):
+                g = None                                     # the stride-0 zeros it returned: nothing else arrived
+        if g is not None and (g.dtype != torch.float32 or g.stride(1) != 1):     # a column block of a wider matrix is read in place
             g = g.contiguous().float()
         inds = ctx.saved_tensors
-        fused = _backward_all(ctx, g, inds)
-        if fused is not None:
-            return fused
+        try:
+            fused = _backward_all(ctx, g, inds, nl)
+            if fused is not None:
+                return fused
+            if nl is not None:                               # a layout outside the fused pass: the matrix after all
+                dx = nl.materialise()
+                g = dx if g is None else g + dx
+        finally:
+            if box is not None:
+                box.clear()
         grads, k = [], 0
         for (n, cols), ind, shapes in zip(ctx.meta, inds, ctx.shapes):
-            need = ctx.needs_input_grad[2 + k + 1:2 + k + 1 + n]
+            need = ctx.needs_input_grad[3 + k + 1:3 + k + 1 + n]
             with torch.cuda.device(ind.device):
                 gp = _backward_from(g, ind, cols, shapes) if any(need) else [None] * n
             grads.append(None)
             grads.extend(t if nd else None for t, nd in zip(gp, need))
             k += 1 + n
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
-def _backward_all(ctx, g, inds):
+def _backward_all(ctx, g, inds, nl=None):
     """All grids of the op in ONE pass over the points (scr_triplane_backward_multi) when they were sampled at the same
     coordinates (the same tensor), each is a plain triple, their column blocks lie back to back in standard order and
     the library knows the channel layout; None otherwise (the caller goes grid by grid)."""
@@ -121,18 +138,22 @@ def _backward_all(ctx, g, inds):
         if n != 3 or tuple(cols) != (cols[0], cols[0] + r, cols[0] + 2 * r):
             return None
         R.append(r); X.append(shapes[0][2]); Y.append(shapes[0][3]); Z.append(shapes[1][3]); col.append(cols[0])
-    if not all(ctx.needs_input_grad[2:][j] for j in range(len(ctx.needs_input_grad) - 2) if j % 4 != 0):
+    if not all(ctx.needs_input_grad[3:][j] for j in range(len(ctx.needs_input_grad) - 3) if j % 4 != 0):
         return None                                          # a plane without a gradient: the per-grid path skips whole grids
     ind, V = inds[0], inds[0].shape[0]
     arr = lambda v: (C.c_int32 * ng)(*v)
     cR, cX, cY, cZ, ccol = arr(R), arr(X), arr(Y), arr(Z), arr(col)
-    gp = [torch.empty(s, dtype=torch.float32, device=g.device) for shapes in ctx.shapes for s in shapes]
+    dev = ind.device
+    gp = [torch.empty(s, dtype=torch.float32, device=dev) for shapes in ctx.shapes for s in shapes]
     ptrs = (C.c_void_p * (3 * ng))(*[t.data_ptr() for t in gp])
-    with torch.cuda.device(ind.device):
+    nlargs = (None, None, 0, None, 0) if nl is None else (nl.coef.data_ptr(), nl.dy.data_ptr(), nl.dy.stride(0), nl.x.data_ptr(),
+                                                        nl.x.stride(0))
+    with torch.cuda.device(dev):
         nbytes = _C.lib.scr_triplane_backward_multi_scratch_bytes(V, ng, cR, cX, cY, cZ)
-        scratch = _C.scratch(max(int(nbytes), 16), g.device)
-        rc = _C.lib.scr_triplane_backward_multi(V, ind.data_ptr(), ind.stride(0), ng, cR, cX, cY, cZ, ccol, g.data_ptr(),
-                                                g.stride(0), ptrs, scratch.data_ptr(), _stream())
+        scratch = _C.scratch(max(int(nbytes), 16), dev)
+        rc = _C.lib.scr_triplane_backward_multi(V, ind.data_ptr(), ind.stride(0), ng, cR, cX, cY, cZ, ccol,
+                                                None if g is None else g.data_ptr(), 0 if g is None else g.stride(0), ptrs,
+                                                scratch.data_ptr(), *nlargs, _stream())
     if rc == 3:
         return None
     _C.check(rc)
@@ -141,7 +162,7 @@ def _backward_all(ctx, g, inds):
         out.append(None)
         out.extend(gp[k:k + n])
         k += n
-    return (None, None, *out)
+    return (None, None, None, *out)
 
 
 def _prep_ind(ind):
@@ -161,7 +182,12 @@ def multi_triplane_sample(grids):
         flat.append(prepped[id(ind)])
         flat.extend(planes)
         width = max(width, max(cols) + R)
-    return _TriPlaneSample.apply(tuple(meta), width, *flat)
+    from .anchor_gather import DeferredDx
+    box = DeferredDx(width) if torch.is_grad_enabled() else None
+    out = _TriPlaneSample.apply(tuple(meta), width, box, *flat)
+    if box is not None:
+        out._scr_deferred_dx = box      # a fused BatchNorm-Linear that consumes the whole matrix leaves coefficients instead of dx
+    return out
 
 
 def triplane_sample(ind, planes, cols=None):

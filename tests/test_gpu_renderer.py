@@ -805,6 +805,56 @@ def test_gather_backward_forms_the_batchnorm_linear_dx_itself(N, second_use):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("V,layout,second_use", [(3000, "10-5-5", False), (300_017, "10-5-5", False), (300_017, "10-5-5", True),
+                                                 (100_003, "5-5", False), (100_003, "15-5", False), (50_000, "4", False)])
+def test_triplane_backward_forms_the_batchnorm_linear_dx_itself(V, layout, second_use):
+    """Round 6 hand-over on the plane branch (csrc/triplane.hip tp_scatter9_kernel DX): with the sampled matrix feeding the
+    fused BatchNorm-Linear, that op's backward leaves coefficients and a stride-0 zero gradient, and the pass that bins the
+    points forms every point's gradient row dx = k0 + x k1 + dy Gi itself.  Same plane gradients as with the materialised
+    matrix (the terms differ by the order of a 32-term fp32 sum; the plane sums themselves are exact): 2e-6 of the
+    tensor's scale; also with a second consumer of the matrix; a layout outside the fused pass ("4": R = 4) materialises
+    the matrix after all and agrees too."""
+    from splatco_amd import scene_model as sm
+    from splatco_amd.triplane import multi_triplane_sample
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(V + len(layout))
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    Rs = [int(t) for t in layout.split("-")]
+    sizes = [(40, 36, 44), (24, 20, 28), (12, 16, 10)][:len(Rs)]
+    ind = (torch.rand(V, 3, device=dev, generator=g) * 2.1 - 1.05)
+    planes, grids, col = [], [], 0
+    for R, (X, Y, Z) in zip(Rs, sizes):
+        tri = [r(1, R, X, Y).requires_grad_(), r(1, R, X, Z).requires_grad_(), r(1, R, Y, Z).requires_grad_()]
+        planes += tri
+        grids.append((tri, (col, col + R, col + 2 * R)))
+        col += 3 * R
+    width = col
+    G, c = (r(32, width) * 0.2).requires_grad_(), r(32).requires_grad_()
+    w_y, w_x = r(V, 32), r(V, width)
+
+    def run(defer):
+        for t in planes + [G, c]:
+            t.grad = None
+        x = multi_triplane_sample([(ind, tuple(tri), cols) for tri, cols in grids])
+        box = x._scr_deferred_dx
+        assert box.width == width
+        y, _, _ = sm._NormLinearFn.apply(x, G, c, 1e-5, None, box if defer else None)
+        loss = (y * w_y).sum()
+        if second_use:
+            loss = loss + (x * w_x).sum()
+        loss.backward()
+        assert box.coef is None
+        return [t.grad.clone() for t in planes] + [G.grad.clone(), c.grad.clone()]
+
+    want, got = run(False), run(True)
+    for k, (a, b) in enumerate(zip(want, got)):
+        scale = float(a.abs().max())
+        assert a.shape == b.shape and torch.isfinite(b).all()
+        assert float((a - b).abs().max()) <= 2e-6 * scale, (k, float((a - b).abs().max()), scale)
+    assert torch.equal(run(True)[0], got[0])        # bit-reproducible
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N", [40, 50_001, 1_400_003])      # one partial tile; 79 workgroups; more workgroups than statistics rows (second-level reduction)
 def test_gather_produced_column_statistics_feed_the_batchnorm(N):
     """The anchor gather sums (x - x[0]) and (x - x[0])^2 per column of g_fea while its rows sit in LDS
