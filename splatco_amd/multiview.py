@@ -399,8 +399,12 @@ class GradArena:
         byte mask + one host read of the per-range row counts (every rank derives the same message sizes from the same
         union); if the union holds less than `sparse_threshold` of the anchors, the sink's range units are exchanged as
         PACKED rows (gather -> all_reduce -> scatter back at reduce()) instead of whole ranges.  At MatrixCity scale a view
-        sees a small part of the scene: 5.7 GB of per-anchor gradient shrink with the union.  Needs the gradient sink and a
-        full exchange (not reduce(gather=False))."""
+        sees a small part of the scene: 5.7 GB of per-anchor gradient shrink with the union.  Needs the gradient sink.
+        With the sharded optimizer (reduce(gather=False)) the two combine without an owner map: the packed rows are summed by
+        an ALL-reduce, so every rank ends up with the complete gradient of every union row -- a superset of the owned slices
+        adam.ShardedFusedAdam reads (rows outside the union are zero everywhere, which is their sum) -- while the dense
+        units (planes, MLPs) stop after their reduce-scatter as before.  On the wire per step: 2 f S for the gradients
+        (f = union fraction, S = per-anchor bytes) + S for the parameter all-gather, against S + S dense: ahead below f = 0.5."""
         self._rows, self._packed, self.last_union_fraction = None, [], None
         if not self.sparse_rows or self._sink is None or not self.active:
             return False
@@ -536,8 +540,8 @@ class GradArena:
         all-gathers the parameters instead of the gradients (adam.ShardedFusedAdam: Adam's work and moments / world)."""
         if not gather and self.mode != "rs_ag":
             raise ValueError("GradArena.reduce(gather=False) needs mode='rs_ag'")
-        if not gather and self._rows is not None:
-            raise ValueError("GradArena.reduce(gather=False) after set_row_union(): the packed rows are exchanged in full")
+        # (gather=False after set_row_union(): the packed units were ALL-reduced -- complete on every rank, which covers the
+        # owned slices; only the dense units stop after the reduce-scatter)
         self._settle_sink()
         if self.active:
             order = self._order if self._order is not None else list(range(len(self.units)))

@@ -94,7 +94,7 @@ def collaborative_step(pc, views, gt_images, pipe, bg_color, optimizer=None, buc
     total, out, vis, rendered = None, None, None, []
     from .adam import ShardedFusedAdam
     sharded = isinstance(optimizer, ShardedFusedAdam)
-    want_union = arena is not None and arena.sparse_rows and not sharded and arena.active
+    want_union = arena is not None and arena.sparse_rows and arena.active      # (also under the sharded optimizer: set_row_union)
     union = None
     try:
         # (stage(): opt-in roctx ranges, _C.markers_enable / SPLATCO_MARKERS=1; nothing when off)

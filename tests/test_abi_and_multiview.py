@@ -406,6 +406,31 @@ for sparse in (False, True):
 for mode in ("all_reduce", "rs_ag"):
     for it in range(2):
         assert same(sparse_out[(True, mode, it)], sparse_out[(False, mode, it)]), ("row-sparse exchange", mode, it)
+# ---- ... combined with the sharded optimizer (round 6): reduce(gather=False) after set_row_union() -- the packed rows are
+# ALL-reduced (complete on every rank), the dense unit stops after its reduce-scatter; what the sharded Adam reads, the
+# owned slices, equals the dense exchange's there
+arena = GradArena([other] + pa, chunk_bytes=4096, mode="rs_ag", overlap=True, anchor_ranges=4, sparse_rows=True, sparse_threshold=0.9,
+                  check_rows=True)
+sink = arena.attach_sink(pa)
+for it in range(2):
+    arena.zero()
+    assert arena.set_row_union(mask if rank != world - 1 or it == 0 else None)
+    (other * oval).sum().backward()
+    last_has_views = not (rank == world - 1 and it == 1)
+    for r, (n0, n1) in enumerate(sink.ranges):
+        for t, v in zip(sink.tensors, mvals):
+            t[n0:n1] = v[n0:n1] if last_has_views else 0.0
+        sink.fresh = False
+        if rank == 0:
+            sink.on_range(r)
+    arena.reduce(gather=False)
+    want = sparse_out[(False, "rs_ag", it)]
+    for i, lo, hi in arena.owned_slices():
+        assert same(arena.flat[lo:hi], want[lo:hi]), ("row-sparse x sharded: owned slice", i, lo, hi, it)
+    for i in arena._sink_ids:          # the per-anchor gradients are complete everywhere (all-reduced packed rows)
+        o = arena.offsets[i]
+        assert same(arena.flat[o:o + arena.params[i].numel()], want[o:o + arena.params[i].numel()]), ("row-sparse x sharded: sink", i, it)
+arena.close()
 # check_rows (debug): a gradient row OUTSIDE the union of the visible anchors -- which the packed exchange would drop from the sum
 # without a trace -- is refused.  Every rank plants one (the check is local; all ranks raise at the same range, none is left
 # inside a collective)
