@@ -530,7 +530,7 @@ def run_cfg1(args, rank, world, dev):
     from splatco_amd.synthetic import synthetic_gaussians
 
     P, W, H = P_CFG1, W_CFG1, H_CFG1
-    g = synthetic_gaussians(P, W, H, seed=0, sigma_scale=args.sigma_scale)
+    g = synthetic_gaussians(P, W, H, seed=0, sigma_scale=args.sigma_scale, scene=args.scene)
     cam = make_view(rank, W, H)
     rast = GaussianRasterizer(settings_for(cam, g["bg"], dev))
     t = lambda a: torch.tensor(a, device=dev, requires_grad=True)
@@ -697,6 +697,12 @@ def run_cfg1(args, rank, world, dev):
                                  "frac_of_measured_peak": round(algorithmic_bytes(k, P, I, npix) / (ms * 1e-3) / 1e9 / peak, 3)}
                              for k, ms in sorted(kern.items(), key=lambda kv: -kv[1]) if ms > 0},
     }
+    if args.scene != "uniform":
+        out["config"]["workload"] += (f" -- DEVELOPER SCENE '{args.scene}': 80 % of the Gaussians in the central eighth of the image "
+                                      "(not the headline: longest-tile-first scheduling and the merge-path sort at work)")
+        out["config"]["scene"] = args.scene
+        out["config"]["largest_tile_entries"] = int(st.max_tile)
+        out["config"]["mean_list_entries_per_tile"] = round(I / (((W + 15) // 16) * ((H + 15) // 16)), 1)
     if args.sigma_scale != 1.0:
         out["config"]["workload"] += f" -- DEVELOPER SWEEP POINT: every screen-space sigma x {args.sigma_scale} (sparser tile lists)"
         out["config"]["sigma_scale"] = args.sigma_scale
@@ -706,7 +712,7 @@ def run_cfg1(args, rank, world, dev):
     if exposed is not None:
         out["exchange"] = exposed
     hip_image = state["img"].detach().cpu().numpy()
-    if world == 1 and not args.no_cfg2 and args.sigma_scale == 1.0:
+    if world == 1 and not args.no_cfg2 and args.sigma_scale == 1.0 and args.scene == "uniform":
         # the largest single-GPU configuration (BASELINE.json configs[2]) measured by the same process, after the headline:
         # cfg1 stays the line's metric / value, cfg2 rides along so that it is timed under the driver's clock too
         del params, leaves, means2D, dL, st
@@ -719,7 +725,7 @@ def run_cfg1(args, rank, world, dev):
                                           "kernel_ms_per_step", "peak_mem_GiB", "time_settle_steps")}
         out["cfg2"]["kernel_rooflines"] = {k: {kk: v[kk] for kk in ("ms_per_step", "GBps", "frac_of_measured_peak") if kk in v}
                                            for k, v in c2["kernel_rooflines"].items()}
-    if world == 1 and not args.no_cpu_baseline and args.sigma_scale == 1.0:
+    if world == 1 and not args.no_cpu_baseline and args.sigma_scale == 1.0 and args.scene == "uniform":
         out["cpu_baseline"], out["psnr_match_db"] = cpu_baseline(g, cam, dev, hip_image)
     return out
 
@@ -1057,6 +1063,9 @@ def main():
                     help="with --gpus N: run the N ranks on ONE device over gloo, log every collective of one step (name, bytes, "
                          "order), check that all ranks issue the same sequence and print it -- the sequence the first RCCL run "
                          "can be diffed against.  No timing is reported.")
+    ap.add_argument("--scene", choices=("uniform", "clustered"), default="uniform",
+                    help="cfg1 developer scene: 'clustered' moves 80 %% of the Gaussians into the central eighth of the image "
+                         "(uneven tile lists: the tile scheduler and the deep-list sort are timed, not just tested); the headline is 'uniform'")
     ap.add_argument("--sigma-scale", type=float, default=1.0,
                     help="cfg1 developer sweep: multiply every screen-space sigma (sparser tile lists; the headline is 1.0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

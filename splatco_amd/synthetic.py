@@ -25,16 +25,25 @@ def synthetic_camera(width, height, fovx_deg=60.0):
     return make_camera(np.eye(3), np.zeros(3), FoVx, FoVy, width, height)
 
 
-def synthetic_gaussians(P, width, height, seed=0, fovx_deg=60.0, sigma_scale=1.0):
+def synthetic_gaussians(P, width, height, seed=0, fovx_deg=60.0, sigma_scale=1.0, scene="uniform"):
     """Returns float32 numpy arrays: means3D[P,3], scales[P,3], rotations[P,4], opacities[P,1],
     colors[P,3] and bg[3].  sigma_scale: multiplies every screen-space sigma (1 = the benchmark scene of SURVEY.md 8d;
-    smaller = the same Gaussians, same positions, sparser tile lists -- bench.py's --sigma-scale sweep)."""
+    smaller = the same Gaussians, same positions, sparser tile lists -- bench.py's --sigma-scale sweep).
+    scene: "uniform" (the benchmark scene: pixel positions uniform over the image) or "clustered" (a developer scene, same
+    draws: 80 % of the Gaussians moved into the central eighth of the image -- a quarter of its width x half of its height --
+    so that tile lists differ by an order of magnitude: what a real capture looks like to the tile scheduler and the sort)."""
     rng = np.random.default_rng(seed)
     tanfovx = math.tan(math.radians(fovx_deg) / 2)
     tanfovy = tanfovx * height / width
     f = width / (2.0 * tanfovx)
     px = rng.uniform(0.0, width, P)
     py = rng.uniform(0.0, height, P)
+    if scene == "clustered":
+        inner = np.arange(P) % 5 != 0          # 80 %, decided by the index: the other draws stay those of the uniform scene
+        px = np.where(inner, width * 0.375 + px * 0.25, px)
+        py = np.where(inner, height * 0.25 + py * 0.5, py)
+    elif scene != "uniform":
+        raise ValueError(f"unknown scene {scene!r}")
     z = rng.uniform(2.0, 20.0, P)
     sig = np.exp(rng.uniform(math.log(0.5), math.log(5.0), (P, 3))) * float(sigma_scale)
     q = rng.standard_normal((P, 4))
