@@ -204,9 +204,9 @@ class GradArena:
     the sink's per-range callback from the last anchor-gather backward of the step -- and reduce() declares the rest
     ready.  Collectives are matched across ranks by ISSUE ORDER, so the order must not depend on what happened on a
     rank: units are issued strictly in one agreed order, as far as the contiguous ready prefix reaches.  The first
-    exchange runs in index order from reduce(); the ranks then agree on the order for all later steps (hook order as
-    observed, MIN over ranks of the positions, so every rank derives the same permutation from the same reduced
-    vector; sink ranges next; parameters nobody saw a gradient for last).  A rank without local views -- no hook fires,
+    exchange runs in index order from reduce(); the ranks then agree on the order for all later steps (the order in which
+    hooks fired and anchor ranges were reported, as observed, MIN over ranks of the positions, so every rank derives the
+    same permutation from the same reduced vector; parameters nobody saw a gradient for last).  A rank without local views -- no hook fires,
     everything goes out from reduce() -- therefore issues exactly the sequence the others do.
     mode "all_reduce": dist.all_reduce(SUM) per piece.  mode "rs_ag": reduce_scatter_tensor + all_gather_into_tensor
     on a piece padded to a multiple of the world size (on the point-to-point xGMI mesh every rank then owns 1/world
@@ -510,6 +510,7 @@ class GradArena:
                                "exchange was issued): the arena expects ONE backward() per step")
         if k is not None and not self._ready[k]:
             self._ready[k] = True
+            self._fire_log.append(k)
             self._flush()
 
     def _agree_order(self):
@@ -527,9 +528,14 @@ class GradArena:
         pos, fmin, fneg = t[:n], t[n:2 * n], t[2 * n:]
         if any(a != -b for a, b in zip(fmin, fneg)):
             raise RuntimeError("GradArena: the ranks attached different gradient sinks (the unit tables differ)")
-        fired = sorted((k for k in range(n) if not flags[k] and pos[k] < n), key=lambda k: (pos[k], k))
+        # every unit in the order it became final, the sink's anchor ranges among the parameters (round 6: with the tri-plane
+        # features sampled before the gather, FeaturePlanes.presample, the ranges are final BEFORE the plane parameters and
+        # must not queue behind them); ranges nobody reported (no rank had views this step) keep their place behind the
+        # parameters that fired; parameters nobody saw a gradient for last
+        fired = sorted((k for k in range(n) if pos[k] < n), key=lambda k: (pos[k], k))
+        quiet_ranges = [k for k in range(n) if flags[k] and pos[k] >= n]
         silent = [k for k in range(n) if not flags[k] and pos[k] >= n]
-        self._order = fired + [k for k in range(n) if flags[k]] + silent
+        self._order = fired + quiet_ranges + silent
 
     def reduce(self, gather=True):
         """SUM over ranks of everything in the arena; returns when the reduced gradients are usable on the current

@@ -48,8 +48,17 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     from .expand import visible_indices
     idx = visible_indices(visible_mask)             # on the GPU csrc/expand.hip: count / scan / write, one host read of the count
     from . import anchor_gather as _ag
-    g_fea = None
+    g_fea, presampled = None, None
     if _ag.fused_gather_taken(pc, fused_heads):
+        sink = getattr(pc, "_grad_sink", None)
+        if (sink is not None and sink.ranges and sink.on_range is not None and torch.is_grad_enabled()
+                and hasattr(pc.feat_planes, "presample")):
+            # A multi-rank training step (the gradient sink hands the per-anchor gradients to the exchange range by range):
+            # the tri-plane features are sampled BEFORE the gather is applied -- autograd then runs the gather's backward
+            # before the tri-plane / attention backward, and the exchange of the per-anchor gradients overlaps them
+            # (FeaturePlanes.presample; the sample positions are detached in the reference, scene/gaussian_model.py:210).
+            # Same kernels, same values; one extra [V,3] index_select.
+            presampled = pc.feat_planes.presample(pc._anchor.detach().index_select(0, idx))
         # the four gathers, exp(_scaling) and the [V,71] concatenation of :23-31 as one pass (csrc/anchor_gather.hip)
         feat, anchor, grid_offsets, grid_scaling, g_fea = _ag.gather_anchors(pc, idx)
     else:
@@ -86,7 +95,10 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         # the three heads as ONE fp32-MFMA kernel per direction (csrc/mlp_heads.hip): x = cat(feat, ob_view, geo_fea)
         # (:58-60) is never built, ob_view (:34-38) is computed inside, and geo_fea is read as the two matrices
         # FeaturePlanes' two GEMMs leave behind (its cat, scene/gaussian_model.py:166, is skipped as well)
-        geo_a, geo_b = pc.feat_planes.inference(anchor, g_fea, 0, parts=True)
+        if presampled is not None:
+            geo_a, geo_b = pc.feat_planes.inference(anchor, g_fea, 0, parts=True, presampled=presampled)
+        else:
+            geo_a, geo_b = pc.feat_planes.inference(anchor, g_fea, 0, parts=True)
         neural_opacity, color, scale_rot = _mh.mlp_heads(pc, feat, anchor, viewpoint_camera.camera_center, geo_a, geo_b)
         ob_view = None
     else:

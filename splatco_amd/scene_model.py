@@ -493,52 +493,77 @@ class FeaturePlanes(nn.Module):               # scene/gaussian_model.py:97-169
         L = self.activate_level + 1
         return [p for mods in (self.k0s[L:], self.models[L:], self.CTX_models[L:]) for m in mods for p in m.parameters()]
 
-    def forward(self, x, g_fea, Q=0, parts=False):
-        """parts=True: return the two 32-column halves (plane branch, attribute branch) instead of their
-        concatenation, when they exist as separate matrices (the fused MLP heads read them as they are)."""
+    def _fused_path(self):
+        L = self.activate_level + 1
+        return FUSE_NORM_LINEAR and all(m[0].training for m in list(self.models[:L]) + list(self.CTX_models[:L]))
+
+    def presample(self, x, Q=0):
+        """The sampling half of forward() on its own: (feats, col_at) for forward(..., presampled=...), or None when this
+        configuration does not take the fused path.  WHY it exists: autograd runs the backward of what was created LATER
+        first.  Sampled before the anchor gather is applied (the coordinates are detached, scene/gaussian_model.py:210, so
+        they can be gathered separately), the tri-plane backward -- a quarter of the anchor path's backward -- runs AFTER
+        the gather's, i.e. after the per-anchor gradients are final: in a multi-rank step their exchange (99 % of the
+        bytes) is then on the wire while the tri-plane and attention backward passes still compute."""
+        if not self._fused_path() or x.dim() != 2 or not all(self.k0s[i].fused_ok(x) for i in range(self.activate_level + 1)):
+            return None
+        return self._sample_all(x, Q)
+
+    def _sample_all(self, x, Q):
         L = self.activate_level + 1
         col_at = None
-        if FUSE_NORM_LINEAR and all(m[0].training for m in list(self.models[:L]) + list(self.CTX_models[:L])):
+        # every active grid samples straight into its columns of one matrix (no torch.cat of the grids' outputs)
+        from .triplane import multi_triplane_sample
+        specs, col, shared, noise_cols = [], 0, {}, []
+        first = 0
+        if L > 1 and STACK_LEVEL0 and self._stackable():
+            # The attention grid and the level-0 plain grid have the same size and the same box: every point
+            # samples both at the same texels.  The plain grid's plane is stacked on the attention grid's pair planes
+            # (plane | attended twin | level-0 plane: 3 r channels) and the two grids are sampled -- and their
+            # gradients scattered -- as ONE: one gather / one record of 15 channels per projection instead of 10 + 5.
+            # The samples of projection q land at columns 15 q .. 15 q + 15 where the reference's concatenation
+            # (scene/gaussian_model.py:160-166) has grid 0's at 10 q .. and grid 1's at 30 + 5 q ..: col_at tells
+            # the BatchNorm-Linear fold, which is free to keep its input columns in any order.
+            g0, g1 = self.k0s[0], self.k0s[1]
+            r = g1.channels // 3
+            ind3, pairs, _ = g0.sample_spec(x, 0)
+            shared.setdefault(g0.bounds_key(), ind3)
+            stacked = tuple(torch.cat((pr, pl), dim=1) for pr, pl in zip(pairs, (g1.xy_plane, g1.xz_plane, g1.yz_plane)))
+            specs.append((ind3, stacked, (0, 3 * r, 6 * r)))
+            col_at = [(j // (2 * r)) * 3 * r + j % (2 * r) for j in range(6 * r)]
+            col_at += [q * 3 * r + 2 * r + k for q in range(3) for k in range(r)]
+            noise_cols = [(q * 3 * r + 2 * r, r) for q in range(3)]
+            col, first = 9 * r, 2
+        for i in range(first, L):
+            # grids with the same box sample at the same normalised coordinates: ONE tensor, which also lets the
+            # backward of all grids run as one pass over the points
+            key = self.k0s[i].bounds_key()
+            spec = self.k0s[i].sample_spec(x, col, shared.get(key))
+            shared.setdefault(key, spec[0])
+            specs.append(spec)
+            if not self.k0s[i].TAflag:
+                noise_cols.append((col, self.k0s[i].get_dim()))
+            col += self.k0s[i].get_dim()
+        if col_at is not None:
+            col_at += list(range(len(col_at), col))
+        feats = multi_triplane_sample(specs)
+        if Q != 0:                       # uniform noise on the plain grids' blocks only (scene/grids.py:159-181)
+            for c0, w in noise_cols:
+                feats[:, c0:c0 + w] += torch.empty(feats.shape[0], w, device=feats.device).uniform_(-0.5, 0.5) * Q
+        return feats, col_at
+
+    def forward(self, x, g_fea, Q=0, parts=False, presampled=None):
+        """parts=True: return the two 32-column halves (plane branch, attribute branch) instead of their
+        concatenation, when they exist as separate matrices (the fused MLP heads read them as they are).
+        presampled: what presample(x, Q) returned for the same x (see there)."""
+        L = self.activate_level + 1
+        col_at = None
+        if self._fused_path():
             # sum_i cat(Linear(BN(feat_i)), Linear(BN(g_fea))) is linear in the normalised inputs: two GEMMs
-            if x.dim() == 2 and all(self.k0s[i].fused_ok(x) for i in range(L)):
+            if presampled is not None:
+                feats, col_at = presampled
+            elif x.dim() == 2 and all(self.k0s[i].fused_ok(x) for i in range(L)):
                 # every active grid samples straight into its columns of one matrix (no torch.cat of the grids' outputs)
-                from .triplane import multi_triplane_sample
-                specs, col, shared, noise_cols = [], 0, {}, []
-                first = 0
-                if L > 1 and STACK_LEVEL0 and self._stackable():
-                    # The attention grid and the level-0 plain grid have the same size and the same box: every point
-                    # samples both at the same texels.  The plain grid's plane is stacked on the attention grid's pair planes
-                    # (plane | attended twin | level-0 plane: 3 r channels) and the two grids are sampled -- and their
-                    # gradients scattered -- as ONE: one gather / one record of 15 channels per projection instead of 10 + 5.
-                    # The samples of projection q land at columns 15 q .. 15 q + 15 where the reference's concatenation
-                    # (scene/gaussian_model.py:160-166) has grid 0's at 10 q .. and grid 1's at 30 + 5 q ..: col_at tells
-                    # the BatchNorm-Linear fold, which is free to keep its input columns in any order.
-                    g0, g1 = self.k0s[0], self.k0s[1]
-                    r = g1.channels // 3
-                    ind3, pairs, _ = g0.sample_spec(x, 0)
-                    shared.setdefault(g0.bounds_key(), ind3)
-                    stacked = tuple(torch.cat((pr, pl), dim=1) for pr, pl in zip(pairs, (g1.xy_plane, g1.xz_plane, g1.yz_plane)))
-                    specs.append((ind3, stacked, (0, 3 * r, 6 * r)))
-                    col_at = [(j // (2 * r)) * 3 * r + j % (2 * r) for j in range(6 * r)]
-                    col_at += [q * 3 * r + 2 * r + k for q in range(3) for k in range(r)]
-                    noise_cols = [(q * 3 * r + 2 * r, r) for q in range(3)]
-                    col, first = 9 * r, 2
-                for i in range(first, L):
-                    # grids with the same box sample at the same normalised coordinates: ONE tensor, which also lets the
-                    # backward of all grids run as one pass over the points
-                    key = self.k0s[i].bounds_key()
-                    spec = self.k0s[i].sample_spec(x, col, shared.get(key))
-                    shared.setdefault(key, spec[0])
-                    specs.append(spec)
-                    if not self.k0s[i].TAflag:
-                        noise_cols.append((col, self.k0s[i].get_dim()))
-                    col += self.k0s[i].get_dim()
-                if col_at is not None:
-                    col_at += list(range(len(col_at), col))
-                feats = multi_triplane_sample(specs)
-                if Q != 0:                       # uniform noise on the plain grids' blocks only (scene/grids.py:159-181)
-                    for c0, w in noise_cols:
-                        feats[:, c0:c0 + w] += torch.empty(feats.shape[0], w, device=feats.device).uniform_(-0.5, 0.5) * Q
+                feats, col_at = self._sample_all(x, Q)
             else:
                 feats = torch.cat([self.k0s[i](x, Q) for i in range(L)], dim=1) if L > 1 else self.k0s[0](x, Q)
             a = _norm_linear(feats, [self.models[i][0] for i in range(L)], [self.models[i][1] for i in range(L)], col_at=col_at)
@@ -566,9 +591,13 @@ class GaussianLearner(nn.Module):             # scene/gaussian_model.py:184-220
         from .tv import feature_planes_tv
         feature_planes_tv(self._feat, w)
 
-    def inference(self, xyz, g_fea, Q0, parts=False):
+    def presample(self, xyz):
+        """FeaturePlanes.presample at the noise level inference() uses: hand the result to inference(presampled=...)."""
+        return self._feat.presample(xyz.detach(), self.Q0)
+
+    def inference(self, xyz, g_fea, Q0, parts=False, presampled=None):
         # the reference ignores the Q0 argument and uses self.Q0 (:209-215); xyz is detached
-        out = self._feat(xyz.detach(), g_fea, self.Q0, parts=parts)
+        out = self._feat(xyz.detach(), g_fea, self.Q0, parts=parts, presampled=presampled)
         if parts and not isinstance(out, tuple):
             out = (out[:, :32], out[:, 32:])
         return out

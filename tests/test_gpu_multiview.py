@@ -275,6 +275,54 @@ def _check_param_grads(pc):
     assert planes[3].xy_plane.grad is None            # the 2800^2 level is never sampled
 
 
+def test_per_anchor_gradients_are_final_before_the_triplane_backward_runs():
+    """Round 6, DESIGN.md section 7: in a multi-rank step (the gradient sink reports anchor RANGES) the tri-plane features are
+    sampled before the anchor gather is applied (FeaturePlanes.presample), so autograd runs the gather's backward -- which
+    forms the attribute branch's dx itself and finishes the per-anchor gradients range by range -- BEFORE the tri-plane and
+    attention backward passes: their exchange is on the wire while those still compute.  Checked on one GPU with a
+    stand-in for the arena: every range is reported before the first plane gradient appears, and all gradients equal
+    those of the ordinary order bit for bit (same kernels on the same values)."""
+    import math
+    from splatco_amd import anchor_gather as ag
+    from splatco_amd.cameras import look_at_camera
+    from splatco_amd.renderer import prefilter_voxel, render
+    from splatco_amd.synthetic import synthetic_anchor_model
+    dev = torch.device("cuda:0")
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False)
+    bg = torch.ones(3, device=dev)
+    cam = look_at_camera(eye=(0.2, -0.1, -5.0), target=(0, 0, 0), up=(0, -1, 0), FoVx=math.radians(60), width=320, height=200).to(dev)
+    target = torch.rand(3, 200, 320, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    N = 40_000
+    results = []
+    for ranged in (False, True):
+        pc = synthetic_anchor_model(N, 5, dev, plane_size=280)
+        pc.train()
+        names = ("_anchor_feat", "_anchor", "_offset", "_scaling")
+        grads = [torch.full_like(getattr(pc, n), float("nan")) for n in names]
+        sink = ag.GradSink(*grads)
+        events = []
+        if ranged:
+            step = (N // 4 + 63) // 64 * 64
+            sink.ranges = [(a, min(N, a + step)) for a in range(0, N, step)]
+            sink.on_range = lambda r: events.append(("range", r))
+        pc._grad_sink = sink
+        planes = [p for p in pc.feat_planes._feat.parameters() if p.dim() == 4 and p.requires_grad]
+        for p in planes[:3]:
+            p.register_post_accumulate_grad_hook(lambda _p: events.append(("plane", 0)))
+        vis = prefilter_voxel(cam, pc, pipe, bg)
+        out = render(cam, pc, pipe, bg, visible_mask=vis, retain_grad=True)
+        ((out["render"] - target).abs().mean() + 0.01 * out["scaling"].prod(dim=1).mean()).backward()
+        pc._grad_sink = None
+        if ranged:
+            kinds = [e[0] for e in events]
+            assert kinds.count("range") == len(sink.ranges) and "plane" in kinds
+            assert max(i for i, k in enumerate(kinds) if k == "range") < min(i for i, k in enumerate(kinds) if k == "plane"), kinds
+        results.append([g.clone() for g in grads] + [p.grad.clone() for p in pc.parameters() if p.grad is not None and not any(p is getattr(pc, n) for n in names)])
+    assert len(results[0]) == len(results[1]) > 8
+    for a, b in zip(*results):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_cfg3_5M_anchors_mv4_sequential_views_on_one_gpu():
     """configs[3] as the REFERENCE executes it (train.py:171-240): the four views of --mv 4 rendered one after another on
     one GPU, four rasterizer graphs alive, one backward; here through collaborative_step at world size 1 with the gradient
