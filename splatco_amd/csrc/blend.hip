@@ -730,13 +730,21 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 const float4 va = *(const float4*)trr, vb = *(const float4*)(trr + 4);
                 asm volatile("" ::: "memory");
                 const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-                s0 = wgt[0][0] * v[0]; s1 = wgt[1][0] * v[0]; s2 = wgt[2][0] * v[0];
+                // two chains of four per sum (even / odd pixel rows), added at the end: half the rounding depth of one chain
+                // of eight -- the conic gradients of needle-like Gaussians amplify the moments' last bits -- and six
+                // independent fma chains instead of three
+                float e0 = wgt[0][0] * v[0], e1 = wgt[1][0] * v[0], e2 = wgt[2][0] * v[0];
+                float o0 = wgt[0][1] * v[1], o1 = wgt[1][1] * v[1], o2 = wgt[2][1] * v[1];
 #pragma unroll
-                for (int y = 1; y < 8; ++y) {
-                    s0 = __builtin_fmaf(wgt[0][y], v[y], s0);
-                    s1 = __builtin_fmaf(wgt[1][y], v[y], s1);
-                    s2 = __builtin_fmaf(wgt[2][y], v[y], s2);
+                for (int y = 2; y < 8; y += 2) {
+                    e0 = __builtin_fmaf(wgt[0][y], v[y], e0);
+                    e1 = __builtin_fmaf(wgt[1][y], v[y], e1);
+                    e2 = __builtin_fmaf(wgt[2][y], v[y], e2);
+                    o0 = __builtin_fmaf(wgt[0][y + 1], v[y + 1], o0);
+                    o1 = __builtin_fmaf(wgt[1][y + 1], v[y + 1], o1);
+                    o2 = __builtin_fmaf(wgt[2][y + 1], v[y + 1], o2);
                 }
+                s0 = e0 + o0; s1 = e1 + o1; s2 = e2 + o2;
                 const float t0 = xw * s0, t1 = xw * t0, t2 = xw * s1;      // x S0, x^2 S0, x S1 (colour lanes: 0)
                 column_fold(s0, s1, s2, t0, t1, t2);
             } else {
