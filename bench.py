@@ -72,15 +72,18 @@ def algorithmic_bytes(kernel, P, I, npix, extra=None):
         "expand_kernel": 4 * n + 56 * n + 36 * V + 56 * P + 5 * n,   # count pass + candidates read + Gaussians written + index / mask
         "expand_backward_kernel": 56 * P + 60 * n + 36 * V + 4 * n,
         "triplane_forward_kernel": 4 * (240 * V + 12 * V + 60 * V),  # four sampled grids (attention grid twice): corner gathers + coords + 15 outputs
-        "plane_sample_backward_kernels": 12 * (240 * V / 3 + 8 * V + 20 * V),   # twelve planes: corner scatter + coords + 5 gradient columns
+        # twelve planes: corner scatter + coords + 5 gradient columns -- formed by the binning pass from the sampled matrix (the same
+        # 20 bytes per plane) and the BatchNorm-Linear's upstream gradient dy [V,32], read once (round 6)
+        "plane_sample_backward_kernels": 12 * (240 * V / 3 + 8 * V + 20 * V) + 4 * V * 32,
         "l1_ssim_forward_kernel": 2 * 12 * npix + 3 * 12 * npix,
         "l1_ssim_backward_kernel": 2 * 12 * npix + 3 * 12 * npix + 12 * npix,
         "mlp_heads_kernel": 4 * V * (32 + 3 + 64) + 4 * V * 110 + 4 * V * 96,             # inputs + outputs + saved hidden layer
         "mlp_heads_backward_kernel": 4 * V * (32 + 3 + 64 + 96 + 40 + 110) + 4 * V * (32 + 3 + 64),   # inputs, hidden, outputs(y), upstream; input gradients
         # BatchNorm-Linear pair of FeaturePlanes (d = 60 and 71 columns): statistics pass + GEMM pass forward;
-        # dy^T x pass + dx pass backward (x re-read by every pass: the algorithm needs the statistics first)
+        # dy^T x pass backward (x re-read by every pass: the algorithm needs the statistics first).  The dx pass is gone from
+        # this class since round 6: the producers of the two matrices form its rows (anchor gather backward, tri-plane binning)
         "norm_linear_kernels": 4 * V * (2 * (60 + 71) + 2 * 32),
-        "norm_linear_backward_kernels": 4 * V * (2 * (60 + 71) + 2 * 2 * 32 + (60 + 71)),
+        "norm_linear_backward_kernels": 4 * V * ((60 + 71) + 2 * 32),
         # attention of the level-0 grid (C stacked channels, HW pixels; forward + backward of one step): the planes are read
         # by the pools, the channel reduction and the apply pass, and written twice as pair planes; backward reads the
         # planes twice, the pair-plane gradients three halves, writes the plane gradients and updates them once more
