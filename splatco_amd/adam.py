@@ -206,7 +206,12 @@ class ShardedFusedAdam:
         rank's slice of a piece is its 1/world of it, exactly the layout of the parameter all-gather in step()); the result
         is handed out as VIEWS of that buffer -- one full-size transient per moment instead of four (two buffers all-reduced,
         then a clone of every parameter's moments: 4 x 5.7 GB per rank at 20 M anchors, at the point of the run -- a
-        re-layout, densification, a checkpoint -- where head-room is smallest)."""
+        re-layout, densification, a checkpoint -- where head-room is smallest).
+        VIEW SEMANTICS: the moments of different parameters share one transient buffer per key and are NOT copies of the
+        optimizer's state -- editing one in place changes nothing in the optimizer and nothing on other ranks; a caller that
+        wants to mutate (densification's state surgery) clones what it edits and hands the result to load_full_state().
+        Exercised over gloo at world 2 / 4 / 8 (CPU and HIP path) and under RCCL in a one-rank group only: no multi-GPU
+        hardware has run this path."""
         import torch.distributed as dist
         out = {i: {"step": torch.tensor(float(self.steps[i]))} for i in range(len(self.arena.params))}
         for key, shard in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
