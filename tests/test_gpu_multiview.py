@@ -199,7 +199,9 @@ if int(sys.argv[2]) >= 2:
     from splatco_amd.adam import FusedAdam, ShardedFusedAdam
     pc_c, params_c, _, groups_c = make()
     pc_d, params_d, _, groups_d = make()
-    arena_c = GradArena(params_c, chunk_bytes=4 << 20, mode="rs_ag", anchor_ranges=4)
+    # (round 6: the sharded side also exchanges its per-anchor gradients ROW-SPARSE -- packed rows all-reduced, i.e. complete on
+    # every rank, dense units reduce-scattered: the combination GradArena.set_row_union describes; threshold lifted so it packs)
+    arena_c = GradArena(params_c, chunk_bytes=4 << 20, mode="rs_ag", anchor_ranges=4, sparse_rows=True, sparse_threshold=1.01, check_rows=True)
     opt_c = ShardedFusedAdam(groups_c, arena_c, eps=1e-15)
     arena_d = GradArena(params_d, chunk_bytes=4 << 20, mode="all_reduce", anchor_ranges=4)
     opt_d = FusedAdam(groups_d, eps=1e-15)
@@ -225,6 +227,7 @@ if int(sys.argv[2]) >= 2:
     for it in range(3, 5):
         for pc_x, opt_x, arena_x in ((pc_c, opt_c, arena_c), (pc_d, opt_d, arena_d)):
             collaborative_step(pc_x, views, gts, pipe, bg, optimizer=opt_x, arena=arena_x, iteration=4 * (it + 1), tv_weight=TVW)
+    assert arena_c.last_union_fraction is not None and 0.5 < arena_c.last_union_fraction <= 1.0      # the packed path was taken
     for i, (a, b) in enumerate(zip(params_c, params_d)):
         worst = max(worst, rel(a, b))
         # (two replicated replicas drift apart like this too: 3.7e-6 max-abs on a weight matrix after three steps in the probe)
