@@ -367,10 +367,11 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restrict
 // and contracts them with per-lane weights that are constants of the tile --
 //     Y columns (c < 4):       (1, y, y^2)                  ->  S0 = sum_y Y,  S1 = sum_y y Y,  S2 = sum_y y^2 Y
 //     alpha T columns (c >= 4): dL/dpixel_0..2 at (x, y)    ->  the three colour sums of the pixel column x
-// -- 24 fmas, the same instruction stream for both kinds.  Three more products (x S0, x^2 S0, x S1; the weight x is 0 in the
+// -- 24 multiply-adds (two half-chains of four per sum, added: 27 issues), the same instruction stream for both kinds.  Three
+// more products (x S0, x^2 S0, x S1; the weight x is 0 in the
 // colour lanes) and the sum over the eight x lanes of a column is left: one bank-masked DPP level that folds the six values
 // into three registers (the 4-lane banks of even parity keep (S0, S1, S2), the odd ones (x S0, x^2 S0, x S1)) and two
-// quad_perm butterflies -- 12 DPP adds.  Per four splats: 27 plain + 12 DPP issues where the folds took 18 swaps + 37;
+// quad_perm butterflies -- 12 DPP adds.  Per four splats: 30 plain + 12 DPP issues where the folds took 18 swaps + 37;
 // always added in the same order (bit-reproducible).  The DPP part is one asm block: hipcc splits the builtin DPP form into
 // v_mov_dpp + v_add pairs padded with s_nop; here the three chains are interleaved so that every DPP source was written at
 // least two instructions earlier (the 2-wait-state VALU-write -> DPP-read hazard); the leading s_nop 1 covers the
@@ -664,7 +665,6 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
             float Y[4], Wt[4];  // Y and alpha T of each splat
             uint32_t jj[4] = {0u, 0u, 0u, 0u};
             unsigned long long hits[4] = {0ull, 0ull, 0ull, 0ull};
-            unsigned long long any = 0ull;
             // all four records first (one LDS round trip per group instead of four)
             float4 ra[4], rb[4];
             float2 rc[4];
@@ -703,7 +703,6 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 Gs[u] = sel(hit, ar, 0.0f);
                 al[u] = vmin(c099, Gs[u]);
                 om[u] = 1.0f - al[u];
-                any |= hit;
                 if (SAFE) hits[u] = hit;
                 jj[u] = j;
             }
@@ -716,8 +715,10 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 }
                 splat_pixel_grad<SAFE>(ps, Tu[u], rb[u], rc[u].x, Gs[u], al[u], hits[u], Y[u], Wt[u]);
             }
-            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-            if (any) {
+            // (a group none of whose splats reaches any pixel of the quadrant -- 0.1 % of them at the benchmark density -- goes
+            // through the same path with zeros: a wave-uniform skip cost every group five scalar instructions)
+            float s0, s1, s2;
+            {
                 // the block's stores and loads are LDS operations of ONE wave: they execute in issue order; the compiler
                 // must not move them across each other (it sees per-thread addresses only)
                 asm volatile("" ::: "memory");
@@ -747,8 +748,6 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint32_t* __restric
                 s0 = e0 + o0; s1 = e1 + o1; s2 = e2 + o2;
                 const float t0 = xw * s0, t1 = xw * t0, t2 = xw * s1;      // x S0, x^2 S0, x S1 (colour lanes: 0)
                 column_fold(s0, s1, s2, t0, t1, t2);
-            } else {
-                SCR_COUNT(12, TAIL ? k + 1 : 4);
             }
             // column rcol & 3 is splat u of the group, entry k - u of the wave's list; every listed position is written
             if (rstore && (!TAIL || k - rcu >= 0)) {
