@@ -467,9 +467,9 @@ def valu_object(dom, avg_ms):
     c_plain = 1.0 / rate("v_fma_f32 @8")
     c_four = 1.0 / min(rate("v_add_f32 dpp row_shr @5"), rate("v_cmp_lt_f32 -> sgpr pair @5"), rate("v_cndmask_b32_e64 sgpr mask @5"))
     c_two_pass = 2.0 / min(rate("v_exp_f32 @5"), rate("v_permlane32_swap @5"))
-    # DPP + compares + selects among the VALU instructions of the inner loop (tools/isa_mix.py, profiles/r06_isa_mix.txt: 12 + 12 + 15 of 184
+    # DPP + compares + selects among the VALU instructions of the inner loop (tools/isa_mix.py, profiles/r06_isa_mix.txt: 12 + 12 + 15 of 182
     # since the round-6 reduction; round 2-5: 41 of 217, with 13 two-pass permlane swaps that are gone)
-    four_share = {"blend_backward_kernel": 39.0 / 184.0, "blend_forward_kernel": 0.12}.get(dom, 0.0)
+    four_share = {"blend_backward_kernel": 39.0 / 182.0, "blend_forward_kernel": 0.12}.get(dom, 0.0)
     n_two = max(passes - n_inst, 0)
     n_four = four_share * n_inst
     n_plain = max(n_inst - n_two - n_four, 0)
