@@ -987,28 +987,57 @@ __device__ __forceinline__ void tp_sample_plane_rp(const float* __restrict__ pla
     for (int r = 0; r < R; ++r) out[r] = ((v[r] * w00 + v[2 * R + r] * w01) + v[R + r] * w10) + v[3 * R + r] * w11;
 }
 
+// The 3 R samples of a point leave through LDS when the grid's three column blocks lie back to back (the layout of
+// scene/gaussian_model.py:160-166's concatenation): a point's samples are then ONE run of 12 R bytes in its row, and the
+// workgroup writes its 256 runs with consecutive lanes on consecutive dwords.  Written straight from the registers every
+// store instruction put its 64 dwords into 64 different rows (4 ld bytes apart): twice the bytes of the matrix arrived at
+// HBM as partial lines (round 6: WRITE_SIZE 2.18 GB against 1.10 GB of samples at configs[2]).
 template <int R, int CL>
 __global__ void __launch_bounds__(256)
 triplane_forward_kernel(int64_t V, const float* __restrict__ coords, int cs, const float* __restrict__ xy,
                         const float* __restrict__ xz, const float* __restrict__ yz, int X, int Y, int Z,
                         float* __restrict__ out, int ld, int col_xy, int col_xz, int col_yz) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= V) return;
-    const float x = coords[i * cs], y = coords[i * cs + 1], z = coords[i * cs + 2];
-    float* o = out + i * ld;
-    // coordinate pairs of scene/grids.py:148-150: grid x indexes the LAST plane dimension
-    if (CL == 2) {
-        tp_sample_plane_rp<R>(xy, X, Y, y, x, o + col_xy);
-        tp_sample_plane_rp<R>(xz, X, Z, z, x, o + col_xz);
-        tp_sample_plane_rp<R>(yz, Y, Z, z, y, o + col_yz);
-    } else if (CL) {
-        tp_sample_plane_cl<R>(xy, X, Y, y, x, o + col_xy);
-        tp_sample_plane_cl<R>(xz, X, Z, z, x, o + col_xz);
-        tp_sample_plane_cl<R>(yz, Y, Z, z, y, o + col_yz);
-    } else {
-        tp_sample_plane<R>(xy, X, Y, y, x, o + col_xy);  // xy_plane [R,X,Y] at ind[..., [1, 0]]
-        tp_sample_plane<R>(xz, X, Z, z, x, o + col_xz);  // xz_plane [R,X,Z] at ind[..., [2, 0]]
-        tp_sample_plane<R>(yz, Y, Z, z, y, o + col_yz);  // yz_plane [R,Y,Z] at ind[..., [2, 1]]
+    constexpr int TS = 3 * R + 1;                       // odd row stride: the threads' runs start in different banks
+    __shared__ float tile[256 * TS];
+    const int64_t i0 = (int64_t)blockIdx.x * 256, i = i0 + threadIdx.x;
+    const bool staged = col_xz == col_xy + R && col_yz == col_xy + 2 * R;      // workgroup-uniform
+    if (i < V) {
+        const float x = coords[i * cs], y = coords[i * cs + 1], z = coords[i * cs + 2];
+        float o[3 * R];
+        // coordinate pairs of scene/grids.py:148-150: grid x indexes the LAST plane dimension
+        if (CL == 2) {
+            tp_sample_plane_rp<R>(xy, X, Y, y, x, o);
+            tp_sample_plane_rp<R>(xz, X, Z, z, x, o + R);
+            tp_sample_plane_rp<R>(yz, Y, Z, z, y, o + 2 * R);
+        } else if (CL) {
+            tp_sample_plane_cl<R>(xy, X, Y, y, x, o);
+            tp_sample_plane_cl<R>(xz, X, Z, z, x, o + R);
+            tp_sample_plane_cl<R>(yz, Y, Z, z, y, o + 2 * R);
+        } else {
+            tp_sample_plane<R>(xy, X, Y, y, x, o);          // xy_plane [R,X,Y] at ind[..., [1, 0]]
+            tp_sample_plane<R>(xz, X, Z, z, x, o + R);      // xz_plane [R,X,Z] at ind[..., [2, 0]]
+            tp_sample_plane<R>(yz, Y, Z, z, y, o + 2 * R);  // yz_plane [R,Y,Z] at ind[..., [2, 1]]
+        }
+        if (staged) {
+#pragma unroll
+            for (int c = 0; c < 3 * R; ++c) tile[threadIdx.x * TS + c] = o[c];
+        } else {
+            float* row = out + i * ld;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                row[col_xy + r] = o[r];
+                row[col_xz + r] = o[R + r];
+                row[col_yz + r] = o[2 * R + r];
+            }
+        }
+    }
+    if (!staged) return;
+    __syncthreads();
+    const int rows = (int)min((int64_t)256, V - i0);
+    float* dst = out + i0 * ld + col_xy;
+    for (int e = threadIdx.x; e < rows * 3 * R; e += 256) {
+        const int row = e / (3 * R), c = e - row * (3 * R);
+        dst[(size_t)row * ld + c] = tile[row * TS + c];
     }
 }
 
